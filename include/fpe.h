@@ -1,0 +1,198 @@
+/*
+ * fpe.h — C ABI of the MI355X foothold-search engine (libfpe.so).
+ *
+ * Drop-in boundary for ONE hot path of lukechencqu/quadrupedal_foothold_planner: the per-leg
+ * foothold search and per-cycle recurrence inside the `plan_global_footholds` service.
+ * File:line citations are relative to the reference checkout
+ * (foothold_planner/src/FootholdPlanner.cpp = "cpp", include/foothold_planner/FootholdPlanner.hpp
+ * = "hpp").  The reference has no FFI of its own; each entry point names the reference seam it
+ * replaces and INTEGRATION.md shows the binding a maintainer adds to FootholdPlanner.cpp.
+ *
+ * Conventions: every function returns an int status (FPE_OK = 0, negative = error); nothing
+ * throws, nothing prints.  Callers own every host buffer; the engine owns device memory.  Inputs
+ * are read-only and may be freed on return (synchronous entry points) or once the given stream
+ * has passed the call (…_device entry points).  the fpe_upload_map, fpe_plan and fpe_search_legs families
+ * may be called concurrently from different threads: a plan uses the map snapshot that was
+ * current when it entered (the reference instead races on gridmap_, cpp:506 vs cpp:818).
+ */
+#ifndef FPE_H
+#define FPE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fpe_engine* fpe_handle;
+
+enum fpe_status {
+    FPE_OK = 0,
+    FPE_E_INVALID_ARG = -1, /* null pointer, non-positive size, non-finite pose, too many vertices … */
+    FPE_E_NO_MAP = -2,      /* plan/search before any fpe_upload_map (reference: empty gridmap_) */
+    FPE_E_HIP = -3,         /* a HIP runtime call failed; fpe_last_error() has the text */
+    FPE_E_NO_DEVICE = -4,   /* no usable gfx950 device / HIP code object not loadable */
+    FPE_E_UNSUPPORTED = -5, /* search radius / foot radius too large for the on-chip tile */
+    FPE_E_NOMEM = -6
+};
+
+/* ROS parameters of the path, with the reference's member types (readParameters cpp:248-314;
+ * hpp:609-619, hpp:657-697).  Floats stay floats: the reference promotes them to double at each
+ * use and that decides chosen indices (e.g. ceil(double(0.1f)/0.02) = 6 rings, not 5). */
+typedef struct fpe_params {
+    float footRadius;                 /* cpp:255 */
+    float defaultFootholdThreshold;   /* cpp:257 */
+    float candidateFootholdThreshold; /* cpp:258 */
+    float searchRadius;               /* cpp:261 */
+    float stepLength;                 /* cpp:262 */
+    float length, width, l1;          /* laikago_kinematics/{length,width,l1}, cpp:285-287 */
+    float skew;                       /* laikago_kinematics/skewLength -> isos_.skew, cpp:290 */
+    int32_t RF_FIRST;                 /* cpp:264 */
+    double h;                         /* h_ (cpp:336), hard-coded 0.01 in the reference */
+    double lateralDrift;              /* ajustedPose_[1] += -0.007 per cycle (cpp:1578) */
+} fpe_params;
+
+/* yaml values of foothold_planner/config/foothold_planner.yaml:10-64 */
+int fpe_params_yaml(fpe_params* out);
+/* code defaults of readParameters (cpp:255-290) */
+int fpe_params_code_defaults(fpe_params* out);
+
+/* One element of the batch axis.  position = initialPose_ (cpp:293-295).  The remaining fields are
+ * build-defined extensions (not in the reference): zeros reproduce the reference exactly. */
+typedef struct fpe_pose {
+    double position[3];
+    int32_t gait;                /* 0 = trot (reference), 1 = 4-phase walk (build-defined) */
+    float leg_search_radius[4];  /* RF,RH,LH,LF; <= 0 -> fpe_params.searchRadius */
+    int32_t leg_polygon_kind[4]; /* 0 = reference rectangle getSearchPolygon (cpp:2496-2517);
+                                    1 = build-defined hexagon */
+} fpe_pose;
+
+/* Geometry + storage of the traversability map message handed to gridmapCallback (cpp:504-536).
+ * storage_order 0 = the grid_map_msgs/GridMap Float32MultiArray / Eigen::MatrixXf layout
+ * (column-major: buffer cell (i,j) at i + j*rows); 1 = row-major.  start_index is the circular
+ * buffer origin GridMap::getStartIndex() (= msg.outer_start_index / inner_start_index mapped by
+ * GridMapRosConverter).  The engine canonicalises to start index (0,0),
+ * row-major, on the device. */
+typedef struct fpe_map_desc {
+    int32_t rows, cols;     /* getSize()(0), getSize()(1): rows span x, cols span y */
+    double resolution;      /* getResolution() */
+    double position[2];     /* getPosition() (map centre) */
+    int32_t start_index[2]; /* getStartIndex() (row, col) */
+    int32_t storage_order;  /* 0 column-major, 1 row-major */
+} fpe_map_desc;
+
+/* One nominal-track foothold = result of checkFoothold (cpp:2001-2036, hpp:94-100). */
+typedef struct fpe_foothold {
+    int32_t row, col; /* chosen grid index: spiral cell, or getIndex(centre) for a default hit; -1 none */
+    double x, y;      /* footholdResult.point.x/y (cell centre, or the continuous centre) */
+    float z;          /* getFootholdMeanHeight (returns float, cpp:2520); 0 when invalid */
+    uint8_t valid;    /* footholdValidation (cpp:2013, 2023) */
+    uint8_t source;   /* 0 default-disc hit, 1 spiral candidate, 2 none, 3 radius over the tile bound */
+    uint8_t foot_id;  /* Foothold.msg foot_id: 0 RF, 1 RH, 2 LH, 3 LF (cpp:686-698) */
+    uint8_t gait_cycle_id; /* Foothold.msg gait_cycle_id = gaitCycleIndex (cpp:1378) */
+} fpe_foothold;
+
+/* One centroid-track foothold = result of checkFootholdUseCentroidMethod (cpp:1605-1997). */
+typedef struct fpe_centroid_foothold {
+    double x, y;
+    float z;
+    int32_t row, col; /* getIndex(x,y) on the full map; -1 when the result was left untouched */
+    uint8_t code;     /* 0 whole region valid, 1 case 1, 2/3 case 2 upper/lower, 4 case 3,
+                         5 no case (result (0,0,0)), 6 getSubmap failed (result (0,0,0)) */
+    uint8_t pad[3];
+} fpe_centroid_foothold;
+
+/* Output buffers of a chained plan; any pointer may be NULL (that product is skipped).
+ * Index convention: record (b, g, leg) at ((b * n_cycles) + g) * 4 + leg. */
+typedef struct fpe_plan_out {
+    fpe_foothold* nominal;           /* [B * n_cycles * 4] — what the service returns (cpp:1588) */
+    fpe_centroid_foothold* centroid; /* [B * n_cycles * 4] — global_footholds_centroid (cpp:1448-1462) */
+    double* default_next;            /* [B * n_cycles * 4 * 3] default track x,y,z (cpp:1344-1347) */
+    uint8_t* cycle_ok;               /* [B * n_cycles] footholdValidation_ per cycle (cpp:1323) */
+    double* stance;                  /* [B * 4 * 3] RF/RH/LH/LF_initialPosition_ (cpp:350-378) */
+} fpe_plan_out;
+
+/* One open-loop checkFoothold call (hpp:94-100) with an arbitrary polygon (grid_map::Polygon). */
+#define FPE_MAX_POLYGON_VERTICES 8
+typedef struct fpe_leg_query {
+    double cx, cy;       /* center */
+    float search_radius; /* searchRadius */
+    int32_t n_vertices;
+    double vx[FPE_MAX_POLYGON_VERTICES], vy[FPE_MAX_POLYGON_VERTICES];
+} fpe_leg_query;
+
+/* foothold_planner_msgs/Foothold (Foothold.msg:1-3) and foothold_planner_msgs/GlobalFootholds
+ * (GlobalFootholds.msg:1-5) as filled by globalFootholdPlan (cpp:591-699, 1378-1396, 1574, 1588):
+ * 4 stance entries (gait_cycle_id 0) then 4 per VALID cycle (gait_cycle_id = cycle index). */
+typedef struct fpe_msg_foothold {
+    double x, y, z;        /* geometry_msgs/Point point */
+    uint8_t foot_id;       /* 0 RF, 1 RH, 2 LH, 3 LF */
+    uint8_t gait_cycle_id;
+    uint8_t pad[6];
+} fpe_msg_foothold;
+typedef struct fpe_global_footholds {
+    uint8_t success;             /* validity of the LAST cycle (cpp:1380, 1574) */
+    uint8_t gait_cycles;         /* request.gait_cycles (cpp:592-593) */
+    uint8_t gait_cycles_succeed; /* index+1 of the last valid cycle (cpp:1379) */
+    uint8_t pad;
+    int32_t n_footholds;         /* entries used in `footholds` */
+    fpe_msg_foothold footholds[4 + 4 * 255];
+} fpe_global_footholds;
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+/* One engine per process per GPU (device_id = LOCAL_RANK under torch.distributed). */
+int fpe_create(int device_id, fpe_handle* out);
+int fpe_destroy(fpe_handle h);
+const char* fpe_last_error(fpe_handle h); /* thread-local text of the last failure on this thread */
+const char* fpe_version(void);
+
+/* ---- map ingest: replaces GridMapRosConverter::fromMessage in gridmapCallback (cpp:504-536) ---
+ * Host pointers, `rows*cols` floats per layer in desc->storage_order.  Uploads both layers to HBM
+ * once, canonicalised (row-major, start index 0); the new snapshot becomes current atomically. */
+int fpe_upload_map(fpe_handle h, const fpe_map_desc* desc, const float* traversability, const float* elevation);
+/* Same with DEVICE pointers (e.g. a map RCCL-broadcast from rank 0); async on `stream`. */
+int fpe_upload_map_device(fpe_handle h, const fpe_map_desc* desc, const float* d_traversability,
+                          const float* d_elevation, void* stream);
+int fpe_map_info(fpe_handle h, fpe_map_desc* out); /* geometry of the current snapshot */
+
+/* Build-defined: upper bound of fpe_pose.leg_search_radius the device-resident entry points size
+ * their LDS tile for (the host-buffer entry points scan the poses themselves).  Default 0 =
+ * fpe_params.searchRadius only; legs asking for more come back invalid with source = 3. */
+int fpe_set_max_leg_search_radius(fpe_handle h, float radius);
+
+/* ---- chained plan: replaces the body of the per-cycle loop of globalFootholdPlan (cpp:762-1579)
+ * — getDefaultFootholds, getFootholdSearchGridMap, 4x checkFootholdUseCentroidMethod (cpp:818-821),
+ * 4x std::thread(checkFoothold) + join (cpp:863-909), the commit rule (cpp:1323-1576) and the
+ * lateral drift (cpp:1578) — for B independent initial poses.  The NLopt "opt" track
+ * (cpp:913-1319) is not part of the path. */
+int fpe_plan(fpe_handle h, const fpe_params* params, const fpe_pose* poses, int32_t B, int32_t n_cycles,
+             const fpe_plan_out* out);
+/* Device-resident variant: d_poses and every non-NULL pointer of d_out are DEVICE pointers; the
+ * launch is asynchronous on `stream` (a hipStream_t; NULL = default stream). */
+int fpe_plan_device(fpe_handle h, const fpe_params* params, const fpe_pose* d_poses, int32_t B,
+                    int32_t n_cycles, const fpe_plan_out* d_out, void* stream);
+
+/* ---- open-loop per-leg search: replaces checkFoothold (cpp:2001-2036) one call per query ------ */
+int fpe_search_legs(fpe_handle h, const fpe_params* params, const fpe_leg_query* queries, int32_t n,
+                    fpe_foothold* out);
+int fpe_search_legs_device(fpe_handle h, const fpe_params* params, const fpe_leg_query* d_queries, int32_t n,
+                           fpe_foothold* d_out, void* stream);
+
+/* ---- service-shaped call: one pose, response content of plan_global_footholds (cpp:539-1602) -- */
+int fpe_plan_service(fpe_handle h, const fpe_params* params, const double initial_position[3],
+                     uint8_t gait_cycles, fpe_global_footholds* response);
+
+/* ---- host-side helpers (no GPU needed) -------------------------------------------------------- */
+/* SpiralIterator visiting order as index offsets (di,dj) for rings 0..n_rings (generateRing walk,
+ * consumed from the back).  Writes min(count, max_cells) entries of (di, dj, ring); returns count. */
+int fpe_spiral_offsets(int32_t n_rings, int32_t* out_di_dj_ring, int32_t max_cells);
+/* Half-width (cells) of the LDS tile a (searchRadius, footRadius, resolution) triple needs. */
+int fpe_tile_halfwidth(float search_radius, float foot_radius, double resolution);
+/* Algorithmic bytes per foothold used for the roofline:
+ * 4*W^2 + 8*n_foot + 16 with W = 2*(floor(R/res+0.5)+floor(rf/res))+1. */
+double fpe_algorithmic_bytes_per_foothold(float search_radius, float foot_radius, double resolution);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPE_H */

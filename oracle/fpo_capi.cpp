@@ -1,0 +1,245 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see fpo_planner.hpp / fpo_gridmap.hpp).
+// Plain C entry points so tests/, smoke() and bench.py's cpu_baseline leg can drive the CPU
+// restatement through ctypes.  Record layouts are documented in oracle/fpo.py (numpy dtypes).
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "fpo_planner.hpp"
+
+using namespace fpo;
+
+extern "C" {
+
+struct fpo_map {
+    int32_t rows, cols;
+    double resolution;
+    double position[2];
+    const float* traversability;  // rows*cols
+    const float* elevation;       // rows*cols
+    int32_t row_major;            // 1: (i,j) at i*cols+j ; 0: column-major i+j*rows (grid_map native)
+};
+
+struct fpo_leg {  // 32 bytes
+    int32_t row, col;
+    double x, y;
+    float z;
+    uint8_t valid, source, pad[2];
+};
+struct fpo_centroid {  // 32 bytes
+    double x, y;
+    float z;
+    int32_t row, col;
+    uint8_t code, pad[3];
+};
+struct fpo_query {  // one checkFoothold call
+    double cx, cy;
+    float search_radius;
+    int32_t n_vertices;
+    double vx[8], vy[8];
+};
+
+static GridMap buildMap(const fpo_map* m) {
+    GridMap g;
+    g.size = {m->rows, m->cols};
+    g.res = m->resolution;
+    g.length = {static_cast<double>(m->rows) * g.res, static_cast<double>(m->cols) * g.res};
+    g.position = {m->position[0], m->position[1]};
+    const size_t n = (size_t)m->rows * m->cols;
+    g.trav.resize(n);
+    g.elev.resize(n);
+    if (m->row_major) {
+        for (int i = 0; i < m->rows; ++i)
+            for (int j = 0; j < m->cols; ++j) {
+                g.trav[(size_t)i + (size_t)j * m->rows] = m->traversability[(size_t)i * m->cols + j];
+                g.elev[(size_t)i + (size_t)j * m->rows] = m->elevation[(size_t)i * m->cols + j];
+            }
+    } else {
+        std::memcpy(g.trav.data(), m->traversability, n * sizeof(float));
+        std::memcpy(g.elev.data(), m->elevation, n * sizeof(float));
+    }
+    return g;
+}
+
+// Opaque prepared map (avoids rebuilding the column-major copy for every call).
+void* fpo_map_create(const fpo_map* m) { return new GridMap(buildMap(m)); }
+void fpo_map_destroy(void* h) { delete static_cast<GridMap*>(h); }
+
+static void planRange(const GridMap& map, const Params& p, const PoseSpec* poses, int b0, int b1, int nCycles,
+                      fpo_leg* nominal, fpo_centroid* centroid, double* defaultNext, uint8_t* cycleOk,
+                      double* stance) {
+    PlanOutput out;
+    for (int b = b0; b < b1; ++b) {
+        planGlobalFootholds(map, p, poses[b], nCycles, out);
+        for (int k = 0; k < nCycles * 4; ++k) {
+            const size_t o = (size_t)b * nCycles * 4 + k;
+            if (nominal) {
+                fpo_leg& r = nominal[o];
+                std::memset(&r, 0, sizeof(r));
+                const LegResult& s = out.nominal[k];
+                r.row = s.row; r.col = s.col; r.x = s.x; r.y = s.y; r.z = s.z; r.valid = s.valid; r.source = s.source;
+            }
+            if (centroid) {
+                fpo_centroid& r = centroid[o];
+                std::memset(&r, 0, sizeof(r));
+                const CentroidResult& s = out.centroid[k];
+                r.x = s.x; r.y = s.y; r.z = s.z; r.row = s.row; r.col = s.col; r.code = s.code;
+            }
+            if (defaultNext) {
+                defaultNext[o * 3 + 0] = out.defaultNext[k].x;
+                defaultNext[o * 3 + 1] = out.defaultNext[k].y;
+                defaultNext[o * 3 + 2] = out.defaultNext[k].z;
+            }
+        }
+        if (cycleOk)
+            for (int g = 0; g < nCycles; ++g) cycleOk[(size_t)b * nCycles + g] = out.cycleOk[g];
+        if (stance)
+            for (int l = 0; l < 4; ++l) {
+                stance[((size_t)b * 4 + l) * 3 + 0] = out.stance[l].x;
+                stance[((size_t)b * 4 + l) * 3 + 1] = out.stance[l].y;
+                stance[((size_t)b * 4 + l) * 3 + 2] = out.stance[l].z;
+            }
+    }
+}
+
+// Chained plan for B poses.  threads <= 1: caller thread; otherwise std::thread over pose blocks.
+int fpo_plan(const void* mapHandle, const Params* params, const PoseSpec* poses, int B, int nCycles,
+             int threads, fpo_leg* nominal, fpo_centroid* centroid, double* defaultNext, uint8_t* cycleOk,
+             double* stance) {
+    const GridMap& map = *static_cast<const GridMap*>(mapHandle);
+    if (threads <= 1) {
+        planRange(map, *params, poses, 0, B, nCycles, nominal, centroid, defaultNext, cycleOk, stance);
+        return 0;
+    }
+    std::atomic<int> nextBlock{0};
+    const int block = 16;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&]() {
+            for (;;) {
+                int b0 = nextBlock.fetch_add(block);
+                if (b0 >= B) break;
+                planRange(map, *params, poses, b0, std::min(B, b0 + block), nCycles, nominal, centroid,
+                          defaultNext, cycleOk, stance);
+            }
+        });
+    for (auto& th : pool) th.join();
+    return 0;
+}
+
+// n independent checkFoothold calls (cpp:2001) with arbitrary polygons.
+int fpo_search_legs(const void* mapHandle, const Params* params, const fpo_query* q, int n, fpo_leg* out) {
+    const GridMap& map = *static_cast<const GridMap*>(mapHandle);
+    for (int k = 0; k < n; ++k) {
+        Polygon poly;
+        for (int v = 0; v < q[k].n_vertices; ++v) poly.addVertex({q[k].vx[v], q[k].vy[v]});
+        LegResult r;
+        checkFoothold(map, {q[k].cx, q[k].cy}, params->footRadius, q[k].search_radius, poly, *params, r);
+        std::memset(&out[k], 0, sizeof(fpo_leg));
+        out[k].row = r.row; out[k].col = r.col; out[k].x = r.x; out[k].y = r.y; out[k].z = r.z;
+        out[k].valid = r.valid; out[k].source = r.source;
+    }
+    return 0;
+}
+
+int fpo_centroid_method(const void* mapHandle, const Params* params, double x, double y, float searchRadius,
+                        fpo_centroid* out) {
+    const GridMap& map = *static_cast<const GridMap*>(mapHandle);
+    CentroidResult r;
+    checkFootholdUseCentroidMethod(map, {x, y}, searchRadius, *params, r);
+    std::memset(out, 0, sizeof(*out));
+    out->x = r.x; out->y = r.y; out->z = r.z; out->row = r.row; out->col = r.col; out->code = r.code;
+    return 0;
+}
+
+float fpo_mean_height(const void* mapHandle, double x, double y, float radius, double h) {
+    return getFootholdMeanHeight(*static_cast<const GridMap*>(mapHandle), {x, y}, radius, h);
+}
+
+// ---- grid_map semantics probes (KATs / property tests) ------------------------------------------
+int fpo_spiral_cells(const void* mapHandle, double cx, double cy, double radius, int32_t* ij, int maxCells) {
+    const GridMap& map = *static_cast<const GridMap*>(mapHandle);
+    int n = 0;
+    for (SpiralIterator it(map, {cx, cy}, radius); !it.isPastEnd(); ++it) {
+        if (n < maxCells) {
+            ij[2 * n] = (*it).i;
+            ij[2 * n + 1] = (*it).j;
+        }
+        ++n;
+    }
+    return n;
+}
+int fpo_circle_cells(const void* mapHandle, double cx, double cy, double radius, int32_t* ij, int maxCells) {
+    const GridMap& map = *static_cast<const GridMap*>(mapHandle);
+    int n = 0;
+    for (CircleIterator it(map, {cx, cy}, radius); !it.isPastEnd(); ++it) {
+        if (n < maxCells) {
+            ij[2 * n] = (*it).i;
+            ij[2 * n + 1] = (*it).j;
+        }
+        ++n;
+    }
+    return n;
+}
+int fpo_get_index(const void* mapHandle, double x, double y, int32_t* ij) {
+    const GridMap& map = *static_cast<const GridMap*>(mapHandle);
+    Idx2 idx;
+    bool ok = map.getIndex({x, y}, idx);
+    ij[0] = idx.i;
+    ij[1] = idx.j;
+    return ok ? 1 : 0;
+}
+int fpo_get_position(const void* mapHandle, int i, int j, double* xy) {
+    const GridMap& map = *static_cast<const GridMap*>(mapHandle);
+    Vec2 p{0, 0};
+    bool ok = map.getPosition({i, j}, p);
+    xy[0] = p.x;
+    xy[1] = p.y;
+    return ok ? 1 : 0;
+}
+// out: [tl_i, tl_j, rows, cols], pos_len: [px, py, lx, ly]
+int fpo_submap_info(const void* mapHandle, double x, double y, double lx, double ly, int32_t* out, double* posLen) {
+    const GridMap& map = *static_cast<const GridMap*>(mapHandle);
+    SubmapInfo info;
+    bool ok = getSubmapInformation(info, {x, y}, {lx, ly}, map.length, map.position, map.res, map.size);
+    if (!ok) return 0;
+    out[0] = info.topLeft.i; out[1] = info.topLeft.j; out[2] = info.size.i; out[3] = info.size.j;
+    posLen[0] = info.position.x; posLen[1] = info.position.y; posLen[2] = info.length.x; posLen[3] = info.length.y;
+    return 1;
+}
+int fpo_polygon_inside(const double* vx, const double* vy, int n, double x, double y) {
+    Polygon poly;
+    for (int v = 0; v < n; ++v) poly.addVertex({vx[v], vy[v]});
+    return poly.isInside({x, y}) ? 1 : 0;
+}
+void fpo_polygon_center(const double* feet12, double* out3) {
+    Point3 f[4];
+    for (int l = 0; l < 4; ++l) {
+        f[l].x = feet12[l * 3];
+        f[l].y = feet12[l * 3 + 1];
+        f[l].z = feet12[l * 3 + 2];
+    }
+    Point3 c = getPolygonCenter(f[0], f[1], f[2], f[3]);
+    out3[0] = c.x; out3[1] = c.y; out3[2] = c.z;
+}
+void fpo_constants(const Params* p, double* out /*[14]*/) {
+    Constants c = makeConstants(*p);
+    out[0] = c.LbHalf; out[1] = c.WbHalfNeg; out[2] = c.WbHalfPos;
+    for (int l = 0; l < 4; ++l) { out[3 + l] = c.biasX[l]; out[7 + l] = c.biasY[l]; }
+    out[11] = c.stepHalf; out[12] = c.step; out[13] = c.stepQuarter;
+}
+int fpo_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(Params);
+        case 1: return (int)sizeof(PoseSpec);
+        case 2: return (int)sizeof(fpo_leg);
+        case 3: return (int)sizeof(fpo_centroid);
+        case 4: return (int)sizeof(fpo_query);
+        case 5: return (int)sizeof(fpo_map);
+    }
+    return -1;
+}
+
+}  // extern "C"

@@ -1,0 +1,396 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see fpo_planner.hpp / fpo_gridmap.hpp).
+// Restates /root/reference/foothold_planner/src/FootholdPlanner.cpp ("cpp:") for the hot path.
+#include "fpo_planner.hpp"
+
+#include <cmath>
+
+namespace fpo {
+
+// initialize(), cpp:340-421.  lengthBase/widthBase are FLOAT members (hpp:666-667); widthBase is
+// computed in f32 (cpp:341); every later use promotes the float to double first.
+Constants makeConstants(const Params& p) {
+    Constants c;
+    const float lengthBase = p.length;            // cpp:340
+    const float widthBase = p.width + p.l1 * 2;   // cpp:341 (f32 arithmetic)
+    c.LbHalf = lengthBase * 0.5;                  // cpp:350
+    c.WbHalfNeg = -widthBase * 0.5;               // cpp:351
+    c.WbHalfPos = widthBase * 0.5;                // cpp:359
+    if (p.RF_FIRST) {                             // cpp:403-411
+        c.biasX[RF] = 0.5 * lengthBase + p.skew;
+        c.biasY[RF] = -0.5 * widthBase;
+        c.biasX[RH] = -0.5 * lengthBase - p.skew;
+        c.biasY[RH] = -0.5 * widthBase;
+        c.biasX[LH] = -0.5 * lengthBase + p.skew;
+        c.biasY[LH] = 0.5 * widthBase;
+        c.biasX[LF] = 0.5 * lengthBase - p.skew;
+        c.biasY[LF] = 0.5 * widthBase;
+    } else {                                      // cpp:412-421
+        c.biasX[RF] = 0.5 * lengthBase - p.skew;
+        c.biasY[RF] = -0.5 * widthBase;
+        c.biasX[RH] = -0.5 * lengthBase + p.skew;
+        c.biasY[RH] = -0.5 * widthBase;
+        c.biasX[LH] = -0.5 * lengthBase - p.skew;
+        c.biasY[LH] = 0.5 * widthBase;
+        c.biasX[LF] = 0.5 * lengthBase + p.skew;
+        c.biasY[LF] = 0.5 * widthBase;
+    }
+    c.stepHalf = p.stepLength / 2;     // cpp:2693: float / int -> float, then promoted
+    c.step = p.stepLength;             // cpp:2199
+    c.stepQuarter = p.stepLength / 4;  // walk extension (build-defined)
+    return c;
+}
+
+// cpp:2039-2082.  false iff the disc is empty or a FINITE cell is below the threshold; NaN cells
+// are ignored; `validation = true` closes every iteration (cpp:2078).
+bool checkDefaultFoothold(const GridMap& map, const Vec2& center, float footRadius, const Params& p) {
+    bool validation = false;
+    for (CircleIterator it(map, center, footRadius); !it.isPastEnd(); ++it) {
+        const float v = map.travAt(*it);
+        if (GridMap::isValid(v)) {                        // cpp:2055
+            if (v < p.defaultFootholdThreshold) {         // cpp:2057
+                validation = false;
+                break;                                    // cpp:2066
+            }
+        }
+        validation = true;                                // cpp:2078
+    }
+    return validation;
+}
+
+// cpp:2117-2163.
+bool checkCirclePolygonFoothold(const GridMap& map, const Vec2& center, float footRadius,
+                                const Polygon& polygon, const Params& p) {
+    bool validation = false;
+    for (CircleIterator it(map, center, footRadius); !it.isPastEnd(); ++it) {
+        const float v = map.travAt(*it);
+        if (GridMap::isValid(v)) {                        // cpp:2132
+            Vec2 cell{0, 0};
+            map.getPosition(*it, cell);                   // cpp:2136
+            if (v < p.candidateFootholdThreshold || false == polygon.isInside(cell)) {  // cpp:2138
+                validation = false;
+                break;                                    // cpp:2147
+            }
+        }
+        validation = true;                                // cpp:2159
+    }
+    return validation;
+}
+
+// cpp:2085-2114: first valid cell in SpiralIterator order.
+bool checkCandidateFoothold(const GridMap& map, const Vec2& spiralCenter, float footRadius,
+                            float searchRadius, const Polygon& polygon, const Params& p, LegResult& out) {
+    bool validation = false;
+    for (SpiralIterator it(map, spiralCenter, searchRadius); !it.isPastEnd(); ++it) {
+        Vec2 footCenter{0, 0};
+        map.getPosition(*it, footCenter);                 // cpp:2098
+        validation = checkCirclePolygonFoothold(map, footCenter, footRadius, polygon, p);  // cpp:2100
+        if (validation) {
+            Vec2 q{0, 0};
+            map.getPosition(*it, q);                      // cpp:2105
+            out.x = q.x;
+            out.y = q.y;
+            out.row = (*it).i;
+            out.col = (*it).j;
+            break;
+        }
+    }
+    return validation;
+}
+
+// cpp:2520-2554.  f32 sequential sum in CircleIterator (row-major bbox) order; NaN -> 0.0 and
+// counted; values >= 10 skipped; empty count -> last iHeight; "+ h" in f64, returned as float.
+float getFootholdMeanHeight(const GridMap& map, const Vec2& center, float radius, double h) {
+    float iHeight = 0.0, meanHeight = 0.0;
+    int i = 0;
+    for (CircleIterator it(map, center, radius); !it.isPastEnd(); ++it) {
+        const float e = map.elevAt(*it);
+        if (GridMap::isValid(e)) {
+            iHeight = e;
+        } else {
+            iHeight = 0.0;
+        }
+        if (iHeight < 10) {
+            i++;
+            meanHeight = meanHeight + iHeight;
+        }
+    }
+    if (i != 0) {
+        meanHeight = meanHeight / i;
+    } else {
+        meanHeight = iHeight;
+    }
+    return static_cast<float>(meanHeight + h);
+}
+
+// cpp:2001-2036.  z is measured at the DEFAULT centre even when a candidate was chosen (cpp:2029).
+void checkFoothold(const GridMap& map, const Vec2& center, float footRadius, float searchRadius,
+                   const Polygon& polygon, const Params& p, LegResult& out) {
+    out = LegResult();
+    bool defaultFootholdIsvalid = checkDefaultFoothold(map, center, footRadius, p);  // cpp:2012
+    out.valid = defaultFootholdIsvalid;
+    out.x = center.x;                                     // cpp:2016-2017
+    out.y = center.y;
+    bool candidateFootholdIsvalid = false;
+    if (!defaultFootholdIsvalid) {
+        candidateFootholdIsvalid = checkCandidateFoothold(map, center, footRadius, searchRadius, polygon, p, out);
+        out.valid = candidateFootholdIsvalid;             // cpp:2023
+    }
+    if (defaultFootholdIsvalid | candidateFootholdIsvalid) {
+        out.z = getFootholdMeanHeight(map, center, footRadius, p.h);  // cpp:2029
+    }
+    if (defaultFootholdIsvalid) {
+        Idx2 idx;
+        map.getIndex(center, idx);  // reporting only
+        out.row = idx.i;
+        out.col = idx.j;
+        out.source = 0;
+    } else if (candidateFootholdIsvalid) {
+        out.source = 1;
+    } else {
+        out.source = 2;
+        out.row = out.col = -1;
+    }
+}
+
+// cpp:1605-1997.  `searchRadius` is searchRadius_ in the reference (cpp:1616-1617).
+void checkFootholdUseCentroidMethod(const GridMap& gridmap, const Vec2& p, float searchRadius,
+                                    const Params& prm, CentroidResult& out) {
+    out = CentroidResult();
+    Vec2 rect;
+    rect.x = searchRadius * 2;  // cpp:1616 (float * int -> float)
+    rect.y = searchRadius;      // cpp:1617
+    bool isSuccess;
+    GridMap map = gridmap.getSubmap(p, rect, isSuccess);  // cpp:1627
+    if (!isSuccess) {
+        out.code = 6;  // cpp:1628-1631: return false, result untouched
+        return;
+    }
+    // cpp:1649-1658: whole-region test, raw `<` (NaN passes, -inf blocks), linear storage order
+    bool wholeRegionValid = false;
+    const size_t n = map.trav.size();
+    for (size_t i = 0; i < n; ++i) {
+        if (map.trav[i] < prm.defaultFootholdThreshold) {
+            wholeRegionValid = false;
+            break;
+        }
+        wholeRegionValid = true;
+    }
+    const int topRow = 0, bottomRow = map.size.i - 1, rightCol = map.size.j - 1;  // cpp:1679-1682
+
+    auto finish = [&](const Vec2& q, uint8_t code) {
+        out.z = getFootholdMeanHeight(gridmap, q, prm.footRadius, prm.h);  // on gridmap_ (cpp:1687, 1820)
+        out.x = q.x;
+        out.y = q.y;
+        out.code = code;
+        Idx2 idx;
+        gridmap.getIndex(q, idx);  // reporting only
+        out.row = idx.i;
+        out.col = idx.j;
+    };
+
+    if (wholeRegionValid) {  // cpp:1684-1689
+        finish(p, 0);
+        return;
+    }
+    // cpp:1717-1750: row scan.  The reference's LineIterator end index (row, size(1)) reads one
+    // cell past the last column (UB); the oracle scans columns 0..size(1)-1 only (App. D).
+    int minRow = 0, maxRow = 0, k = 0;
+    for (int j = 0; j < bottomRow + 1; ++j) {
+        int i = 0;
+        for (int c = 0; c < map.size.j; ++c)
+            if (map.travAt({j, c}) < prm.defaultFootholdThreshold) ++i;  // cpp:1736
+        if (i > ((rightCol + 1) * 0.5)) {  // cpp:1743
+            if (k == 0) minRow = j;
+            maxRow = j;
+            ++k;
+        }
+    }
+    Idx2 newIndex;
+    uint8_t code;
+    if (minRow == topRow && maxRow != bottomRow) {  // case 1, cpp:1777-1786
+        newIndex.i = static_cast<int>(std::floor((maxRow + bottomRow + 1) * 0.5));
+        newIndex.j = static_cast<int>(std::floor((rightCol + 1) * 0.5));
+        code = 1;
+    } else if (minRow != topRow && maxRow != bottomRow) {  // case 2, cpp:1843-1886
+        if ((minRow - topRow) >= (bottomRow - maxRow)) {
+            newIndex.i = static_cast<int>(std::ceil(minRow * 0.5));
+            newIndex.j = static_cast<int>(std::floor((rightCol + 0) * 0.5));
+            code = 2;
+        } else {
+            newIndex.i = static_cast<int>(std::floor((maxRow + bottomRow) * 0.5));
+            newIndex.j = static_cast<int>(std::floor((rightCol + 0) * 0.5));
+            code = 3;
+        }
+    } else if (minRow != topRow && maxRow == bottomRow) {  // case 3, cpp:1944-1952
+        newIndex.i = static_cast<int>(std::ceil(minRow * 0.5));
+        newIndex.j = static_cast<int>(std::floor((rightCol + 0) * 0.5));
+        code = 4;
+    } else {
+        out.code = 5;  // minRow == topRow && maxRow == bottomRow: no branch, result stays (0,0,0)
+        return;
+    }
+    Vec2 newRegionCentroid{0, 0};
+    map.getPosition(newIndex, newRegionCentroid);  // cpp:1816 (on the SUBMAP)
+    finish(newRegionCentroid, code);
+}
+
+// cpp:2421-2463.
+Point3 getPolygonCenter(const Point3& rf, const Point3& rh, const Point3& lh, const Point3& lf) {
+    int n = 4;
+    double x1, y1, x2, y2, x3 = 0, y3 = 0;
+    double sum_x = 0, sum_y = 0, sum_s = 0;
+    x1 = rf.x;
+    y1 = rf.y;
+    x2 = rh.x;
+    y2 = rh.y;
+    for (int i = 1; i <= n - 2; i++) {
+        switch (i) {
+            case 1:
+                x3 = lh.x;
+                y3 = lh.y;
+                break;
+            case 2:
+                x3 = lf.x;
+                y3 = lf.y;
+                break;
+        }
+        double s = ((x2 - x1) * (y3 - y1) - (x3 - x1) * (y2 - y1)) / 2.0;
+        sum_x += (x1 + x2 + x3) * s;
+        sum_y += (y1 + y2 + y3) * s;
+        sum_s += s;
+        x2 = x3;
+        y2 = y3;
+    }
+    Point3 c;
+    c.x = sum_x / sum_s / 3.0;
+    c.y = sum_y / sum_s / 3.0;
+    c.z = (rf.z + rh.z + lh.z + lf.z) / 4.0;
+    return c;
+}
+
+// cpp:2496-2517 (kind 0).  Vertex order LU, RU, RD, LD; `radius` is float, promoted per use.
+// kind 1 (build-defined, App. E): flattened hexagon with the same x extent and y half-extent
+// 0.5*r*kHexH, all vertices from products of doubles so host and device agree bit for bit.
+Polygon getSearchPolygon(const Point3& center, float radius, int kind) {
+    Polygon polygon;
+    if (kind == 0) {
+        polygon.addVertex({center.x + radius, center.y + 0.5 * radius});
+        polygon.addVertex({center.x + radius, center.y - 0.5 * radius});
+        polygon.addVertex({center.x - radius, center.y - 0.5 * radius});
+        polygon.addVertex({center.x - radius, center.y + 0.5 * radius});
+    } else {
+        const double r = radius;
+        const double hx = 0.5 * r;
+        const double hy = (0.5 * r) * 0.8660254037844386;
+        polygon.addVertex({center.x + r, center.y});
+        polygon.addVertex({center.x + hx, center.y - hy});
+        polygon.addVertex({center.x - hx, center.y - hy});
+        polygon.addVertex({center.x - r, center.y});
+        polygon.addVertex({center.x - hx, center.y + hy});
+        polygon.addVertex({center.x + hx, center.y + hy});
+    }
+    return polygon;
+}
+
+// globalFootholdPlan, cpp:539-1602, for one initial pose.  Tracks: 0 default, 1 centroid, 2 nominal.
+// A gait cycle is a sequence of phases, each with a set of swing legs and a centre advance:
+//   trot (reference): ONE phase, all four legs, advance stepLength_ (cpp:762-1579);
+//   walk (build-defined): four single-leg phases, advance stepLength_/4 each, swing order
+//        LF,RH,RF,LH (RF_FIRST=false) or RF,LH,LF,RH; a phase commits iff its swing leg is valid;
+//        cycleOk = AND over the phases; the lateral drift is applied once per cycle.
+void planGlobalFootholds(const GridMap& map, const Params& p, const PoseSpec& ps, int nCycles,
+                         PlanOutput& out) {
+    const Constants c = makeConstants(p);
+    const double* pose = ps.pose;
+    out.nominal.assign((size_t)nCycles * 4, LegResult());
+    out.centroid.assign((size_t)nCycles * 4, CentroidResult());
+    out.defaultNext.assign((size_t)nCycles * 4, Point3());
+    out.cycleOk.assign((size_t)nCycles, 0);
+
+    // cpp:350-378: initial stance = hip rectangle + initialPose_
+    const double sx[4] = {c.LbHalf, -c.LbHalf, -c.LbHalf, c.LbHalf};
+    const double sy[4] = {c.WbHalfNeg, c.WbHalfNeg, c.WbHalfPos, c.WbHalfPos};
+    for (int l = 0; l < 4; ++l) {
+        Point3 s;
+        s.x = sx[l];
+        s.y = sy[l];
+        s.z = 0;
+        s.x += pose[0];
+        s.y += pose[1];
+        s.z += pose[2];
+        out.stance[l] = s;
+    }
+    // setFirstGait, cpp:2679-2699 (x -= stepLength_/2), for every track (cpp:562-588)
+    Point3 cur[3][4];
+    for (int t = 0; t < 3; ++t)
+        for (int l = 0; l < 4; ++l) {
+            cur[t][l] = out.stance[l];
+            cur[t][l].x = out.stance[l].x - c.stepHalf;
+        }
+    double ajustedPoseY = 0.0;  // cpp:759
+
+    static const int walkOrderLF[4] = {LF, RH, RF, LH};
+    static const int walkOrderRF[4] = {RF, LH, LF, RH};
+    const int nPhases = ps.gait == 1 ? 4 : 1;
+    const double advance = ps.gait == 1 ? c.stepQuarter : c.step;
+
+    for (int g = 0; g < nCycles; ++g) {  // cpp:762
+        bool cycleOk = true;
+        for (int ph = 0; ph < nPhases; ++ph) {
+            unsigned mask = 0xF;
+            if (ps.gait == 1) mask = 1u << (p.RF_FIRST ? walkOrderRF[ph] : walkOrderLF[ph]);
+
+            Point3 next[3][4];
+            Polygon nominalPoly[4];
+            for (int t = 0; t < 3; ++t) {
+                // getDefaultFootholds cpp:2265-2284 / getFootholdSearchGridMap cpp:2191-2213
+                Point3 C = getPolygonCenter(cur[t][RF], cur[t][RH], cur[t][LH], cur[t][LF]);
+                Point3 N;
+                N.x = C.x + advance;              // cpp:2199 / 2270
+                N.y = pose[1] + ajustedPoseY;     // cpp:2201 / 2272
+                N.z = C.z;
+                for (int l = 0; l < 4; ++l) {     // getDefaultFootholdNext, cpp:2411-2418 (z = 0)
+                    next[t][l].x = N.x + c.biasX[l];
+                    next[t][l].y = N.y + c.biasY[l];
+                    next[t][l].z = 0;
+                }
+            }
+            LegResult nom[4];
+            CentroidResult cen[4];
+            bool phaseOk = true;
+            for (int l = 0; l < 4; ++l) {
+                if (!(mask & (1u << l))) continue;
+                const float R = ps.legRadius[l] > 0 ? ps.legRadius[l] : p.searchRadius;
+                // default track height, cpp:2289-2301
+                next[0][l].z = getFootholdMeanHeight(map, {next[0][l].x, next[0][l].y}, p.footRadius, p.h);
+                // centroid track, cpp:818-821
+                checkFootholdUseCentroidMethod(map, {next[1][l].x, next[1][l].y}, R, p, cen[l]);
+                // nominal track: centre from the CENTROID track, polygon from the NOMINAL track
+                // (cpp:861-869)
+                nominalPoly[l] = getSearchPolygon(next[2][l], R, ps.legPoly[l]);  // cpp:2235-2244
+                checkFoothold(map, {next[1][l].x, next[1][l].y}, p.footRadius, R, nominalPoly[l], p, nom[l]);
+                phaseOk = phaseOk && nom[l].valid;  // cpp:1323
+                out.nominal[(size_t)g * 4 + l] = nom[l];
+                out.centroid[(size_t)g * 4 + l] = cen[l];
+                out.defaultNext[(size_t)g * 4 + l] = next[0][l];
+            }
+            if (phaseOk) {  // cpp:1332-1483: commit every track
+                for (int l = 0; l < 4; ++l) {
+                    if (!(mask & (1u << l))) continue;
+                    cur[0][l] = next[0][l];                                   // cpp:1338-1341
+                    cur[2][l].x = nom[l].x;                                   // cpp:1413-1416
+                    cur[2][l].y = nom[l].y;
+                    cur[2][l].z = nom[l].z;
+                    cur[1][l].x = cen[l].x;                                   // cpp:1480-1483
+                    cur[1][l].y = cen[l].y;
+                    cur[1][l].z = cen[l].z;
+                }
+            }
+            cycleOk = cycleOk && phaseOk;  // cpp:1571-1576: nothing advances on failure
+        }
+        out.cycleOk[g] = cycleOk;
+        ajustedPoseY += p.lateralDrift;  // cpp:1578
+    }
+}
+
+}  // namespace fpo

@@ -1,0 +1,104 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see fpo_gridmap.hpp header).  PARITY UNPINNED: the
+// reference has no tests / golden vectors for this path; fidelity is argued by citation.
+//
+// CPU restatement of the reference's foothold-search hot path
+// (/root/reference/foothold_planner/src/FootholdPlanner.cpp, "cpp:" below; header "hpp:").
+// Every function cites the reference lines it follows and keeps the reference's float/double
+// typing and expression order.  Deliberate divergences:
+//   * maps are passed by const reference, not by value (hpp:94-143 deep-copy every layer);
+//   * the centroid row scan stays in bounds (cpp:1719-1720 reads one cell past the last column);
+//   * no ROS publishing / logging / NLopt "opt" track (cpp:913-1319: does not feed the response).
+// Build-defined extensions (NOT in the reference): batch of poses, 4-phase walk
+// gait, per-leg search radius / polygon kind.  With gait = trot, radius override <= 0 and polygon
+// kind 0 the code path is exactly the reference's.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "fpo_gridmap.hpp"
+
+namespace fpo {
+
+enum Leg { RF = 0, RH = 1, LH = 2, LF = 3 };  // foot_id order, cpp:685-699
+
+// ROS params of the path (cpp:248-314) with the reference's types (hpp:609-619, 657-697).
+struct Params {
+    float footRadius;                  // cpp:255
+    float defaultFootholdThreshold;    // cpp:257
+    float candidateFootholdThreshold;  // cpp:258
+    float searchRadius;                // cpp:261
+    float stepLength;                  // cpp:262
+    float length, width, l1;           // laikago_kinematics, cpp:285-287
+    float skew;                        // isos_.skew, cpp:290
+    int RF_FIRST;                      // cpp:264
+    double h;                          // h_ = 0.01, cpp:336
+    double lateralDrift;               // ajustedPose_[1] += -0.007, cpp:1578
+};
+
+// One body pose of the batch.  Reference: initialPose_ (cpp:293-295); the rest is build-defined.
+struct PoseSpec {
+    double pose[3];
+    int gait;            // 0 trot (reference), 1 walk (build-defined)
+    float legRadius[4];  // <= 0: use Params::searchRadius
+    int legPoly[4];      // 0 reference rectangle (cpp:2496-2517), 1 build-defined hexagon
+};
+
+struct Point3 {
+    double x = 0, y = 0, z = 0;
+};
+
+// One nominal-track leg result (checkFoothold, cpp:2001-2036).
+struct LegResult {
+    int row = -1, col = -1;  // chosen grid index
+    double x = 0, y = 0;
+    float z = 0;         // getFootholdMeanHeight returns float (cpp:2520); z stays 0 when invalid
+    uint8_t valid = 0;   // footholdValidation
+    uint8_t source = 2;  // 0 default-disc hit, 1 spiral candidate, 2 none
+};
+
+// One centroid-track leg result (checkFootholdUseCentroidMethod, cpp:1605-1997).
+struct CentroidResult {
+    double x = 0, y = 0;
+    float z = 0;
+    int row = -1, col = -1;  // index of (x, y) on the full map, -1 when the result is untouched
+    // 0 whole region valid; 1 case 1; 2 case 2 upper band; 3 case 2 lower band; 4 case 3;
+    // 5 no case (first and last row blocked, result left (0,0,0)); 6 getSubmap failed (0,0,0)
+    uint8_t code = 5;
+};
+
+struct Constants {
+    double LbHalf, WbHalfNeg, WbHalfPos;  // lengthBase*0.5, -widthBase*0.5, widthBase*0.5
+    double biasX[4], biasY[4];            // defaultBias, cpp:403-421
+    double stepHalf;                      // double(stepLength_/2) (f32 division), cpp:2693
+    double step;                          // double(stepLength_)
+    double stepQuarter;                   // double(stepLength_/4) — walk extension only
+};
+Constants makeConstants(const Params& p);
+
+// --- per-leg functions (names follow the reference) ---------------------------------------------
+bool checkDefaultFoothold(const GridMap& map, const Vec2& center, float footRadius, const Params& p);
+bool checkCirclePolygonFoothold(const GridMap& map, const Vec2& center, float footRadius,
+                                const Polygon& polygon, const Params& p);
+bool checkCandidateFoothold(const GridMap& map, const Vec2& spiralCenter, float footRadius,
+                            float searchRadius, const Polygon& polygon, const Params& p, LegResult& out);
+float getFootholdMeanHeight(const GridMap& map, const Vec2& center, float radius, double h);
+void checkFoothold(const GridMap& map, const Vec2& center, float footRadius, float searchRadius,
+                   const Polygon& polygon, const Params& p, LegResult& out);
+void checkFootholdUseCentroidMethod(const GridMap& map, const Vec2& defaultFoothold, float searchRadius,
+                                    const Params& p, CentroidResult& out);
+Point3 getPolygonCenter(const Point3& rf, const Point3& rh, const Point3& lh, const Point3& lf);
+Polygon getSearchPolygon(const Point3& center, float radius, int kind = 0);
+
+// --- the chained plan for ONE initial pose (globalFootholdPlan, cpp:539-1602) --------------------
+struct PlanOutput {
+    // arrays sized nCycles*4 (index g*4+leg) except cycleOk (nCycles)
+    std::vector<LegResult> nominal;
+    std::vector<CentroidResult> centroid;
+    std::vector<Point3> defaultNext;  // default-track next positions with z (cpp:774-781)
+    std::vector<uint8_t> cycleOk;     // footholdValidation_ per cycle (cpp:1323)
+    Point3 stance[4];                 // RF/RH/LH/LF_initialPosition_ (cpp:350-378)
+};
+void planGlobalFootholds(const GridMap& map, const Params& p, const PoseSpec& pose, int nCycles,
+                         PlanOutput& out);
+
+}  // namespace fpo

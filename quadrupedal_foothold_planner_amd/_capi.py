@@ -1,0 +1,182 @@
+"""ctypes binding of libfpe.so (include/fpe.h).  Record layouts are numpy structured dtypes that
+mirror the C structs byte for byte; `check_layout()` asserts the sizes against the library."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+FPE_OK = 0
+FPE_E_INVALID_ARG = -1
+FPE_E_NO_MAP = -2
+FPE_E_HIP = -3
+FPE_E_NO_DEVICE = -4
+FPE_E_UNSUPPORTED = -5
+FPE_E_NOMEM = -6
+
+MAX_POLYGON_VERTICES = 8
+
+PARAMS_DTYPE = np.dtype(
+    [
+        ("footRadius", "<f4"),
+        ("defaultFootholdThreshold", "<f4"),
+        ("candidateFootholdThreshold", "<f4"),
+        ("searchRadius", "<f4"),
+        ("stepLength", "<f4"),
+        ("length", "<f4"),
+        ("width", "<f4"),
+        ("l1", "<f4"),
+        ("skew", "<f4"),
+        ("RF_FIRST", "<i4"),
+        ("h", "<f8"),
+        ("lateralDrift", "<f8"),
+    ],
+    align=True,
+)
+POSE_DTYPE = np.dtype(
+    [("position", "<f8", (3,)), ("gait", "<i4"), ("leg_search_radius", "<f4", (4,)), ("leg_polygon_kind", "<i4", (4,))],
+    align=True,
+)
+FOOTHOLD_DTYPE = np.dtype(
+    [("row", "<i4"), ("col", "<i4"), ("x", "<f8"), ("y", "<f8"), ("z", "<f4"), ("valid", "u1"), ("source", "u1"),
+     ("foot_id", "u1"), ("gait_cycle_id", "u1")],
+    align=True,
+)
+CENTROID_DTYPE = np.dtype(
+    [("x", "<f8"), ("y", "<f8"), ("z", "<f4"), ("row", "<i4"), ("col", "<i4"), ("code", "u1"), ("pad", "u1", (3,))],
+    align=True,
+)
+QUERY_DTYPE = np.dtype(
+    [("cx", "<f8"), ("cy", "<f8"), ("search_radius", "<f4"), ("n_vertices", "<i4"),
+     ("vx", "<f8", (MAX_POLYGON_VERTICES,)), ("vy", "<f8", (MAX_POLYGON_VERTICES,))],
+    align=True,
+)
+MSG_FOOTHOLD_DTYPE = np.dtype(
+    [("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("foot_id", "u1"), ("gait_cycle_id", "u1"), ("pad", "u1", (6,))],
+    align=True,
+)
+GLOBAL_FOOTHOLDS_DTYPE = np.dtype(
+    [("success", "u1"), ("gait_cycles", "u1"), ("gait_cycles_succeed", "u1"), ("pad", "u1"), ("n_footholds", "<i4"),
+     ("footholds", MSG_FOOTHOLD_DTYPE, (4 + 4 * 255,))],
+    align=True,
+)
+
+
+class MapDesc(C.Structure):
+    _fields_ = [
+        ("rows", C.c_int32),
+        ("cols", C.c_int32),
+        ("resolution", C.c_double),
+        ("position", C.c_double * 2),
+        ("start_index", C.c_int32 * 2),
+        ("storage_order", C.c_int32),
+    ]
+
+
+class PlanOut(C.Structure):
+    _fields_ = [
+        ("nominal", C.c_void_p),
+        ("centroid", C.c_void_p),
+        ("default_next", C.c_void_p),
+        ("cycle_ok", C.c_void_p),
+        ("stance", C.c_void_p),
+    ]
+
+
+# every symbol include/fpe.h declares (tests check the library exports each of them)
+EXPORTED_SYMBOLS = [
+    "fpe_params_yaml",
+    "fpe_params_code_defaults",
+    "fpe_create",
+    "fpe_destroy",
+    "fpe_last_error",
+    "fpe_version",
+    "fpe_upload_map",
+    "fpe_upload_map_device",
+    "fpe_map_info",
+    "fpe_set_max_leg_search_radius",
+    "fpe_plan",
+    "fpe_plan_device",
+    "fpe_search_legs",
+    "fpe_search_legs_device",
+    "fpe_plan_service",
+    "fpe_spiral_offsets",
+    "fpe_tile_halfwidth",
+    "fpe_algorithmic_bytes_per_foothold",
+]
+
+_lib = None
+
+
+class EngineUnavailable(RuntimeError):
+    """libfpe.so is missing / not loadable, or no gfx950 device: the product has no CPU path."""
+
+
+def lib():
+    """Load libfpe.so (building it with hipcc first if the in-tree .so is missing or stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        path = _build.build_engine()
+    except Exception as e:  # hipcc missing or compile error: fail loudly, never fall back
+        if not os.path.exists(_build.LIB_PATH):
+            raise EngineUnavailable(f"cannot build libfpe.so: {e}") from e
+        path = _build.LIB_PATH
+    try:
+        L = C.CDLL(path)
+    except OSError as e:
+        raise EngineUnavailable(f"cannot load {path}: {e}") from e
+    vp, i32, f32, f64 = C.c_void_p, C.c_int32, C.c_float, C.c_double
+    L.fpe_version.restype = C.c_char_p
+    L.fpe_last_error.restype = C.c_char_p
+    L.fpe_last_error.argtypes = [vp]
+    L.fpe_params_yaml.argtypes = [vp]
+    L.fpe_params_code_defaults.argtypes = [vp]
+    L.fpe_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.fpe_destroy.argtypes = [vp]
+    L.fpe_upload_map.argtypes = [vp, C.POINTER(MapDesc), vp, vp]
+    L.fpe_upload_map_device.argtypes = [vp, C.POINTER(MapDesc), vp, vp, vp]
+    L.fpe_map_info.argtypes = [vp, C.POINTER(MapDesc)]
+    L.fpe_set_max_leg_search_radius.argtypes = [vp, f32]
+    L.fpe_plan.argtypes = [vp, vp, vp, i32, i32, C.POINTER(PlanOut)]
+    L.fpe_plan_device.argtypes = [vp, vp, vp, i32, i32, C.POINTER(PlanOut), vp]
+    L.fpe_search_legs.argtypes = [vp, vp, vp, i32, vp]
+    L.fpe_search_legs_device.argtypes = [vp, vp, vp, i32, vp, vp]
+    L.fpe_plan_service.argtypes = [vp, vp, vp, C.c_uint8, vp]
+    L.fpe_spiral_offsets.argtypes = [i32, vp, i32]
+    L.fpe_tile_halfwidth.argtypes = [f32, f32, f64]
+    L.fpe_algorithmic_bytes_per_foothold.restype = f64
+    L.fpe_algorithmic_bytes_per_foothold.argtypes = [f32, f32, f64]
+    _lib = L
+    return L
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def params_yaml():
+    p = np.zeros(1, dtype=PARAMS_DTYPE)
+    assert lib().fpe_params_yaml(ptr(p)) == FPE_OK
+    return p
+
+
+def params_code_defaults():
+    p = np.zeros(1, dtype=PARAMS_DTYPE)
+    assert lib().fpe_params_code_defaults(ptr(p)) == FPE_OK
+    return p
+
+
+def spiral_offsets(n_rings):
+    n = lib().fpe_spiral_offsets(n_rings, None, 0)
+    if n < 0:
+        raise ValueError("n_rings out of range")
+    out = np.zeros((n, 3), dtype=np.int32)
+    lib().fpe_spiral_offsets(n_rings, ptr(out), n)
+    return out
+
+
+def algorithmic_bytes_per_foothold(search_radius, foot_radius, resolution):
+    return float(lib().fpe_algorithmic_bytes_per_foothold(np.float32(search_radius), np.float32(foot_radius), float(resolution)))

@@ -1,0 +1,421 @@
+// fpe_engine.cpp — the C ABI of include/fpe.h over the gfx950 kernels (fpe_kernels.hip).
+// Owns device memory: immutable map snapshots (swapped atomically, so a plan keeps the snapshot it
+// started with — the reference races on gridmap_, cpp:506 vs cpp:818) and the spiral rank table.
+// There is NO CPU compute path: without a usable GPU every compute entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fpe_host.hpp"
+
+namespace fpe {
+// fpe_kernels.hip
+hipError_t launch_plan_chained(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const fpe_pose* d_poses,
+                               int B, int nCycles, const fpe_plan_out& d_out, hipStream_t stream);
+hipError_t launch_search_legs(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const fpe_leg_query* d_q,
+                              int n, fpe_foothold* d_out, hipStream_t stream);
+hipError_t launch_canonicalise(const float* d_src, float* d_dst, int rows, int cols, int si, int sj, int srcRowMajor,
+                               hipStream_t stream);
+hipError_t set_max_lds(size_t planBytes, size_t searchBytes);
+size_t plan_lds_bytes(const PlanConsts& pc);
+size_t search_lds_bytes(const PlanConsts& pc);
+}  // namespace fpe
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+int fail_hip(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return FPE_E_HIP;
+}
+#define FPE_HIP(call)                                     \
+    do {                                                  \
+        hipError_t e_ = (call);                           \
+        if (e_ != hipSuccess) return fail_hip(e_, #call); \
+    } while (0)
+
+struct MapSnapshot {
+    fpe::MapGeom g;
+    float* d_trav = nullptr;
+    float* d_elev = nullptr;
+    ~MapSnapshot() {
+        if (d_trav) (void)hipFree(d_trav);
+        if (d_elev) (void)hipFree(d_elev);
+    }
+};
+
+constexpr size_t kMaxLdsBytes = 160 * 1024;
+
+}  // namespace
+
+struct fpe_engine {
+    int device = 0;
+    std::mutex mu;
+    std::shared_ptr<MapSnapshot> map;
+    int16_t* d_di = nullptr;
+    int16_t* d_dj = nullptr;
+    uint8_t* d_ring = nullptr;
+    int32_t* d_ringStart = nullptr;
+    int maxRing = 0;
+    float maxLegSearchRadius = 0.0f;  // fpe_set_max_leg_search_radius
+    size_t ldsConfigured = 0;
+
+    fpe::SpiralLut lut() const { return fpe::SpiralLut{d_di, d_dj, d_ring, d_ringStart, maxRing}; }
+};
+
+namespace {
+
+int prepare_call(fpe_engine* h, const fpe_params* params, float maxRadius, std::shared_ptr<MapSnapshot>& snap,
+                 fpe::PlanConsts& pc, size_t& planLds, size_t& searchLds) {
+    if (!h || !params) return fail(FPE_E_INVALID_ARG, "null handle or params");
+    int rc = fpe::validate_params(*params);
+    if (rc != FPE_OK) return fail(rc, "non-finite or negative parameter");
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        snap = h->map;
+        maxRadius = std::max(maxRadius, std::max(params->searchRadius, h->maxLegSearchRadius));
+    }
+    if (!snap) return fail(FPE_E_NO_MAP, "no map uploaded");
+    fpe::derive_constants(*params, snap->g.res, maxRadius, pc);
+    if (fpe::spiral_rings(maxRadius, snap->g.res) > h->maxRing)
+        return fail(FPE_E_UNSUPPORTED, "search radius needs more spiral rings than the rank table holds");
+    planLds = fpe::plan_lds_bytes(pc);
+    searchLds = fpe::search_lds_bytes(pc);
+    if (planLds > kMaxLdsBytes || searchLds > kMaxLdsBytes)
+        return fail(FPE_E_UNSUPPORTED, "search/foot radius too large for the 160 KiB LDS tile");
+    FPE_HIP(hipSetDevice(h->device));
+    if (std::max(planLds, searchLds) > 48 * 1024) {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (std::max(planLds, searchLds) > h->ldsConfigured) {
+            FPE_HIP(fpe::set_max_lds(planLds, searchLds));
+            h->ldsConfigured = std::max(planLds, searchLds);
+        }
+    }
+    return FPE_OK;
+}
+
+fpe::DevMap dev_map(const MapSnapshot& s) { return fpe::DevMap{s.g, s.d_trav, s.d_elev}; }
+
+int check_desc(const fpe_map_desc* d) {
+    if (!d) return fail(FPE_E_INVALID_ARG, "null map descriptor");
+    if (d->rows <= 0 || d->cols <= 0 || d->rows > 32768 || d->cols > 32768)
+        return fail(FPE_E_INVALID_ARG, "map size out of range");
+    if (!(d->resolution > 0.0) || !std::isfinite(d->resolution)) return fail(FPE_E_INVALID_ARG, "bad resolution");
+    if (!std::isfinite(d->position[0]) || !std::isfinite(d->position[1])) return fail(FPE_E_INVALID_ARG, "bad position");
+    if (d->start_index[0] < 0 || d->start_index[0] >= d->rows || d->start_index[1] < 0 || d->start_index[1] >= d->cols)
+        return fail(FPE_E_INVALID_ARG, "start index out of range");
+    if (d->storage_order != 0 && d->storage_order != 1) return fail(FPE_E_INVALID_ARG, "bad storage order");
+    return FPE_OK;
+}
+
+int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, const float* elev, bool srcOnDevice,
+                  hipStream_t stream) {
+    if (!h || !trav || !elev) return fail(FPE_E_INVALID_ARG, "null argument");
+    int rc = check_desc(desc);
+    if (rc != FPE_OK) return rc;
+    FPE_HIP(hipSetDevice(h->device));
+    const size_t n = static_cast<size_t>(desc->rows) * desc->cols;
+    auto snap = std::make_shared<MapSnapshot>();
+    snap->g = fpe::make_geom(desc->rows, desc->cols, desc->resolution, desc->position[0], desc->position[1]);
+    FPE_HIP(hipMalloc(reinterpret_cast<void**>(&snap->d_trav), n * sizeof(float)));
+    FPE_HIP(hipMalloc(reinterpret_cast<void**>(&snap->d_elev), n * sizeof(float)));
+    const bool canonical = desc->storage_order == 1 && desc->start_index[0] == 0 && desc->start_index[1] == 0;
+    const float* src[2] = {trav, elev};
+    float* dst[2] = {snap->d_trav, snap->d_elev};
+    float* staging = nullptr;
+    if (!srcOnDevice && !canonical) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&staging), n * sizeof(float)));
+    for (int l = 0; l < 2; ++l) {
+        if (canonical) {
+            FPE_HIP(hipMemcpyAsync(dst[l], src[l], n * sizeof(float),
+                                   srcOnDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+        } else {
+            const float* dsrc = src[l];
+            if (!srcOnDevice) {
+                FPE_HIP(hipMemcpyAsync(staging, src[l], n * sizeof(float), hipMemcpyHostToDevice, stream));
+                dsrc = staging;
+            }
+            FPE_HIP(fpe::launch_canonicalise(dsrc, dst[l], desc->rows, desc->cols, desc->start_index[0],
+                                             desc->start_index[1], desc->storage_order, stream));
+        }
+        if (!srcOnDevice) FPE_HIP(hipStreamSynchronize(stream));  // host buffers may be freed on return
+    }
+    if (staging) FPE_HIP(hipFree(staging));
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->map = snap;  // readers holding the old snapshot keep it alive until they finish
+    }
+    return FPE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fpe_version(void) { return "fpe 0.1.0 (gfx950, wave64; one workgroup per pose, one wavefront per leg)"; }
+
+const char* fpe_last_error(fpe_handle) { return g_err.c_str(); }
+
+int fpe_create(int device_id, fpe_handle* out) {
+    if (!out) return fail(FPE_E_INVALID_ARG, "null out handle");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail(FPE_E_NO_DEVICE, "no HIP device visible");
+    if (device_id < 0 || device_id >= count) return fail(FPE_E_INVALID_ARG, "device id out of range");
+    FPE_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    FPE_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(FPE_E_NO_DEVICE, std::string("device is not gfx950: ") + prop.gcnArchName);
+    fpe_engine* h = new (std::nothrow) fpe_engine();
+    if (!h) return fail(FPE_E_NOMEM, "out of host memory");
+    h->device = device_id;
+    fpe::SpiralTable t;
+    fpe::build_spiral_table(fpe::kMaxRings, t);
+    h->maxRing = t.maxRing;
+    const size_t n = t.di.size();
+    auto cleanup = [&]() { fpe_destroy(h); };
+#define FPE_HIP_C(call)                       \
+    do {                                      \
+        hipError_t e_ = (call);               \
+        if (e_ != hipSuccess) {               \
+            cleanup();                        \
+            return fail_hip(e_, #call);       \
+        }                                     \
+    } while (0)
+    FPE_HIP_C(hipMalloc(reinterpret_cast<void**>(&h->d_di), n * sizeof(int16_t)));
+    FPE_HIP_C(hipMalloc(reinterpret_cast<void**>(&h->d_dj), n * sizeof(int16_t)));
+    FPE_HIP_C(hipMalloc(reinterpret_cast<void**>(&h->d_ring), n * sizeof(uint8_t)));
+    FPE_HIP_C(hipMalloc(reinterpret_cast<void**>(&h->d_ringStart), t.ringStart.size() * sizeof(int32_t)));
+    FPE_HIP_C(hipMemcpy(h->d_di, t.di.data(), n * sizeof(int16_t), hipMemcpyHostToDevice));
+    FPE_HIP_C(hipMemcpy(h->d_dj, t.dj.data(), n * sizeof(int16_t), hipMemcpyHostToDevice));
+    FPE_HIP_C(hipMemcpy(h->d_ring, t.ring.data(), n * sizeof(uint8_t), hipMemcpyHostToDevice));
+    FPE_HIP_C(hipMemcpy(h->d_ringStart, t.ringStart.data(), t.ringStart.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+#undef FPE_HIP_C
+    *out = h;
+    return FPE_OK;
+}
+
+int fpe_destroy(fpe_handle h) {
+    if (!h) return FPE_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    if (h->d_di) (void)hipFree(h->d_di);
+    if (h->d_dj) (void)hipFree(h->d_dj);
+    if (h->d_ring) (void)hipFree(h->d_ring);
+    if (h->d_ringStart) (void)hipFree(h->d_ringStart);
+    h->map.reset();
+    delete h;
+    return FPE_OK;
+}
+
+int fpe_set_max_leg_search_radius(fpe_handle h, float radius) {
+    if (!h || !(radius >= 0.0f) || !std::isfinite(radius)) return fail(FPE_E_INVALID_ARG, "bad radius");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->maxLegSearchRadius = radius;
+    return FPE_OK;
+}
+
+int fpe_upload_map(fpe_handle h, const fpe_map_desc* desc, const float* traversability, const float* elevation) {
+    return upload_common(h, desc, traversability, elevation, false, nullptr);
+}
+
+int fpe_upload_map_device(fpe_handle h, const fpe_map_desc* desc, const float* d_traversability,
+                          const float* d_elevation, void* stream) {
+    return upload_common(h, desc, d_traversability, d_elevation, true, static_cast<hipStream_t>(stream));
+}
+
+int fpe_map_info(fpe_handle h, fpe_map_desc* out) {
+    if (!h || !out) return fail(FPE_E_INVALID_ARG, "null argument");
+    std::shared_ptr<MapSnapshot> snap;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        snap = h->map;
+    }
+    if (!snap) return fail(FPE_E_NO_MAP, "no map uploaded");
+    out->rows = snap->g.rows;
+    out->cols = snap->g.cols;
+    out->resolution = snap->g.res;
+    out->position[0] = snap->g.posX;
+    out->position[1] = snap->g.posY;
+    out->start_index[0] = out->start_index[1] = 0;
+    out->storage_order = 1;
+    return FPE_OK;
+}
+
+int fpe_plan_device(fpe_handle h, const fpe_params* params, const fpe_pose* d_poses, int32_t B, int32_t n_cycles,
+                    const fpe_plan_out* d_out, void* stream) {
+    if (!d_poses || !d_out) return fail(FPE_E_INVALID_ARG, "null argument");
+    if (B <= 0 || n_cycles <= 0 || n_cycles > 255) return fail(FPE_E_INVALID_ARG, "B and n_cycles must be in [1, ..] / [1, 255]");
+    std::shared_ptr<MapSnapshot> snap;
+    fpe::PlanConsts pc;
+    size_t planLds, searchLds;
+    int rc = prepare_call(h, params, 0.0f, snap, pc, planLds, searchLds);
+    if (rc != FPE_OK) return rc;
+    FPE_HIP(fpe::launch_plan_chained(dev_map(*snap), pc, h->lut(), d_poses, B, n_cycles, *d_out,
+                                     static_cast<hipStream_t>(stream)));
+    return FPE_OK;
+}
+
+int fpe_plan(fpe_handle h, const fpe_params* params, const fpe_pose* poses, int32_t B, int32_t n_cycles,
+             const fpe_plan_out* out) {
+    if (!poses || !out) return fail(FPE_E_INVALID_ARG, "null argument");
+    if (B <= 0 || n_cycles <= 0 || n_cycles > 255) return fail(FPE_E_INVALID_ARG, "B and n_cycles must be in [1, ..] / [1, 255]");
+    float maxRadius = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        for (int k = 0; k < 3; ++k)
+            if (!std::isfinite(poses[b].position[k]) || std::fabs(poses[b].position[k]) > 1e9)
+                return fail(FPE_E_INVALID_ARG, "non-finite pose");
+        if (poses[b].gait != 0 && poses[b].gait != 1) return fail(FPE_E_INVALID_ARG, "unknown gait");
+        for (int l = 0; l < 4; ++l) {
+            if (std::isfinite(poses[b].leg_search_radius[l])) maxRadius = std::max(maxRadius, poses[b].leg_search_radius[l]);
+            if (poses[b].leg_polygon_kind[l] != 0 && poses[b].leg_polygon_kind[l] != 1)
+                return fail(FPE_E_INVALID_ARG, "unknown polygon kind");
+        }
+    }
+    std::shared_ptr<MapSnapshot> snap;
+    fpe::PlanConsts pc;
+    size_t planLds, searchLds;
+    int rc = prepare_call(h, params, maxRadius, snap, pc, planLds, searchLds);
+    if (rc != FPE_OK) return rc;
+
+    const size_t nRec = static_cast<size_t>(B) * n_cycles * 4;
+    struct Scratch {  // per-call device buffers + stream (plans may run concurrently)
+        hipStream_t stream = nullptr;
+        void* p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        ~Scratch() {
+            for (void* q : p)
+                if (q) (void)hipFree(q);
+            if (stream) (void)hipStreamDestroy(stream);
+        }
+    } s;
+    FPE_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    FPE_HIP(hipMalloc(&s.p[0], static_cast<size_t>(B) * sizeof(fpe_pose)));
+    FPE_HIP(hipMemcpyAsync(s.p[0], poses, static_cast<size_t>(B) * sizeof(fpe_pose), hipMemcpyHostToDevice, s.stream));
+    fpe_plan_out d;
+    std::memset(&d, 0, sizeof(d));
+    if (out->nominal) { FPE_HIP(hipMalloc(&s.p[1], nRec * sizeof(fpe_foothold))); d.nominal = static_cast<fpe_foothold*>(s.p[1]); }
+    if (out->centroid) { FPE_HIP(hipMalloc(&s.p[2], nRec * sizeof(fpe_centroid_foothold))); d.centroid = static_cast<fpe_centroid_foothold*>(s.p[2]); }
+    if (out->default_next) { FPE_HIP(hipMalloc(&s.p[3], nRec * 3 * sizeof(double))); d.default_next = static_cast<double*>(s.p[3]); }
+    if (out->cycle_ok) { FPE_HIP(hipMalloc(&s.p[4], static_cast<size_t>(B) * n_cycles)); d.cycle_ok = static_cast<uint8_t*>(s.p[4]); }
+    if (out->stance) { FPE_HIP(hipMalloc(&s.p[5], static_cast<size_t>(B) * 12 * sizeof(double))); d.stance = static_cast<double*>(s.p[5]); }
+    // walk-gait poses leave the records of non-swing phases untouched only if a cycle is skipped;
+    // zero the buffers so every record is defined
+    if (d.nominal) FPE_HIP(hipMemsetAsync(d.nominal, 0, nRec * sizeof(fpe_foothold), s.stream));
+    if (d.centroid) FPE_HIP(hipMemsetAsync(d.centroid, 0, nRec * sizeof(fpe_centroid_foothold), s.stream));
+    if (d.default_next) FPE_HIP(hipMemsetAsync(d.default_next, 0, nRec * 3 * sizeof(double), s.stream));
+    FPE_HIP(fpe::launch_plan_chained(dev_map(*snap), pc, h->lut(), static_cast<const fpe_pose*>(s.p[0]), B, n_cycles, d, s.stream));
+    if (out->nominal) FPE_HIP(hipMemcpyAsync(out->nominal, d.nominal, nRec * sizeof(fpe_foothold), hipMemcpyDeviceToHost, s.stream));
+    if (out->centroid) FPE_HIP(hipMemcpyAsync(out->centroid, d.centroid, nRec * sizeof(fpe_centroid_foothold), hipMemcpyDeviceToHost, s.stream));
+    if (out->default_next) FPE_HIP(hipMemcpyAsync(out->default_next, d.default_next, nRec * 3 * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+    if (out->cycle_ok) FPE_HIP(hipMemcpyAsync(out->cycle_ok, d.cycle_ok, static_cast<size_t>(B) * n_cycles, hipMemcpyDeviceToHost, s.stream));
+    if (out->stance) FPE_HIP(hipMemcpyAsync(out->stance, d.stance, static_cast<size_t>(B) * 12 * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+    FPE_HIP(hipStreamSynchronize(s.stream));
+    return FPE_OK;
+}
+
+int fpe_search_legs_device(fpe_handle h, const fpe_params* params, const fpe_leg_query* d_queries, int32_t n,
+                           fpe_foothold* d_out, void* stream) {
+    if (!d_queries || !d_out) return fail(FPE_E_INVALID_ARG, "null argument");
+    if (n <= 0) return fail(FPE_E_INVALID_ARG, "n must be positive");
+    std::shared_ptr<MapSnapshot> snap;
+    fpe::PlanConsts pc;
+    size_t planLds, searchLds;
+    int rc = prepare_call(h, params, 0.0f, snap, pc, planLds, searchLds);
+    if (rc != FPE_OK) return rc;
+    FPE_HIP(fpe::launch_search_legs(dev_map(*snap), pc, h->lut(), d_queries, n, d_out, static_cast<hipStream_t>(stream)));
+    return FPE_OK;
+}
+
+int fpe_search_legs(fpe_handle h, const fpe_params* params, const fpe_leg_query* queries, int32_t n, fpe_foothold* out) {
+    if (!queries || !out) return fail(FPE_E_INVALID_ARG, "null argument");
+    if (n <= 0) return fail(FPE_E_INVALID_ARG, "n must be positive");
+    float maxRadius = 0.0f;
+    for (int k = 0; k < n; ++k) {
+        if (!std::isfinite(queries[k].cx) || !std::isfinite(queries[k].cy) || std::fabs(queries[k].cx) > 1e9 ||
+            std::fabs(queries[k].cy) > 1e9)
+            return fail(FPE_E_INVALID_ARG, "non-finite query centre");
+        if (!(queries[k].search_radius >= 0.0f) || !std::isfinite(queries[k].search_radius))
+            return fail(FPE_E_INVALID_ARG, "bad search radius");
+        if (queries[k].n_vertices < 0 || queries[k].n_vertices > FPE_MAX_POLYGON_VERTICES)
+            return fail(FPE_E_INVALID_ARG, "too many polygon vertices");
+        maxRadius = std::max(maxRadius, queries[k].search_radius);
+    }
+    std::shared_ptr<MapSnapshot> snap;
+    fpe::PlanConsts pc;
+    size_t planLds, searchLds;
+    int rc = prepare_call(h, params, maxRadius, snap, pc, planLds, searchLds);
+    if (rc != FPE_OK) return rc;
+    struct Scratch {
+        hipStream_t stream = nullptr;
+        void* p[2] = {nullptr, nullptr};
+        ~Scratch() {
+            for (void* q : p)
+                if (q) (void)hipFree(q);
+            if (stream) (void)hipStreamDestroy(stream);
+        }
+    } s;
+    FPE_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    FPE_HIP(hipMalloc(&s.p[0], static_cast<size_t>(n) * sizeof(fpe_leg_query)));
+    FPE_HIP(hipMalloc(&s.p[1], static_cast<size_t>(n) * sizeof(fpe_foothold)));
+    FPE_HIP(hipMemcpyAsync(s.p[0], queries, static_cast<size_t>(n) * sizeof(fpe_leg_query), hipMemcpyHostToDevice, s.stream));
+    FPE_HIP(fpe::launch_search_legs(dev_map(*snap), pc, h->lut(), static_cast<const fpe_leg_query*>(s.p[0]), n,
+                                    static_cast<fpe_foothold*>(s.p[1]), s.stream));
+    FPE_HIP(hipMemcpyAsync(out, s.p[1], static_cast<size_t>(n) * sizeof(fpe_foothold), hipMemcpyDeviceToHost, s.stream));
+    FPE_HIP(hipStreamSynchronize(s.stream));
+    return FPE_OK;
+}
+
+int fpe_plan_service(fpe_handle h, const fpe_params* params, const double initial_position[3], uint8_t gait_cycles,
+                     fpe_global_footholds* response) {
+    if (!initial_position || !response) return fail(FPE_E_INVALID_ARG, "null argument");
+    fpe_pose pose;
+    std::memset(&pose, 0, sizeof(pose));
+    pose.position[0] = initial_position[0];
+    pose.position[1] = initial_position[1];
+    pose.position[2] = initial_position[2];
+    const int N = gait_cycles;
+    double stance[12];
+    if (N == 0) {
+        // the reference's loop body never runs (cpp:762); the stance comes from initialize()
+        if (!h || !params) return fail(FPE_E_INVALID_ARG, "null handle or params");
+        fpe::PlanConsts pc;
+        fpe::derive_constants(*params, 1.0, params->searchRadius, pc);
+        for (int l = 0; l < 4; ++l) {
+            double sx = (l == 0 || l == 3) ? pc.LbHalf : -pc.LbHalf;
+            double sy = (l <= 1) ? pc.WbHalfNeg : pc.WbHalfPos;
+            double sz = 0;
+            sx += pose.position[0];
+            sy += pose.position[1];
+            sz += pose.position[2];
+            stance[l * 3] = sx; stance[l * 3 + 1] = sy; stance[l * 3 + 2] = sz;
+        }
+        fpe::assemble_global_footholds(nullptr, nullptr, stance, 0, response);
+        return FPE_OK;
+    }
+    std::vector<fpe_foothold> nominal(static_cast<size_t>(N) * 4);
+    std::vector<uint8_t> ok(static_cast<size_t>(N));
+    fpe_plan_out out;
+    std::memset(&out, 0, sizeof(out));
+    out.nominal = nominal.data();
+    out.cycle_ok = ok.data();
+    out.stance = stance;
+    int rc = fpe_plan(h, params, &pose, 1, N, &out);
+    if (rc != FPE_OK) return rc;
+    fpe::assemble_global_footholds(nominal.data(), ok.data(), stance, N, response);
+    return FPE_OK;
+}
+
+}  // extern "C"

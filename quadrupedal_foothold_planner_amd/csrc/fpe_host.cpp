@@ -1,0 +1,229 @@
+// fpe_host.cpp — host-side logic of the engine (no GPU calls in this file).
+#include "fpe_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace fpe {
+
+// ---- SpiralIterator visiting order ---------------------------------------------------------------
+// grid_map SpiralIterator::generateRing walks ring d counter-clockwise from offset (d, 0), keeping
+// to cells whose truncated Euclidean index distance equals d, and the iterator then pops cells from
+// the BACK of the ring vector; so ring d is visited in the reverse of the walk.
+// The table holds the unfiltered order; the in-map test and the in-radius test of the last two
+// rings only remove entries, they never reorder (fpe_kernels.hip::candidate_search_wave).
+namespace {
+inline int sgn(int v) { return (v > 0) - (v < 0); }
+inline int trunc_norm(int x, int y) {
+    return static_cast<int>(std::sqrt(static_cast<double>(x) * x + static_cast<double>(y) * y));
+}
+}  // namespace
+
+void build_spiral_table(int nRings, SpiralTable& out) {
+    out.di.clear();
+    out.dj.clear();
+    out.ring.clear();
+    out.ringStart.assign(1, 0);
+    out.maxRing = nRings;
+    out.di.push_back(0);
+    out.dj.push_back(0);
+    out.ring.push_back(0);
+    std::vector<std::pair<int, int>> walk;
+    for (int d = 1; d <= nRings; ++d) {
+        out.ringStart.push_back(static_cast<int32_t>(out.di.size()));
+        walk.clear();
+        int px = d, py = 0;
+        do {
+            walk.emplace_back(px, py);
+            const int nx = -sgn(py), ny = sgn(px);
+            if (nx != 0 && trunc_norm(px + nx, py) == d) {
+                px += nx;
+            } else if (ny != 0 && trunc_norm(px, py + ny) == d) {
+                py += ny;
+            } else {
+                px += nx;
+                py += ny;
+            }
+        } while (px != d || py != 0);
+        for (auto it = walk.rbegin(); it != walk.rend(); ++it) {
+            out.di.push_back(static_cast<int16_t>(it->first));
+            out.dj.push_back(static_cast<int16_t>(it->second));
+            out.ring.push_back(static_cast<uint8_t>(d));
+        }
+    }
+    out.ringStart.push_back(static_cast<int32_t>(out.di.size()));  // end sentinel = ringStart[nRings+1]
+}
+
+int spiral_rings(float searchRadius, double resolution) {
+    const double R = static_cast<double>(searchRadius);
+    return static_cast<int>(static_cast<unsigned int>(std::ceil(R / resolution)));
+}
+
+int tile_halfwidth(float maxSearchRadius, float footRadius, double resolution) {
+    const double R = static_cast<double>(maxSearchRadius);
+    const double rf = static_cast<double>(footRadius);
+    const int nRings = static_cast<int>(std::ceil(R / resolution));
+    const int nFootBox = static_cast<int>(std::ceil(rf / resolution)) + 1;  // bbox of a disc around any point
+    // candidates reach nRings cells from the centre index and their discs nFootBox further; the
+    // centroid rectangle reaches ceil(R/res)+1 rows; +1 guards the continuous-centre offset
+    return nRings + nFootBox + 1;
+}
+
+int validate_params(const fpe_params& p) {
+    const float fs[] = {p.footRadius, p.defaultFootholdThreshold, p.candidateFootholdThreshold, p.searchRadius,
+                        p.stepLength, p.length, p.width, p.l1, p.skew};
+    for (float f : fs)
+        if (!std::isfinite(f)) return FPE_E_INVALID_ARG;
+    if (!(p.footRadius >= 0.0f) || !(p.searchRadius >= 0.0f)) return FPE_E_INVALID_ARG;
+    if (!std::isfinite(p.h) || !std::isfinite(p.lateralDrift)) return FPE_E_INVALID_ARG;
+    return FPE_OK;
+}
+
+// initialize(), cpp:340-421.  lengthBase / widthBase / skew / stepLength_ are float members
+// (hpp:657-668, 683, 613); widthBase is computed in f32 (cpp:341); each use below promotes the
+// float operand to double exactly where the reference's expression does.
+void derive_constants(const fpe_params& p, double resolution, float maxSearchRadius, PlanConsts& c) {
+    std::memset(&c, 0, sizeof(c));
+    c.footRadius = p.footRadius;
+    c.thrDefault = p.defaultFootholdThreshold;
+    c.thrCandidate = p.candidateFootholdThreshold;
+    c.searchRadius = p.searchRadius;
+    c.rf = static_cast<double>(p.footRadius);
+    c.rf2 = c.rf * c.rf;  // CircleIterator: radiusSquare_ = pow(radius_, 2)
+    const float lengthBase = p.length;           // cpp:340
+    const float widthBase = p.width + p.l1 * 2;  // cpp:341
+    c.LbHalf = lengthBase * 0.5;                 // cpp:350
+    c.WbHalfNeg = -widthBase * 0.5;              // cpp:351
+    c.WbHalfPos = widthBase * 0.5;               // cpp:359
+    const double k = static_cast<double>(p.skew);
+    // cpp:403-421: RF_FIRST flips the sign of skew
+    c.biasX[0] = p.RF_FIRST ? 0.5 * lengthBase + k : 0.5 * lengthBase - k;     // RF
+    c.biasX[1] = p.RF_FIRST ? -0.5 * lengthBase - k : -0.5 * lengthBase + k;   // RH
+    c.biasX[2] = p.RF_FIRST ? -0.5 * lengthBase + k : -0.5 * lengthBase - k;   // LH
+    c.biasX[3] = p.RF_FIRST ? 0.5 * lengthBase - k : 0.5 * lengthBase + k;     // LF
+    c.biasY[0] = -0.5 * widthBase;
+    c.biasY[1] = -0.5 * widthBase;
+    c.biasY[2] = 0.5 * widthBase;
+    c.biasY[3] = 0.5 * widthBase;
+    c.stepHalf = p.stepLength / 2;     // cpp:2693 (float / int)
+    c.step = p.stepLength;             // cpp:2199
+    c.stepQuarter = p.stepLength / 4;  // build-defined walk gait
+    c.h = p.h;
+    c.drift = p.lateralDrift;
+    c.RF_FIRST = p.RF_FIRST ? 1 : 0;
+    c.maxSearchRadius = maxSearchRadius;
+    c.tileH = tile_halfwidth(maxSearchRadius, p.footRadius, resolution);
+    c.tileW = 2 * c.tileH + 1;
+    c.tileWMagic = fastdiv_magic(static_cast<uint32_t>(c.tileW));
+}
+
+// globalFootholdPlan message bookkeeping: cpp:681-699 (stance entries), cpp:1378-1396 (valid
+// cycle), cpp:1574 (invalid cycle: success=false, nothing appended).
+void assemble_global_footholds(const fpe_foothold* nominal, const uint8_t* cycleOk, const double* stance,
+                               int nCycles, fpe_global_footholds* msg) {
+    std::memset(msg, 0, sizeof(*msg));
+    msg->gait_cycles = static_cast<uint8_t>(nCycles);
+    msg->gait_cycles_succeed = 0;
+    msg->success = 0;
+    int n = 0;
+    for (int l = 0; l < 4; ++l) {
+        fpe_msg_foothold& f = msg->footholds[n++];
+        f.x = stance[l * 3 + 0];
+        f.y = stance[l * 3 + 1];
+        f.z = stance[l * 3 + 2];
+        f.foot_id = static_cast<uint8_t>(l);
+        f.gait_cycle_id = 0;
+    }
+    for (int g = 0; g < nCycles; ++g) {
+        if (cycleOk[g]) {
+            msg->gait_cycles_succeed = static_cast<uint8_t>(g + 1);
+            msg->success = 1;
+            for (int l = 0; l < 4; ++l) {
+                const fpe_foothold& s = nominal[g * 4 + l];
+                fpe_msg_foothold& f = msg->footholds[n++];
+                f.x = s.x;
+                f.y = s.y;
+                f.z = static_cast<double>(s.z);
+                f.foot_id = static_cast<uint8_t>(l);
+                f.gait_cycle_id = static_cast<uint8_t>(g);
+            }
+        } else {
+            msg->success = 0;
+        }
+    }
+    msg->n_footholds = n;
+}
+
+}  // namespace fpe
+
+// ---- C ABI: host-only entry points -----------------------------------------------------------------
+extern "C" {
+
+int fpe_params_yaml(fpe_params* p) {  // foothold_planner/config/foothold_planner.yaml:10-64
+    if (!p) return FPE_E_INVALID_ARG;
+    p->footRadius = float(0.02);
+    p->defaultFootholdThreshold = float(0.9);
+    p->candidateFootholdThreshold = float(0.7);
+    p->searchRadius = float(0.1);
+    p->stepLength = float(0.18);
+    p->length = float(0.4387);
+    p->width = float(0.175);
+    p->l1 = float(0.037);
+    p->skew = float(0.04);
+    p->RF_FIRST = 0;
+    p->h = 0.01;
+    p->lateralDrift = -0.007;
+    return FPE_OK;
+}
+
+int fpe_params_code_defaults(fpe_params* p) {  // readParameters, cpp:255-290
+    if (!p) return FPE_E_INVALID_ARG;
+    p->footRadius = float(0.03);
+    p->defaultFootholdThreshold = float(0.7);
+    p->candidateFootholdThreshold = float(0.7);
+    p->searchRadius = float(0.1);
+    p->stepLength = float(0.2);
+    p->length = float(0.4387);
+    p->width = float(0.175);
+    p->l1 = float(0.037);
+    p->skew = float(0.1);
+    p->RF_FIRST = 0;
+    p->h = 0.01;
+    p->lateralDrift = -0.007;
+    return FPE_OK;
+}
+
+int fpe_spiral_offsets(int32_t n_rings, int32_t* out, int32_t max_cells) {
+    if (n_rings < 0 || n_rings > fpe::kMaxRings) return FPE_E_INVALID_ARG;
+    fpe::SpiralTable t;
+    fpe::build_spiral_table(n_rings, t);
+    const int n = static_cast<int>(t.di.size());
+    if (out)
+        for (int k = 0; k < n && k < max_cells; ++k) {
+            out[3 * k + 0] = t.di[k];
+            out[3 * k + 1] = t.dj[k];
+            out[3 * k + 2] = t.ring[k];
+        }
+    return n;
+}
+
+int fpe_tile_halfwidth(float search_radius, float foot_radius, double resolution) {
+    if (!(resolution > 0.0)) return FPE_E_INVALID_ARG;
+    return fpe::tile_halfwidth(search_radius, foot_radius, resolution);
+}
+
+double fpe_algorithmic_bytes_per_foothold(float search_radius, float foot_radius, double resolution) {
+    const double R = static_cast<double>(search_radius), rf = static_cast<double>(foot_radius);
+    const int nS = static_cast<int>(std::floor(R / resolution + 0.5));
+    const int nF = static_cast<int>(std::floor(rf / resolution));
+    const int W = 2 * (nS + nF) + 1;
+    int nFoot = 0;  // cells of a cell-centred foot disc
+    const int reach = nF + 1;
+    for (int a = -reach; a <= reach; ++a)
+        for (int b = -reach; b <= reach; ++b)
+            if ((static_cast<double>(a * a + b * b)) * resolution * resolution <= rf * rf) ++nFoot;
+    return 4.0 * W * W + 8.0 * nFoot + 16.0;
+}
+
+}  // extern "C"

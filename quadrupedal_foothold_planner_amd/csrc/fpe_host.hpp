@@ -1,0 +1,40 @@
+// fpe_host.hpp — host-side logic of the engine that needs no GPU: parameter typing, derived
+// constants, the spiral rank table, tile sizing and GlobalFootholds message assembly.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "fpe_device.hpp"
+
+namespace fpe {
+
+// Upper bound of SpiralIterator rings the rank table is built for (ceil(R/res) must not exceed it).
+constexpr int kMaxRings = 96;
+
+struct SpiralTable {
+    std::vector<int16_t> di, dj;
+    std::vector<uint8_t> ring;
+    std::vector<int32_t> ringStart;  // [nRings + 2]
+    int maxRing = 0;
+};
+// SpiralIterator visiting order for rings 0..nRings as index offsets from the centre cell
+// (grid_map SpiralIterator::generateRing; consumed from the back — SURVEY.md App. A.5).
+void build_spiral_table(int nRings, SpiralTable& out);
+
+// initialize() constants with the reference's float/double typing (cpp:340-421, 2693).
+void derive_constants(const fpe_params& p, double resolution, float maxSearchRadius, PlanConsts& out);
+
+// Tile half-width (cells) that covers: every spiral candidate's foot disc, the default disc and
+// the centroid rectangle for search radii up to maxSearchRadius.
+int tile_halfwidth(float maxSearchRadius, float footRadius, double resolution);
+
+// number of rings ceil(double(R)/res) as SpiralIterator computes it
+int spiral_rings(float searchRadius, double resolution);
+
+int validate_params(const fpe_params& p);
+
+// GlobalFootholds message content from one pose's plan outputs (cpp:591-699, 1378-1396, 1574).
+void assemble_global_footholds(const fpe_foothold* nominal, const uint8_t* cycleOk, const double* stance,
+                               int nCycles, fpe_global_footholds* msg);
+
+}  // namespace fpe

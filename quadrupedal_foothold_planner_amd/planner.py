@@ -1,0 +1,155 @@
+"""Host-side mirror of the reference's interface for the hot path, over the C ABI (include/fpe.h).
+
+`FootholdPlanner` keeps the reference's names for the seam it replaces
+(/root/reference/foothold_planner/src/FootholdPlanner.cpp): `gridmapCallback` (cpp:504),
+`globalFootholdPlan` (cpp:539), `checkFoothold` (cpp:2001).  The batch entry points `plan` /
+`plan_device` are the build-defined batch axis.  There is no CPU path: if
+libfpe.so cannot be loaded or no gfx950 GPU is present, construction raises EngineUnavailable.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import (CENTROID_DTYPE, FOOTHOLD_DTYPE, GLOBAL_FOOTHOLDS_DTYPE, POSE_DTYPE, PARAMS_DTYPE, QUERY_DTYPE,
+                    EngineUnavailable, MapDesc, PlanOut, ptr)
+
+
+class FpeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"fpe error {code}: {msg}")
+        self.code = code
+
+
+def make_poses(xyz, gait=0, leg_search_radius=None, leg_polygon_kind=None):
+    """Build an fpe_pose array from [B,3] positions (+ optional build-defined extensions)."""
+    xyz = np.asarray(xyz, dtype=np.float64).reshape(-1, 3)
+    poses = np.zeros(xyz.shape[0], dtype=POSE_DTYPE)
+    poses["position"] = xyz
+    poses["gait"] = gait
+    if leg_search_radius is not None:
+        poses["leg_search_radius"] = leg_search_radius
+    if leg_polygon_kind is not None:
+        poses["leg_polygon_kind"] = leg_polygon_kind
+    return poses
+
+
+class FootholdPlanner:
+    """One engine per process per GPU."""
+
+    def __init__(self, device_id=0, params=None):
+        self._lib = _capi.lib()
+        self._h = C.c_void_p()
+        rc = self._lib.fpe_create(int(device_id), C.byref(self._h))
+        if rc != _capi.FPE_OK:
+            msg = self._lib.fpe_last_error(None).decode()
+            self._h = None
+            if rc == _capi.FPE_E_NO_DEVICE:
+                raise EngineUnavailable(f"fpe_create failed: {msg} (the engine has no CPU fallback)")
+            raise FpeError(rc, msg)
+        self.params = _capi.params_yaml() if params is None else np.array(params, dtype=PARAMS_DTYPE).reshape(1)
+        self.device_id = int(device_id)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fpe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != _capi.FPE_OK:
+            raise FpeError(rc, self._lib.fpe_last_error(self._h).decode())
+
+    # ---- map ingest (gridmapCallback, cpp:504-536) -------------------------------------------------
+    def gridmapCallback(self, traversability, elevation, resolution, position=(0.0, 0.0), start_index=(0, 0),
+                        storage_order="row"):
+        """Upload both layers once to HBM.  `storage_order`: "row" ((rows, cols) C arrays) or
+        "col" (grid_map_msgs column-major buffers, flat or (cols, rows))."""
+        trav = np.ascontiguousarray(traversability, dtype=np.float32)
+        elev = np.ascontiguousarray(elevation, dtype=np.float32)
+        if storage_order == "row":
+            rows, cols = trav.shape
+        else:
+            cols, rows = trav.shape
+        d = MapDesc(rows, cols, float(resolution), (C.c_double * 2)(*map(float, position)),
+                    (C.c_int32 * 2)(*map(int, start_index)), 1 if storage_order == "row" else 0)
+        self._check(self._lib.fpe_upload_map(self._h, C.byref(d), ptr(trav), ptr(elev)))
+        self.rows, self.cols, self.resolution = rows, cols, float(resolution)
+
+    def upload_map_device(self, d_trav_ptr, d_elev_ptr, rows, cols, resolution, position=(0.0, 0.0), start_index=(0, 0),
+                          storage_order="row", stream=None):
+        d = MapDesc(rows, cols, float(resolution), (C.c_double * 2)(*map(float, position)),
+                    (C.c_int32 * 2)(*map(int, start_index)), 1 if storage_order == "row" else 0)
+        self._check(self._lib.fpe_upload_map_device(self._h, C.byref(d), C.c_void_p(d_trav_ptr), C.c_void_p(d_elev_ptr),
+                                                    C.c_void_p(stream or 0)))
+        self.rows, self.cols, self.resolution = rows, cols, float(resolution)
+
+    def map_info(self):
+        d = MapDesc()
+        self._check(self._lib.fpe_map_info(self._h, C.byref(d)))
+        return {"rows": d.rows, "cols": d.cols, "resolution": d.resolution, "position": tuple(d.position)}
+
+    def set_max_leg_search_radius(self, r):
+        self._check(self._lib.fpe_set_max_leg_search_radius(self._h, np.float32(r)))
+
+    # ---- chained plan, host buffers ------------------------------------------------------------------
+    def plan(self, poses, n_cycles, products=("nominal", "centroid", "default", "cycle_ok", "stance")):
+        poses = np.ascontiguousarray(poses, dtype=POSE_DTYPE)
+        B = poses.shape[0]
+        out = {}
+        po = PlanOut()
+        if "nominal" in products:
+            out["nominal"] = np.zeros((B, n_cycles, 4), dtype=FOOTHOLD_DTYPE)
+            po.nominal = ptr(out["nominal"])
+        if "centroid" in products:
+            out["centroid"] = np.zeros((B, n_cycles, 4), dtype=CENTROID_DTYPE)
+            po.centroid = ptr(out["centroid"])
+        if "default" in products:
+            out["default"] = np.zeros((B, n_cycles, 4, 3), dtype=np.float64)
+            po.default_next = ptr(out["default"])
+        if "cycle_ok" in products:
+            out["cycle_ok"] = np.zeros((B, n_cycles), dtype=np.uint8)
+            po.cycle_ok = ptr(out["cycle_ok"])
+        if "stance" in products:
+            out["stance"] = np.zeros((B, 4, 3), dtype=np.float64)
+            po.stance = ptr(out["stance"])
+        self._check(self._lib.fpe_plan(self._h, ptr(self.params), ptr(poses), B, int(n_cycles), C.byref(po)))
+        return out
+
+    # ---- chained plan, device-resident (torch tensors / raw pointers) ----------------------------------
+    def plan_device(self, d_poses_ptr, B, n_cycles, d_nominal_ptr=0, d_centroid_ptr=0, d_default_ptr=0,
+                    d_cycle_ok_ptr=0, d_stance_ptr=0, stream=0):
+        po = PlanOut(d_nominal_ptr or None, d_centroid_ptr or None, d_default_ptr or None, d_cycle_ok_ptr or None,
+                     d_stance_ptr or None)
+        self._check(self._lib.fpe_plan_device(self._h, ptr(self.params), C.c_void_p(d_poses_ptr), int(B), int(n_cycles),
+                                              C.byref(po), C.c_void_p(stream or 0)))
+
+    # ---- open-loop per-leg search (checkFoothold, cpp:2001-2036) -----------------------------------------
+    def checkFoothold(self, queries):
+        queries = np.ascontiguousarray(queries, dtype=QUERY_DTYPE)
+        out = np.zeros(queries.shape[0], dtype=FOOTHOLD_DTYPE)
+        self._check(self._lib.fpe_search_legs(self._h, ptr(self.params), ptr(queries), queries.shape[0], ptr(out)))
+        return out
+
+    def search_legs_device(self, d_queries_ptr, n, d_out_ptr, stream=0):
+        self._check(self._lib.fpe_search_legs_device(self._h, ptr(self.params), C.c_void_p(d_queries_ptr), int(n),
+                                                     C.c_void_p(d_out_ptr), C.c_void_p(stream or 0)))
+
+    # ---- the service (globalFootholdPlan, cpp:539-1602): response content for one pose ---------------------
+    def globalFootholdPlan(self, gait_cycles, initial_position):
+        msg = np.zeros(1, dtype=GLOBAL_FOOTHOLDS_DTYPE)
+        pos = np.ascontiguousarray(initial_position, dtype=np.float64).reshape(3)
+        self._check(self._lib.fpe_plan_service(self._h, ptr(self.params), ptr(pos), int(gait_cycles) & 0xFF, ptr(msg)))
+        m = msg[0]
+        n = int(m["n_footholds"])
+        return {
+            "success": bool(m["success"]),
+            "gait_cycles": int(m["gait_cycles"]),
+            "gait_cycles_succeed": int(m["gait_cycles_succeed"]),
+            "footholds": m["footholds"][:n].copy(),
+        }

@@ -1,0 +1,222 @@
+"""Known-answer tests that pin the oracle (CPU restatement) to the only checkable artefacts the
+reference offers and to analytic closed forms (App. A.5, B.6).
+The reference has no tests: parity stays "unpinned" beyond these."""
+import numpy as np
+import pytest
+
+from oracle import fpo
+from tests.conftest import oracle_poses, yaml_params
+
+
+def flat(rows=200, cols=200, res=0.02, pos=(0.0, 0.0)):
+    return fpo.OracleMap(np.ones((rows, cols), np.float32), np.zeros((rows, cols), np.float32), res, pos)
+
+
+def test_readme_y_value_pins_float_typing():
+    # README.md:91 `y: -0.124499998987` == double(float(0.175f + 0.037f*2)) * 0.5 (cpp:341, 351)
+    c = fpo.constants(yaml_params())
+    assert c["WbHalfPos"] == 0.12449999898672104
+    assert c["WbHalfNeg"] == -0.12449999898672104
+    assert f"{c['WbHalfPos']:.12f}" == "0.124499998987"
+    # cpp:556 comment: stance {0.219,-0.124, -0.219,-0.124, -0.219,0.124, 0.219,0.124} to 3 decimals
+    assert c["LbHalf"] == 0.21934999525547028
+    assert f"{c['LbHalf']:.3f}" == "0.219" and f"{c['WbHalfPos']:.3f}" == "0.124"
+
+
+def test_constants_bias_and_steps():
+    c = fpo.constants(yaml_params())
+    k = float(np.float32(0.04))
+    lb = float(np.float32(0.4387))
+    assert c["biasX"].tolist() == [0.5 * lb - k, -0.5 * lb + k, -0.5 * lb - k, 0.5 * lb + k]
+    assert c["step"] == 0.18000000715255737
+    assert c["stepHalf"] == float(np.float32(0.18) / np.float32(2))
+    p = yaml_params()
+    p["RF_FIRST"] = 1
+    c2 = fpo.constants(p)
+    assert c2["biasX"].tolist() == [0.5 * lb + k, -0.5 * lb - k, -0.5 * lb + k, 0.5 * lb - k]
+
+
+def test_index_position_roundtrip_and_orientation():
+    m = flat(200, 100, 0.02)
+    ok, x, y = m.get_position(0, 0)
+    assert ok and x == pytest.approx(1.99) and y == pytest.approx(0.99)  # (0,0) = largest x, largest y
+    ok, x2, y2 = m.get_position(199, 99)
+    assert x2 == pytest.approx(-1.99) and y2 == pytest.approx(-0.99)
+    for (i, j) in [(0, 0), (17, 31), (199, 99)]:
+        ok, x, y = m.get_position(i, j)
+        assert m.get_index(x, y) == (True, i, j)
+    assert m.get_position(200, 0)[0] is False
+    assert m.get_index(2.5, 0.0)[0] is False  # outside
+
+
+def test_spiral_ring1_order_and_center_first():
+    # ring 1 visit order (reverse of the generateRing walk)
+    m = flat()
+    ok, cx, cy = m.get_position(100, 100)
+    cells = m.spiral_cells(cx, cy, float(np.float32(0.1)))
+    rel = (cells - np.array([100, 100])).tolist()
+    assert rel[0] == [0, 0]
+    assert rel[1:9] == [[1, -1], [0, -1], [-1, -1], [-1, 0], [-1, 1], [0, 1], [1, 1], [1, 0]]
+
+
+def test_spiral_ring_count_uses_float_radius():
+    # ceil(double(0.1f)/0.02) = 6 rings, not 5; ring 6 is always filtered out -> 81 cells
+    m = flat()
+    ok, cx, cy = m.get_position(100, 100)
+    cells = m.spiral_cells(cx, cy, float(np.float32(0.1)))
+    assert len(cells) == 81
+    d = np.abs(cells - np.array([100, 100])).max()
+    assert d == 5
+    assert len({tuple(c) for c in cells.tolist()}) == len(cells)
+
+
+@pytest.mark.parametrize("res,rf,expect", [(0.02, 0.02, 1), (0.02, 0.03, 9), (0.01, 0.02, 9), (0.005, 0.02, 45)])
+def test_cell_centred_foot_disc_sizes(res, rf, expect):
+    m = flat(400, 400, res)
+    ok, cx, cy = m.get_position(200, 200)
+    cells = m.circle_cells(cx, cy, float(np.float32(rf)))
+    assert len(cells) == expect
+    # row-major bbox order (i outer, j inner)
+    keys = [(int(a), int(b)) for a, b in cells]
+    assert keys == sorted(keys)
+
+
+def test_polygon_rectangle_is_half_open():
+    # App. A.6: cx-r <= x < cx+r and cy-r/2 <= y < cy+r/2
+    r = float(np.float32(0.1))
+    cx, cy = 0.3, -0.2
+    vx = [cx + r, cx + r, cx - r, cx - r]
+    vy = [cy + 0.5 * r, cy - 0.5 * r, cy - 0.5 * r, cy + 0.5 * r]
+    assert fpo.polygon_inside(vx, vy, cx, cy)
+    assert fpo.polygon_inside(vx, vy, cx - r, cy)
+    assert not fpo.polygon_inside(vx, vy, cx + r, cy)
+    assert fpo.polygon_inside(vx, vy, cx, cy - 0.5 * r)
+    assert not fpo.polygon_inside(vx, vy, cx, cy + 0.5 * r)
+
+
+def test_submap_rect_is_11x6_at_2cm():
+    m = flat()
+    R = np.float32(0.1)
+    ok, o, pl = m.submap_info(0.013, -0.007, float(R * 2), float(R))
+    assert ok and o[2] == 11 and o[3] == 6
+
+
+def test_mean_height_semantics():
+    trav = np.ones((50, 50), np.float32)
+    elev = np.full((50, 50), 0.25, np.float32)
+    m = fpo.OracleMap(trav, elev, 0.01)
+    ok, cx, cy = m.get_position(25, 25)
+    rf = np.float32(0.02)
+    assert m.mean_height(cx, cy, rf) == float(np.float32(float(np.float32(0.25)) + 0.01))
+    # NaN -> 0.0 and counted; >= 10 skipped (cpp:2532-2545)
+    elev2 = elev.copy()
+    elev2[25, 25] = np.nan
+    elev2[24, 25] = 12.0
+    m2 = fpo.OracleMap(trav, elev2, 0.01)
+    s = np.float32(0)
+    for _ in range(7):
+        s = np.float32(s + np.float32(0.25))
+    expect = np.float32(float(np.float32(s / np.float32(8))) + 0.01)
+    assert m2.mean_height(cx, cy, rf) == float(expect)
+    # far outside the map: empty disc -> h
+    assert m.mean_height(50.0, 50.0, rf) == float(np.float32(0.01))
+
+
+def test_flat_map_closed_form_B6():
+    # SURVEY App. B.6 with the yaml pose (-0.21, -1.87) on a map that contains the trajectory
+    p = yaml_params()
+    m = flat(400, 400, 0.02)
+    out = m.plan(p, oracle_poses([[-0.21, -1.87, 0.0]]), 8)
+    s = 0.18000000715255737
+    lb2, wb2, k = 0.21934999525547028, 0.12449999898672104, 0.03999999910593033
+    bias = [(lb2 - k, -wb2), (-lb2 + k, -wb2), (-lb2 - k, wb2), (lb2 + k, wb2)]
+    z = 0.009999999776482582
+    assert out["cycle_ok"].all()
+    nom = out["nominal"][0]
+    for g in range(8):
+        for l in range(4):
+            assert nom[g, l]["valid"] == 1 and nom[g, l]["source"] == 0
+            assert nom[g, l]["x"] == pytest.approx(-0.21 + s / 2 + g * s + bias[l][0], abs=1e-12)
+            assert nom[g, l]["y"] == pytest.approx(-1.87 - 0.007 * g + bias[l][1], abs=1e-12)
+            assert float(nom[g, l]["z"]) == z
+    # g = 0 rounded values quoted in the survey
+    assert [round(float(nom[0, l]["x"]), 5) for l in range(4)] == [0.05935, -0.29935, -0.37935, 0.13935]
+    assert [round(float(nom[0, l]["y"]), 4) for l in range(4)] == [-1.9945, -1.9945, -1.7455, -1.7455]
+    # flat map: the three tracks coincide
+    assert np.allclose(out["centroid"][0]["x"], nom["x"], atol=0, rtol=0)
+    assert np.array_equal(out["default"][0][..., 0], nom["x"])
+
+
+def test_single_blocked_cell_picks_first_spiral_neighbour():
+    # App. A.5 KAT: centre on a cell centre whose own cell is blocked -> offset (1,-1)
+    rows = cols = 200
+    trav = np.ones((rows, cols), np.float32)
+    trav[100, 100] = 0.1
+    m = fpo.OracleMap(trav, np.zeros((rows, cols), np.float32), 0.02)
+    ok, cx, cy = m.get_position(100, 100)
+    R = float(np.float32(0.1))
+    q = np.zeros(1, dtype=fpo.QUERY_DTYPE)
+    q["cx"], q["cy"], q["search_radius"], q["n_vertices"] = cx, cy, np.float32(0.1), 4
+    q["vx"][0, :4] = [cx + R, cx + R, cx - R, cx - R]
+    q["vy"][0, :4] = [cy + 0.5 * R, cy - 0.5 * R, cy - 0.5 * R, cy + 0.5 * R]
+    r = m.search_legs(yaml_params(), q)[0]
+    assert r["valid"] == 1 and r["source"] == 1
+    assert (r["row"], r["col"]) == (101, 99)
+    assert r["x"] == pytest.approx(cx - 0.02) and r["y"] == pytest.approx(cy + 0.02)
+    # z is taken at the DEFAULT centre (cpp:2029)
+    assert float(r["z"]) == 0.009999999776482582
+
+
+def test_centroid_cases():
+    p = yaml_params()
+    rows = cols = 200
+    base = np.ones((rows, cols), np.float32)
+    elev = np.zeros((rows, cols), np.float32)
+    m0 = fpo.OracleMap(base, elev, 0.02)
+    ok, cx, cy = m0.get_position(100, 100)
+    R = np.float32(0.1)
+    ok, o, _ = m0.submap_info(cx, cy, float(R * 2), float(R))
+    tl_i, tl_j, ni, nj = [int(v) for v in o]
+    assert m0.centroid_method(p, cx, cy, R)["code"] == 0
+    # case 1: blocked band at the top rows (largest x)
+    t = base.copy(); t[tl_i:tl_i + 3, :] = 0.1
+    r = fpo.OracleMap(t, elev, 0.02).centroid_method(p, cx, cy, R)
+    assert r["code"] == 1 and r["row"] == tl_i + (2 + ni - 1 + 1) // 2 and r["col"] == tl_j + nj // 2
+    # case 3: blocked band at the bottom
+    t = base.copy(); t[tl_i + ni - 2:tl_i + ni, :] = 0.1
+    r = fpo.OracleMap(t, elev, 0.02).centroid_method(p, cx, cy, R)
+    assert r["code"] == 4 and r["row"] == tl_i + int(np.ceil((ni - 2) * 0.5)) and r["col"] == tl_j + (nj - 1) // 2
+    # case 2: band in the middle, upper part larger or equal -> upper
+    t = base.copy(); t[tl_i + 5:tl_i + 7, :] = 0.1
+    r = fpo.OracleMap(t, elev, 0.02).centroid_method(p, cx, cy, R)
+    assert r["code"] == 2 and r["row"] == tl_i + 3
+    t = base.copy(); t[tl_i + 2:tl_i + 4, :] = 0.1
+    r = fpo.OracleMap(t, elev, 0.02).centroid_method(p, cx, cy, R)
+    assert r["code"] == 3 and r["row"] == tl_i + (3 + ni - 1) // 2
+    # everything blocked: no branch, result stays (0,0,0)
+    t = np.full((rows, cols), 0.1, np.float32)
+    r = fpo.OracleMap(t, elev, 0.02).centroid_method(p, cx, cy, R)
+    assert r["code"] == 5 and r["x"] == 0 and r["y"] == 0 and r["z"] == 0
+    # one bad cell, no blocked row: handled as "row 0 blocked" -> case 1 (App. D)
+    t = base.copy(); t[tl_i + 4, tl_j + 2] = 0.1
+    r = fpo.OracleMap(t, elev, 0.02).centroid_method(p, cx, cy, R)
+    assert r["code"] == 1 and r["row"] == tl_i + (0 + ni - 1 + 1) // 2
+    # NaN passes the raw `<` tests
+    t = base.copy(); t[tl_i:tl_i + ni, tl_j:tl_j + nj] = np.nan
+    assert fpo.OracleMap(t, elev, 0.02).centroid_method(p, cx, cy, R)["code"] == 0
+    # centre outside the map: getSubmap fails, result untouched
+    assert m0.centroid_method(p, 50.0, 0.0, R)["code"] == 6
+
+
+def test_invalid_cycle_does_not_advance_but_drift_applies():
+    # B.5: a blocked world -> every cycle invalid, nothing advances, y drift still accumulates
+    p = yaml_params()
+    rows = cols = 200
+    m = fpo.OracleMap(np.full((rows, cols), 0.1, np.float32), np.zeros((rows, cols), np.float32), 0.02)
+    out = m.plan(p, oracle_poses([[-1.0, 0.0, 0.0]]), 3)
+    assert not out["cycle_ok"].any()
+    nom = out["nominal"][0]
+    assert (nom["valid"] == 0).all() and (nom["z"] == 0).all()
+    # centre x identical every cycle (no advance); y moves by -0.007 per cycle
+    assert nom[0, 0]["x"] == nom[1, 0]["x"] == nom[2, 0]["x"]
+    assert nom[1, 0]["y"] - nom[0, 0]["y"] == pytest.approx(-0.007, abs=1e-15)
