@@ -97,11 +97,19 @@ bool checkCandidateFoothold(const GridMap& map, const Vec2& spiralCenter, float 
     return validation;
 }
 
+// Oracle-defined guard (NOT in the reference): a search centre must be finite and of sane
+// magnitude.  A NaN centre is reachable once the centroid track has committed its "no case"
+// (0,0,0) results (cpp:1777-1944) and the feet polygon degenerates; the reference then feeds NaN to
+// getIndexFromPosition's (int) cast — undefined behaviour.  Defined here (and in the engine) as
+// "no cell is visited": invalid leg, getSubmap failure, mean height = h.
+static bool centreUsable(const Vec2& c) { return std::fabs(c.x) <= 1e9 && std::fabs(c.y) <= 1e9; }
+
 // cpp:2520-2554.  f32 sequential sum in CircleIterator (row-major bbox) order; NaN -> 0.0 and
 // counted; values >= 10 skipped; empty count -> last iHeight; "+ h" in f64, returned as float.
 float getFootholdMeanHeight(const GridMap& map, const Vec2& center, float radius, double h) {
     float iHeight = 0.0, meanHeight = 0.0;
     int i = 0;
+    if (!centreUsable(center)) return static_cast<float>(meanHeight + h);
     for (CircleIterator it(map, center, radius); !it.isPastEnd(); ++it) {
         const float e = map.elevAt(*it);
         if (GridMap::isValid(e)) {
@@ -126,6 +134,11 @@ float getFootholdMeanHeight(const GridMap& map, const Vec2& center, float radius
 void checkFoothold(const GridMap& map, const Vec2& center, float footRadius, float searchRadius,
                    const Polygon& polygon, const Params& p, LegResult& out) {
     out = LegResult();
+    if (!centreUsable(center)) {  // oracle-defined, see centreUsable
+        out.x = center.x;
+        out.y = center.y;
+        return;
+    }
     bool defaultFootholdIsvalid = checkDefaultFoothold(map, center, footRadius, p);  // cpp:2012
     out.valid = defaultFootholdIsvalid;
     out.x = center.x;                                     // cpp:2016-2017
@@ -156,6 +169,10 @@ void checkFoothold(const GridMap& map, const Vec2& center, float footRadius, flo
 void checkFootholdUseCentroidMethod(const GridMap& gridmap, const Vec2& p, float searchRadius,
                                     const Params& prm, CentroidResult& out) {
     out = CentroidResult();
+    if (!centreUsable(p)) {  // oracle-defined, see centreUsable
+        out.code = 6;
+        return;
+    }
     Vec2 rect;
     rect.x = searchRadius * 2;  // cpp:1616 (float * int -> float)
     rect.y = searchRadius;      // cpp:1617

@@ -25,6 +25,13 @@ __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
+// A search centre must be finite and of sane magnitude.  The reference has no such test: a
+// non-finite centre (reachable once the centroid track has committed its "no case" (0,0,0)
+// results, cpp:1777-1944, and the feet polygon degenerates) sends NaN through
+// getIndexFromPosition's (int) cast, which is undefined behaviour.  Engine and oracle both define
+// it as "no cell is visited": invalid leg, getSubmap failure, mean height = h.
+__device__ __forceinline__ bool centre_usable(double x, double y) { return fabs(x) <= 1e9 && fabs(y) <= 1e9; }
+
 // ---- per-wave search context (all members wave-uniform) ---------------------------------------
 struct LegCtx {
     double cx, cy;   // search centre = centroid-track next position of this leg (cpp:861-862)
@@ -93,6 +100,7 @@ __device__ void fold_polygon(const DevMap& m, const PlanConsts& pc, const LegCtx
 // getFootholdMeanHeight (cpp:2520-2554) for one disc, cooperatively: lanes test membership and
 // load elevation, then the f32 sum is accumulated in the CircleIterator's row-major order.
 __device__ float mean_height_wave(const DevMap& m, const PlanConsts& pc, double cx, double cy, int lane) {
+    if (!centre_usable(cx, cy)) return static_cast<float>(static_cast<double>(0.0f) + pc.h);  // no cell visited
     const BBox bb = circle_bbox(m.g, cx, cy, pc.rf);
     const int ni = uni(bb.ni), nj = uni(bb.nj), i0 = uni(bb.i0), j0 = uni(bb.j0);
     const int nb = ni * nj;
@@ -502,7 +510,11 @@ __global__ __launch_bounds__(256) void plan_chained_kernel(DevMap m, PlanConsts 
                 NominalOut no;
                 CentroidOut co;
                 float zDefault = 0.0f;
-                if (radiusOk) {
+                if (radiusOk && !centre_usable(c.cx, c.cy)) {
+                    no.row = no.col = -1; no.x = c.cx; no.y = c.cy; no.z = 0.0f; no.valid = 0; no.source = 2;
+                    co.x = co.y = 0.0; co.z = 0.0f; co.row = co.col = -1; co.code = 6;
+                    if (out.default_next) zDefault = mean_height_wave(m, pc, nx[0], ny[0], lane);
+                } else if (radiusOk) {
                     stage_tile(m, pc, c, tile, lane);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -587,7 +599,9 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
     c.vx = sh.polyX[w];
     c.vy = sh.polyY[w];
     NominalOut no;
-    if (Rf <= pc.maxSearchRadius && Rf >= 0.0f && nv >= 0 && nv <= FPE_MAX_POLYGON_VERTICES) {
+    if (!centre_usable(c.cx, c.cy)) {
+        no.row = no.col = -1; no.x = c.cx; no.y = c.cy; no.z = 0.0f; no.valid = 0; no.source = 2;
+    } else if (Rf <= pc.maxSearchRadius && Rf >= 0.0f && nv >= 0 && nv <= FPE_MAX_POLYGON_VERTICES) {
         stage_tile(m, pc, c, tile, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -1,0 +1,124 @@
+"""CPU-only checks of the product: the C-ABI library builds/loads and exports every symbol of
+include/fpe.h, and the host logic (spiral rank table, tile sizing, params, message assembly)
+agrees with the oracle.  No compute call is made without a GPU."""
+import ctypes as C
+import re
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fpo
+from quadrupedal_foothold_planner_amd import _capi, synth
+from tests.conftest import yaml_params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = _capi.lib()
+    hdr = open(os.path.join(ROOT, "include", "fpe.h")).read()
+    declared = set(re.findall(r"\b(fpe_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_capi.EXPORTED_SYMBOLS), declared ^ set(_capi.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.fpe_version()
+
+
+def test_record_layouts_match_between_engine_and_oracle():
+    assert _capi.PARAMS_DTYPE == fpo.PARAMS_DTYPE
+    assert _capi.POSE_DTYPE.itemsize == fpo.POSE_DTYPE.itemsize == 64
+    assert _capi.FOOTHOLD_DTYPE.itemsize == 32 and _capi.CENTROID_DTYPE.itemsize == 32
+    assert _capi.QUERY_DTYPE.itemsize == fpo.QUERY_DTYPE.itemsize
+    assert _capi.MSG_FOOTHOLD_DTYPE.itemsize == 32
+    assert _capi.GLOBAL_FOOTHOLDS_DTYPE.itemsize == 8 + 32 * (4 + 4 * 255)
+
+
+def test_params_defaults_match_yaml_and_code():
+    y = _capi.params_yaml()
+    assert y.tobytes() == yaml_params().tobytes()
+    c = _capi.params_code_defaults()[0]
+    assert c["footRadius"] == np.float32(0.03) and c["stepLength"] == np.float32(0.2) and c["skew"] == np.float32(0.1)
+    assert c["defaultFootholdThreshold"] == np.float32(0.7)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from quadrupedal_foothold_planner_amd.planner import FootholdPlanner
+
+    with pytest.raises(_capi.EngineUnavailable):
+        FootholdPlanner(0)
+
+
+@pytest.mark.parametrize("res,R", [(0.02, 0.1), (0.01, 0.15), (0.005, 0.1), (0.03, 0.2)])
+def test_spiral_rank_table_equals_oracle_iterator_order(res, R):
+    """The engine's host-built rank table (prefix of rings 0..nRings-2) must be the oracle's
+    SpiralIterator order on a map large enough that nothing is clipped."""
+    rows = 600
+    m = fpo.OracleMap(np.ones((rows, rows), np.float32), np.zeros((rows, rows), np.float32), res)
+    ok, cx, cy = m.get_position(300, 300)
+    Rd = float(np.float32(R))
+    n_rings = int(np.ceil(Rd / res))
+    cells = m.spiral_cells(cx, cy, Rd) - np.array([300, 300])
+    table = _capi.spiral_offsets(n_rings)
+    # every offset with trunc(norm) == d appears exactly once in ring d
+    for d in range(n_rings + 1):
+        ring = table[table[:, 2] == d][:, :2]
+        want = {(a, b) for a in range(-d - 1, d + 2) for b in range(-d - 1, d + 2) if int(np.sqrt(a * a + b * b)) == d}
+        assert {tuple(x) for x in ring.tolist()} == want and len(ring) == len(want)
+    # unfiltered rings (<= nRings-2) are a prefix of the oracle's order
+    n_unfiltered = int((table[:, 2] <= n_rings - 2).sum())
+    assert np.array_equal(table[:n_unfiltered, :2], cells[:n_unfiltered])
+    # filtered rings keep the table's relative order
+    rank = {tuple(t[:2]): k for k, t in enumerate(table.tolist())}
+    ks = [rank[tuple(c)] for c in cells.tolist()]
+    assert ks == sorted(ks)
+
+
+def test_tile_halfwidth_covers_search_footprint():
+    L = _capi.lib()
+    for res, R, rf in [(0.02, 0.1, 0.02), (0.01, 0.15, 0.02), (0.005, 0.1, 0.02), (0.02, 0.1, 0.03)]:
+        H = L.fpe_tile_halfwidth(np.float32(R), np.float32(rf), res)
+        n_rings = int(np.ceil(float(np.float32(R)) / res))
+        assert H >= n_rings + int(np.ceil(float(np.float32(rf)) / res)) + 1
+
+
+def test_algorithmic_bytes_per_foothold_matches_survey_table():
+    # 508 / 2204 / 4444 / 9212 B
+    f = _capi.algorithmic_bytes_per_foothold
+    assert f(0.1, 0.02, 0.02) == 508
+    assert f(0.1, 0.02, 0.01) == 2204
+    assert f(0.15, 0.02, 0.01) == 4444
+    assert f(0.1, 0.02, 0.005) == 9212
+
+
+def test_service_message_for_zero_cycles_needs_no_gpu():
+    """gait_cycles = 0: the reference's loop never runs; the response holds the 4 stance entries."""
+    L = _capi.lib()
+    msg = np.zeros(1, dtype=_capi.GLOBAL_FOOTHOLDS_DTYPE)
+    p = _capi.params_yaml()
+    pos = np.array([-0.21, -1.87, 0.3])
+    # a handle is required by the ABI; without a GPU fpe_create fails, so only run the host part when it exists
+    h = C.c_void_p()
+    rc = L.fpe_create(0, C.byref(h))
+    if rc != _capi.FPE_OK:
+        assert rc == _capi.FPE_E_NO_DEVICE
+        assert L.fpe_plan_service(None, _capi.ptr(p), _capi.ptr(pos), 0, _capi.ptr(msg)) == _capi.FPE_E_INVALID_ARG
+        return
+    assert L.fpe_plan_service(h, _capi.ptr(p), _capi.ptr(pos), 0, _capi.ptr(msg)) == _capi.FPE_OK
+    m = msg[0]
+    assert m["n_footholds"] == 4 and m["success"] == 0 and m["gait_cycles_succeed"] == 0
+    assert m["footholds"]["y"][0] == -0.12449999898672104 + -1.87
+    L.fpe_destroy(h)
+
+
+def test_synthetic_generator_is_deterministic():
+    a = synth.rough_map(64, 48, 0.02, seed=5)
+    b = synth.rough_map(64, 48, 0.02, seed=5)
+    assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+    assert np.isnan(a[0]).sum() > 0 and (a[0] < 0.7).sum() > 0
+    p = synth.poses_in_map(32, 20.0, 20.0, 8, 0.18, seed=6)
+    assert p["position"][:, 0].max() <= 10 - 0.6 - 8 * 0.18

@@ -1,0 +1,231 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the oracle on the same seeded
+inputs.  Bar: chosen grid indices / flags / x / y bit-exact, z within 1e-6 (north_star)."""
+import numpy as np
+import pytest
+
+from oracle import fpo
+from quadrupedal_foothold_planner_amd import _capi, synth
+from quadrupedal_foothold_planner_amd.planner import FootholdPlanner, make_poses
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def planner():
+    p = FootholdPlanner(0)
+    yield p
+    p.close()
+
+
+def set_params(planner, **kw):
+    planner.params = _capi.params_yaml()
+    for k, v in kw.items():
+        planner.params[k] = v
+
+
+def test_cfg1_flat_reference_case(planner):
+    """BASELINE configs[0]: trot, 8 cycles, 200x200 @2cm flat map, one pose (the reference's own case)."""
+    set_params(planner)
+    trav, elev, res, poses, n, _ = synth.make_config("cfg1")
+    eng, ora = util.run_both(planner, trav, elev, res, poses, n)
+    util.assert_plan_equal(eng, ora)
+    assert eng["cycle_ok"].all() and (eng["nominal"]["source"] == 0).all()
+    # closed form of SURVEY App. B.6
+    s = 0.18000000715255737
+    assert eng["nominal"][0, 3, 0]["x"] == pytest.approx(-1.0 + s / 2 + 3 * s + (0.21934999525547028 - 0.03999999910593033), abs=1e-12)
+
+
+def test_cfg2_rough_terrain_batch(planner):
+    """BASELINE configs[1] at a size the oracle finishes in seconds (full B=4096)."""
+    set_params(planner)
+    trav, elev, res, poses, n, _ = synth.make_config("cfg2")
+    eng, ora = util.run_both(planner, trav, elev, res, poses, n, threads=8)
+    util.assert_plan_equal(eng, ora)
+    src = eng["nominal"]["source"]
+    assert (src == 1).sum() > 100, "terrain should force spiral searches"
+    assert (eng["centroid"]["code"] > 0).sum() > 100, "terrain should exercise the centroid row scan"
+
+
+@pytest.mark.parametrize("res,R,rows", [(0.01, 0.1, 600), (0.01, 0.15, 600), (0.005, 0.1, 800), (0.03, 0.1, 300), (0.02, 0.06, 400)])
+def test_resolutions_and_radii(planner, res, R, rows):
+    set_params(planner, searchRadius=np.float32(R))
+    trav, elev = synth.rough_map(rows, rows, res, seed=11)
+    side = rows * res
+    poses = synth.poses_in_map(96, side, side, 6, 0.18, seed=12, margin=0.7)
+    eng, ora = util.run_both(planner, trav, elev, res, poses, 6, threads=8)
+    util.assert_plan_equal(eng, ora)
+
+
+def test_code_default_params_foot_radius_003(planner):
+    planner.params = _capi.params_code_defaults()
+    trav, elev = synth.rough_map(400, 400, 0.02, seed=21)
+    poses = synth.poses_in_map(128, 8.0, 8.0, 6, 0.2, seed=22, margin=0.8)
+    eng, ora = util.run_both(planner, trav, elev, 0.02, poses, 6, threads=8)
+    util.assert_plan_equal(eng, ora)
+
+
+def test_rf_first_and_map_offset(planner):
+    set_params(planner, RF_FIRST=1)
+    trav, elev = synth.rough_map(400, 300, 0.02, seed=31, position=(3.7, -1.3))
+    poses = synth.poses_uniform(128, (3.7 - 3.2, 3.7 + 1.0), (-1.3 - 2.2, -1.3 + 2.2), seed=32)
+    eng, ora = util.run_both(planner, trav, elev, 0.02, poses, 8, position=(3.7, -1.3), threads=8)
+    util.assert_plan_equal(eng, ora)
+
+
+def test_walk_gait_and_mixed_polygons(planner):
+    """Build-defined extensions: walk gait, per-leg radii, hexagon polygons."""
+    set_params(planner)
+    trav, elev = synth.rough_map(500, 500, 0.01, seed=41)
+    poses = synth.poses_in_map(128, 5.0, 5.0, 6, 0.18, seed=42, margin=0.7)
+    rng = np.random.default_rng(43)
+    poses["gait"] = rng.integers(0, 2, size=128)
+    poses["leg_search_radius"] = rng.uniform(0.06, 0.15, size=(128, 4)).astype(np.float32)
+    poses["leg_polygon_kind"] = rng.integers(0, 2, size=(128, 4))
+    eng, ora = util.run_both(planner, trav, elev, 0.01, poses, 6, threads=8)
+    util.assert_plan_equal(eng, ora)
+    assert (eng["nominal"]["valid"] == 1).any()
+
+
+def test_hostile_maps(planner):
+    """NaN-rich, -inf/+inf, elevation >= 10, everything blocked."""
+    set_params(planner)
+    rng = np.random.default_rng(51)
+    rows = cols = 300
+    trav = rng.uniform(0.5, 1.0, size=(rows, cols)).astype(np.float32)
+    trav[rng.random((rows, cols)) < 0.2] = np.nan
+    trav[rng.random((rows, cols)) < 0.01] = -np.inf
+    trav[rng.random((rows, cols)) < 0.01] = np.inf
+    elev = rng.uniform(-0.2, 0.2, size=(rows, cols)).astype(np.float32)
+    elev[rng.random((rows, cols)) < 0.1] = np.nan
+    elev[rng.random((rows, cols)) < 0.05] = 11.0
+    poses = synth.poses_in_map(128, 6.0, 6.0, 6, 0.18, seed=52, margin=0.7)
+    eng, ora = util.run_both(planner, trav, elev, 0.02, poses, 6, threads=8)
+    util.assert_plan_equal(eng, ora)
+    assert (eng["cycle_ok"] == 0).any() and (eng["cycle_ok"] == 1).any(), "commit and skip paths must both run"
+    blocked = np.full((rows, cols), 0.1, np.float32)
+    eng, ora = util.run_both(planner, blocked, elev, 0.02, poses[:16], 4)
+    util.assert_plan_equal(eng, ora)
+    assert not eng["cycle_ok"].any()
+
+
+def test_poses_near_and_outside_the_border(planner):
+    set_params(planner)
+    trav, elev = synth.rough_map(200, 200, 0.02, seed=61)  # 4 x 4 m
+    xs = np.linspace(-2.6, 2.3, 50)
+    ys = np.linspace(-2.4, 2.4, 7)
+    xyz = np.array([[x, y, 0.0] for x in xs for y in ys])
+    poses = make_poses(xyz)
+    eng, ora = util.run_both(planner, trav, elev, 0.02, poses, 5, threads=8)
+    util.assert_plan_equal(eng, ora)
+    assert (eng["centroid"]["code"] == 6).any(), "some legs must fall outside the map"
+
+
+def test_open_loop_checkFoothold_with_arbitrary_polygons(planner):
+    set_params(planner)
+    trav, elev = synth.rough_map(400, 400, 0.02, seed=71)
+    planner.gridmapCallback(trav, elev, 0.02)
+    rng = np.random.default_rng(72)
+    n = 2000
+    q = np.zeros(n, dtype=_capi.QUERY_DTYPE)
+    q["cx"] = rng.uniform(-3.5, 3.5, n)
+    q["cy"] = rng.uniform(-3.5, 3.5, n)
+    q["search_radius"] = rng.choice(np.array([0.06, 0.1, 0.12], np.float32), n)
+    for k in range(n):
+        nv = int(rng.integers(0, 9))
+        q["n_vertices"][k] = nv
+        if nv:
+            ang = np.sort(rng.uniform(0, 2 * np.pi, nv))
+            rad = rng.uniform(0.05, 0.2, nv)
+            q["vx"][k, :nv] = q["cx"][k] + rng.uniform(-0.03, 0.03) + rad * np.cos(ang)
+            q["vy"][k, :nv] = q["cy"][k] + rng.uniform(-0.03, 0.03) + rad * np.sin(ang)
+    eng = planner.checkFoothold(q)
+    ora = fpo.OracleMap(trav, elev, 0.02).search_legs(util.to_oracle_params(planner.params), util.to_oracle_queries(q))
+    util.assert_nominal_equal(eng, ora, "checkFoothold")
+    assert (eng["source"] == 1).sum() > 20
+
+
+def test_single_blocked_cell_kat_on_gpu(planner):
+    set_params(planner)
+    trav = np.ones((200, 200), np.float32)
+    trav[100, 100] = 0.1
+    planner.gridmapCallback(trav, np.zeros((200, 200), np.float32), 0.02)
+    cx = 0.5 * 4.0 - 0.01 - 0.02 * 100
+    R = float(np.float32(0.1))
+    q = np.zeros(1, dtype=_capi.QUERY_DTYPE)
+    q["cx"], q["cy"], q["search_radius"], q["n_vertices"] = cx, cx, np.float32(0.1), 4
+    q["vx"][0, :4] = [cx + R, cx + R, cx - R, cx - R]
+    q["vy"][0, :4] = [cx + 0.5 * R, cx - 0.5 * R, cx - 0.5 * R, cx + 0.5 * R]
+    r = planner.checkFoothold(q)[0]
+    assert (r["valid"], r["source"], r["row"], r["col"]) == (1, 1, 101, 99)
+
+
+def test_grid_map_message_layout_is_canonicalised(planner):
+    """Column-major buffers with a circular-buffer start index give the same plan as the canonical map."""
+    set_params(planner)
+    rows, cols = 240, 200
+    trav, elev = synth.rough_map(rows, cols, 0.02, seed=81)
+    poses = synth.poses_in_map(64, rows * 0.02, cols * 0.02, 5, 0.18, seed=82, margin=0.7)
+    planner.gridmapCallback(trav, elev, 0.02)
+    ref = planner.plan(poses, 5)
+    si, sj = 37, 151
+    # buffer (bi, bj) holds unwrapped ((bi - si) % rows, (bj - sj) % cols); stored column-major
+    buf_t = np.roll(trav, (si, sj), axis=(0, 1))
+    buf_e = np.roll(elev, (si, sj), axis=(0, 1))
+    planner.gridmapCallback(np.ascontiguousarray(buf_t.T), np.ascontiguousarray(buf_e.T), 0.02, start_index=(si, sj),
+                            storage_order="col")
+    got = planner.plan(poses, 5)
+    for k in ref:
+        a, b = ref[k], got[k]
+        assert a.tobytes() == b.tobytes() or np.array_equal(a, b, equal_nan=True) if a.dtype.names is None else a.tobytes() == b.tobytes(), k
+
+
+def test_service_message(planner):
+    """plan_global_footholds response content (cpp:591-699, 1378-1396, 1574) vs the oracle's cycle flags."""
+    set_params(planner)
+    trav, elev = synth.rough_map(400, 400, 0.02, seed=1, bad_frac=0.45)  # harsh: some cycles must fail
+    planner.gridmapCallback(trav, elev, 0.02)
+    omap = fpo.OracleMap(trav, elev, 0.02)
+    rng = np.random.default_rng(91)
+    seen_fail = False
+    for _ in range(24):
+        pos = [rng.uniform(-3.2, -2.0), rng.uniform(-3, 3), 0.25]
+        msg = planner.globalFootholdPlan(8, pos)
+        o = omap.plan(util.to_oracle_params(planner.params), util.to_oracle_poses(make_poses([pos])), 8)
+        ok = o["cycle_ok"][0]
+        assert msg["gait_cycles"] == 8
+        assert msg["success"] == bool(ok[-1])
+        assert msg["gait_cycles_succeed"] == (int(np.nonzero(ok)[0][-1]) + 1 if ok.any() else 0)
+        f = msg["footholds"]
+        assert len(f) == 4 + 4 * int(ok.sum())
+        assert np.array_equal(np.stack([f["x"][:4], f["y"][:4], f["z"][:4]], 1), o["stance"][0])
+        assert f["gait_cycle_id"][:4].tolist() == [0, 0, 0, 0] and f["foot_id"][:4].tolist() == [0, 1, 2, 3]
+        k = 4
+        for g in range(8):
+            if ok[g]:
+                for l in range(4):
+                    assert f["x"][k] == o["nominal"][0, g, l]["x"] and f["y"][k] == o["nominal"][0, g, l]["y"]
+                    assert abs(f["z"][k] - float(o["nominal"][0, g, l]["z"])) <= util.Z_TOL
+                    assert f["foot_id"][k] == l and f["gait_cycle_id"][k] == g
+                    k += 1
+        seen_fail |= not ok.all()
+    assert seen_fail, "the harsh map should make some cycles fail (commit/skip path)"
+
+
+def test_errors_are_codes_not_crashes(planner):
+    from quadrupedal_foothold_planner_amd.planner import FpeError
+
+    fresh = FootholdPlanner(0)
+    with pytest.raises(FpeError) as e:
+        fresh.plan(make_poses([[0, 0, 0]]), 2)
+    assert e.value.code == _capi.FPE_E_NO_MAP
+    fresh.close()
+    set_params(planner, searchRadius=np.float32(5.0))
+    planner.gridmapCallback(*synth.flat_map(100, 100), 0.02)
+    with pytest.raises(FpeError) as e:
+        planner.plan(make_poses([[0, 0, 0]]), 2)
+    assert e.value.code == _capi.FPE_E_UNSUPPORTED
+    set_params(planner)
+    with pytest.raises(FpeError) as e:
+        planner.plan(make_poses([[np.nan, 0, 0]]), 2)
+    assert e.value.code == _capi.FPE_E_INVALID_ARG
