@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py — footholds/sec of the chained foothold plan on MI355X.
+
+A "step" = one pass of the hot path over one batch: fpe_plan_device on B poses x N cycles x 4
+legs with the map and the poses already resident in HBM, every product of the three tracks
+written (nominal, centroid, default, cycle flags, stance); at N>1 GPUs the step also contains the
+RCCL all-gather of the selected (nominal) footholds, as north_star names it.  Weak scaling: every
+rank plans its own B poses (a contiguous shard of the global seeded list of N*B poses).
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per foothold (SURVEY.md
+§8(d): 508 B at 2 cm / R=0.1) x footholds per launch / mean kernel time (HIP events on the launch
+stream) — stated against the 8 TB/s HBM peak although this path is latency/ALU bound and the map
+is cache resident.  `cpu_baseline` times the oracle (oracle/, "port") on the host cores
+of the same box on the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="headline", help="headline | cfg2 | cfg3 | cfg5 (quadrupedal_foothold_planner_amd.synth.CONFIGS)")
+    ap.add_argument("--batch", type=int, default=None, help="poses per GPU (default: the config's B)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target seconds of oracle work per baseline leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(trav, elev, res, params, poses, n_cycles, target_s):
+    """Time the oracle (CPU restatement) on the same workload: single thread and all host cores."""
+    from oracle import fpo
+    from tests.util import to_oracle_params, to_oracle_poses
+
+    omap = fpo.OracleMap(trav, elev, res)
+    op, oposes = to_oracle_params(params), to_oracle_poses(poses)
+    per_pass = poses.shape[0] * n_cycles * 4
+    cores = os.cpu_count() or 1
+    out = {}
+    for label, threads in (("single", 1), ("all", cores)):
+        omap.plan(op, oposes[: min(256, len(oposes))], n_cycles, threads=threads)  # warm
+        t0 = time.perf_counter()
+        passes = 0
+        while True:
+            omap.plan(op, oposes, n_cycles, threads=threads)
+            passes += 1
+            dt = time.perf_counter() - t0
+            if dt >= target_s or passes >= 200:
+                break
+        out[label] = (passes * per_pass / dt, passes, dt)
+    return {
+        "value": out["all"][0],
+        "unit": "footholds/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"oracle/libfpo.so (copy-free CPU restatement, -O2) on the full step workload "
+                  f"({per_pass} footholds) x {out['all'][1]} passes, {cores} std::thread workers, {out['all'][2]:.1f} s",
+        "single_thread_value": out["single"][0],
+        "single_thread_sample": f"{out['single'][1]} passes, {out['single'][2]:.1f} s",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from quadrupedal_foothold_planner_amd import _capi, synth
+    from quadrupedal_foothold_planner_amd import dist as fdist
+    from quadrupedal_foothold_planner_amd.planner import FootholdPlanner
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    # ---- workload --------------------------------------------------------------------------------
+    cfg = synth.CONFIGS[args.config]
+    B = args.batch or cfg["B"]
+    n_cycles = cfg["n_cycles"]
+    planner = FootholdPlanner(local_rank)
+    params = planner.params
+    trav, elev, res, poses_all, n_cycles, extra = synth.make_config(args.config, B=B * world)
+    if "search_radius" in extra:
+        params["searchRadius"] = np.float32(extra["search_radius"])
+    if "max_leg_search_radius" in extra:
+        planner.set_max_leg_search_radius(extra["max_leg_search_radius"])
+    rows, cols = trav.shape
+    # map: replicated; rank 0's copy is broadcast over RCCL, then canonicalised into the engine
+    d_trav, d_elev = fdist.broadcast_map(torch.from_numpy(trav), torch.from_numpy(elev), dev)
+    torch.cuda.synchronize()
+    planner.upload_map_device(d_trav.data_ptr(), d_elev.data_ptr(), rows, cols, res, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    lo, hi = fdist.shard_range(B * world, rank, world)
+    poses = poses_all[lo:hi]
+    d_poses = torch.from_numpy(poses.view(np.uint8).reshape(-1)).to(dev)
+    n_rec = B * n_cycles * 4
+    rec = _capi.FOOTHOLD_DTYPE.itemsize
+    d_nom = torch.zeros(n_rec * rec, dtype=torch.uint8, device=dev)
+    d_cen = torch.zeros(n_rec * _capi.CENTROID_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    d_def = torch.zeros(n_rec * 3, dtype=torch.float64, device=dev)
+    d_ok = torch.zeros(B * n_cycles, dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(B * 12, dtype=torch.float64, device=dev)
+
+    stream = torch.cuda.current_stream()
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record(stream)
+        planner.plan_device(d_poses.data_ptr(), B, n_cycles, d_nom.data_ptr(), d_cen.data_ptr(), d_def.data_ptr(),
+                            d_ok.data_ptr(), d_st.data_ptr(), stream=stream.cuda_stream)
+        if ev is not None:
+            ev[1].record(stream)
+        if world > 1:
+            return fdist.all_gather_records(d_nom, B * world * n_cycles * 4, rec)
+        return d_nom
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        gathered = step(events[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+
+    footholds_per_step = 4 * n_cycles * B * world
+    value = footholds_per_step * args.steps / elapsed
+    R = float(params["searchRadius"][0])
+    alg_bytes = _capi.algorithmic_bytes_per_foothold(R, float(params["footRadius"][0]), res)
+    achieved = alg_bytes * (4 * n_cycles * B) / (kernel_ms * 1e-3) / 1e9  # GB/s, per launch on one GPU
+    peak = 8000.0
+
+    # sanity: the last step's results are real (not a skipped/cached launch)
+    ok_frac = float(d_ok.float().mean().item())
+    valid_frac = float(torch.from_numpy(np.frombuffer(d_nom.cpu().numpy().tobytes(), dtype=_capi.FOOTHOLD_DTYPE)["valid"].copy()).float().mean())
+
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get(args.config, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": "footholds/sec (4 legs x N cycles x B poses) on 1k^2 @2cm map",
+        "value": value,
+        "unit": "footholds/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.config}: {rows}x{cols} @{res*100:g}cm rough terrain (seed {cfg.get('terrain')}), "
+                        f"B={B} poses/GPU (seed {cfg.get('pose_seed')}), {'walk' if cfg.get('gait') else 'trot'}, "
+                        f"{n_cycles} cycles, searchRadius {R:.3g}, all products written",
+            "poses_per_gpu": B,
+            "n_cycles": n_cycles,
+            "footholds_per_step": footholds_per_step,
+            "generator": synth.GENERATOR_VERSION,
+            "cycle_ok_fraction": ok_frac,
+            "valid_leg_fraction": valid_frac,
+            "exchange": "all_gather of nominal footholds (RCCL)" if world > 1 else "none",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": peak,
+            "unit": "GB/s",
+            "frac": achieved / peak,
+            "traffic": traffic,
+            "kernel": "plan_chained_kernel",
+            "kernel_ms": kernel_ms,
+            "algorithmic_bytes_per_foothold": alg_bytes,
+            "note": "latency/ALU bound; map is L2/Infinity-Cache resident (DESIGN.md)",
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(trav, elev, res, params, poses, n_cycles, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    planner.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

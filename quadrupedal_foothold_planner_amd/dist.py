@@ -1,0 +1,61 @@
+"""Multi-GPU sharding of the batch axis: one process per GPU, torch.distributed (backend "nccl" is
+RCCL on ROCm; "gloo" for CPU tests).
+
+Poses (candidate body trajectories) are independent, so the batch is split into contiguous blocks,
+one per rank; the map is replicated (broadcast once per map from rank 0 over xGMI); the only
+exchange on the path is one all-gather of the selected footholds per plan.
+There is no collective inside the search.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ._capi import FOOTHOLD_DTYPE
+
+
+def shard_range(total, rank, world):
+    """Contiguous block split: the first (total % world) ranks get one extra element."""
+    base, rem = divmod(int(total), int(world))
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def shard_sizes(total, world):
+    return [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+
+
+def broadcast_map(trav, elev, device, src=0):
+    """Replicate both layers from `src`.  trav/elev: float32 tensors of identical shape on every
+    rank (contents only matter on src).  Returns device tensors."""
+    t = trav.to(device).contiguous()
+    e = elev.to(device).contiguous()
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src=src)
+        dist.broadcast(e, src=src)
+    return t, e
+
+
+def all_gather_records(local, total, record_bytes):
+    """All-gather per-rank record blocks (uint8 tensor of shard_len * record_bytes) into the
+    global order.  Uneven shards are padded to the largest shard for the collective and trimmed
+    afterwards, so one all_gather_into_tensor moves everything."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    sizes = shard_sizes(total, world)
+    mx = max(sizes) * record_bytes
+    buf = local
+    if local.numel() != mx:
+        buf = torch.zeros(mx, dtype=torch.uint8, device=local.device)
+        buf[: local.numel()] = local
+    out = torch.empty(mx * world, dtype=torch.uint8, device=local.device)
+    dist.all_gather_into_tensor(out, buf)
+    if all(s == sizes[0] for s in sizes):
+        return out
+    parts = [out[r * mx : r * mx + sizes[r] * record_bytes] for r in range(world)]
+    return torch.cat(parts)
+
+
+def records_to_numpy(t, n_cycles, dtype=FOOTHOLD_DTYPE):
+    a = t.detach().cpu().numpy().view(dtype)
+    return a.reshape(-1, n_cycles, 4)
