@@ -102,7 +102,7 @@ bool checkCandidateFoothold(const GridMap& map, const Vec2& spiralCenter, float 
 // (0,0,0) results (cpp:1777-1944) and the feet polygon degenerates; the reference then feeds NaN to
 // getIndexFromPosition's (int) cast — undefined behaviour.  Defined here (and in the engine) as
 // "no cell is visited": invalid leg, getSubmap failure, mean height = h.
-static bool centreUsable(const Vec2& c) { return std::fabs(c.x) <= 1e9 && std::fabs(c.y) <= 1e9; }
+static bool centreUsable(const Vec2& c) { return std::fabs(c.x) <= 1e6 && std::fabs(c.y) <= 1e6; }
 
 // cpp:2520-2554.  f32 sequential sum in CircleIterator (row-major bbox) order; NaN -> 0.0 and
 // counted; values >= 10 skipped; empty count -> last iHeight; "+ h" in f64, returned as float.

@@ -24,6 +24,8 @@ struct SpiralLut {
     int32_t maxRing;
 };
 
+constexpr int kMaxFootOffsets = 128;
+
 // Per-call constants derived on the host from fpe_params with the reference's typing
 // (initialize(), cpp:340-421; fpe_host.cpp::derive_constants).
 struct PlanConsts {
@@ -37,6 +39,15 @@ struct PlanConsts {
     int32_t tileH, tileW;  // LDS tile half-width / width in cells
     uint32_t tileWMagic;   // fastdiv magic of tileW
     float maxSearchRadius; // radius the tile was sized for
+    int32_t groupOverride; // 0 = automatic lanes-per-leg; 16 / 64 force it (tuning knob FPE_PLAN_GROUP)
+    // Cell offsets of a CELL-CENTRED foot disc (checkCirclePolygonFoothold's CircleIterator around
+    // a spiral candidate), valid only when footRobust != 0: the host proved that no lattice offset
+    // lies within rounding distance of the radius, so the f64 per-candidate bounding-box walk
+    // visits exactly {candidate + offset} ∩ map (fpe_host.cpp::derive_foot_offsets).
+    int32_t nFoot;
+    int32_t footRobust;
+    int8_t footDa[kMaxFootOffsets];
+    int8_t footDb[kMaxFootOffsets];
 };
 
 // Tile flag bits (one byte per cell in LDS).

@@ -88,7 +88,7 @@ int prepare_call(fpe_engine* h, const fpe_params* params, float maxRadius, std::
         maxRadius = std::max(maxRadius, std::max(params->searchRadius, h->maxLegSearchRadius));
     }
     if (!snap) return fail(FPE_E_NO_MAP, "no map uploaded");
-    fpe::derive_constants(*params, snap->g.res, maxRadius, pc);
+    fpe::derive_constants(*params, snap->g, maxRadius, pc);
     if (fpe::spiral_rings(maxRadius, snap->g.res) > h->maxRing)
         return fail(FPE_E_UNSUPPORTED, "search radius needs more spiral rings than the rank table holds");
     planLds = fpe::plan_lds_bytes(pc);
@@ -276,7 +276,7 @@ int fpe_plan(fpe_handle h, const fpe_params* params, const fpe_pose* poses, int3
     float maxRadius = 0.0f;
     for (int b = 0; b < B; ++b) {
         for (int k = 0; k < 3; ++k)
-            if (!std::isfinite(poses[b].position[k]) || std::fabs(poses[b].position[k]) > 1e9)
+            if (!std::isfinite(poses[b].position[k]) || std::fabs(poses[b].position[k]) > 1e6)
                 return fail(FPE_E_INVALID_ARG, "non-finite pose");
         if (poses[b].gait != 0 && poses[b].gait != 1) return fail(FPE_E_INVALID_ARG, "unknown gait");
         for (int l = 0; l < 4; ++l) {
@@ -344,8 +344,8 @@ int fpe_search_legs(fpe_handle h, const fpe_params* params, const fpe_leg_query*
     if (n <= 0) return fail(FPE_E_INVALID_ARG, "n must be positive");
     float maxRadius = 0.0f;
     for (int k = 0; k < n; ++k) {
-        if (!std::isfinite(queries[k].cx) || !std::isfinite(queries[k].cy) || std::fabs(queries[k].cx) > 1e9 ||
-            std::fabs(queries[k].cy) > 1e9)
+        if (!std::isfinite(queries[k].cx) || !std::isfinite(queries[k].cy) || std::fabs(queries[k].cx) > 1e6 ||
+            std::fabs(queries[k].cy) > 1e6)
             return fail(FPE_E_INVALID_ARG, "non-finite query centre");
         if (!(queries[k].search_radius >= 0.0f) || !std::isfinite(queries[k].search_radius))
             return fail(FPE_E_INVALID_ARG, "bad search radius");
@@ -392,7 +392,7 @@ int fpe_plan_service(fpe_handle h, const fpe_params* params, const double initia
         // the reference's loop body never runs (cpp:762); the stance comes from initialize()
         if (!h || !params) return fail(FPE_E_INVALID_ARG, "null handle or params");
         fpe::PlanConsts pc;
-        fpe::derive_constants(*params, 1.0, params->searchRadius, pc);
+        fpe::derive_constants(*params, fpe::make_geom(1, 1, 1.0, 0.0, 0.0), params->searchRadius, pc);
         for (int l = 0; l < 4; ++l) {
             double sx = (l == 0 || l == 3) ? pc.LbHalf : -pc.LbHalf;
             double sy = (l <= 1) ? pc.WbHalfNeg : pc.WbHalfPos;

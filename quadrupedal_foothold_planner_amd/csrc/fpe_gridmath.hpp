@@ -31,6 +31,7 @@ struct MapGeom {
     double posX, posY;    // map centre
     double orgX, orgY;    // 0.5 * len                        (getVectorToOrigin)
     double baseX, baseY;  // pos + (org - 0.5*res)            (mapPosition + getVectorToFirstCell)
+    double rinv;          // fl(1/res): used only to PREDICT a quotient, never to produce one
 };
 
 FPE_HD MapGeom make_geom(int rows, int cols, double res, double px, double py) {
@@ -46,6 +47,7 @@ FPE_HD MapGeom make_geom(int rows, int cols, double res, double px, double py) {
     g.orgY = 0.5 * g.lenY;
     g.baseX = px + (g.orgX - 0.5 * res);
     g.baseY = py + (g.orgY - 0.5 * res);
+    g.rinv = 1.0 / res;
     return g;
 }
 
@@ -55,6 +57,20 @@ FPE_HD double cell_pos(double base, double res, int idx) { return base + res * s
 // getIndexFromPosition, one axis: -(int)(((position - offset) - mapPosition) / resolution).
 FPE_HD int index_of(double x, double org, double pos, double res) {
     return -static_cast<int>(((x - org) - pos) / res);
+}
+
+// Same value as index_of, without the f64 division in the common case.  q' = n * fl(1/res) is
+// within 3.4e-16*|q| of the correctly rounded q = n / res, so trunc(q') == trunc(q) whenever q' is
+// farther than eps = 4.5e-16*|q'| from an integer; otherwise (exact ties such as cell-centre +
+// half-cell radii, or NaN) the true division decides.  Bit-identical to index_of by construction.
+FPE_HD int index_of_fast(double x, double org, double pos, double res, double rinv) {
+    const double n = (x - org) - pos;
+    const double qf = n * rinv;
+    double k = trunc(qf);
+    const double fr = fabs(qf - k);
+    const double eps = fabs(qf) * 4.5e-16 + 1e-290;
+    if (!(fr > eps && fr < 1.0 - eps)) k = trunc(n / res);
+    return -static_cast<int>(k);
 }
 
 // checkIfPositionWithinMap, one axis: t = -((position - mapPosition) - offset); 0 <= t < length.
@@ -95,6 +111,19 @@ FPE_HD BBox circle_bbox(const MapGeom& g, double cx, double cy, double r) {
     return b;
 }
 
+FPE_HD BBox circle_bbox_fast(const MapGeom& g, double cx, double cy, double r) {
+    const double tlx = bound_axis(cx + r, g.orgX, g.posX, g.lenX);
+    const double tly = bound_axis(cy + r, g.orgY, g.posY, g.lenY);
+    const double brx = bound_axis(cx - r, g.orgX, g.posX, g.lenX);
+    const double bry = bound_axis(cy - r, g.orgY, g.posY, g.lenY);
+    BBox b;
+    b.i0 = index_of_fast(tlx, g.orgX, g.posX, g.res, g.rinv);
+    b.j0 = index_of_fast(tly, g.orgY, g.posY, g.res, g.rinv);
+    b.ni = index_of_fast(brx, g.orgX, g.posX, g.res, g.rinv) - b.i0 + 1;
+    b.nj = index_of_fast(bry, g.orgY, g.posY, g.res, g.rinv) - b.j0 + 1;
+    return b;
+}
+
 // CircleIterator::isInside / SpiralIterator::isInside: squared cell-centre distance <= r^2.
 FPE_HD bool cell_in_disc(const MapGeom& g, int i, int j, double cx, double cy, double r2) {
     const double dx = cell_pos(g.baseX, g.res, i) - cx;
@@ -117,13 +146,13 @@ FPE_HD Submap submap_info(const MapGeom& g, double px, double py, double lx, dou
     s.baseX = s.baseY = 0.0;
     const double tlx = bound_axis(px - (-0.5 * lx), g.orgX, g.posX, g.lenX);
     const double tly = bound_axis(py - (-0.5 * ly), g.orgY, g.posY, g.lenY);
-    s.i0 = index_of(tlx, g.orgX, g.posX, g.res);
-    s.j0 = index_of(tly, g.orgY, g.posY, g.res);
+    s.i0 = index_of_fast(tlx, g.orgX, g.posX, g.res, g.rinv);
+    s.j0 = index_of_fast(tly, g.orgY, g.posY, g.res, g.rinv);
     if (!(within_axis(tlx, g.orgX, g.posX, g.lenX) && within_axis(tly, g.orgY, g.posY, g.lenY))) return s;
     const double brx = bound_axis(px + (-0.5 * lx), g.orgX, g.posX, g.lenX);
     const double bry = bound_axis(py + (-0.5 * ly), g.orgY, g.posY, g.lenY);
-    const int i1 = index_of(brx, g.orgX, g.posX, g.res);
-    const int j1 = index_of(bry, g.orgY, g.posY, g.res);
+    const int i1 = index_of_fast(brx, g.orgX, g.posX, g.res, g.rinv);
+    const int j1 = index_of_fast(bry, g.orgY, g.posY, g.res, g.rinv);
     if (!(within_axis(brx, g.orgX, g.posX, g.lenX) && within_axis(bry, g.orgY, g.posY, g.lenY))) return s;
     if (!in_range(s.i0, s.j0, g.rows, g.cols)) return s;  // getPositionFromIndex(topLeft) range check
     const double cornerX = cell_pos(g.baseX, g.res, s.i0) - (-(0.5 * g.res));
@@ -149,6 +178,27 @@ FPE_HD bool polygon_inside(const double* vx, const double* vy, int n, double px,
         if (((vy[i] > py) != (vy[j] > py)) &&
             (px < (vx[j] - vx[i]) * (py - vy[i]) / (vy[j] - vy[i]) + vx[i])) {
             cross++;
+        }
+    }
+    return (cross & 1) != 0;
+}
+
+// Same result as polygon_inside.  For an edge with vx[j] == vx[i] the literal intersection
+// (0 * t) / d + vx[i] is exactly vx[i] (t finite, d != 0 because the edge straddles py), so the
+// division is skipped; every edge of the reference's rectangle that can straddle is of that kind.
+FPE_HD bool polygon_inside_fast(const double* vx, const double* vy, int n, double px, double py) {
+    int cross = 0;
+    for (int i = 0, j = n - 1; i < n; j = i++) {
+        if ((vy[i] > py) != (vy[j] > py)) {
+            const double ex = vx[j] - vx[i];
+            const double t = py - vy[i];
+            double xi;
+            if (ex == 0.0 && fabs(t) <= DBL_MAX) {
+                xi = vx[i];
+            } else {
+                xi = ex * t / (vy[j] - vy[i]) + vx[i];
+            }
+            if (px < xi) cross++;
         }
     }
     return (cross & 1) != 0;

@@ -2,7 +2,9 @@
 #include "fpe_host.hpp"
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace fpe {
@@ -83,7 +85,51 @@ int validate_params(const fpe_params& p) {
 // initialize(), cpp:340-421.  lengthBase / widthBase / skew / stepLength_ are float members
 // (hpp:657-668, 683, 613); widthBase is computed in f32 (cpp:341); each use below promotes the
 // float operand to double exactly where the reference's expression does.
-void derive_constants(const fpe_params& p, double resolution, float maxSearchRadius, PlanConsts& c) {
+// A cell-centred CircleIterator visits cell q = candidate + (a, b) iff the f64 expression
+// dx*dx + dy*dy <= rf*rf holds, with dx = cell_pos(i+a) - cell_pos(i).  In exact
+// arithmetic that is (a^2 + b^2) res^2 <= rf^2, independent of the candidate.  The f64 evaluation
+// differs from the exact value by at most `tol` (two rounded cell positions of magnitude <= |P|+L
+// per axis, then squares and a sum), so when every lattice offset near the circle clears the radius
+// by more than tol the visited set is the same offset list for every candidate, and the
+// iterator's bounding box (>= half a cell of slack) always contains it.  Otherwise footRobust = 0
+// and the kernels walk the literal per-candidate bounding box.
+void derive_foot_offsets(float footRadius, const MapGeom& g, PlanConsts& c) {
+    const double rf = static_cast<double>(footRadius);
+    const double res = g.res;
+    const double rf2 = rf * rf;
+    const double maxAbs = std::max(std::fabs(g.posX) + g.lenX, std::fabs(g.posY) + g.lenY) + rf + res;
+    const double e1 = 4.0 * maxAbs * DBL_EPSILON;                    // |error| of one position difference
+    const double tol = 4.0 * (rf + 2.0 * res) * e1 + 1e-9 * rf2 + 8.0 * DBL_EPSILON * rf2;
+    const int reach = static_cast<int>(std::ceil(rf / res)) + 1;
+    c.nFoot = 0;
+    c.footRobust = 1;
+    if (reach > 100) {
+        c.footRobust = 0;
+        return;
+    }
+    for (int a = -reach; a <= reach; ++a)
+        for (int b = -reach; b <= reach; ++b) {
+            const double d2 = (static_cast<double>(a) * a + static_cast<double>(b) * b) * (res * res);
+            if (std::fabs(d2 - rf2) <= tol) {
+                c.footRobust = 0;  // a lattice point sits on the circle within rounding: stay literal
+                c.nFoot = 0;
+                return;
+            }
+            if (d2 < rf2) {
+                if (c.nFoot >= kMaxFootOffsets) {
+                    c.footRobust = 0;
+                    c.nFoot = 0;
+                    return;
+                }
+                c.footDa[c.nFoot] = static_cast<int8_t>(a);
+                c.footDb[c.nFoot] = static_cast<int8_t>(b);
+                ++c.nFoot;
+            }
+        }
+}
+
+void derive_constants(const fpe_params& p, const MapGeom& geom, float maxSearchRadius, PlanConsts& c) {
+    const double resolution = geom.res;
     std::memset(&c, 0, sizeof(c));
     c.footRadius = p.footRadius;
     c.thrDefault = p.defaultFootholdThreshold;
@@ -116,6 +162,10 @@ void derive_constants(const fpe_params& p, double resolution, float maxSearchRad
     c.tileH = tile_halfwidth(maxSearchRadius, p.footRadius, resolution);
     c.tileW = 2 * c.tileH + 1;
     c.tileWMagic = fastdiv_magic(static_cast<uint32_t>(c.tileW));
+    const char* grp = std::getenv("FPE_PLAN_GROUP");
+    c.groupOverride = grp ? std::atoi(grp) : 0;
+    derive_foot_offsets(p.footRadius, geom, c);
+    if (std::getenv("FPE_LITERAL_DISCS")) c.footRobust = 0;  // test knob: force the literal bounding-box walk
 }
 
 // globalFootholdPlan message bookkeeping: cpp:681-699 (stance entries), cpp:1378-1396 (valid

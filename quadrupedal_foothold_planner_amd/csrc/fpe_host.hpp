@@ -22,7 +22,11 @@ struct SpiralTable {
 void build_spiral_table(int nRings, SpiralTable& out);
 
 // initialize() constants with the reference's float/double typing (cpp:340-421, 2693).
-void derive_constants(const fpe_params& p, double resolution, float maxSearchRadius, PlanConsts& out);
+void derive_constants(const fpe_params& p, const MapGeom& g, float maxSearchRadius, PlanConsts& out);
+
+// Offsets of a cell-centred disc of radius double(footRadius) and the proof that they are
+// rounding-robust on this map (see PlanConsts::footRobust).
+void derive_foot_offsets(float footRadius, const MapGeom& g, PlanConsts& out);
 
 // Tile half-width (cells) that covers: every spiral candidate's foot disc, the default disc and
 // the centroid rectangle for search radii up to maxSearchRadius.

@@ -1,13 +1,18 @@
 // fpe_kernels.hip — hand-written HIP for gfx950 (MI355X, wave64): the foothold-search hot path.
 //
-// Layout: one workgroup (256 threads = 4 wavefronts) per body pose; wavefront w searches leg w
-// (RF, RH, LH, LF) — the device counterpart of the reference's 4 std::thread(checkFoothold)
-// (cpp:863-909).  The gait-cycle chain of globalFootholdPlan (cpp:762-1579) runs inside the
-// workgroup: feet of the three tracks live in LDS, every cycle ends with a commit/skip decision.
-// Each wavefront stages the traversability window around its search centre into LDS as one flag
-// byte per cell (coalesced row reads), then evaluates the default disc, the spiral candidates
-// (rank table + wave ballot = argmin of SpiralIterator rank), the centroid rectangle and the mean
-// heights from those flags.  No MFMA: nothing here is a contraction.
+// Work decomposition.  A body pose is one chain of gait cycles (globalFootholdPlan, cpp:762-1579);
+// inside a cycle the four legs are independent (the reference's 4 std::thread(checkFoothold),
+// cpp:863-909).  A leg is searched by a GROUP of G lanes (template parameter):
+//   G = 16: one wavefront per pose, lanes 16*l..16*l+15 = leg l — the per-leg f64 geometry of the
+//           four legs runs as ONE vector instruction stream and the cross-leg exchange never
+//           leaves the wavefront (default for small tiles, e.g. 2 cm maps);
+//   G = 64: one workgroup of 4 wavefronts per pose, wavefront w = leg w (large tiles: 1 cm / 0.5 cm
+//           maps with 10^2..10^3 spiral candidates per leg).
+// Each group stages the traversability window it needs into LDS as one flag byte per cell (first
+// the region of the default disc + centroid rectangle; the full spiral window only when the
+// default foothold fails), then evaluates the default disc, the spiral candidates (rank table +
+// ballot = argmin of SpiralIterator rank), the centroid rectangle and the mean heights.
+// No MFMA: nothing here is a contraction.
 //
 // All geometry is f64 in the reference's expression order (fpe_gridmath.hpp); compile with
 // -ffp-contract=off.  Reference citations: "cpp:" = foothold_planner/src/FootholdPlanner.cpp.
@@ -19,24 +24,50 @@ namespace fpe {
 
 namespace {
 
-constexpr int kWave = 64;
-
-__device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & (kWave - 1); }
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
-
 // A search centre must be finite and of sane magnitude.  The reference has no such test: a
 // non-finite centre (reachable once the centroid track has committed its "no case" (0,0,0)
 // results, cpp:1777-1944, and the feet polygon degenerates) sends NaN through
 // getIndexFromPosition's (int) cast, which is undefined behaviour.  Engine and oracle both define
 // it as "no cell is visited": invalid leg, getSubmap failure, mean height = h.
-__device__ __forceinline__ bool centre_usable(double x, double y) { return fabs(x) <= 1e9 && fabs(y) <= 1e9; }
+__device__ __forceinline__ bool centre_usable(double x, double y) { return fabs(x) <= 1e6 && fabs(y) <= 1e6; }
 
-// ---- per-wave search context (all members wave-uniform) ---------------------------------------
+// ---- lane group ------------------------------------------------------------------------------------
+template <int G>
+struct Grp {
+    int sub;    // lane index inside the group, 0..G-1
+    int gbase;  // first lane of the group inside its wavefront
+    __device__ __forceinline__ explicit Grp(int tid) : sub(tid & (G - 1)), gbase((tid & 63) & ~(G - 1)) {}
+    __device__ __forceinline__ unsigned long long ballot(bool p) const {
+        const unsigned long long m = __ballot(p);
+        if (G == 64) return m;
+        return (m >> gbase) & ((1ull << (G & 63)) - 1ull);
+    }
+    __device__ __forceinline__ bool any(bool p) const { return ballot(p) != 0ull; }
+    template <class T>
+    __device__ __forceinline__ T bcast(T v, int l) const {
+        return __shfl(v, gbase + l);
+    }
+};
+
+// t / d and t % d for 0 <= t < 2^22, 1 <= d < 2^22 without the 32-bit udiv sequence: one f32
+// reciprocal estimate and one exact integer fix-up step (the estimate is off by at most 1).
+__device__ __forceinline__ void divmod_small(int t, int d, float dinv, int& q, int& r) {
+    q = static_cast<int>(static_cast<float>(t) * dinv);
+    r = t - q * d;
+    if (r < 0) {
+        q -= 1;
+        r += d;
+    } else if (r >= d) {
+        q += 1;
+        r -= d;
+    }
+}
+__device__ __forceinline__ float rcp_small(int d) { return __frcp_rn(static_cast<float>(d)); }
+
+// ---- per-leg search context (group-uniform) -----------------------------------------------------------
 struct LegCtx {
     double cx, cy;   // search centre = centroid-track next position of this leg (cpp:861-862)
-    double R, R2;    // double(float searchRadius), R*R (SpiralIterator radiusSquare_)
-    float Rf;        // the float radius (centroid rectangle uses searchRadius_*2 in f32, cpp:1616)
+    double R2;       // double(float searchRadius)^2 (SpiralIterator radiusSquare_)
     int nRings;      // ceil(R / res)
     int ici, icj;    // getIndex(centre)
     int ti0, tj0;    // tile origin (cell index of tile[0])
@@ -45,133 +76,190 @@ struct LegCtx {
     const double* vy;
 };
 
-__device__ __forceinline__ uint8_t tile_at(const uint8_t* tile, const PlanConsts& pc, const LegCtx& c, int i, int j) {
+__device__ __forceinline__ uint8_t tile_at(const uint8_t* tile, int W, const LegCtx& c, int i, int j) {
     const int a = i - c.ti0, b = j - c.tj0;
-    // cells a search can touch are inside the tile by construction (tileH); anything else is
-    // treated as "outside the map" instead of reading out of bounds
-    if (static_cast<unsigned>(a) >= static_cast<unsigned>(pc.tileW) ||
-        static_cast<unsigned>(b) >= static_cast<unsigned>(pc.tileW))
+    // cells a search can touch are inside the tile by construction (tileH); anything else reads as
+    // "outside the map" instead of out of bounds
+    if (static_cast<unsigned>(a) >= static_cast<unsigned>(W) || static_cast<unsigned>(b) >= static_cast<unsigned>(W))
         return 0;
-    return tile[a * pc.tileW + b];
+    return tile[a * W + b];
 }
 
-// Stage the flag tile: coalesced reads of the traversability rows, one byte per cell to LDS.
-__device__ void stage_tile(const DevMap& m, const PlanConsts& pc, const LegCtx& c, uint8_t* tile, int lane) {
+__device__ __forceinline__ uint8_t classify(const DevMap& m, const PlanConsts& pc, int i, int j) {
+    uint8_t f = 0;
+    if (in_range(i, j, m.g.rows, m.g.cols)) {
+        const float v = m.trav[static_cast<size_t>(i) * m.g.cols + j];
+        f = kFlagInMap;
+        if (__builtin_isfinite(v)) f |= kFlagFinite;
+        if (v < pc.thrDefault) f |= kFlagBelowDef;
+        if (v < pc.thrCandidate) f |= kFlagBelowCand;
+    }
+    return f;
+}
+
+// Stage a rectangle of cells [i0, i0+ni) x [j0, j0+nj) of the flag tile (coalesced row reads).
+template <int G>
+__device__ void stage_region(const DevMap& m, const PlanConsts& pc, const LegCtx& c, uint8_t* tile, const Grp<G>& g,
+                             int i0, int j0, int ni, int nj) {
+    const int W = pc.tileW;
+    const int n = ni * nj;
+    const float njInv = rcp_small(nj);
+    for (int t = g.sub; t < n; t += G) {
+        int a, bq;
+        divmod_small(t, nj, njInv, a, bq);
+        const int i = i0 + a, j = j0 + bq;
+        const int ta = i - c.ti0, tb = j - c.tj0;
+        if (static_cast<unsigned>(ta) < static_cast<unsigned>(W) && static_cast<unsigned>(tb) < static_cast<unsigned>(W))
+            tile[ta * W + tb] = classify(m, pc, i, j);
+    }
+}
+
+// Full spiral window, with the polygon test folded in (only when the spiral search runs).
+// checkCirclePolygonFoothold (cpp:2132-2138): a FINITE cell fails when it is below the candidate
+// threshold or its centre is outside the polygon; non-finite cells never fail.
+template <int G>
+__device__ void stage_full_tile(const DevMap& m, const PlanConsts& pc, const LegCtx& c, uint8_t* tile, const Grp<G>& g) {
     const int W = pc.tileW;
     const int n = W * W;
-    for (int t = lane; t < n; t += kWave) {
+    for (int t = g.sub; t < n; t += G) {
         const int a = static_cast<int>(fastdiv(static_cast<uint32_t>(t), pc.tileWMagic));
         const int b = t - a * W;
         const int i = c.ti0 + a, j = c.tj0 + b;
-        uint8_t f = 0;
-        if (in_range(i, j, m.g.rows, m.g.cols)) {
-            const float v = m.trav[static_cast<size_t>(i) * m.g.cols + j];
-            f = kFlagInMap;
-            if (__builtin_isfinite(v)) f |= kFlagFinite;
-            if (v < pc.thrDefault) f |= kFlagBelowDef;
-            if (v < pc.thrCandidate) f |= kFlagBelowCand;
+        uint8_t f = classify(m, pc, i, j);
+        if ((f & kFlagInMap) && (f & kFlagFinite)) {
+            bool fail = (f & kFlagBelowCand) != 0;
+            if (!fail) {
+                const double px = cell_pos(m.g.baseX, m.g.res, i);
+                const double py = cell_pos(m.g.baseY, m.g.res, j);
+                fail = !polygon_inside_fast(c.vx, c.vy, c.nv, px, py);
+            }
+            if (fail) f |= kFlagFail;
         }
         tile[t] = f;
     }
 }
 
-// Second pass, only when the spiral search runs: fold the polygon test into kFlagFail.
-// checkCirclePolygonFoothold (cpp:2132-2138): a FINITE cell fails when it is below the candidate
-// threshold or its centre is outside the polygon; non-finite cells never fail.
-__device__ void fold_polygon(const DevMap& m, const PlanConsts& pc, const LegCtx& c, uint8_t* tile, int lane) {
-    const int W = pc.tileW;
-    const int n = W * W;
-    for (int t = lane; t < n; t += kWave) {
-        uint8_t f = tile[t];
-        if ((f & kFlagInMap) && (f & kFlagFinite)) {
-            bool fail = (f & kFlagBelowCand) != 0;
-            if (!fail) {
-                const int a = static_cast<int>(fastdiv(static_cast<uint32_t>(t), pc.tileWMagic));
-                const int b = t - a * W;
-                const double px = cell_pos(m.g.baseX, m.g.res, c.ti0 + a);
-                const double py = cell_pos(m.g.baseY, m.g.res, c.tj0 + b);
-                fail = !polygon_inside(c.vx, c.vy, c.nv, px, py);
-            }
-            if (fail) tile[t] = f | kFlagFail;
+// In-order f32 accumulation of getFootholdMeanHeight (cpp:2539-2545) over the visited lanes of one
+// round: lanes are cells in the CircleIterator's row-major order.
+template <int G>
+__device__ __forceinline__ void accumulate_heights(const Grp<G>& g, bool vis, float v, float& sum, float& last, int& cnt) {
+    unsigned long long mask = g.ballot(vis);
+    while (mask) {
+        const int l = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const float e = g.bcast(v, l);
+        last = e;
+        if (e < 10) {  // cpp:2539
+            cnt++;
+            sum = sum + e;
         }
     }
 }
 
-// getFootholdMeanHeight (cpp:2520-2554) for one disc, cooperatively: lanes test membership and
-// load elevation, then the f32 sum is accumulated in the CircleIterator's row-major order.
-__device__ float mean_height_wave(const DevMap& m, const PlanConsts& pc, double cx, double cy, int lane) {
+__device__ __forceinline__ float finish_mean(float sum, float last, int cnt, double h) {
+    const float mean = (cnt != 0) ? (sum / cnt) : last;       // cpp:2547-2551
+    return static_cast<float>(static_cast<double>(mean) + h);  // cpp:2553 (float + double)
+}
+
+// getFootholdMeanHeight (cpp:2520-2554) for one disc, cooperatively.
+template <int G>
+__device__ float mean_height_grp(const DevMap& m, const PlanConsts& pc, double cx, double cy, const Grp<G>& g) {
     if (!centre_usable(cx, cy)) return static_cast<float>(static_cast<double>(0.0f) + pc.h);  // no cell visited
-    const BBox bb = circle_bbox(m.g, cx, cy, pc.rf);
-    const int ni = uni(bb.ni), nj = uni(bb.nj), i0 = uni(bb.i0), j0 = uni(bb.j0);
-    const int nb = ni * nj;
-    const uint32_t magic = fastdiv_magic(static_cast<uint32_t>(nj));
+    const BBox bb = circle_bbox_fast(m.g, cx, cy, pc.rf);
+    const int nb = bb.ni * bb.nj;
+    const float njInv = rcp_small(bb.nj);
     float sum = 0.0f, last = 0.0f;
     int cnt = 0;
-    for (int base = 0; base < nb; base += kWave) {
-        const int t = base + lane;
+    for (int base = 0; base < nb; base += G) {
+        const int t = base + g.sub;
         bool vis = false;
         float v = 0.0f;
         if (t < nb) {
-            const int a = static_cast<int>(fastdiv(static_cast<uint32_t>(t), magic));
-            const int i = i0 + a, j = j0 + (t - a * nj);
+            int a, bq;
+            divmod_small(t, bb.nj, njInv, a, bq);
+            const int i = bb.i0 + a, j = bb.j0 + bq;
             if (in_range(i, j, m.g.rows, m.g.cols) && cell_in_disc(m.g, i, j, cx, cy, pc.rf2)) {
                 vis = true;
                 const float e = m.elev[static_cast<size_t>(i) * m.g.cols + j];
                 v = __builtin_isfinite(e) ? e : 0.0f;  // cpp:2532-2537
             }
         }
-        unsigned long long mask = __ballot(vis);
-        while (mask) {
-            const int l = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const float e = __shfl(v, l);
-            last = e;
-            if (e < 10) {  // cpp:2539
-                cnt++;
-                sum = sum + e;
-            }
-        }
+        accumulate_heights(g, vis, v, sum, last, cnt);
     }
-    const float mean = (cnt != 0) ? (sum / cnt) : last;           // cpp:2547-2551
-    return static_cast<float>(static_cast<double>(mean) + pc.h);  // cpp:2553 (float + double)
+    return finish_mean(sum, last, cnt, pc.h);
 }
 
-// checkDefaultFoothold (cpp:2039-2082): valid iff the disc around the CONTINUOUS centre visits at
-// least one cell and no finite visited cell is below defaultFootholdThreshold_.
-__device__ bool default_check_wave(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const uint8_t* tile, int lane) {
-    const BBox bb = circle_bbox(m.g, c.cx, c.cy, pc.rf);
-    const int ni = uni(bb.ni), nj = uni(bb.nj), i0 = uni(bb.i0), j0 = uni(bb.j0);
-    const int nb = ni * nj;
-    const uint32_t magic = fastdiv_magic(static_cast<uint32_t>(nj));
+// One pass over the disc around the CONTINUOUS centre that serves both
+//   checkDefaultFoothold (cpp:2039-2082): valid iff >= 1 cell visited and no finite visited cell is
+//     below defaultFootholdThreshold_ (flags from the LDS tile), and
+//   getFootholdMeanHeight at the centre (cpp:2029, 1687): elevation straight from HBM/L2.
+template <int G>
+__device__ bool centre_disc_pass(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const uint8_t* tile,
+                                 const BBox& bb, const Grp<G>& g, float& zCentre) {
+    const int nb = bb.ni * bb.nj;
+    const float njInv = rcp_small(bb.nj);
+    float sum = 0.0f, last = 0.0f;
+    int cnt = 0;
     bool any = false, fail = false;
-    for (int base = 0; base < nb; base += kWave) {
-        const int t = base + lane;
+    for (int base = 0; base < nb; base += G) {
+        const int t = base + g.sub;
+        bool vis = false;
+        float v = 0.0f;
         if (t < nb) {
-            const int a = static_cast<int>(fastdiv(static_cast<uint32_t>(t), magic));
-            const int i = i0 + a, j = j0 + (t - a * nj);
+            int a, bq;
+            divmod_small(t, bb.nj, njInv, a, bq);
+            const int i = bb.i0 + a, j = bb.j0 + bq;
             if (in_range(i, j, m.g.rows, m.g.cols) && cell_in_disc(m.g, i, j, c.cx, c.cy, pc.rf2)) {
-                any = true;
-                const uint8_t f = tile_at(tile, pc, c, i, j);
+                vis = true;
+                const float e = m.elev[static_cast<size_t>(i) * m.g.cols + j];
+                v = __builtin_isfinite(e) ? e : 0.0f;
+                const uint8_t f = tile_at(tile, pc.tileW, c, i, j);
                 if ((f & kFlagFinite) && (f & kFlagBelowDef)) fail = true;
             }
         }
+        any |= vis;
+        accumulate_heights(g, vis, v, sum, last, cnt);
     }
-    return wave_any(any) && !wave_any(fail);
+    zCentre = finish_mean(sum, last, cnt, pc.h);
+    return g.any(any) && !g.any(fail);
 }
 
-// checkCirclePolygonFoothold (cpp:2117-2163) for the cell-centred disc of candidate (i, j),
-// one lane per candidate.
+// A finite cell fails checkCirclePolygonFoothold's test (cpp:2132-2138) when it is below the
+// candidate threshold or its centre is outside the search polygon; non-finite cells never fail.
+__device__ __forceinline__ bool cell_fails_direct(const DevMap& m, const PlanConsts& pc, const LegCtx& c, int i, int j) {
+    const float v = m.trav[static_cast<size_t>(i) * m.g.cols + j];
+    if (!__builtin_isfinite(v)) return false;
+    if (v < pc.thrCandidate) return true;
+    return !polygon_inside_fast(c.vx, c.vy, c.nv, cell_pos(m.g.baseX, m.g.res, i), cell_pos(m.g.baseY, m.g.res, j));
+}
+
+// checkCirclePolygonFoothold (cpp:2117-2163) for the cell-centred disc of candidate (i, j), one
+// lane per candidate.  kTile: per-cell verdicts come from the LDS tile (stage_full_tile), else
+// they are evaluated on demand from the map (tiny discs: fewer cells than the tile has).
+// Disc membership: the host-proved offset table when pc.footRobust, else the literal
+// CircleIterator bounding-box walk in f64.
+template <bool kTile>
 __device__ __forceinline__ bool candidate_disc_ok(const DevMap& m, const PlanConsts& pc, const LegCtx& c,
                                                   const uint8_t* tile, int i, int j) {
+    if (pc.footRobust) {
+        for (int k = 0; k < pc.nFoot; ++k) {
+            const int qi = i + pc.footDa[k], qj = j + pc.footDb[k];
+            if (!in_range(qi, qj, m.g.rows, m.g.cols)) continue;
+            const bool fail = kTile ? (tile_at(tile, pc.tileW, c, qi, qj) & kFlagFail) != 0 : cell_fails_direct(m, pc, c, qi, qj);
+            if (fail) return false;
+        }
+        return true;  // the candidate's own cell (offset 0,0) is always visited
+    }
     const double fx = cell_pos(m.g.baseX, m.g.res, i);
     const double fy = cell_pos(m.g.baseY, m.g.res, j);
-    const BBox bb = circle_bbox(m.g, fx, fy, pc.rf);
+    const BBox bb = circle_bbox_fast(m.g, fx, fy, pc.rf);
     bool any = false;
     for (int a = 0; a < bb.ni; ++a) {
         for (int b = 0; b < bb.nj; ++b) {
             const int qi = bb.i0 + a, qj = bb.j0 + b;
             if (in_range(qi, qj, m.g.rows, m.g.cols) && cell_in_disc(m.g, qi, qj, fx, fy, pc.rf2)) {
-                if (tile_at(tile, pc, c, qi, qj) & kFlagFail) return false;
+                const bool fail = kTile ? (tile_at(tile, pc.tileW, c, qi, qj) & kFlagFail) != 0 : cell_fails_direct(m, pc, c, qi, qj);
+                if (fail) return false;
                 any = true;
             }
         }
@@ -181,12 +269,13 @@ __device__ __forceinline__ bool candidate_disc_ok(const DevMap& m, const PlanCon
 
 // checkCandidateFoothold (cpp:2085-2114): first valid cell in SpiralIterator order.  Lane k of a
 // round evaluates the candidate of rank base+k; the lowest set ballot bit is the argmin of rank.
-__device__ bool candidate_search_wave(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LegCtx& c,
-                                      const uint8_t* tile, int lane, int& wi, int& wj) {
+template <int G, bool kTile>
+__device__ bool candidate_search_grp(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LegCtx& c,
+                                     const uint8_t* tile, const Grp<G>& g, int& wi, int& wj) {
     const int nR = c.nRings < lut.maxRing ? c.nRings : lut.maxRing;
-    const int M = uni(lut.ringStart[nR + 1]);
-    for (int base = 0; base < M; base += kWave) {
-        const int k = base + lane;
+    const int M = lut.ringStart[nR + 1];
+    for (int base = 0; base < M; base += G) {
+        const int k = base + g.sub;
         bool ok = false;
         int i = 0, j = 0;
         if (k < M) {
@@ -197,21 +286,22 @@ __device__ bool candidate_search_wave(const DevMap& m, const PlanConsts& pc, con
                 // SpiralIterator::generateRing filters rings nRings-1 and nRings by isInside;
                 // the centre cell (ring 0) is pushed unfiltered by the constructor
                 const int r = lut.ring[k];
-                if (r >= 1 && (r == c.nRings || r + 1 == c.nRings))
-                    ok = cell_in_disc(m.g, i, j, c.cx, c.cy, c.R2);
+                if (r >= 1 && (r == c.nRings || r + 1 == c.nRings)) ok = cell_in_disc(m.g, i, j, c.cx, c.cy, c.R2);
             }
-            if (ok) ok = candidate_disc_ok(m, pc, c, tile, i, j);
+            if (ok) ok = candidate_disc_ok<kTile>(m, pc, c, tile, i, j);
         }
-        const unsigned long long mask = __ballot(ok);
+        const unsigned long long mask = g.ballot(ok);
         if (mask) {
             const int l = __builtin_ctzll(mask);
-            wi = __shfl(i, l);
-            wj = __shfl(j, l);
+            wi = g.bcast(i, l);
+            wj = g.bcast(j, l);
             return true;
         }
     }
     return false;
 }
+
+constexpr int kOnDemandMaxFoot = 4;
 
 struct CentroidOut {
     double x, y;
@@ -220,10 +310,11 @@ struct CentroidOut {
     int code;
 };
 
-// checkFootholdUseCentroidMethod (cpp:1605-1997) on the rectangle (2R x R) around the centre.
-// zCentre = mean height at the centre (the whole-region-valid result reuses it, cpp:1687).
-__device__ CentroidOut centroid_wave(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const uint8_t* tile,
-                                     float zCentre, int lane) {
+// checkFootholdUseCentroidMethod (cpp:1605-1997) on the rectangle s around the centre (flags
+// already staged).  zCentre = mean height at the centre (whole-region-valid result, cpp:1687).
+template <int G>
+__device__ CentroidOut centroid_grp(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const uint8_t* tile,
+                                    const Submap& s, float zCentre, const Grp<G>& g) {
     CentroidOut o;
     o.x = 0.0;
     o.y = 0.0;
@@ -231,23 +322,21 @@ __device__ CentroidOut centroid_wave(const DevMap& m, const PlanConsts& pc, cons
     o.row = -1;
     o.col = -1;
     o.code = 5;
-    const double lx = static_cast<double>(c.Rf * 2);  // cpp:1616: float * int stays float
-    const double ly = static_cast<double>(c.Rf);      // cpp:1617
-    const Submap s = submap_info(m.g, c.cx, c.cy, lx, ly);
     if (!s.ok) {  // cpp:1628-1631
         o.code = 6;
         return o;
     }
-    const int ni = uni(s.ni), nj = uni(s.nj), i0 = uni(s.i0), j0 = uni(s.j0);
+    const int ni = s.ni, nj = s.nj;
     const int ncell = ni * nj;
-    const uint32_t magic = fastdiv_magic(static_cast<uint32_t>(nj));
+    const float njInv = rcp_small(nj);
     // whole-region test, cpp:1649-1658 (raw `<`: NaN passes)
     bool below = false;
-    for (int t = lane; t < ncell; t += kWave) {
-        const int a = static_cast<int>(fastdiv(static_cast<uint32_t>(t), magic));
-        if (tile_at(tile, pc, c, i0 + a, j0 + (t - a * nj)) & kFlagBelowDef) below = true;
+    for (int t = g.sub; t < ncell; t += G) {
+        int a, bq;
+        divmod_small(t, nj, njInv, a, bq);
+        if (tile_at(tile, pc.tileW, c, s.i0 + a, s.j0 + bq) & kFlagBelowDef) below = true;
     }
-    const bool whole = ncell > 0 && !wave_any(below);
+    const bool whole = ncell > 0 && !g.any(below);
     if (whole) {  // cpp:1684-1689
         o.x = c.cx;
         o.y = c.cy;
@@ -260,16 +349,16 @@ __device__ CentroidOut centroid_wave(const DevMap& m, const PlanConsts& pc, cons
     // row scan, cpp:1717-1750 (in-bounds columns only): lane = row
     const int bottomRow = ni - 1, rightCol = nj - 1;
     int minRow = 0, maxRow = 0, k = 0;
-    for (int rbase = 0; rbase < ni; rbase += kWave) {
-        const int r = rbase + lane;
+    for (int rbase = 0; rbase < ni; rbase += G) {
+        const int r = rbase + g.sub;
         bool blocked = false;
         if (r < ni) {
             int cnt = 0;
             for (int cc = 0; cc < nj; ++cc)
-                if (tile_at(tile, pc, c, i0 + r, j0 + cc) & kFlagBelowDef) ++cnt;
+                if (tile_at(tile, pc.tileW, c, s.i0 + r, s.j0 + cc) & kFlagBelowDef) ++cnt;
             blocked = cnt > ((rightCol + 1) * 0.5);  // cpp:1743
         }
-        const unsigned long long mask = __ballot(blocked);
+        const unsigned long long mask = g.ballot(blocked);
         if (mask) {
             if (k == 0) minRow = rbase + __builtin_ctzll(mask);
             maxRow = rbase + 63 - __builtin_clzll(mask);
@@ -300,9 +389,9 @@ __device__ CentroidOut centroid_wave(const DevMap& m, const PlanConsts& pc, cons
     // map.getPosition(newIndex) on the SUBMAP (cpp:1816), height on the full map (cpp:1820)
     o.x = cell_pos(s.baseX, m.g.res, newRow);
     o.y = cell_pos(s.baseY, m.g.res, newCol);
-    o.z = mean_height_wave(m, pc, o.x, o.y, lane);
-    o.row = index_of(o.x, m.g.orgX, m.g.posX, m.g.res);
-    o.col = index_of(o.y, m.g.orgY, m.g.posY, m.g.res);
+    o.z = mean_height_grp(m, pc, o.x, o.y, g);
+    o.row = index_of_fast(o.x, m.g.orgX, m.g.posX, m.g.res, m.g.rinv);
+    o.col = index_of_fast(o.y, m.g.orgY, m.g.posY, m.g.res, m.g.rinv);
     return o;
 }
 
@@ -313,53 +402,91 @@ struct NominalOut {
     int valid, source;
 };
 
-// checkFoothold (cpp:2001-2036).  zCentre = getFootholdMeanHeight at the DEFAULT centre, which the
-// reference uses even when a spiral candidate was chosen (cpp:2029).
-__device__ NominalOut nominal_wave(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LegCtx& c,
-                                   uint8_t* tile, float zCentre, int lane) {
-    NominalOut o;
-    o.x = c.cx;  // cpp:2016-2017
-    o.y = c.cy;
+__device__ __forceinline__ void nominal_invalid(NominalOut& o, double cx, double cy, int source) {
+    o.row = o.col = -1;
+    o.x = cx;  // cpp:2016-2017
+    o.y = cy;
     o.z = 0.0f;
-    o.row = -1;
-    o.col = -1;
     o.valid = 0;
-    o.source = 2;
-    if (default_check_wave(m, pc, c, tile, lane)) {  // cpp:2012
-        o.valid = 1;
-        o.source = 0;
-        o.row = c.ici;
-        o.col = c.icj;
-        o.z = zCentre;
-        return o;
-    }
-    fold_polygon(m, pc, c, tile, lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    int wi = 0, wj = 0;
-    if (candidate_search_wave(m, pc, lut, c, tile, lane, wi, wj)) {  // cpp:2022
-        o.valid = 1;
-        o.source = 1;
-        o.row = wi;
-        o.col = wj;
-        o.x = cell_pos(m.g.baseX, m.g.res, wi);  // cpp:2105-2107
-        o.y = cell_pos(m.g.baseY, m.g.res, wj);
-        o.z = zCentre;
-    }
-    return o;
+    o.source = source;
 }
 
-__device__ __forceinline__ void init_ctx(LegCtx& c, const DevMap& m, const PlanConsts& pc, double cx, double cy, float Rf) {
-    c.cx = cx;
-    c.cy = cy;
-    c.Rf = Rf;
-    c.R = static_cast<double>(Rf);
-    c.R2 = c.R * c.R;
-    c.nRings = static_cast<int>(static_cast<unsigned int>(ceil(c.R / m.g.res)));
-    c.ici = index_of(cx, m.g.orgX, m.g.posX, m.g.res);
-    c.icj = index_of(cy, m.g.orgY, m.g.posY, m.g.res);
+// Per-leg constants that do not change along the chain.
+struct LegConst {
+    float Rf;       // float search radius (cpp:1616 uses searchRadius_*2 in f32)
+    double R2;      // double(Rf)^2
+    int nRings;     // ceil(double(Rf) / res), SpiralIterator::nRings_
+    double lx, ly;  // centroid rectangle (cpp:1616-1617)
+};
+__device__ __forceinline__ LegConst make_leg_const(float Rf, double res) {
+    LegConst k;
+    k.Rf = Rf;
+    const double R = static_cast<double>(Rf);
+    k.R2 = R * R;
+    k.nRings = static_cast<int>(static_cast<unsigned int>(ceil(R / res)));
+    k.lx = static_cast<double>(Rf * 2);
+    k.ly = static_cast<double>(Rf);
+    return k;
+}
+
+// One leg: centroid method (cpp:1605-1997) + checkFoothold (cpp:2001-2036) around the same centre.
+// wantCentroid=false skips the centroid track (open-loop fpe_search_legs).
+template <int G, bool kCentroid>
+__device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, LegCtx& c, const LegConst& lk,
+                           uint8_t* tile, const Grp<G>& g, NominalOut& no, CentroidOut& co) {
+    c.R2 = lk.R2;
+    c.nRings = lk.nRings;
+    c.ici = index_of_fast(c.cx, m.g.orgX, m.g.posX, m.g.res, m.g.rinv);
+    c.icj = index_of_fast(c.cy, m.g.orgY, m.g.posY, m.g.res, m.g.rinv);
     c.ti0 = c.ici - pc.tileH;
     c.tj0 = c.icj - pc.tileH;
+    // region needed by the common path: bounding box of the default disc (+ the centroid rectangle)
+    const BBox bb = circle_bbox_fast(m.g, c.cx, c.cy, pc.rf);  // CircleIterator(centre, footRadius)
+    Submap s;
+    s.ok = false;
+    int i0 = bb.i0, j0 = bb.j0, i1 = bb.i0 + bb.ni, j1 = bb.j0 + bb.nj;
+    if (kCentroid) {
+        s = submap_info(m.g, c.cx, c.cy, lk.lx, lk.ly);  // getSubmap (cpp:1627)
+        if (s.ok) {
+            i0 = min(i0, s.i0);
+            j0 = min(j0, s.j0);
+            i1 = max(i1, s.i0 + s.ni);
+            j1 = max(j1, s.j0 + s.nj);
+        }
+    }
+    stage_region(m, pc, c, tile, g, i0, j0, i1 - i0, j1 - j0);
+    float zCentre;
+    const bool defaultOk = centre_disc_pass(m, pc, c, tile, bb, g, zCentre);  // cpp:2012 + cpp:2029
+    if (kCentroid) co = centroid_grp(m, pc, c, tile, s, zCentre, g);          // cpp:818-821
+    if (defaultOk) {
+        no.valid = 1;
+        no.source = 0;
+        no.row = c.ici;
+        no.col = c.icj;
+        no.x = c.cx;  // cpp:2016-2017
+        no.y = c.cy;
+        no.z = zCentre;
+        return;
+    }
+    nominal_invalid(no, c.cx, c.cy, 2);
+    int wi = 0, wj = 0;
+    bool found;
+    if (pc.footRobust && pc.nFoot <= kOnDemandMaxFoot) {
+        // tiny foot discs: evaluate the few cells a candidate needs straight from the map
+        found = candidate_search_grp<G, false>(m, pc, lut, c, tile, g, wi, wj);  // cpp:2022
+    } else {
+        stage_full_tile(m, pc, c, tile, g);
+        found = candidate_search_grp<G, true>(m, pc, lut, c, tile, g, wi, wj);
+    }
+    if (found) {
+        no.valid = 1;
+        no.source = 1;
+        no.row = wi;
+        no.col = wj;
+        no.x = cell_pos(m.g.baseX, m.g.res, wi);  // cpp:2105-2107
+        no.y = cell_pos(m.g.baseY, m.g.res, wj);
+        no.z = zCentre;  // z at the DEFAULT centre even for a candidate (cpp:2029)
+    }
 }
 
 __device__ __forceinline__ void store_foothold(fpe_foothold* dst, const NominalOut& o, int leg, int cycle) {
@@ -376,9 +503,10 @@ __device__ __forceinline__ void store_foothold(fpe_foothold* dst, const NominalO
     *dst = f;
 }
 
-// getPolygonCenter (cpp:2421-2463): feet[leg][xyz] in LDS.
-__device__ __forceinline__ void polygon_center(const double (*feet)[3], double& ox, double& oy, double& oz) {
-    double x1 = feet[0][0], y1 = feet[0][1];
+// getPolygonCenter (cpp:2421-2463): feet[leg][xyz] in LDS; x and y only (z of the centre is never
+// used downstream: getDefaultFootholdNext zeroes it, cpp:2411-2418).
+__device__ __forceinline__ void polygon_center_xy(const double (*feet)[3], double& ox, double& oy) {
+    const double x1 = feet[0][0], y1 = feet[0][1];
     double x2 = feet[1][0], y2 = feet[1][1];
     double sum_x = 0, sum_y = 0, sum_s = 0;
 #pragma unroll
@@ -393,14 +521,14 @@ __device__ __forceinline__ void polygon_center(const double (*feet)[3], double& 
     }
     ox = sum_x / sum_s / 3.0;
     oy = sum_y / sum_s / 3.0;
-    oz = (feet[0][2] + feet[1][2] + feet[2][2] + feet[3][2]) / 4.0;
 }
 
-// LDS carve for one pose-workgroup (all offsets multiples of 16).
+// LDS of one pose (all offsets multiples of 16).
 struct PoseShared {
-    double cur[3][4][3];   // current feet of the default / centroid / nominal tracks (cpp:1338, 1413, 1480)
-    double nxt[3][4][3];   // this phase's results per track
-    double polyX[4][8];    // search polygon vertices per leg
+    double cur[3][4][3];  // current feet of the default / centroid / nominal tracks (cpp:1338, 1413, 1480)
+    double nxt[3][4][3];  // this phase's results per track
+    double ctr[3][2];     // feet-polygon centre of each track for this phase
+    double polyX[4][8];   // search polygon vertices per leg
     double polyY[4][8];
     int valid[4];
     int pad[4];
@@ -408,47 +536,59 @@ struct PoseShared {
 
 }  // namespace
 
-// ---- chained plan kernel ------------------------------------------------------------------------
-// grid = B poses, block = 256 (wave w = leg w).  Dynamic LDS = sizeof(PoseShared) + 4 * tileW^2.
-__global__ __launch_bounds__(256) void plan_chained_kernel(DevMap m, PlanConsts pc, SpiralLut lut,
-                                                            const fpe_pose* __restrict__ poses, int B, int nCycles,
-                                                            fpe_plan_out out) {
+// ---- chained plan kernel ------------------------------------------------------------------------------
+// G lanes per leg; a pose owns 4*G consecutive threads; block = max(64, 4*G) threads holds
+// PPB = blockDim / (4*G) poses.  Dynamic LDS per pose = sizeof(PoseShared) + 4 * tileBytes.
+template <int G>
+__global__ __launch_bounds__(G == 64 ? 256 : 64, 4) void plan_chained_kernel(DevMap m, PlanConsts pc, SpiralLut lut,
+                                                                           const fpe_pose* __restrict__ poses, int B,
+                                                                           int nCycles, fpe_plan_out out) {
+    constexpr int kPoseThreads = 4 * G;
+    constexpr int kBlock = (G == 64) ? 256 : 64;
+    constexpr int kPPB = kBlock / kPoseThreads;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    PoseShared& sh = *reinterpret_cast<PoseShared*>(smem);
-    const int b = blockIdx.x;
-    if (b >= B) return;
-    const int leg = static_cast<int>(threadIdx.x) >> 6;
-    const int lane = lane_id();
+    const int tid = static_cast<int>(threadIdx.x);
+    const int slot = tid / kPoseThreads;
+    const int leg = (tid / G) & 3;
+    const Grp<G> g(tid);
     const int tileBytes = (pc.tileW * pc.tileW + 15) & ~15;
-    uint8_t* tile = smem + sizeof(PoseShared) + static_cast<size_t>(leg) * tileBytes;
+    const size_t poseBytes = sizeof(PoseShared) + 4 * static_cast<size_t>(tileBytes);
+    unsigned char* base = smem + static_cast<size_t>(slot) * poseBytes;
+    PoseShared& sh = *reinterpret_cast<PoseShared*>(base);
+    uint8_t* tile = base + sizeof(PoseShared) + static_cast<size_t>(leg) * tileBytes;
 
-    const fpe_pose pose = poses[b];
-    const double x0 = pose.position[0], y0 = pose.position[1], z0 = pose.position[2];
-    const int gait = pose.gait;
-    float Rf = pose.leg_search_radius[leg];
+    int b = blockIdx.x * kPPB + slot;
+    const bool live = b < B;  // padding poses of the last block run the chain on pose B-1, store nothing
+    if (!live) b = B - 1;
+
+    const fpe_pose* pp = poses + b;
+    const double x0 = pp->position[0], y0 = pp->position[1], z0 = pp->position[2];
+    const int gait = pp->gait;
+    float Rf = pp->leg_search_radius[leg];
     if (!(Rf > 0.0f)) Rf = pc.searchRadius;
-    const int polyKind = pose.leg_polygon_kind[leg];
+    const int polyKind = pp->leg_polygon_kind[leg];
     const bool radiusOk = Rf <= pc.maxSearchRadius;
+    const LegConst lk = make_leg_const(Rf, m.g.res);
+    const double biasX = pc.biasX[leg], biasY = pc.biasY[leg];
 
     // initial stance (cpp:350-378) and first-gait shift (setFirstGait, cpp:2679-2699)
-    if (threadIdx.x < 4) {
-        const int l = threadIdx.x;
-        double sx = (l == 0 || l == 3) ? pc.LbHalf : -pc.LbHalf;
-        double sy = (l <= 1) ? pc.WbHalfNeg : pc.WbHalfPos;
+    if (g.sub == 0) {
+        double sx = (leg == 0 || leg == 3) ? pc.LbHalf : -pc.LbHalf;
+        double sy = (leg <= 1) ? pc.WbHalfNeg : pc.WbHalfPos;
         double sz = 0;
         sx += x0;
         sy += y0;
         sz += z0;
-        if (out.stance) {
-            double* st = out.stance + (static_cast<size_t>(b) * 4 + l) * 3;
+        if (out.stance && live) {
+            double* st = out.stance + (static_cast<size_t>(b) * 4 + leg) * 3;
             st[0] = sx;
             st[1] = sy;
             st[2] = sz;
         }
         for (int t = 0; t < 3; ++t) {
-            sh.cur[t][l][0] = sx - pc.stepHalf;
-            sh.cur[t][l][1] = sy;
-            sh.cur[t][l][2] = sz;
+            sh.cur[t][leg][0] = sx - pc.stepHalf;
+            sh.cur[t][leg][1] = sy;
+            sh.cur[t][leg][2] = sz;
         }
     }
     __syncthreads();
@@ -456,53 +596,56 @@ __global__ __launch_bounds__(256) void plan_chained_kernel(DevMap m, PlanConsts 
     double adjY = 0.0;  // ajustedPose_[1], cpp:759
     const int nPhases = (gait == 1) ? 4 : 1;
     const double advance = (gait == 1) ? pc.stepQuarter : pc.step;
+    // swing order LF,RH,RF,LH (RF_FIRST=false) or RF,LH,LF,RH (build-defined walk)
+    const int walkOrder = pc.RF_FIRST ? ((0) | (2 << 2) | (3 << 4) | (1 << 6)) : ((3) | (1 << 2) | (0 << 4) | (2 << 6));
 
-    for (int g = 0; g < nCycles; ++g) {
+    for (int cyc = 0; cyc < nCycles; ++cyc) {
         bool cycleOk = true;
         for (int ph = 0; ph < nPhases; ++ph) {
-            unsigned mask = 0xFu;
-            if (gait == 1) {
-                // swing order LF,RH,RF,LH (RF_FIRST=false) or RF,LH,LF,RH (build-defined walk)
-                const int order = pc.RF_FIRST ? ((0) | (2 << 2) | (3 << 4) | (1 << 6)) : ((3) | (1 << 2) | (0 << 4) | (2 << 6));
-                mask = 1u << ((order >> (2 * ph)) & 3);
-            }
+            const unsigned mask = (gait == 1) ? (1u << ((walkOrder >> (2 * ph)) & 3)) : 0xFu;
             const bool active = (mask >> leg) & 1u;
+
+            // feet-polygon centres: group t computes track t (getPolygonCenter, cpp:2191, 2265)
+            if (leg < 3 && g.sub == 0) {
+                double cx, cy;
+                polygon_center_xy(sh.cur[leg], cx, cy);
+                sh.ctr[leg][0] = cx;
+                sh.ctr[leg][1] = cy;
+            }
+            __syncthreads();
+
             if (active) {
-                // next default positions of this leg on the three tracks (cpp:2190-2213, 2265-2284)
-                double nx[3], ny[3];
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    double cx, cy, cz;
-                    polygon_center(sh.cur[t], cx, cy, cz);
-                    const double Nx = cx + advance;  // cpp:2199
-                    const double Ny = y0 + adjY;     // cpp:2201
-                    nx[t] = Nx + pc.biasX[leg];      // cpp:2414-2415
-                    ny[t] = Ny + pc.biasY[leg];
-                }
+                // next default positions of this leg on the three tracks (cpp:2199-2213, 2270-2284)
+                const double Ny = y0 + adjY;                         // cpp:2201
+                const double nx0 = (sh.ctr[0][0] + advance) + biasX;  // cpp:2199, 2414
+                const double nx1 = (sh.ctr[1][0] + advance) + biasX;
+                const double nx2 = (sh.ctr[2][0] + advance) + biasX;
+                const double ny = Ny + biasY;                        // identical on the three tracks
                 // search polygon from the NOMINAL track (cpp:2235-2244, getSearchPolygon cpp:2496-2517)
-                if (lane == 0) {
+                if (g.sub == 0) {
                     const double r = static_cast<double>(Rf);
+                    double* vx = sh.polyX[leg];
+                    double* vy = sh.polyY[leg];
                     if (polyKind == 0) {
-                        sh.polyX[leg][0] = nx[2] + r;  sh.polyY[leg][0] = ny[2] + 0.5 * r;
-                        sh.polyX[leg][1] = nx[2] + r;  sh.polyY[leg][1] = ny[2] - 0.5 * r;
-                        sh.polyX[leg][2] = nx[2] - r;  sh.polyY[leg][2] = ny[2] - 0.5 * r;
-                        sh.polyX[leg][3] = nx[2] - r;  sh.polyY[leg][3] = ny[2] + 0.5 * r;
+                        vx[0] = nx2 + r;  vy[0] = ny + 0.5 * r;
+                        vx[1] = nx2 + r;  vy[1] = ny - 0.5 * r;
+                        vx[2] = nx2 - r;  vy[2] = ny - 0.5 * r;
+                        vx[3] = nx2 - r;  vy[3] = ny + 0.5 * r;
                     } else {
                         const double hx = 0.5 * r;
                         const double hy = (0.5 * r) * 0.8660254037844386;
-                        sh.polyX[leg][0] = nx[2] + r;   sh.polyY[leg][0] = ny[2];
-                        sh.polyX[leg][1] = nx[2] + hx;  sh.polyY[leg][1] = ny[2] - hy;
-                        sh.polyX[leg][2] = nx[2] - hx;  sh.polyY[leg][2] = ny[2] - hy;
-                        sh.polyX[leg][3] = nx[2] - r;   sh.polyY[leg][3] = ny[2];
-                        sh.polyX[leg][4] = nx[2] - hx;  sh.polyY[leg][4] = ny[2] + hy;
-                        sh.polyX[leg][5] = nx[2] + hx;  sh.polyY[leg][5] = ny[2] + hy;
+                        vx[0] = nx2 + r;   vy[0] = ny;
+                        vx[1] = nx2 + hx;  vy[1] = ny - hy;
+                        vx[2] = nx2 - hx;  vy[2] = ny - hy;
+                        vx[3] = nx2 - r;   vy[3] = ny;
+                        vx[4] = nx2 - hx;  vy[4] = ny + hy;
+                        vx[5] = nx2 + hx;  vy[5] = ny + hy;
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
 
                 LegCtx c;
-                init_ctx(c, m, pc, nx[1], ny[1], Rf);  // centre from the CENTROID track (cpp:861-862)
+                c.cx = nx1;  // centre from the CENTROID track (cpp:861-862)
+                c.cy = ny;
                 c.nv = (polyKind == 0) ? 4 : 6;
                 c.vx = sh.polyX[leg];
                 c.vy = sh.polyY[leg];
@@ -510,62 +653,57 @@ __global__ __launch_bounds__(256) void plan_chained_kernel(DevMap m, PlanConsts 
                 NominalOut no;
                 CentroidOut co;
                 float zDefault = 0.0f;
-                if (radiusOk && !centre_usable(c.cx, c.cy)) {
-                    no.row = no.col = -1; no.x = c.cx; no.y = c.cy; no.z = 0.0f; no.valid = 0; no.source = 2;
+                if (!radiusOk) {
+                    nominal_invalid(no, c.cx, c.cy, 3);
                     co.x = co.y = 0.0; co.z = 0.0f; co.row = co.col = -1; co.code = 6;
-                    if (out.default_next) zDefault = mean_height_wave(m, pc, nx[0], ny[0], lane);
-                } else if (radiusOk) {
-                    stage_tile(m, pc, c, tile, lane);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    const float zCentre = mean_height_wave(m, pc, c.cx, c.cy, lane);
-                    co = centroid_wave(m, pc, c, tile, zCentre, lane);       // cpp:818-821
-                    no = nominal_wave(m, pc, lut, c, tile, zCentre, lane);   // cpp:863-903
-                    if (out.default_next)                                    // cpp:2289-2301
-                        zDefault = mean_height_wave(m, pc, nx[0], ny[0], lane);
+                } else if (!centre_usable(c.cx, c.cy)) {
+                    nominal_invalid(no, c.cx, c.cy, 2);
+                    co.x = co.y = 0.0; co.z = 0.0f; co.row = co.col = -1; co.code = 6;
                 } else {
-                    no.row = no.col = -1; no.x = c.cx; no.y = c.cy; no.z = 0.0f; no.valid = 0; no.source = 3;
-                    co.x = co.y = 0.0; co.z = 0.0f; co.row = co.col = -1; co.code = 6;
+                    search_leg<G, true>(m, pc, lut, c, lk, tile, g, no, co);
                 }
-                if (lane == 0) {
+                if (out.default_next) zDefault = mean_height_grp(m, pc, nx0, ny, g);  // cpp:2289-2301
+                if (g.sub == 0) {
                     sh.valid[leg] = no.valid;
-                    sh.nxt[0][leg][0] = nx[0]; sh.nxt[0][leg][1] = ny[0]; sh.nxt[0][leg][2] = static_cast<double>(zDefault);
+                    sh.nxt[0][leg][0] = nx0;   sh.nxt[0][leg][1] = ny;    sh.nxt[0][leg][2] = static_cast<double>(zDefault);
                     sh.nxt[1][leg][0] = co.x;  sh.nxt[1][leg][1] = co.y;  sh.nxt[1][leg][2] = static_cast<double>(co.z);
                     sh.nxt[2][leg][0] = no.x;  sh.nxt[2][leg][1] = no.y;  sh.nxt[2][leg][2] = static_cast<double>(no.z);
-                    const size_t o = (static_cast<size_t>(b) * nCycles + g) * 4 + leg;
-                    if (out.nominal) store_foothold(out.nominal + o, no, leg, g);
-                    if (out.centroid) {
-                        fpe_centroid_foothold cf;
-                        cf.x = co.x; cf.y = co.y; cf.z = co.z; cf.row = co.row; cf.col = co.col;
-                        cf.code = static_cast<uint8_t>(co.code); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
-                        out.centroid[o] = cf;
-                    }
-                    if (out.default_next) {
-                        out.default_next[o * 3 + 0] = nx[0];
-                        out.default_next[o * 3 + 1] = ny[0];
-                        out.default_next[o * 3 + 2] = static_cast<double>(zDefault);
+                    if (live) {
+                        const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
+                        if (out.nominal) store_foothold(out.nominal + o, no, leg, cyc);
+                        if (out.centroid) {
+                            fpe_centroid_foothold cf;
+                            cf.x = co.x; cf.y = co.y; cf.z = co.z; cf.row = co.row; cf.col = co.col;
+                            cf.code = static_cast<uint8_t>(co.code); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
+                            out.centroid[o] = cf;
+                        }
+                        if (out.default_next) {
+                            out.default_next[o * 3 + 0] = nx0;
+                            out.default_next[o * 3 + 1] = ny;
+                            out.default_next[o * 3 + 2] = static_cast<double>(zDefault);
+                        }
                     }
                 }
-            } else if (lane == 0) {
+            } else if (g.sub == 0) {
                 sh.valid[leg] = 1;  // non-swing legs do not vote
             }
             __syncthreads();
             // footholdValidation_ = AND of the swing legs' flags (cpp:1323); commit or skip (cpp:1332-1576)
             const bool phaseOk = (sh.valid[0] & sh.valid[1] & sh.valid[2] & sh.valid[3]) != 0;
-            __syncthreads();
-            if (phaseOk && active && lane < 9) {
-                const int t = lane / 3, k = lane - t * 3;
+            if (phaseOk && active && g.sub < 9) {
+                const int t = g.sub / 3, k = g.sub - t * 3;
                 sh.cur[t][leg][k] = sh.nxt[t][leg][k];
             }
             __syncthreads();
             cycleOk = cycleOk && phaseOk;
         }
-        if (threadIdx.x == 0 && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + g] = cycleOk ? 1 : 0;
+        if (leg == 0 && g.sub == 0 && live && out.cycle_ok)
+            out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = cycleOk ? 1 : 0;
         adjY += pc.drift;  // cpp:1578
     }
 }
 
-// ---- open-loop per-leg search: one wavefront per checkFoothold call (hpp:94-100) ----------------
+// ---- open-loop per-leg search: one wavefront per checkFoothold call (hpp:94-100) ----------------------
 struct QueryShared {
     double polyX[4][8];
     double polyY[4][8];
@@ -576,8 +714,9 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
                                                            fpe_foothold* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     QueryShared& sh = *reinterpret_cast<QueryShared*>(smem);
-    const int w = static_cast<int>(threadIdx.x) >> 6;
-    const int lane = lane_id();
+    const int tid = static_cast<int>(threadIdx.x);
+    const int w = tid >> 6;
+    const Grp<64> g(tid);
     const int q = blockIdx.x * 4 + w;
     if (q >= n) return;
     const int tileBytes = (pc.tileW * pc.tileW + 15) & ~15;
@@ -585,35 +724,31 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
 
     const fpe_leg_query* qp = queries + q;
     const int nv = qp->n_vertices;
-    if (lane < 8) {
-        sh.polyX[w][lane] = lane < nv ? qp->vx[lane] : 0.0;
-        sh.polyY[w][lane] = lane < nv ? qp->vy[lane] : 0.0;
+    if (g.sub < 8) {
+        sh.polyX[w][g.sub] = g.sub < nv ? qp->vx[g.sub] : 0.0;
+        sh.polyY[w][g.sub] = g.sub < nv ? qp->vy[g.sub] : 0.0;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
     const float Rf = qp->search_radius;
     LegCtx c;
-    init_ctx(c, m, pc, qp->cx, qp->cy, Rf);
+    c.cx = qp->cx;
+    c.cy = qp->cy;
     c.nv = nv;
     c.vx = sh.polyX[w];
     c.vy = sh.polyY[w];
     NominalOut no;
+    CentroidOut co;
     if (!centre_usable(c.cx, c.cy)) {
-        no.row = no.col = -1; no.x = c.cx; no.y = c.cy; no.z = 0.0f; no.valid = 0; no.source = 2;
+        nominal_invalid(no, c.cx, c.cy, 2);
     } else if (Rf <= pc.maxSearchRadius && Rf >= 0.0f && nv >= 0 && nv <= FPE_MAX_POLYGON_VERTICES) {
-        stage_tile(m, pc, c, tile, lane);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const float zCentre = mean_height_wave(m, pc, c.cx, c.cy, lane);
-        no = nominal_wave(m, pc, lut, c, tile, zCentre, lane);
+        const LegConst lk = make_leg_const(Rf, m.g.res);
+        search_leg<64, false>(m, pc, lut, c, lk, tile, g, no, co);
     } else {
-        no.row = no.col = -1; no.x = c.cx; no.y = c.cy; no.z = 0.0f; no.valid = 0; no.source = 3;
+        nominal_invalid(no, c.cx, c.cy, 3);
     }
-    if (lane == 0) store_foothold(out + q, no, 0, 0);
+    if (g.sub == 0) store_foothold(out + q, no, 0, 0);
 }
 
-// ---- map ingest: grid_map_msgs layout -> canonical row-major start-index-0 layer ----------------
+// ---- map ingest: grid_map_msgs layout -> canonical row-major start-index-0 layer --------------------
 // src is column-major with circular-buffer start index (si, sj): unwrapped (i, j) lives at buffer
 // index ((i + si) % rows, (j + sj) % cols) (grid_map getBufferIndexFromIndex).  32x32 tiles through
 // LDS so that both the column-major reads and the row-major writes are coalesced.
@@ -649,18 +784,28 @@ __global__ __launch_bounds__(256) void canonicalise_layer_kernel(const float* __
     }
 }
 
-// ---- launch wrappers (called from fpe_engine.cpp) -------------------------------------------------
+// ---- launch wrappers (called from fpe_engine.cpp) ---------------------------------------------------------
+static size_t tile_bytes(const PlanConsts& pc) { return static_cast<size_t>((pc.tileW * pc.tileW + 15) & ~15); }
+
+// lanes per leg for a tile of tileW^2 cells: small windows (2 cm maps) put a whole pose in one
+// wavefront; large windows give every leg its own wavefront
+int plan_group_size(const PlanConsts& pc) {
+    if (pc.groupOverride == 16 || pc.groupOverride == 64) return pc.groupOverride;
+    return (pc.tileW * pc.tileW <= 1024) ? 16 : 64;
+}
 size_t plan_lds_bytes(const PlanConsts& pc) {
-    return sizeof(PoseShared) + 4 * static_cast<size_t>((pc.tileW * pc.tileW + 15) & ~15);
+    return sizeof(PoseShared) + 4 * tile_bytes(pc);  // per block: G=16 and G=64 both hold one pose
 }
-size_t search_lds_bytes(const PlanConsts& pc) {
-    return sizeof(QueryShared) + 4 * static_cast<size_t>((pc.tileW * pc.tileW + 15) & ~15);
-}
+size_t search_lds_bytes(const PlanConsts& pc) { return sizeof(QueryShared) + 4 * tile_bytes(pc); }
 
 hipError_t launch_plan_chained(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const fpe_pose* d_poses,
                                int B, int nCycles, const fpe_plan_out& d_out, hipStream_t stream) {
     const size_t lds = plan_lds_bytes(pc);
-    hipLaunchKernelGGL(plan_chained_kernel, dim3(B), dim3(256), lds, stream, m, pc, lut, d_poses, B, nCycles, d_out);
+    if (plan_group_size(pc) == 16) {
+        hipLaunchKernelGGL(plan_chained_kernel<16>, dim3(B), dim3(64), lds, stream, m, pc, lut, d_poses, B, nCycles, d_out);
+    } else {
+        hipLaunchKernelGGL(plan_chained_kernel<64>, dim3(B), dim3(256), lds, stream, m, pc, lut, d_poses, B, nCycles, d_out);
+    }
     return hipGetLastError();
 }
 
@@ -679,8 +824,11 @@ hipError_t launch_canonicalise(const float* d_src, float* d_dst, int rows, int c
 }
 
 hipError_t set_max_lds(size_t planBytes, size_t searchBytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_chained_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_chained_kernel<16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(planBytes));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_chained_kernel<64>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(planBytes));
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(search_legs_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(searchBytes));

@@ -57,6 +57,58 @@ def test_resolutions_and_radii(planner, res, R, rows):
     util.assert_plan_equal(eng, ora)
 
 
+@pytest.mark.parametrize("group", ["16", "64"])
+def test_both_lane_groupings_agree_with_the_oracle(planner, group, monkeypatch):
+    """The chained kernel has two decompositions (16 lanes per leg = one wavefront per pose, 64 lanes
+    per leg = one wavefront per leg); both must reproduce the oracle on 2 cm and 1 cm maps."""
+    monkeypatch.setenv("FPE_PLAN_GROUP", group)
+    for res, rows, R in [(0.02, 400, 0.1), (0.01, 500, 0.12)]:
+        set_params(planner, searchRadius=np.float32(R))
+        trav, elev = synth.rough_map(rows, rows, res, seed=13, bad_frac=0.15)
+        side = rows * res
+        poses = synth.poses_in_map(160, side, side, 6, 0.18, seed=14, margin=0.7)
+        poses["gait"][::3] = 1
+        eng, ora = util.run_both(planner, trav, elev, res, poses, 6, threads=8)
+        util.assert_plan_equal(eng, ora)
+        assert (eng["nominal"]["source"] == 1).sum() > 50
+
+
+@pytest.mark.parametrize("res,R,rf", [(0.02, 0.1, 0.02), (0.01, 0.1, 0.02), (0.02, 0.1, 0.03)])
+def test_literal_disc_walk_equals_offset_table(planner, res, R, rf, monkeypatch):
+    """FPE_LITERAL_DISCS forces the per-candidate f64 bounding-box walk (the path taken when the host
+    cannot prove the foot-disc offset table rounding-robust); both must match the oracle."""
+    set_params(planner, searchRadius=np.float32(R), footRadius=np.float32(rf))
+    rows = 400
+    trav, elev = synth.rough_map(rows, rows, res, seed=17, bad_frac=0.2)
+    side = rows * res
+    poses = synth.poses_in_map(96, side, side, 5, 0.18, seed=18, margin=0.7)
+    for literal in (False, True):
+        if literal:
+            monkeypatch.setenv("FPE_LITERAL_DISCS", "1")
+        eng, ora = util.run_both(planner, trav, elev, res, poses, 5, threads=8)
+        util.assert_plan_equal(eng, ora)
+    assert (eng["nominal"]["source"] == 1).sum() > 50
+
+
+def test_exact_ties_take_the_exact_division_path(planner):
+    """Binary-exact geometry (res 0.25, radii 0.25/0.5, poses on the lattice) puts positions exactly on
+    cell boundaries, where the division-free index prediction must defer to the true division."""
+    planner.params = _capi.params_yaml()
+    for k, v in dict(footRadius=0.25, searchRadius=1.0, stepLength=1.0, length=2.0, width=1.0, l1=0.25, skew=0.25).items():
+        planner.params[k] = np.float32(v)
+    planner.params["lateralDrift"] = -0.125
+    rng = np.random.default_rng(15)
+    rows = cols = 160  # 40 x 40 m at 0.25 m
+    trav = rng.uniform(0.4, 1.0, size=(rows, cols)).astype(np.float32)
+    elev = rng.uniform(-0.5, 0.5, size=(rows, cols)).astype(np.float32)
+    xs = rng.integers(-60, 20, size=128) * 0.125
+    ys = rng.integers(-60, 60, size=128) * 0.125
+    poses = make_poses(np.stack([xs, ys, np.zeros(128)], 1))
+    eng, ora = util.run_both(planner, trav, elev, 0.25, poses, 6, threads=8)
+    util.assert_plan_equal(eng, ora)
+    assert (eng["nominal"]["source"] == 1).sum() > 20
+
+
 def test_code_default_params_foot_radius_003(planner):
     planner.params = _capi.params_code_defaults()
     trav, elev = synth.rough_map(400, 400, 0.02, seed=21)
