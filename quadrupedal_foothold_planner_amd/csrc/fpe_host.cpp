@@ -164,6 +164,8 @@ void derive_constants(const fpe_params& p, const MapGeom& geom, float maxSearchR
     c.tileWMagic = fastdiv_magic(static_cast<uint32_t>(c.tileW));
     const char* grp = std::getenv("FPE_PLAN_GROUP");
     c.groupOverride = grp ? std::atoi(grp) : 0;
+    const char* skip = std::getenv("FPE_DEBUG_SKIP");
+    c.debugSkip = skip ? std::atoi(skip) : 0;
     derive_foot_offsets(p.footRadius, geom, c);
     if (std::getenv("FPE_LITERAL_DISCS")) c.footRobust = 0;  // test knob: force the literal bounding-box walk
 }

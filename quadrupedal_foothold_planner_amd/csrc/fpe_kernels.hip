@@ -64,6 +64,82 @@ __device__ __forceinline__ void divmod_small(int t, int d, float dinv, int& q, i
 }
 __device__ __forceinline__ float rcp_small(int d) { return __frcp_rn(static_cast<float>(d)); }
 
+// Pose-level synchronisation: a pose owns one wavefront when G < 64 (LDS operations of a wavefront
+// are executed in order, so only the compiler must not reorder) and four wavefronts when G = 64.
+template <int G>
+__device__ __forceinline__ void pose_sync() {
+    if (G == 64) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- lane-transposed corner arithmetic -------------------------------------------------------------------
+// The f64 "scalar" geometry of a leg is dominated by boundPositionToRange + getIndexFromPosition of
+// box corners: CircleIterator::findSubmapParameters (2 corners x 2 axes per disc) and
+// getSubmapInformation (same for the centroid rectangle).  Instead of every lane repeating all of
+// them, lane s of a group evaluates ONE quantity — box (s >> 2) & 3, corner/axis s & 3
+// (0 top-left x, 1 top-left y, 2 bottom-right x, 3 bottom-right y) — and the integer results are
+// gathered with cross-lane reads.  Same functions, same operands: bit-identical to the scalar form.
+struct Box {
+    double cx, cy, hx, hy;  // centre and half extents: corner = centre +- half extent
+};
+struct CornerVal {
+    int idx;      // getIndexFromPosition of the bounded corner on this lane's axis
+    bool within;  // checkIfPositionWithinMap of the bounded corner on this lane's axis
+};
+__device__ __forceinline__ CornerVal corner_lane(const MapGeom& g, int sub, const Box& b0, const Box& b1, const Box& b2,
+                                                 const Box& b3) {
+    const int q = (sub >> 2) & 3, k = sub & 3;
+    const bool isY = (k & 1) != 0, isBR = (k & 2) != 0;
+    const double cx = q == 0 ? b0.cx : (q == 1 ? b1.cx : (q == 2 ? b2.cx : b3.cx));
+    const double cy = q == 0 ? b0.cy : (q == 1 ? b1.cy : (q == 2 ? b2.cy : b3.cy));
+    const double hx = q == 0 ? b0.hx : (q == 1 ? b1.hx : (q == 2 ? b2.hx : b3.hx));
+    const double hy = q == 0 ? b0.hy : (q == 1 ? b1.hy : (q == 2 ? b2.hy : b3.hy));
+    const double c = isY ? cy : cx, h = isY ? hy : hx;
+    const double v = isBR ? c - h : c + h;
+    const double org = isY ? g.orgY : g.orgX, pos = isY ? g.posY : g.posX, len = isY ? g.lenY : g.lenX;
+    const double bnd = bound_axis(v, org, pos, len);
+    CornerVal r;
+    r.idx = index_of_fast(bnd, org, pos, g.res, g.rinv);
+    r.within = within_axis(bnd, org, pos, len);
+    return r;
+}
+template <int G>
+__device__ __forceinline__ BBox gather_bbox(const Grp<G>& g, int idx, int q) {
+    BBox b;
+    b.i0 = g.bcast(idx, 4 * q + 0);
+    b.j0 = g.bcast(idx, 4 * q + 1);
+    b.ni = g.bcast(idx, 4 * q + 2) - b.i0 + 1;
+    b.nj = g.bcast(idx, 4 * q + 3) - b.j0 + 1;
+    return b;
+}
+// Tail of getSubmapInformation once the four corner indices / within flags are known.
+__device__ __forceinline__ Submap submap_from_corners(const MapGeom& g, const BBox& bb, bool allWithin, double px, double py) {
+    Submap s;
+    s.ok = false;
+    s.i0 = bb.i0;
+    s.j0 = bb.j0;
+    s.ni = bb.ni;
+    s.nj = bb.nj;
+    s.baseX = s.baseY = 0.0;
+    if (!allWithin) return s;
+    if (!in_range(s.i0, s.j0, g.rows, g.cols)) return s;  // getPositionFromIndex(topLeft) range check
+    const double cornerX = cell_pos(g.baseX, g.res, s.i0) - (-(0.5 * g.res));
+    const double cornerY = cell_pos(g.baseY, g.res, s.j0) - (-(0.5 * g.res));
+    const double subLenX = static_cast<double>(s.ni) * g.res;
+    const double subLenY = static_cast<double>(s.nj) * g.res;
+    const double subOrgX = 0.5 * subLenX, subOrgY = 0.5 * subLenY;
+    const double subPosX = cornerX - subOrgX, subPosY = cornerY - subOrgY;
+    if (!(within_axis(px, subOrgX, subPosX, subLenX) && within_axis(py, subOrgY, subPosY, subLenY))) return s;
+    s.baseX = subPosX + (subOrgX - 0.5 * g.res);
+    s.baseY = subPosY + (subOrgY - 0.5 * g.res);
+    s.ok = true;
+    return s;
+}
+
 // ---- per-leg search context (group-uniform) -----------------------------------------------------------
 struct LegCtx {
     double cx, cy;   // search centre = centroid-track next position of this leg (cpp:861-862)
@@ -111,6 +187,35 @@ __device__ void stage_region(const DevMap& m, const PlanConsts& pc, const LegCtx
         const int ta = i - c.ti0, tb = j - c.tj0;
         if (static_cast<unsigned>(ta) < static_cast<unsigned>(W) && static_cast<unsigned>(tb) < static_cast<unsigned>(W))
             tile[ta * W + tb] = classify(m, pc, i, j);
+    }
+}
+
+// Same region, one lane per ROW (small groups): no index division, one row pointer per lane.
+template <int G>
+__device__ void stage_region_rows(const DevMap& m, const PlanConsts& pc, const LegCtx& c, uint8_t* tile, const Grp<G>& g,
+                                  int i0, int j0, int ni, int nj) {
+    const int W = pc.tileW;
+    for (int rbase = 0; rbase < ni; rbase += G) {
+        const int r = rbase + g.sub;
+        const int i = i0 + r, ta = i - c.ti0;
+        if (r < ni && static_cast<unsigned>(ta) < static_cast<unsigned>(W)) {
+            const bool rowIn = i >= 0 && i < m.g.rows;
+            const float* rowp = m.trav + static_cast<size_t>(rowIn ? i : 0) * m.g.cols;
+            uint8_t* trow = tile + ta * W;
+            for (int cc = 0; cc < nj; ++cc) {
+                const int j = j0 + cc, tb = j - c.tj0;
+                if (static_cast<unsigned>(tb) >= static_cast<unsigned>(W)) continue;
+                uint8_t f = 0;
+                if (rowIn && j >= 0 && j < m.g.cols) {
+                    const float v = rowp[j];
+                    f = kFlagInMap;
+                    if (__builtin_isfinite(v)) f |= kFlagFinite;
+                    if (v < pc.thrDefault) f |= kFlagBelowDef;
+                    if (v < pc.thrCandidate) f |= kFlagBelowCand;
+                }
+                trow[tb] = f;
+            }
+        }
     }
 }
 
@@ -163,9 +268,9 @@ __device__ __forceinline__ float finish_mean(float sum, float last, int cnt, dou
 
 // getFootholdMeanHeight (cpp:2520-2554) for one disc, cooperatively.
 template <int G>
-__device__ float mean_height_grp(const DevMap& m, const PlanConsts& pc, double cx, double cy, const Grp<G>& g) {
+__device__ float mean_height_grp(const DevMap& m, const PlanConsts& pc, double cx, double cy, const BBox& bb,
+                                 const Grp<G>& g) {
     if (!centre_usable(cx, cy)) return static_cast<float>(static_cast<double>(0.0f) + pc.h);  // no cell visited
-    const BBox bb = circle_bbox_fast(m.g, cx, cy, pc.rf);
     const int nb = bb.ni * bb.nj;
     const float njInv = rcp_small(bb.nj);
     float sum = 0.0f, last = 0.0f;
@@ -328,34 +433,25 @@ __device__ CentroidOut centroid_grp(const DevMap& m, const PlanConsts& pc, const
     }
     const int ni = s.ni, nj = s.nj;
     const int ncell = ni * nj;
-    const float njInv = rcp_small(nj);
-    // whole-region test, cpp:1649-1658 (raw `<`: NaN passes)
-    bool below = false;
-    for (int t = g.sub; t < ncell; t += G) {
-        int a, bq;
-        divmod_small(t, nj, njInv, a, bq);
-        if (tile_at(tile, pc.tileW, c, s.i0 + a, s.j0 + bq) & kFlagBelowDef) below = true;
-    }
-    const bool whole = ncell > 0 && !g.any(below);
-    if (whole) {  // cpp:1684-1689
-        o.x = c.cx;
-        o.y = c.cy;
-        o.z = zCentre;
-        o.row = c.ici;
-        o.col = c.icj;
-        o.code = 0;
-        return o;
-    }
-    // row scan, cpp:1717-1750 (in-bounds columns only): lane = row
+    const int W = pc.tileW;
     const int bottomRow = ni - 1, rightCol = nj - 1;
+    // One pass, lane = row: per-row count of cells below the default threshold (raw `<`, NaN passes)
+    // gives both the whole-region test (cpp:1649-1658) and the row scan (cpp:1717-1750; in-bounds
+    // columns only).
+    bool anyBelow = false;
     int minRow = 0, maxRow = 0, k = 0;
     for (int rbase = 0; rbase < ni; rbase += G) {
         const int r = rbase + g.sub;
         bool blocked = false;
         if (r < ni) {
             int cnt = 0;
-            for (int cc = 0; cc < nj; ++cc)
-                if (tile_at(tile, pc.tileW, c, s.i0 + r, s.j0 + cc) & kFlagBelowDef) ++cnt;
+            const int ta = s.i0 + r - c.ti0, tb0 = s.j0 - c.tj0;
+            if (static_cast<unsigned>(ta) < static_cast<unsigned>(W) && tb0 >= 0 && tb0 + nj <= W) {
+                const uint8_t* trow = tile + ta * W + tb0;
+                for (int cc = 0; cc < nj; ++cc)
+                    if (trow[cc] & kFlagBelowDef) ++cnt;
+            }
+            anyBelow |= cnt > 0;
             blocked = cnt > ((rightCol + 1) * 0.5);  // cpp:1743
         }
         const unsigned long long mask = g.ballot(blocked);
@@ -364,6 +460,16 @@ __device__ CentroidOut centroid_grp(const DevMap& m, const PlanConsts& pc, const
             maxRow = rbase + 63 - __builtin_clzll(mask);
             k += __builtin_popcountll(mask);
         }
+    }
+    const bool whole = ncell > 0 && !g.any(anyBelow);
+    if (whole) {  // cpp:1684-1689
+        o.x = c.cx;
+        o.y = c.cy;
+        o.z = zCentre;
+        o.row = c.ici;
+        o.col = c.icj;
+        o.code = 0;
+        return o;
     }
     int newRow, newCol;
     if (minRow == 0 && maxRow != bottomRow) {  // case 1, cpp:1777-1786
@@ -389,9 +495,20 @@ __device__ CentroidOut centroid_grp(const DevMap& m, const PlanConsts& pc, const
     // map.getPosition(newIndex) on the SUBMAP (cpp:1816), height on the full map (cpp:1820)
     o.x = cell_pos(s.baseX, m.g.res, newRow);
     o.y = cell_pos(s.baseY, m.g.res, newCol);
-    o.z = mean_height_grp(m, pc, o.x, o.y, g);
-    o.row = index_of_fast(o.x, m.g.orgX, m.g.posX, m.g.res, m.g.rinv);
-    o.col = index_of_fast(o.y, m.g.orgY, m.g.posY, m.g.res, m.g.rinv);
+    // lanes 0-3: corners of the result's foot disc; lanes 4-5: getIndex(result) (zero half extent)
+    const Box disc{o.x, o.y, pc.rf, pc.rf}, self{o.x, o.y, 0.0, 0.0};
+    const int q = (g.sub >> 2) & 3, kk = g.sub & 3;
+    int idx;
+    if (q == 0) {
+        idx = corner_lane(m.g, g.sub, disc, disc, disc, disc).idx;
+    } else {
+        const bool isY = (kk & 1) != 0;
+        idx = index_of_fast(isY ? o.y : o.x, isY ? m.g.orgY : m.g.orgX, isY ? m.g.posY : m.g.posX, m.g.res, m.g.rinv);
+    }
+    const BBox rb = gather_bbox(g, idx, 0);
+    o.z = mean_height_grp(m, pc, o.x, o.y, rb, g);
+    o.row = g.bcast(idx, 4);
+    o.col = g.bcast(idx, 5);
     return o;
 }
 
@@ -430,34 +547,39 @@ __device__ __forceinline__ LegConst make_leg_const(float Rf, double res) {
 }
 
 // One leg: centroid method (cpp:1605-1997) + checkFoothold (cpp:2001-2036) around the same centre.
-// wantCentroid=false skips the centroid track (open-loop fpe_search_legs).
+// bb = CircleIterator box of the centre disc, s = getSubmap geometry of the centroid rectangle (both
+// from the corner lanes).  kCentroid=false skips the centroid track (open-loop fpe_search_legs).
 template <int G, bool kCentroid>
 __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, LegCtx& c, const LegConst& lk,
-                           uint8_t* tile, const Grp<G>& g, NominalOut& no, CentroidOut& co) {
+                           uint8_t* tile, const Grp<G>& g, const BBox& bb, const Submap& s, NominalOut& no,
+                           CentroidOut& co) {
     c.R2 = lk.R2;
     c.nRings = lk.nRings;
-    c.ici = index_of_fast(c.cx, m.g.orgX, m.g.posX, m.g.res, m.g.rinv);
-    c.icj = index_of_fast(c.cy, m.g.orgY, m.g.posY, m.g.res, m.g.rinv);
     c.ti0 = c.ici - pc.tileH;
     c.tj0 = c.icj - pc.tileH;
     // region needed by the common path: bounding box of the default disc (+ the centroid rectangle)
-    const BBox bb = circle_bbox_fast(m.g, c.cx, c.cy, pc.rf);  // CircleIterator(centre, footRadius)
-    Submap s;
-    s.ok = false;
     int i0 = bb.i0, j0 = bb.j0, i1 = bb.i0 + bb.ni, j1 = bb.j0 + bb.nj;
-    if (kCentroid) {
-        s = submap_info(m.g, c.cx, c.cy, lk.lx, lk.ly);  // getSubmap (cpp:1627)
-        if (s.ok) {
-            i0 = min(i0, s.i0);
-            j0 = min(j0, s.j0);
-            i1 = max(i1, s.i0 + s.ni);
-            j1 = max(j1, s.j0 + s.nj);
+    if (kCentroid && s.ok) {
+        i0 = min(i0, s.i0);
+        j0 = min(j0, s.j0);
+        i1 = max(i1, s.i0 + s.ni);
+        j1 = max(j1, s.j0 + s.nj);
+    }
+    if (!(pc.debugSkip & 8)) {
+        if (G <= 16) {
+            stage_region_rows(m, pc, c, tile, g, i0, j0, i1 - i0, j1 - j0);
+        } else {
+            stage_region(m, pc, c, tile, g, i0, j0, i1 - i0, j1 - j0);
         }
     }
-    stage_region(m, pc, c, tile, g, i0, j0, i1 - i0, j1 - j0);
-    float zCentre;
-    const bool defaultOk = centre_disc_pass(m, pc, c, tile, bb, g, zCentre);  // cpp:2012 + cpp:2029
-    if (kCentroid) co = centroid_grp(m, pc, c, tile, s, zCentre, g);          // cpp:818-821
+    float zCentre = 0.0f;
+    bool defaultOk = true;
+    if (!(pc.debugSkip & 16)) defaultOk = centre_disc_pass(m, pc, c, tile, bb, g, zCentre);  // cpp:2012 + cpp:2029
+    if (kCentroid) {
+        if (!(pc.debugSkip & 2)) co = centroid_grp(m, pc, c, tile, s, zCentre, g);  // cpp:818-821
+        else { co.x = c.cx; co.y = c.cy; co.z = zCentre; co.row = co.col = 0; co.code = 0; }
+    }
+    if (pc.debugSkip & 4) defaultOk = true;
     if (defaultOk) {
         no.valid = 1;
         no.source = 0;
@@ -591,7 +713,7 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, 4) void plan_chained_kernel(Dev
             sh.cur[t][leg][2] = sz;
         }
     }
-    __syncthreads();
+    pose_sync<G>();
 
     double adjY = 0.0;  // ajustedPose_[1], cpp:759
     const int nPhases = (gait == 1) ? 4 : 1;
@@ -606,13 +728,13 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, 4) void plan_chained_kernel(Dev
             const bool active = (mask >> leg) & 1u;
 
             // feet-polygon centres: group t computes track t (getPolygonCenter, cpp:2191, 2265)
-            if (leg < 3 && g.sub == 0) {
+            if (leg < 3 && g.sub == 0 && !((pc.debugSkip & 32) && cyc > 0)) {
                 double cx, cy;
                 polygon_center_xy(sh.cur[leg], cx, cy);
                 sh.ctr[leg][0] = cx;
                 sh.ctr[leg][1] = cy;
             }
-            __syncthreads();
+            pose_sync<G>();
 
             if (active) {
                 // next default positions of this leg on the three tracks (cpp:2199-2213, 2270-2284)
@@ -653,6 +775,8 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, 4) void plan_chained_kernel(Dev
                 NominalOut no;
                 CentroidOut co;
                 float zDefault = 0.0f;
+                BBox dbox;
+                bool haveDbox = false;
                 if (!radiusOk) {
                     nominal_invalid(no, c.cx, c.cy, 3);
                     co.x = co.y = 0.0; co.z = 0.0f; co.row = co.col = -1; co.code = 6;
@@ -660,9 +784,35 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, 4) void plan_chained_kernel(Dev
                     nominal_invalid(no, c.cx, c.cy, 2);
                     co.x = co.y = 0.0; co.z = 0.0f; co.row = co.col = -1; co.code = 6;
                 } else {
-                    search_leg<G, true>(m, pc, lut, c, lk, tile, g, no, co);
+                    // corner lanes: box 0 = centre foot disc, box 1 = centroid rectangle (half extents
+                    // 0.5*lx, 0.5*ly: p -/+ (-0.5*l) == p +/- 0.5*l exactly), box 2 = default-track disc,
+                    // box 3 = getIndex(centre) (zero half extent)
+                    const Box b0{c.cx, c.cy, pc.rf, pc.rf}, b1{c.cx, c.cy, 0.5 * lk.lx, 0.5 * lk.ly};
+                    const Box b2{nx0, ny, pc.rf, pc.rf};
+                    const int q = (g.sub >> 2) & 3, kk = g.sub & 3;
+                    CornerVal cv;
+                    if (q < 3) {
+                        cv = corner_lane(m.g, g.sub, b0, b1, b2, b2);
+                    } else {
+                        const bool isY = (kk & 1) != 0;
+                        cv.idx = index_of_fast(isY ? c.cy : c.cx, isY ? m.g.orgY : m.g.orgX, isY ? m.g.posY : m.g.posX,
+                                               m.g.res, m.g.rinv);
+                        cv.within = true;
+                    }
+                    const BBox bb = gather_bbox(g, cv.idx, 0);
+                    const BBox rbox = gather_bbox(g, cv.idx, 1);
+                    dbox = gather_bbox(g, cv.idx, 2);
+                    c.ici = g.bcast(cv.idx, 12);
+                    c.icj = g.bcast(cv.idx, 13);
+                    const bool rectWithin = ((g.ballot(cv.within) >> 4) & 0xFull) == 0xFull;
+                    const Submap sm = submap_from_corners(m.g, rbox, rectWithin, c.cx, c.cy);
+                    search_leg<G, true>(m, pc, lut, c, lk, tile, g, bb, sm, no, co);
+                    haveDbox = true;
                 }
-                if (out.default_next) zDefault = mean_height_grp(m, pc, nx0, ny, g);  // cpp:2289-2301
+                if (out.default_next && !(pc.debugSkip & 1)) {  // cpp:2289-2301
+                    if (!haveDbox) dbox = circle_bbox_fast(m.g, nx0, ny, pc.rf);
+                    zDefault = mean_height_grp(m, pc, nx0, ny, dbox, g);
+                }
                 if (g.sub == 0) {
                     sh.valid[leg] = no.valid;
                     sh.nxt[0][leg][0] = nx0;   sh.nxt[0][leg][1] = ny;    sh.nxt[0][leg][2] = static_cast<double>(zDefault);
@@ -687,14 +837,14 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, 4) void plan_chained_kernel(Dev
             } else if (g.sub == 0) {
                 sh.valid[leg] = 1;  // non-swing legs do not vote
             }
-            __syncthreads();
+            pose_sync<G>();
             // footholdValidation_ = AND of the swing legs' flags (cpp:1323); commit or skip (cpp:1332-1576)
             const bool phaseOk = (sh.valid[0] & sh.valid[1] & sh.valid[2] & sh.valid[3]) != 0;
             if (phaseOk && active && g.sub < 9) {
                 const int t = g.sub / 3, k = g.sub - t * 3;
                 sh.cur[t][leg][k] = sh.nxt[t][leg][k];
             }
-            __syncthreads();
+            pose_sync<G>();
             cycleOk = cycleOk && phaseOk;
         }
         if (leg == 0 && g.sub == 0 && live && out.cycle_ok)
@@ -741,7 +891,14 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
         nominal_invalid(no, c.cx, c.cy, 2);
     } else if (Rf <= pc.maxSearchRadius && Rf >= 0.0f && nv >= 0 && nv <= FPE_MAX_POLYGON_VERTICES) {
         const LegConst lk = make_leg_const(Rf, m.g.res);
-        search_leg<64, false>(m, pc, lut, c, lk, tile, g, no, co);
+        const Box b0{c.cx, c.cy, pc.rf, pc.rf}, self{c.cx, c.cy, 0.0, 0.0};
+        const int idx = corner_lane(m.g, g.sub, b0, self, self, self).idx;  // box 1 lanes 4,5 = getIndex(centre)
+        const BBox bb = gather_bbox(g, idx, 0);
+        c.ici = g.bcast(idx, 4);
+        c.icj = g.bcast(idx, 5);
+        Submap sm;
+        sm.ok = false;
+        search_leg<64, false>(m, pc, lut, c, lk, tile, g, bb, sm, no, co);
     } else {
         nominal_invalid(no, c.cx, c.cy, 3);
     }
