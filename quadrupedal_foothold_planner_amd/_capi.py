@@ -119,7 +119,8 @@ def lib():
     if _lib is not None:
         return _lib
     try:
-        path = _build.build_engine()
+        # FPE_LIB: load a specific prebuilt engine (kernel-variant A/B runs); default = in-tree libfpe.so
+        path = os.environ.get("FPE_LIB") or _build.build_engine()
     except Exception as e:  # hipcc missing or compile error: fail loudly, never fall back
         if not os.path.exists(_build.LIB_PATH):
             raise EngineUnavailable(f"cannot build libfpe.so: {e}") from e

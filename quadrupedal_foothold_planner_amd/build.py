@@ -37,7 +37,8 @@ def build_engine(force=False, verbose=False):
     """Build quadrupedal_foothold_planner_amd/libfpe.so if missing or stale; returns its path."""
     if not force and not _stale():
         return LIB_PATH
-    cmd = [HIPCC] + FLAGS + ["-x", "hip"] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB_PATH]
+    extra = os.environ.get("FPE_EXTRA_FLAGS", "").split()
+    cmd = [HIPCC] + FLAGS + extra + ["-x", "hip"] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

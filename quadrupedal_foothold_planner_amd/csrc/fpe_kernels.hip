@@ -173,52 +173,6 @@ __device__ __forceinline__ uint8_t classify(const DevMap& m, const PlanConsts& p
     return f;
 }
 
-// Stage a rectangle of cells [i0, i0+ni) x [j0, j0+nj) of the flag tile (coalesced row reads).
-template <int G>
-__device__ void stage_region(const DevMap& m, const PlanConsts& pc, const LegCtx& c, uint8_t* tile, const Grp<G>& g,
-                             int i0, int j0, int ni, int nj) {
-    const int W = pc.tileW;
-    const int n = ni * nj;
-    const float njInv = rcp_small(nj);
-    for (int t = g.sub; t < n; t += G) {
-        int a, bq;
-        divmod_small(t, nj, njInv, a, bq);
-        const int i = i0 + a, j = j0 + bq;
-        const int ta = i - c.ti0, tb = j - c.tj0;
-        if (static_cast<unsigned>(ta) < static_cast<unsigned>(W) && static_cast<unsigned>(tb) < static_cast<unsigned>(W))
-            tile[ta * W + tb] = classify(m, pc, i, j);
-    }
-}
-
-// Same region, one lane per ROW (small groups): no index division, one row pointer per lane.
-template <int G>
-__device__ void stage_region_rows(const DevMap& m, const PlanConsts& pc, const LegCtx& c, uint8_t* tile, const Grp<G>& g,
-                                  int i0, int j0, int ni, int nj) {
-    const int W = pc.tileW;
-    for (int rbase = 0; rbase < ni; rbase += G) {
-        const int r = rbase + g.sub;
-        const int i = i0 + r, ta = i - c.ti0;
-        if (r < ni && static_cast<unsigned>(ta) < static_cast<unsigned>(W)) {
-            const bool rowIn = i >= 0 && i < m.g.rows;
-            const float* rowp = m.trav + static_cast<size_t>(rowIn ? i : 0) * m.g.cols;
-            uint8_t* trow = tile + ta * W;
-            for (int cc = 0; cc < nj; ++cc) {
-                const int j = j0 + cc, tb = j - c.tj0;
-                if (static_cast<unsigned>(tb) >= static_cast<unsigned>(W)) continue;
-                uint8_t f = 0;
-                if (rowIn && j >= 0 && j < m.g.cols) {
-                    const float v = rowp[j];
-                    f = kFlagInMap;
-                    if (__builtin_isfinite(v)) f |= kFlagFinite;
-                    if (v < pc.thrDefault) f |= kFlagBelowDef;
-                    if (v < pc.thrCandidate) f |= kFlagBelowCand;
-                }
-                trow[tb] = f;
-            }
-        }
-    }
-}
-
 // Full spiral window, with the polygon test folded in (only when the spiral search runs).
 // checkCirclePolygonFoothold (cpp:2132-2138): a FINITE cell fails when it is below the candidate
 // threshold or its centre is outside the polygon; non-finite cells never fail.
@@ -264,69 +218,6 @@ __device__ __forceinline__ void accumulate_heights(const Grp<G>& g, bool vis, fl
 __device__ __forceinline__ float finish_mean(float sum, float last, int cnt, double h) {
     const float mean = (cnt != 0) ? (sum / cnt) : last;       // cpp:2547-2551
     return static_cast<float>(static_cast<double>(mean) + h);  // cpp:2553 (float + double)
-}
-
-// getFootholdMeanHeight (cpp:2520-2554) for one disc, cooperatively.
-template <int G>
-__device__ float mean_height_grp(const DevMap& m, const PlanConsts& pc, double cx, double cy, const BBox& bb,
-                                 const Grp<G>& g) {
-    if (!centre_usable(cx, cy)) return static_cast<float>(static_cast<double>(0.0f) + pc.h);  // no cell visited
-    const int nb = bb.ni * bb.nj;
-    const float njInv = rcp_small(bb.nj);
-    float sum = 0.0f, last = 0.0f;
-    int cnt = 0;
-    for (int base = 0; base < nb; base += G) {
-        const int t = base + g.sub;
-        bool vis = false;
-        float v = 0.0f;
-        if (t < nb) {
-            int a, bq;
-            divmod_small(t, bb.nj, njInv, a, bq);
-            const int i = bb.i0 + a, j = bb.j0 + bq;
-            if (in_range(i, j, m.g.rows, m.g.cols) && cell_in_disc(m.g, i, j, cx, cy, pc.rf2)) {
-                vis = true;
-                const float e = m.elev[static_cast<size_t>(i) * m.g.cols + j];
-                v = __builtin_isfinite(e) ? e : 0.0f;  // cpp:2532-2537
-            }
-        }
-        accumulate_heights(g, vis, v, sum, last, cnt);
-    }
-    return finish_mean(sum, last, cnt, pc.h);
-}
-
-// One pass over the disc around the CONTINUOUS centre that serves both
-//   checkDefaultFoothold (cpp:2039-2082): valid iff >= 1 cell visited and no finite visited cell is
-//     below defaultFootholdThreshold_ (flags from the LDS tile), and
-//   getFootholdMeanHeight at the centre (cpp:2029, 1687): elevation straight from HBM/L2.
-template <int G>
-__device__ bool centre_disc_pass(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const uint8_t* tile,
-                                 const BBox& bb, const Grp<G>& g, float& zCentre) {
-    const int nb = bb.ni * bb.nj;
-    const float njInv = rcp_small(bb.nj);
-    float sum = 0.0f, last = 0.0f;
-    int cnt = 0;
-    bool any = false, fail = false;
-    for (int base = 0; base < nb; base += G) {
-        const int t = base + g.sub;
-        bool vis = false;
-        float v = 0.0f;
-        if (t < nb) {
-            int a, bq;
-            divmod_small(t, bb.nj, njInv, a, bq);
-            const int i = bb.i0 + a, j = bb.j0 + bq;
-            if (in_range(i, j, m.g.rows, m.g.cols) && cell_in_disc(m.g, i, j, c.cx, c.cy, pc.rf2)) {
-                vis = true;
-                const float e = m.elev[static_cast<size_t>(i) * m.g.cols + j];
-                v = __builtin_isfinite(e) ? e : 0.0f;
-                const uint8_t f = tile_at(tile, pc.tileW, c, i, j);
-                if ((f & kFlagFinite) && (f & kFlagBelowDef)) fail = true;
-            }
-        }
-        any |= vis;
-        accumulate_heights(g, vis, v, sum, last, cnt);
-    }
-    zCentre = finish_mean(sum, last, cnt, pc.h);
-    return g.any(any) && !g.any(fail);
 }
 
 // A finite cell fails checkCirclePolygonFoothold's test (cpp:2132-2138) when it is below the
@@ -406,6 +297,49 @@ __device__ bool candidate_search_grp(const DevMap& m, const PlanConsts& pc, cons
     return false;
 }
 
+// ---- direct (L1/L2-served) passes of the common path ------------------------------------------------------
+// At small windows the cells a leg needs in the common case — the default disc and the centroid
+// rectangle, ~10^2 cells — are cheaper to read once straight from the cache hierarchy (lane = cell,
+// lane = row) than to stage through LDS first; the LDS tile is kept for the spiral window of
+// large foot discs (stage_full_tile).
+
+// One pass over a CircleIterator disc (centre c, bounding box bb), lanes = cells in row-major order:
+// getFootholdMeanHeight (cpp:2520-2554) and, when kCheck, checkDefaultFoothold (cpp:2039-2082):
+// valid iff >= 1 cell visited and no finite visited cell is below defaultFootholdThreshold_.
+template <int G, bool kCheck>
+__device__ __forceinline__ float disc_pass_direct(const DevMap& m, const PlanConsts& pc, double cx, double cy,
+                                                  const BBox& bb, const Grp<G>& g, bool& defaultOk) {
+    const int nb = bb.ni * bb.nj;
+    const float njInv = rcp_small(bb.nj);
+    float sum = 0.0f, last = 0.0f;
+    int cnt = 0;
+    bool any = false, fail = false;
+    for (int base = 0; base < nb; base += G) {
+        const int t = base + g.sub;
+        bool vis = false;
+        float v = 0.0f;
+        if (t < nb) {
+            int a, bq;
+            divmod_small(t, bb.nj, njInv, a, bq);
+            const int i = bb.i0 + a, j = bb.j0 + bq;
+            if (in_range(i, j, m.g.rows, m.g.cols) && cell_in_disc(m.g, i, j, cx, cy, pc.rf2)) {
+                vis = true;
+                const size_t off = static_cast<size_t>(i) * m.g.cols + j;
+                const float e = m.elev[off];
+                if (kCheck) {
+                    const float tv = m.trav[off];
+                    if (__builtin_isfinite(tv) && tv < pc.thrDefault) fail = true;  // cpp:2055-2057
+                }
+                v = __builtin_isfinite(e) ? e : 0.0f;  // cpp:2532-2537
+            }
+        }
+        any |= vis;
+        accumulate_heights(g, vis, v, sum, last, cnt);
+    }
+    if (kCheck) defaultOk = g.any(any) && !g.any(fail);
+    return finish_mean(sum, last, cnt, pc.h);
+}
+
 constexpr int kOnDemandMaxFoot = 4;
 
 struct CentroidOut {
@@ -433,7 +367,6 @@ __device__ CentroidOut centroid_grp(const DevMap& m, const PlanConsts& pc, const
     }
     const int ni = s.ni, nj = s.nj;
     const int ncell = ni * nj;
-    const int W = pc.tileW;
     const int bottomRow = ni - 1, rightCol = nj - 1;
     // One pass, lane = row: per-row count of cells below the default threshold (raw `<`, NaN passes)
     // gives both the whole-region test (cpp:1649-1658) and the row scan (cpp:1717-1750; in-bounds
@@ -445,12 +378,10 @@ __device__ CentroidOut centroid_grp(const DevMap& m, const PlanConsts& pc, const
         bool blocked = false;
         if (r < ni) {
             int cnt = 0;
-            const int ta = s.i0 + r - c.ti0, tb0 = s.j0 - c.tj0;
-            if (static_cast<unsigned>(ta) < static_cast<unsigned>(W) && tb0 >= 0 && tb0 + nj <= W) {
-                const uint8_t* trow = tile + ta * W + tb0;
-                for (int cc = 0; cc < nj; ++cc)
-                    if (trow[cc] & kFlagBelowDef) ++cnt;
-            }
+            // the rectangle lies inside the map (clamped corners, s.ok): raw `<`, NaN passes (cpp:1653, 1736)
+            const float* rowp = m.trav + static_cast<size_t>(s.i0 + r) * m.g.cols + s.j0;
+            for (int cc = 0; cc < nj; ++cc)
+                if (rowp[cc] < pc.thrDefault) ++cnt;
             anyBelow |= cnt > 0;
             blocked = cnt > ((rightCol + 1) * 0.5);  // cpp:1743
         }
@@ -496,7 +427,7 @@ __device__ CentroidOut centroid_grp(const DevMap& m, const PlanConsts& pc, const
     o.x = cell_pos(s.baseX, m.g.res, newRow);
     o.y = cell_pos(s.baseY, m.g.res, newCol);
     // lanes 0-3: corners of the result's foot disc; lanes 4-5: getIndex(result) (zero half extent)
-    const Box disc{o.x, o.y, pc.rf, pc.rf}, self{o.x, o.y, 0.0, 0.0};
+    const Box disc{o.x, o.y, pc.rf, pc.rf};
     const int q = (g.sub >> 2) & 3, kk = g.sub & 3;
     int idx;
     if (q == 0) {
@@ -506,7 +437,8 @@ __device__ CentroidOut centroid_grp(const DevMap& m, const PlanConsts& pc, const
         idx = index_of_fast(isY ? o.y : o.x, isY ? m.g.orgY : m.g.orgX, isY ? m.g.posY : m.g.posX, m.g.res, m.g.rinv);
     }
     const BBox rb = gather_bbox(g, idx, 0);
-    o.z = mean_height_grp(m, pc, o.x, o.y, rb, g);
+    bool unused;
+    o.z = disc_pass_direct<G, false>(m, pc, o.x, o.y, rb, g, unused);
     o.row = g.bcast(idx, 4);
     o.col = g.bcast(idx, 5);
     return o;
@@ -557,29 +489,9 @@ __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLu
     c.nRings = lk.nRings;
     c.ti0 = c.ici - pc.tileH;
     c.tj0 = c.icj - pc.tileH;
-    // region needed by the common path: bounding box of the default disc (+ the centroid rectangle)
-    int i0 = bb.i0, j0 = bb.j0, i1 = bb.i0 + bb.ni, j1 = bb.j0 + bb.nj;
-    if (kCentroid && s.ok) {
-        i0 = min(i0, s.i0);
-        j0 = min(j0, s.j0);
-        i1 = max(i1, s.i0 + s.ni);
-        j1 = max(j1, s.j0 + s.nj);
-    }
-    if (!(pc.debugSkip & 8)) {
-        if (G <= 16) {
-            stage_region_rows(m, pc, c, tile, g, i0, j0, i1 - i0, j1 - j0);
-        } else {
-            stage_region(m, pc, c, tile, g, i0, j0, i1 - i0, j1 - j0);
-        }
-    }
-    float zCentre = 0.0f;
     bool defaultOk = true;
-    if (!(pc.debugSkip & 16)) defaultOk = centre_disc_pass(m, pc, c, tile, bb, g, zCentre);  // cpp:2012 + cpp:2029
-    if (kCentroid) {
-        if (!(pc.debugSkip & 2)) co = centroid_grp(m, pc, c, tile, s, zCentre, g);  // cpp:818-821
-        else { co.x = c.cx; co.y = c.cy; co.z = zCentre; co.row = co.col = 0; co.code = 0; }
-    }
-    if (pc.debugSkip & 4) defaultOk = true;
+    const float zCentre = disc_pass_direct<G, true>(m, pc, c.cx, c.cy, bb, g, defaultOk);  // cpp:2012 + cpp:2029
+    if (kCentroid) co = centroid_grp(m, pc, c, tile, s, zCentre, g);                          // cpp:818-821
     if (defaultOk) {
         no.valid = 1;
         no.source = 0;
@@ -661,8 +573,11 @@ struct PoseShared {
 // ---- chained plan kernel ------------------------------------------------------------------------------
 // G lanes per leg; a pose owns 4*G consecutive threads; block = max(64, 4*G) threads holds
 // PPB = blockDim / (4*G) poses.  Dynamic LDS per pose = sizeof(PoseShared) + 4 * tileBytes.
+#ifndef FPE_MINWAVES
+#define FPE_MINWAVES 4
+#endif
 template <int G>
-__global__ __launch_bounds__(G == 64 ? 256 : 64, 4) void plan_chained_kernel(DevMap m, PlanConsts pc, SpiralLut lut,
+__global__ __launch_bounds__(G == 64 ? 256 : 64, FPE_MINWAVES) void plan_chained_kernel(DevMap m, PlanConsts pc, SpiralLut lut,
                                                                            const fpe_pose* __restrict__ poses, int B,
                                                                            int nCycles, fpe_plan_out out) {
     constexpr int kPoseThreads = 4 * G;
@@ -728,7 +643,7 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, 4) void plan_chained_kernel(Dev
             const bool active = (mask >> leg) & 1u;
 
             // feet-polygon centres: group t computes track t (getPolygonCenter, cpp:2191, 2265)
-            if (leg < 3 && g.sub == 0 && !((pc.debugSkip & 32) && cyc > 0)) {
+            if (leg < 3 && g.sub == 0) {
                 double cx, cy;
                 polygon_center_xy(sh.cur[leg], cx, cy);
                 sh.ctr[leg][0] = cx;
@@ -809,9 +724,14 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, 4) void plan_chained_kernel(Dev
                     search_leg<G, true>(m, pc, lut, c, lk, tile, g, bb, sm, no, co);
                     haveDbox = true;
                 }
-                if (out.default_next && !(pc.debugSkip & 1)) {  // cpp:2289-2301
-                    if (!haveDbox) dbox = circle_bbox_fast(m.g, nx0, ny, pc.rf);
-                    zDefault = mean_height_grp(m, pc, nx0, ny, dbox, g);
+                if (out.default_next) {  // cpp:2289-2301
+                    if (!centre_usable(nx0, ny)) {
+                        zDefault = static_cast<float>(static_cast<double>(0.0f) + pc.h);  // no cell visited
+                    } else {
+                        if (!haveDbox) dbox = circle_bbox_fast(m.g, nx0, ny, pc.rf);
+                        bool unused;
+                        zDefault = disc_pass_direct<G, false>(m, pc, nx0, ny, dbox, g, unused);
+                    }
                 }
                 if (g.sub == 0) {
                     sh.valid[leg] = no.valid;
