@@ -90,32 +90,59 @@ struct CornerVal {
     int idx;      // getIndexFromPosition of the bounded corner on this lane's axis
     bool within;  // checkIfPositionWithinMap of the bounded corner on this lane's axis
 };
-__device__ __forceinline__ CornerVal corner_lane(const MapGeom& g, int sub, const Box& b0, const Box& b1, const Box& b2,
-                                                 const Box& b3) {
-    const int q = (sub >> 2) & 3, k = sub & 3;
+// Quantity `id` = box (id >> 2) & 3, corner/axis id & 3.  A box whose bit is set in rawBoxMask is a
+// plain getIndexFromPosition of its centre (no boundPositionToRange), e.g. getIndex(search centre).
+__device__ __forceinline__ CornerVal corner_quantity(const MapGeom& g, int id, const Box& b0, const Box& b1,
+                                                     const Box& b2, const Box& b3, unsigned rawBoxMask) {
+    const int q = (id >> 2) & 3, k = id & 3;
     const bool isY = (k & 1) != 0, isBR = (k & 2) != 0;
+    const bool raw = ((rawBoxMask >> q) & 1u) != 0;
     const double cx = q == 0 ? b0.cx : (q == 1 ? b1.cx : (q == 2 ? b2.cx : b3.cx));
     const double cy = q == 0 ? b0.cy : (q == 1 ? b1.cy : (q == 2 ? b2.cy : b3.cy));
     const double hx = q == 0 ? b0.hx : (q == 1 ? b1.hx : (q == 2 ? b2.hx : b3.hx));
     const double hy = q == 0 ? b0.hy : (q == 1 ? b1.hy : (q == 2 ? b2.hy : b3.hy));
     const double c = isY ? cy : cx, h = isY ? hy : hx;
-    const double v = isBR ? c - h : c + h;
     const double org = isY ? g.orgY : g.orgX, pos = isY ? g.posY : g.posX, len = isY ? g.lenY : g.lenX;
-    const double bnd = bound_axis(v, org, pos, len);
+    const double v = isBR ? c - h : c + h;
+    const double bnd = raw ? c : bound_axis(v, org, pos, len);
     CornerVal r;
     r.idx = index_of_fast(bnd, org, pos, g.res, g.rinv);
-    r.within = within_axis(bnd, org, pos, len);
+    r.within = raw || within_axis(bnd, org, pos, len);
     return r;
 }
-template <int G>
-__device__ __forceinline__ BBox gather_bbox(const Grp<G>& g, int idx, int q) {
-    BBox b;
-    b.i0 = g.bcast(idx, 4 * q + 0);
-    b.j0 = g.bcast(idx, 4 * q + 1);
-    b.ni = g.bcast(idx, 4 * q + 2) - b.i0 + 1;
-    b.nj = g.bcast(idx, 4 * q + 3) - b.j0 + 1;
-    return b;
-}
+
+// NQ quantities (8 or 16) evaluated min(G,16) at a time by the lanes of a group.
+template <int G, int NQ>
+struct Corners {
+    static constexpr int L = (G < 16) ? G : 16;          // lanes used per pass
+    static constexpr int P = (NQ + L - 1) / L;           // passes
+    int idx[P];
+    unsigned within;                                      // bit id = within flag of quantity id
+
+    __device__ __forceinline__ void eval(const MapGeom& mg, const Grp<G>& g, const Box& b0, const Box& b1, const Box& b2,
+                                         const Box& b3, unsigned rawBoxMask) {
+        within = 0u;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int id = (p * L + (g.sub & (L - 1))) & (NQ - 1);
+            const CornerVal cv = corner_quantity(mg, id, b0, b1, b2, b3, rawBoxMask);
+            idx[p] = cv.idx;
+            const unsigned bits = static_cast<unsigned>(g.ballot(cv.within)) & ((1u << L) - 1u);
+            within |= bits << (p * L);
+        }
+    }
+    __device__ __forceinline__ int get(const Grp<G>& g, int id) const { return g.bcast(idx[id / L], id % L); }
+    __device__ __forceinline__ BBox bbox(const Grp<G>& g, int q) const {
+        BBox b;
+        b.i0 = get(g, 4 * q + 0);
+        b.j0 = get(g, 4 * q + 1);
+        b.ni = get(g, 4 * q + 2) - b.i0 + 1;
+        b.nj = get(g, 4 * q + 3) - b.j0 + 1;
+        return b;
+    }
+    __device__ __forceinline__ bool box_within(int q) const { return ((within >> (4 * q)) & 0xFu) == 0xFu; }
+};
+
 // Tail of getSubmapInformation once the four corner indices / within flags are known.
 __device__ __forceinline__ Submap submap_from_corners(const MapGeom& g, const BBox& bb, bool allWithin, double px, double py) {
     Submap s;
@@ -426,21 +453,15 @@ __device__ CentroidOut centroid_grp(const DevMap& m, const PlanConsts& pc, const
     // map.getPosition(newIndex) on the SUBMAP (cpp:1816), height on the full map (cpp:1820)
     o.x = cell_pos(s.baseX, m.g.res, newRow);
     o.y = cell_pos(s.baseY, m.g.res, newCol);
-    // lanes 0-3: corners of the result's foot disc; lanes 4-5: getIndex(result) (zero half extent)
+    // quantities 0-3: corners of the result's foot disc; 4-5: getIndex(result)
     const Box disc{o.x, o.y, pc.rf, pc.rf};
-    const int q = (g.sub >> 2) & 3, kk = g.sub & 3;
-    int idx;
-    if (q == 0) {
-        idx = corner_lane(m.g, g.sub, disc, disc, disc, disc).idx;
-    } else {
-        const bool isY = (kk & 1) != 0;
-        idx = index_of_fast(isY ? o.y : o.x, isY ? m.g.orgY : m.g.orgX, isY ? m.g.posY : m.g.posX, m.g.res, m.g.rinv);
-    }
-    const BBox rb = gather_bbox(g, idx, 0);
+    Corners<G, 8> cr;
+    cr.eval(m.g, g, disc, disc, disc, disc, 0x2u);
+    const BBox rb = cr.bbox(g, 0);
     bool unused;
     o.z = disc_pass_direct<G, false>(m, pc, o.x, o.y, rb, g, unused);
-    o.row = g.bcast(idx, 4);
-    o.col = g.bcast(idx, 5);
+    o.row = cr.get(g, 4);
+    o.col = cr.get(g, 5);
     return o;
 }
 
@@ -577,7 +598,7 @@ struct PoseShared {
 #define FPE_MINWAVES 4
 #endif
 template <int G>
-__global__ __launch_bounds__(G == 64 ? 256 : 64, FPE_MINWAVES) void plan_chained_kernel(DevMap m, PlanConsts pc, SpiralLut lut,
+__global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MINWAVES : 2)) void plan_chained_kernel(DevMap m, PlanConsts pc, SpiralLut lut,
                                                                            const fpe_pose* __restrict__ poses, int B,
                                                                            int nCycles, fpe_plan_out out) {
     constexpr int kPoseThreads = 4 * G;
@@ -704,22 +725,14 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, FPE_MINWAVES) void plan_chained
                     // box 3 = getIndex(centre) (zero half extent)
                     const Box b0{c.cx, c.cy, pc.rf, pc.rf}, b1{c.cx, c.cy, 0.5 * lk.lx, 0.5 * lk.ly};
                     const Box b2{nx0, ny, pc.rf, pc.rf};
-                    const int q = (g.sub >> 2) & 3, kk = g.sub & 3;
-                    CornerVal cv;
-                    if (q < 3) {
-                        cv = corner_lane(m.g, g.sub, b0, b1, b2, b2);
-                    } else {
-                        const bool isY = (kk & 1) != 0;
-                        cv.idx = index_of_fast(isY ? c.cy : c.cx, isY ? m.g.orgY : m.g.orgX, isY ? m.g.posY : m.g.posX,
-                                               m.g.res, m.g.rinv);
-                        cv.within = true;
-                    }
-                    const BBox bb = gather_bbox(g, cv.idx, 0);
-                    const BBox rbox = gather_bbox(g, cv.idx, 1);
-                    dbox = gather_bbox(g, cv.idx, 2);
-                    c.ici = g.bcast(cv.idx, 12);
-                    c.icj = g.bcast(cv.idx, 13);
-                    const bool rectWithin = ((g.ballot(cv.within) >> 4) & 0xFull) == 0xFull;
+                    Corners<G, 16> cs;
+                    cs.eval(m.g, g, b0, b1, b2, b0, 0x8u);
+                    const BBox bb = cs.bbox(g, 0);
+                    const BBox rbox = cs.bbox(g, 1);
+                    dbox = cs.bbox(g, 2);
+                    c.ici = cs.get(g, 12);
+                    c.icj = cs.get(g, 13);
+                    const bool rectWithin = cs.box_within(1);
                     const Submap sm = submap_from_corners(m.g, rbox, rectWithin, c.cx, c.cy);
                     search_leg<G, true>(m, pc, lut, c, lk, tile, g, bb, sm, no, co);
                     haveDbox = true;
@@ -760,9 +773,11 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, FPE_MINWAVES) void plan_chained
             pose_sync<G>();
             // footholdValidation_ = AND of the swing legs' flags (cpp:1323); commit or skip (cpp:1332-1576)
             const bool phaseOk = (sh.valid[0] & sh.valid[1] & sh.valid[2] & sh.valid[3]) != 0;
-            if (phaseOk && active && g.sub < 9) {
-                const int t = g.sub / 3, k = g.sub - t * 3;
-                sh.cur[t][leg][k] = sh.nxt[t][leg][k];
+            if (phaseOk && active) {
+                for (int e = g.sub; e < 9; e += G) {
+                    const int t = e / 3, k = e - t * 3;
+                    sh.cur[t][leg][k] = sh.nxt[t][leg][k];
+                }
             }
             pose_sync<G>();
             cycleOk = cycleOk && phaseOk;
@@ -811,11 +826,12 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
         nominal_invalid(no, c.cx, c.cy, 2);
     } else if (Rf <= pc.maxSearchRadius && Rf >= 0.0f && nv >= 0 && nv <= FPE_MAX_POLYGON_VERTICES) {
         const LegConst lk = make_leg_const(Rf, m.g.res);
-        const Box b0{c.cx, c.cy, pc.rf, pc.rf}, self{c.cx, c.cy, 0.0, 0.0};
-        const int idx = corner_lane(m.g, g.sub, b0, self, self, self).idx;  // box 1 lanes 4,5 = getIndex(centre)
-        const BBox bb = gather_bbox(g, idx, 0);
-        c.ici = g.bcast(idx, 4);
-        c.icj = g.bcast(idx, 5);
+        const Box b0{c.cx, c.cy, pc.rf, pc.rf};
+        Corners<64, 8> cs;
+        cs.eval(m.g, g, b0, b0, b0, b0, 0x2u);  // quantities 4,5 = getIndex(centre)
+        const BBox bb = cs.bbox(g, 0);
+        c.ici = cs.get(g, 4);
+        c.icj = cs.get(g, 5);
         Submap sm;
         sm.ok = false;
         search_leg<64, false>(m, pc, lut, c, lk, tile, g, bb, sm, no, co);
@@ -867,18 +883,26 @@ static size_t tile_bytes(const PlanConsts& pc) { return static_cast<size_t>((pc.
 // lanes per leg for a tile of tileW^2 cells: small windows (2 cm maps) put a whole pose in one
 // wavefront; large windows give every leg its own wavefront
 int plan_group_size(const PlanConsts& pc) {
-    if (pc.groupOverride == 16 || pc.groupOverride == 64) return pc.groupOverride;
-    return (pc.tileW * pc.tileW <= 1024) ? 16 : 64;
+    if (pc.groupOverride == 4 || pc.groupOverride == 8 || pc.groupOverride == 16 || pc.groupOverride == 64)
+        return pc.groupOverride;
+    return (pc.tileW * pc.tileW <= 1024) ? 8 : 64;
 }
 size_t plan_lds_bytes(const PlanConsts& pc) {
-    return sizeof(PoseShared) + 4 * tile_bytes(pc);  // per block: G=16 and G=64 both hold one pose
+    const int G = plan_group_size(pc);
+    const int ppb = G >= 16 ? 1 : 64 / (4 * G);  // poses per 64-thread block
+    return ppb * (sizeof(PoseShared) + 4 * tile_bytes(pc));
 }
 size_t search_lds_bytes(const PlanConsts& pc) { return sizeof(QueryShared) + 4 * tile_bytes(pc); }
 
 hipError_t launch_plan_chained(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const fpe_pose* d_poses,
                                int B, int nCycles, const fpe_plan_out& d_out, hipStream_t stream) {
     const size_t lds = plan_lds_bytes(pc);
-    if (plan_group_size(pc) == 16) {
+    const int G = plan_group_size(pc);
+    if (G == 4) {
+        hipLaunchKernelGGL(plan_chained_kernel<4>, dim3((B + 3) / 4), dim3(64), lds, stream, m, pc, lut, d_poses, B, nCycles, d_out);
+    } else if (G == 8) {
+        hipLaunchKernelGGL(plan_chained_kernel<8>, dim3((B + 1) / 2), dim3(64), lds, stream, m, pc, lut, d_poses, B, nCycles, d_out);
+    } else if (G == 16) {
         hipLaunchKernelGGL(plan_chained_kernel<16>, dim3(B), dim3(64), lds, stream, m, pc, lut, d_poses, B, nCycles, d_out);
     } else {
         hipLaunchKernelGGL(plan_chained_kernel<64>, dim3(B), dim3(256), lds, stream, m, pc, lut, d_poses, B, nCycles, d_out);
@@ -903,6 +927,12 @@ hipError_t launch_canonicalise(const float* d_src, float* d_dst, int rows, int c
 hipError_t set_max_lds(size_t planBytes, size_t searchBytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_chained_kernel<16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(planBytes));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_chained_kernel<8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(planBytes));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_chained_kernel<4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(planBytes));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_chained_kernel<64>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(planBytes));
