@@ -367,6 +367,61 @@ __device__ __forceinline__ float disc_pass_direct(const DevMap& m, const PlanCon
     return finish_mean(sum, last, cnt, pc.h);
 }
 
+// Two-phase form of disc_pass_direct for memory-level parallelism: disc_issue() computes
+// membership and issues the loads of up to kDiscRounds*G cells; disc_consume() runs after other
+// independent work (the centroid row scan) has overlapped their latency.  Larger discs fall back to
+// the single-phase pass inside disc_consume().
+constexpr int kDiscRounds = 2;
+struct DiscLoads {
+    float e[kDiscRounds];  // elevation of this lane's cell in round r
+    float t[kDiscRounds];  // traversability (centre disc only)
+    bool vis[kDiscRounds];
+    bool pipelined;
+};
+template <int G, bool kCheck>
+__device__ __forceinline__ void disc_issue(const DevMap& m, const PlanConsts& pc, double cx, double cy, const BBox& bb,
+                                           const Grp<G>& g, DiscLoads& d) {
+    const int nb = bb.ni * bb.nj;
+    d.pipelined = nb <= kDiscRounds * G;
+    if (!d.pipelined) return;
+    const float njInv = rcp_small(bb.nj);
+#pragma unroll
+    for (int r = 0; r < kDiscRounds; ++r) {
+        const int t = r * G + g.sub;
+        d.vis[r] = false;
+        d.e[r] = 0.0f;
+        d.t[r] = 0.0f;
+        if (t < nb) {
+            int a, bq;
+            divmod_small(t, bb.nj, njInv, a, bq);
+            const int i = bb.i0 + a, j = bb.j0 + bq;
+            if (in_range(i, j, m.g.rows, m.g.cols) && cell_in_disc(m.g, i, j, cx, cy, pc.rf2)) {
+                d.vis[r] = true;
+                const size_t off = static_cast<size_t>(i) * m.g.cols + j;
+                d.e[r] = m.elev[off];
+                if (kCheck) d.t[r] = m.trav[off];
+            }
+        }
+    }
+}
+template <int G, bool kCheck>
+__device__ __forceinline__ float disc_consume(const DevMap& m, const PlanConsts& pc, double cx, double cy, const BBox& bb,
+                                              const Grp<G>& g, const DiscLoads& d, bool& defaultOk) {
+    if (!d.pipelined) return disc_pass_direct<G, kCheck>(m, pc, cx, cy, bb, g, defaultOk);
+    float sum = 0.0f, last = 0.0f;
+    int cnt = 0;
+    bool any = false, fail = false;
+#pragma unroll
+    for (int r = 0; r < kDiscRounds; ++r) {
+        const float v = __builtin_isfinite(d.e[r]) ? d.e[r] : 0.0f;                                 // cpp:2532-2537
+        if (kCheck && d.vis[r] && __builtin_isfinite(d.t[r]) && d.t[r] < pc.thrDefault) fail = true;  // cpp:2055-2057
+        any |= d.vis[r];
+        accumulate_heights(g, d.vis[r], v, sum, last, cnt);
+    }
+    if (kCheck) defaultOk = g.any(any) && !g.any(fail);
+    return finish_mean(sum, last, cnt, pc.h);
+}
+
 constexpr int kOnDemandMaxFoot = 4;
 
 struct CentroidOut {
@@ -378,26 +433,21 @@ struct CentroidOut {
 
 // checkFootholdUseCentroidMethod (cpp:1605-1997) on the rectangle s around the centre (flags
 // already staged).  zCentre = mean height at the centre (whole-region-valid result, cpp:1687).
+struct CentroidScan {
+    bool whole;
+    int minRow, maxRow;
+};
+// Row scan of the centroid rectangle, lane = row: per-row count of cells below the default threshold
+// (raw `<`, NaN passes) gives both the whole-region test (cpp:1649-1658) and the first/last blocked
+// rows (cpp:1717-1750; in-bounds columns only).
 template <int G>
-__device__ CentroidOut centroid_grp(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const uint8_t* tile,
-                                    const Submap& s, float zCentre, const Grp<G>& g) {
-    CentroidOut o;
-    o.x = 0.0;
-    o.y = 0.0;
-    o.z = 0.0f;
-    o.row = -1;
-    o.col = -1;
-    o.code = 5;
-    if (!s.ok) {  // cpp:1628-1631
-        o.code = 6;
-        return o;
-    }
+__device__ CentroidScan centroid_scan(const DevMap& m, const PlanConsts& pc, const Submap& s, const Grp<G>& g) {
+    CentroidScan r0;
+    r0.whole = false;
+    r0.minRow = r0.maxRow = 0;
+    if (!s.ok) return r0;
     const int ni = s.ni, nj = s.nj;
-    const int ncell = ni * nj;
-    const int bottomRow = ni - 1, rightCol = nj - 1;
-    // One pass, lane = row: per-row count of cells below the default threshold (raw `<`, NaN passes)
-    // gives both the whole-region test (cpp:1649-1658) and the row scan (cpp:1717-1750; in-bounds
-    // columns only).
+    const int rightCol = nj - 1;
     bool anyBelow = false;
     int minRow = 0, maxRow = 0, k = 0;
     for (int rbase = 0; rbase < ni; rbase += G) {
@@ -419,8 +469,31 @@ __device__ CentroidOut centroid_grp(const DevMap& m, const PlanConsts& pc, const
             k += __builtin_popcountll(mask);
         }
     }
-    const bool whole = ncell > 0 && !g.any(anyBelow);
-    if (whole) {  // cpp:1684-1689
+    r0.whole = ni * nj > 0 && !g.any(anyBelow);
+    r0.minRow = minRow;
+    r0.maxRow = maxRow;
+    return r0;
+}
+
+// checkFootholdUseCentroidMethod (cpp:1605-1997) given the row scan.  zCentre = mean height at the
+// centre (the whole-region-valid result reuses it, cpp:1687).
+template <int G>
+__device__ CentroidOut centroid_finish(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const Submap& s,
+                                       const CentroidScan& sc, float zCentre, const Grp<G>& g) {
+    CentroidOut o;
+    o.x = 0.0;
+    o.y = 0.0;
+    o.z = 0.0f;
+    o.row = -1;
+    o.col = -1;
+    o.code = 5;
+    if (!s.ok) {  // cpp:1628-1631
+        o.code = 6;
+        return o;
+    }
+    const int bottomRow = s.ni - 1, rightCol = s.nj - 1;
+    const int minRow = sc.minRow, maxRow = sc.maxRow;
+    if (sc.whole) {  // cpp:1684-1689
         o.x = c.cx;
         o.y = c.cy;
         o.z = zCentre;
@@ -499,20 +572,39 @@ __device__ __forceinline__ LegConst make_leg_const(float Rf, double res) {
     return k;
 }
 
+// Default-track mean height request (getDefaultFootholds, cpp:2289-2301) riding along with a leg search.
+struct DefaultDisc {
+    bool want;
+    double x, y;
+    BBox bb;
+    float z;
+};
+
 // One leg: centroid method (cpp:1605-1997) + checkFoothold (cpp:2001-2036) around the same centre.
 // bb = CircleIterator box of the centre disc, s = getSubmap geometry of the centroid rectangle (both
 // from the corner lanes).  kCentroid=false skips the centroid track (open-loop fpe_search_legs).
 template <int G, bool kCentroid>
 __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, LegCtx& c, const LegConst& lk,
-                           uint8_t* tile, const Grp<G>& g, const BBox& bb, const Submap& s, NominalOut& no,
-                           CentroidOut& co) {
+                           uint8_t* tile, const Grp<G>& g, const BBox& bb, const Submap& s, DefaultDisc& dflt,
+                           NominalOut& no, CentroidOut& co) {
     c.R2 = lk.R2;
     c.nRings = lk.nRings;
     c.ti0 = c.ici - pc.tileH;
     c.tj0 = c.icj - pc.tileH;
+    // issue the centre-disc (and default-track disc) loads, overlap them with the centroid row scan
+    DiscLoads dc;
+    disc_issue<G, true>(m, pc, c.cx, c.cy, bb, g, dc);
+    DiscLoads dd;
+    if (dflt.want) disc_issue<G, false>(m, pc, dflt.x, dflt.y, dflt.bb, g, dd);
+    CentroidScan sc;
+    if (kCentroid) sc = centroid_scan(m, pc, s, g);
     bool defaultOk = true;
-    const float zCentre = disc_pass_direct<G, true>(m, pc, c.cx, c.cy, bb, g, defaultOk);  // cpp:2012 + cpp:2029
-    if (kCentroid) co = centroid_grp(m, pc, c, tile, s, zCentre, g);                          // cpp:818-821
+    const float zCentre = disc_consume<G, true>(m, pc, c.cx, c.cy, bb, g, dc, defaultOk);  // cpp:2012 + cpp:2029
+    if (kCentroid) co = centroid_finish(m, pc, c, s, sc, zCentre, g);                        // cpp:818-821
+    if (dflt.want) {
+        bool unused;
+        dflt.z = disc_consume<G, false>(m, pc, dflt.x, dflt.y, dflt.bb, g, dd, unused);     // cpp:2289-2301
+    }
     if (defaultOk) {
         no.valid = 1;
         no.source = 0;
@@ -734,14 +826,21 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
                     c.icj = cs.get(g, 13);
                     const bool rectWithin = cs.box_within(1);
                     const Submap sm = submap_from_corners(m.g, rbox, rectWithin, c.cx, c.cy);
-                    search_leg<G, true>(m, pc, lut, c, lk, tile, g, bb, sm, no, co);
+                    DefaultDisc dflt;
+                    dflt.want = out.default_next != nullptr && centre_usable(nx0, ny);
+                    dflt.x = nx0;
+                    dflt.y = ny;
+                    dflt.bb = dbox;
+                    dflt.z = static_cast<float>(static_cast<double>(0.0f) + pc.h);  // value when no cell is visited
+                    search_leg<G, true>(m, pc, lut, c, lk, tile, g, bb, sm, dflt, no, co);
+                    zDefault = dflt.z;
                     haveDbox = true;
                 }
-                if (out.default_next) {  // cpp:2289-2301
+                if (out.default_next && !haveDbox) {  // cpp:2289-2301 (leg search skipped: radius / centre unusable)
                     if (!centre_usable(nx0, ny)) {
                         zDefault = static_cast<float>(static_cast<double>(0.0f) + pc.h);  // no cell visited
                     } else {
-                        if (!haveDbox) dbox = circle_bbox_fast(m.g, nx0, ny, pc.rf);
+                        dbox = circle_bbox_fast(m.g, nx0, ny, pc.rf);
                         bool unused;
                         zDefault = disc_pass_direct<G, false>(m, pc, nx0, ny, dbox, g, unused);
                     }
@@ -834,7 +933,9 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
         c.icj = cs.get(g, 5);
         Submap sm;
         sm.ok = false;
-        search_leg<64, false>(m, pc, lut, c, lk, tile, g, bb, sm, no, co);
+        DefaultDisc dflt;
+        dflt.want = false;
+        search_leg<64, false>(m, pc, lut, c, lk, tile, g, bb, sm, dflt, no, co);
     } else {
         nominal_invalid(no, c.cx, c.cy, 3);
     }
