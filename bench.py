@@ -131,7 +131,7 @@ def main():
         if ev is not None:
             ev[1].record(stream)
         if world > 1:
-            return fdist.all_gather_records(d_nom, B * world * n_cycles * 4, rec)
+            return fdist.all_gather_records(d_nom, B * world, n_cycles * 4 * rec)
         return d_nom
 
     for _ in range(args.warmup):

@@ -1,0 +1,79 @@
+// fpe_ros_adapter.hpp — header-only glue between the reference's ROS node and libfpe.so.
+//
+// NOT built in this repository (neither this image nor the GPU box has ROS1 / grid_map): compile
+// it inside the reference's catkin package with -DFPE_WITH_ROS and link -lfpe.  It keeps the
+// service name, message types and subscriber of the reference untouched (cpp:188, cpp:219, cpp:237)
+// and only replaces (a) the body of gridmapCallback's map copy and (b) the per-cycle loop of
+// globalFootholdPlan for the nominal response.  See INTEGRATION.md for the three call sites.
+#pragma once
+#ifdef FPE_WITH_ROS
+
+#include <foothold_planner_msgs/GlobalFootholds.h>
+#include <grid_map_core/GridMap.hpp>
+
+#include <stdexcept>
+#include <string>
+
+#include "fpe.h"
+
+namespace fpe_ros {
+
+class Engine {
+public:
+    explicit Engine(int device = 0) {
+        if (fpe_create(device, &h_) != FPE_OK) throw std::runtime_error(std::string("fpe_create: ") + fpe_last_error(nullptr));
+    }
+    ~Engine() { fpe_destroy(h_); }
+    Engine(const Engine&) = delete;
+    Engine& operator=(const Engine&) = delete;
+
+    // gridmapCallback (cpp:504-536): hand the two layers to the GPU once per message.  grid_map
+    // stores Eigen::MatrixXf (column-major) with a circular-buffer start index; the engine
+    // canonicalises on the device, so no host-side copy of the layers is made here.
+    bool upload(const grid_map::GridMap& map) {
+        if (!map.exists("traversability") || !map.exists("elevation")) return false;
+        fpe_map_desc d;
+        d.rows = map.getSize()(0);
+        d.cols = map.getSize()(1);
+        d.resolution = map.getResolution();
+        d.position[0] = map.getPosition().x();
+        d.position[1] = map.getPosition().y();
+        d.start_index[0] = map.getStartIndex()(0);
+        d.start_index[1] = map.getStartIndex()(1);
+        d.storage_order = 0;  // Eigen column-major
+        return fpe_upload_map(h_, &d, map["traversability"].data(), map["elevation"].data()) == FPE_OK;
+    }
+
+    // globalFootholdPlan (cpp:539-1602): nominal response for one initial pose.  `params` carries
+    // the node's ROS parameters with their member types (readParameters, cpp:248-314).
+    bool plan(const fpe_params& params, const double initialPose[3], uint8_t gaitCycles,
+              foothold_planner_msgs::GlobalFootholds& msg) {
+        if (fpe_plan_service(h_, &params, initialPose, gaitCycles, &resp_) != FPE_OK) return false;  // cpp:566/933: service fails
+        msg.success = resp_.success;
+        msg.gait_cycles = resp_.gait_cycles;
+        msg.gait_cycles_succeed = resp_.gait_cycles_succeed;
+        msg.footholds.clear();  // cpp:591
+        msg.footholds.reserve(resp_.n_footholds);
+        for (int k = 0; k < resp_.n_footholds; ++k) {
+            foothold_planner_msgs::Foothold f;
+            f.point.x = resp_.footholds[k].x;
+            f.point.y = resp_.footholds[k].y;
+            f.point.z = resp_.footholds[k].z;
+            f.foot_id = resp_.footholds[k].foot_id;
+            f.gait_cycle_id = resp_.footholds[k].gait_cycle_id;
+            msg.footholds.push_back(f);
+        }
+        return true;
+    }
+
+    const char* lastError() const { return fpe_last_error(h_); }
+    fpe_handle handle() const { return h_; }
+
+private:
+    fpe_handle h_ = nullptr;
+    fpe_global_footholds resp_;
+};
+
+}  // namespace fpe_ros
+
+#endif  // FPE_WITH_ROS

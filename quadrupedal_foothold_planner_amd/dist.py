@@ -35,15 +35,16 @@ def broadcast_map(trav, elev, device, src=0):
     return t, e
 
 
-def all_gather_records(local, total, record_bytes):
-    """All-gather per-rank record blocks (uint8 tensor of shard_len * record_bytes) into the
-    global order.  Uneven shards are padded to the largest shard for the collective and trimmed
-    afterwards, so one all_gather_into_tensor moves everything."""
+def all_gather_records(local, total_poses, pose_bytes):
+    """All-gather per-rank result blocks into the global pose order.  `local` is this rank's uint8
+    tensor of shard_poses * pose_bytes (pose_bytes = n_cycles * 4 * record size); shards follow
+    shard_range(total_poses, rank, world).  Uneven shards are padded to the largest shard for the
+    collective and trimmed afterwards, so one all_gather_into_tensor moves everything."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world = dist.get_world_size()
-    sizes = shard_sizes(total, world)
-    mx = max(sizes) * record_bytes
+    sizes = shard_sizes(total_poses, world)
+    mx = max(sizes) * pose_bytes
     buf = local
     if local.numel() != mx:
         buf = torch.zeros(mx, dtype=torch.uint8, device=local.device)
@@ -52,7 +53,7 @@ def all_gather_records(local, total, record_bytes):
     dist.all_gather_into_tensor(out, buf)
     if all(s == sizes[0] for s in sizes):
         return out
-    parts = [out[r * mx : r * mx + sizes[r] * record_bytes] for r in range(world)]
+    parts = [out[r * mx : r * mx + sizes[r] * pose_bytes] for r in range(world)]
     return torch.cat(parts)
 
 

@@ -1,0 +1,64 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard the batch, each plans its shard (the oracle
+stands in for the per-rank compute here — the engine needs a GPU), and the all-gather reassembles
+the global result byte-identically to the unsharded plan.  Also covers uneven shards and the map
+broadcast."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, B, n_cycles, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import fpo
+    from quadrupedal_foothold_planner_amd import dist as fdist
+    from quadrupedal_foothold_planner_amd import synth
+    from tests.conftest import yaml_params
+    from tests.util import to_oracle_poses
+
+    # rank 0 owns the map; everyone else starts from zeros and receives it by broadcast
+    trav0, elev0 = synth.rough_map(160, 160, 0.02, seed=3)
+    if rank != 0:
+        trav0, elev0 = np.zeros_like(trav0), np.zeros_like(elev0)
+    t, e = fdist.broadcast_map(torch.from_numpy(trav0), torch.from_numpy(elev0), torch.device("cpu"))
+    trav, elev = t.numpy(), e.numpy()
+    poses = synth.poses_in_map(B, 3.2, 3.2, n_cycles, 0.18, seed=4, margin=0.65)
+    lo, hi = fdist.shard_range(B, rank, world)
+    omap = fpo.OracleMap(trav, elev, 0.02)
+    out = omap.plan(yaml_params(), to_oracle_poses(poses[lo:hi]), n_cycles)
+    local = torch.from_numpy(np.ascontiguousarray(out["nominal"]).view(np.uint8).reshape(-1))
+    gathered = fdist.all_gather_records(local, B, n_cycles * 4 * fpo.LEG_DTYPE.itemsize)
+    if rank == 0:
+        full = omap.plan(yaml_params(), to_oracle_poses(poses), n_cycles)
+        ok = gathered.numpy().tobytes() == np.ascontiguousarray(full["nominal"]).tobytes()
+        open(os.path.join(tmpdir, "result"), "w").write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [64, 37])
+def test_sharded_plan_all_gather_equals_unsharded(tmp_path, B):
+    port = 29500 + (os.getpid() + B) % 2000
+    mp.spawn(_worker, args=(2, port, B, 4, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "result").read() == "ok"
+
+
+def test_shard_ranges_partition_exactly():
+    from quadrupedal_foothold_planner_amd import dist as fdist
+
+    for total in (1, 7, 64, 4096, 262144):
+        for world in (1, 2, 3, 4, 8):
+            spans = [fdist.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == fdist.shard_sizes(total, world)
