@@ -457,8 +457,16 @@ __device__ CentroidScan centroid_scan(const DevMap& m, const PlanConsts& pc, con
             int cnt = 0;
             // the rectangle lies inside the map (clamped corners, s.ok): raw `<`, NaN passes (cpp:1653, 1736)
             const float* rowp = m.trav + static_cast<size_t>(s.i0 + r) * m.g.cols + s.j0;
-            for (int cc = 0; cc < nj; ++cc)
-                if (rowp[cc] < pc.thrDefault) ++cnt;
+            // columns in chunks of 8 independent loads (clamped index, predicated count): one memory
+            // round trip per chunk instead of one per cell
+            for (int c0 = 0; c0 < nj; c0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = rowp[min(c0 + u, nj - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (c0 + u < nj && v[u] < pc.thrDefault) ++cnt;
+            }
             anyBelow |= cnt > 0;
             blocked = cnt > ((rightCol + 1) * 0.5);  // cpp:1743
         }
