@@ -172,6 +172,7 @@ struct LegCtx {
     double cx, cy;   // search centre = centroid-track next position of this leg (cpp:861-862)
     double R2;       // double(float searchRadius)^2 (SpiralIterator radiusSquare_)
     int nRings;      // ceil(R / res)
+    int nCand;       // spiral table entries of rings 0..nRings
     int ici, icj;    // getIndex(centre)
     int ti0, tj0;    // tile origin (cell index of tile[0])
     int nv;          // polygon vertex count
@@ -292,25 +293,54 @@ __device__ __forceinline__ bool candidate_disc_ok(const DevMap& m, const PlanCon
 
 // checkCandidateFoothold (cpp:2085-2114): first valid cell in SpiralIterator order.  Lane k of a
 // round evaluates the candidate of rank base+k; the lowest set ballot bit is the argmin of rank.
+// The first kLutHeadRounds*G entries of the spiral rank table, held in registers for the whole
+// chain (they are the same for every leg and cycle): the common spiral search ends within them, so
+// it never waits on a table load.
+constexpr int kLutHeadRounds = 2;
+struct LutHead {
+    int dij[kLutHeadRounds];   // di | dj << 16 of entry r*G + sub
+    int ring[kLutHeadRounds];
+};
+template <int G>
+__device__ __forceinline__ LutHead load_lut_head(const SpiralLut& lut, const Grp<G>& g) {
+    LutHead h;
+    const int total = lut.ringStart[lut.maxRing + 1];
+#pragma unroll
+    for (int r = 0; r < kLutHeadRounds; ++r) {
+        const int k = min(r * G + g.sub, total - 1);
+        h.dij[r] = (static_cast<int>(lut.di[k]) & 0xFFFF) | (static_cast<int>(lut.dj[k]) << 16);
+        h.ring[r] = lut.ring[k];
+    }
+    return h;
+}
+
 template <int G, bool kTile>
-__device__ bool candidate_search_grp(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LegCtx& c,
-                                     const uint8_t* tile, const Grp<G>& g, int& wi, int& wj) {
-    const int nR = c.nRings < lut.maxRing ? c.nRings : lut.maxRing;
-    const int M = lut.ringStart[nR + 1];
-    for (int base = 0; base < M; base += G) {
+__device__ bool candidate_search_grp(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head,
+                                     const LegCtx& c, const uint8_t* tile, const Grp<G>& g, int& wi, int& wj) {
+    const int M = c.nCand;
+    int round = 0;
+    for (int base = 0; base < M; base += G, ++round) {
         const int k = base + g.sub;
         bool ok = false;
         int i = 0, j = 0;
         if (k < M) {
-            i = c.ici + lut.di[k];
-            j = c.icj + lut.dj[k];
-            ok = in_range(i, j, m.g.rows, m.g.cols);
-            if (ok) {
-                // SpiralIterator::generateRing filters rings nRings-1 and nRings by isInside;
-                // the centre cell (ring 0) is pushed unfiltered by the constructor
-                const int r = lut.ring[k];
-                if (r >= 1 && (r == c.nRings || r + 1 == c.nRings)) ok = cell_in_disc(m.g, i, j, c.cx, c.cy, c.R2);
+            int di, dj, r;
+            if (round < kLutHeadRounds) {
+                const int e = round == 0 ? head.dij[0] : head.dij[1];
+                di = static_cast<int16_t>(e & 0xFFFF);
+                dj = e >> 16;
+                r = round == 0 ? head.ring[0] : head.ring[1];
+            } else {
+                di = lut.di[k];
+                dj = lut.dj[k];
+                r = lut.ring[k];
             }
+            i = c.ici + di;
+            j = c.icj + dj;
+            ok = in_range(i, j, m.g.rows, m.g.cols);
+            // SpiralIterator::generateRing filters rings nRings-1 and nRings by isInside;
+            // the centre cell (ring 0) is pushed unfiltered by the constructor
+            if (ok && r >= 1 && (r == c.nRings || r + 1 == c.nRings)) ok = cell_in_disc(m.g, i, j, c.cx, c.cy, c.R2);
             if (ok) ok = candidate_disc_ok<kTile>(m, pc, c, tile, i, j);
         }
         const unsigned long long mask = g.ballot(ok);
@@ -567,14 +597,16 @@ struct LegConst {
     float Rf;       // float search radius (cpp:1616 uses searchRadius_*2 in f32)
     double R2;      // double(Rf)^2
     int nRings;     // ceil(double(Rf) / res), SpiralIterator::nRings_
+    int nCand;      // spiral rank-table entries of rings 0..nRings
     double lx, ly;  // centroid rectangle (cpp:1616-1617)
 };
-__device__ __forceinline__ LegConst make_leg_const(float Rf, double res) {
+__device__ __forceinline__ LegConst make_leg_const(float Rf, double res, const SpiralLut& lut) {
     LegConst k;
     k.Rf = Rf;
     const double R = static_cast<double>(Rf);
     k.R2 = R * R;
     k.nRings = static_cast<int>(static_cast<unsigned int>(ceil(R / res)));
+    k.nCand = lut.ringStart[(k.nRings < lut.maxRing ? k.nRings : lut.maxRing) + 1];
     k.lx = static_cast<double>(Rf * 2);
     k.ly = static_cast<double>(Rf);
     return k;
@@ -592,11 +624,13 @@ struct DefaultDisc {
 // bb = CircleIterator box of the centre disc, s = getSubmap geometry of the centroid rectangle (both
 // from the corner lanes).  kCentroid=false skips the centroid track (open-loop fpe_search_legs).
 template <int G, bool kCentroid>
-__device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, LegCtx& c, const LegConst& lk,
+__device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head, LegCtx& c,
+                           const LegConst& lk,
                            uint8_t* tile, const Grp<G>& g, const BBox& bb, const Submap& s, DefaultDisc& dflt,
                            NominalOut& no, CentroidOut& co) {
     c.R2 = lk.R2;
     c.nRings = lk.nRings;
+    c.nCand = lk.nCand;
     c.ti0 = c.ici - pc.tileH;
     c.tj0 = c.icj - pc.tileH;
     // issue the centre-disc (and default-track disc) loads, overlap them with the centroid row scan
@@ -628,10 +662,10 @@ __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLu
     bool found;
     if (pc.footRobust && pc.nFoot <= kOnDemandMaxFoot) {
         // tiny foot discs: evaluate the few cells a candidate needs straight from the map
-        found = candidate_search_grp<G, false>(m, pc, lut, c, tile, g, wi, wj);  // cpp:2022
+        found = candidate_search_grp<G, false>(m, pc, lut, head, c, tile, g, wi, wj);  // cpp:2022
     } else {
         stage_full_tile(m, pc, c, tile, g);
-        found = candidate_search_grp<G, true>(m, pc, lut, c, tile, g, wi, wj);
+        found = candidate_search_grp<G, true>(m, pc, lut, head, c, tile, g, wi, wj);
     }
     if (found) {
         no.valid = 1;
@@ -726,7 +760,8 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
     if (!(Rf > 0.0f)) Rf = pc.searchRadius;
     const int polyKind = pp->leg_polygon_kind[leg];
     const bool radiusOk = Rf <= pc.maxSearchRadius;
-    const LegConst lk = make_leg_const(Rf, m.g.res);
+    const LegConst lk = make_leg_const(Rf, m.g.res, lut);
+    const LutHead head = load_lut_head(lut, g);
     const double biasX = pc.biasX[leg], biasY = pc.biasY[leg];
 
     // initial stance (cpp:350-378) and first-gait shift (setFirstGait, cpp:2679-2699)
@@ -840,7 +875,7 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
                     dflt.y = ny;
                     dflt.bb = dbox;
                     dflt.z = static_cast<float>(static_cast<double>(0.0f) + pc.h);  // value when no cell is visited
-                    search_leg<G, true>(m, pc, lut, c, lk, tile, g, bb, sm, dflt, no, co);
+                    search_leg<G, true>(m, pc, lut, head, c, lk, tile, g, bb, sm, dflt, no, co);
                     zDefault = dflt.z;
                     haveDbox = true;
                 }
@@ -932,7 +967,8 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
     if (!centre_usable(c.cx, c.cy)) {
         nominal_invalid(no, c.cx, c.cy, 2);
     } else if (Rf <= pc.maxSearchRadius && Rf >= 0.0f && nv >= 0 && nv <= FPE_MAX_POLYGON_VERTICES) {
-        const LegConst lk = make_leg_const(Rf, m.g.res);
+        const LegConst lk = make_leg_const(Rf, m.g.res, lut);
+        const LutHead head = load_lut_head(lut, g);
         const Box b0{c.cx, c.cy, pc.rf, pc.rf};
         Corners<64, 8> cs;
         cs.eval(m.g, g, b0, b0, b0, b0, 0x2u);  // quantities 4,5 = getIndex(centre)
@@ -943,7 +979,7 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
         sm.ok = false;
         DefaultDisc dflt;
         dflt.want = false;
-        search_leg<64, false>(m, pc, lut, c, lk, tile, g, bb, sm, dflt, no, co);
+        search_leg<64, false>(m, pc, lut, head, c, lk, tile, g, bb, sm, dflt, no, co);
     } else {
         nominal_invalid(no, c.cx, c.cy, 3);
     }
