@@ -178,6 +178,8 @@ struct LegCtx {
     int nv;          // polygon vertex count
     const double* vx;  // polygon vertices (LDS)
     const double* vy;
+    const int8_t* footDa;  // foot-disc offset table (LDS copy of PlanConsts::footDa/footDb)
+    const int8_t* footDb;
 };
 
 __device__ __forceinline__ uint8_t tile_at(const uint8_t* tile, int W, const LegCtx& c, int i, int j) {
@@ -266,8 +268,11 @@ template <bool kTile>
 __device__ __forceinline__ bool candidate_disc_ok(const DevMap& m, const PlanConsts& pc, const LegCtx& c,
                                                   const uint8_t* tile, int i, int j) {
     if (pc.footRobust) {
+        if (pc.nFoot == 1) {  // the disc is the candidate's own cell (e.g. rf 0.02 on a 2 cm map)
+            return kTile ? (tile_at(tile, pc.tileW, c, i, j) & kFlagFail) == 0 : !cell_fails_direct(m, pc, c, i, j);
+        }
         for (int k = 0; k < pc.nFoot; ++k) {
-            const int qi = i + pc.footDa[k], qj = j + pc.footDb[k];
+            const int qi = i + c.footDa[k], qj = j + c.footDb[k];
             if (!in_range(qi, qj, m.g.rows, m.g.cols)) continue;
             const bool fail = kTile ? (tile_at(tile, pc.tileW, c, qi, qj) & kFlagFail) != 0 : cell_fails_direct(m, pc, c, qi, qj);
             if (fail) return false;
@@ -721,6 +726,8 @@ struct PoseShared {
     double polyY[4][8];
     int valid[4];
     int pad[4];
+    int8_t footDa[kMaxFootOffsets];
+    int8_t footDb[kMaxFootOffsets];
 };
 
 }  // namespace
@@ -764,6 +771,10 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
     const LutHead head = load_lut_head(lut, g);
     const double biasX = pc.biasX[leg], biasY = pc.biasY[leg];
 
+    for (int k = tid % kPoseThreads; k < pc.nFoot; k += kPoseThreads) {
+        sh.footDa[k] = pc.footDa[k];
+        sh.footDb[k] = pc.footDb[k];
+    }
     // initial stance (cpp:350-378) and first-gait shift (setFirstGait, cpp:2679-2699)
     if (g.sub == 0) {
         double sx = (leg == 0 || leg == 3) ? pc.LbHalf : -pc.LbHalf;
@@ -842,6 +853,8 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
                 c.nv = (polyKind == 0) ? 4 : 6;
                 c.vx = sh.polyX[leg];
                 c.vy = sh.polyY[leg];
+                c.footDa = sh.footDa;
+                c.footDb = sh.footDb;
 
                 NominalOut no;
                 CentroidOut co;
@@ -934,6 +947,8 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
 struct QueryShared {
     double polyX[4][8];
     double polyY[4][8];
+    int8_t footDa[kMaxFootOffsets];
+    int8_t footDb[kMaxFootOffsets];
 };
 
 __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts pc, SpiralLut lut,
@@ -951,6 +966,10 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
 
     const fpe_leg_query* qp = queries + q;
     const int nv = qp->n_vertices;
+    for (int k = g.sub; k < pc.nFoot; k += 64) {  // every wavefront writes the same bytes, then reads its own writes
+        sh.footDa[k] = pc.footDa[k];
+        sh.footDb[k] = pc.footDb[k];
+    }
     if (g.sub < 8) {
         sh.polyX[w][g.sub] = g.sub < nv ? qp->vx[g.sub] : 0.0;
         sh.polyY[w][g.sub] = g.sub < nv ? qp->vy[g.sub] : 0.0;
@@ -962,6 +981,8 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
     c.nv = nv;
     c.vx = sh.polyX[w];
     c.vy = sh.polyY[w];
+    c.footDa = sh.footDa;
+    c.footDb = sh.footDb;
     NominalOut no;
     CentroidOut co;
     if (!centre_usable(c.cx, c.cy)) {
