@@ -166,6 +166,8 @@ void derive_constants(const fpe_params& p, const MapGeom& geom, float maxSearchR
     c.groupOverride = grp ? std::atoi(grp) : 0;
     const char* skip = std::getenv("FPE_DEBUG_SKIP");
     c.debugSkip = skip ? std::atoi(skip) : 0;
+    const char* tr = std::getenv("FPE_TRACE_PTR");
+    c.trace = tr ? reinterpret_cast<unsigned long long*>(std::strtoull(tr, nullptr, 0)) : nullptr;
     derive_foot_offsets(p.footRadius, geom, c);
     if (std::getenv("FPE_LITERAL_DISCS")) c.footRobust = 0;  // test knob: force the literal bounding-box walk
 }

@@ -24,6 +24,19 @@ namespace fpe {
 
 namespace {
 
+// profiling-only timeline stamps (pc.trace != null): slot = ((block * 8 + cycle) * 16 + point)
+// compiled in only with -DFPE_TRACE (scratch/trace.py); a no-op in the shipped library
+__device__ __forceinline__ void stamp(const PlanConsts& pc, int cyc, int point) {
+#ifdef FPE_TRACE
+    if (pc.trace && blockIdx.x < 256 && cyc < 8 && threadIdx.x == 0)
+        pc.trace[(static_cast<size_t>(blockIdx.x) * 8 + cyc) * 16 + point] = __builtin_readcyclecounter();
+#else
+    (void)pc;
+    (void)cyc;
+    (void)point;
+#endif
+}
+
 // A search centre must be finite and of sane magnitude.  The reference has no such test: a
 // non-finite centre (reachable once the centroid track has committed its "no case" (0,0,0)
 // results, cpp:1777-1944, and the feet polygon degenerates) sends NaN through
@@ -106,6 +119,8 @@ __device__ __forceinline__ CornerVal corner_quantity(const MapGeom& g, int id, c
     const double v = isBR ? c - h : c + h;
     const double bnd = raw ? c : bound_axis(v, org, pos, len);
     CornerVal r;
+    // index_of_fast: hipcc if-converts its rare exact-division fallback into straight-line code; measured
+    // faster here than either a per-lane or a wave-uniform branch (0.0766 vs 0.0783 ms per launch)
     r.idx = index_of_fast(bnd, org, pos, g.res, g.rinv);
     r.within = raw || within_axis(bnd, org, pos, len);
     return r;
@@ -173,6 +188,7 @@ struct LegCtx {
     double R2;       // double(float searchRadius)^2 (SpiralIterator radiusSquare_)
     int nRings;      // ceil(R / res)
     int nCand;       // spiral table entries of rings 0..nRings
+    int cyc;         // gait cycle (profiling stamps only)
     int ici, icj;    // getIndex(centre)
     int ti0, tj0;    // tile origin (cell index of tile[0])
     int nv;          // polygon vertex count
@@ -518,12 +534,74 @@ __device__ CentroidScan centroid_scan(const DevMap& m, const PlanConsts& pc, con
     return r0;
 }
 
+// Two-phase form of centroid_scan: rows_issue() starts the loads of up to kRowChunks*G rows x 8
+// columns right after the corner arithmetic; rows_finish() counts after the disc membership math
+// has overlapped their latency.  Larger rectangles fall back to centroid_scan().
+constexpr int kRowChunks = 2;
+struct RowLoads {
+    float v[kRowChunks][8];
+    bool pipelined;
+};
+template <int G>
+__device__ __forceinline__ void rows_issue(const DevMap& m, const Submap& s, const Grp<G>& g, RowLoads& rl) {
+    rl.pipelined = s.ok && s.ni <= kRowChunks * G && s.nj <= 8;
+    if (!rl.pipelined) return;
+#pragma unroll
+    for (int ch = 0; ch < kRowChunks; ++ch) {
+        const int r = min(ch * G + g.sub, s.ni - 1);  // clamped: idle lanes re-read the last row
+        const float* rowp = m.trav + static_cast<size_t>(s.i0 + r) * m.g.cols + s.j0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rl.v[ch][u] = rowp[min(u, s.nj - 1)];
+    }
+}
+template <int G>
+__device__ __forceinline__ CentroidScan rows_finish(const DevMap& m, const PlanConsts& pc, const Submap& s,
+                                                    const Grp<G>& g, const RowLoads& rl) {
+    if (!rl.pipelined) return centroid_scan(m, pc, s, g);
+    CentroidScan r0;
+    const int ni = s.ni, nj = s.nj, rightCol = nj - 1;
+    bool anyBelow = false;
+    int minRow = 0, maxRow = 0, k = 0;
+#pragma unroll
+    for (int ch = 0; ch < kRowChunks; ++ch) {
+        const int r = ch * G + g.sub;
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u < nj && rl.v[ch][u] < pc.thrDefault) ++cnt;  // raw `<`, NaN passes (cpp:1653, 1736)
+        const bool live = r < ni;
+        anyBelow |= live && cnt > 0;
+        const bool blocked = live && cnt > ((rightCol + 1) * 0.5);  // cpp:1743
+        const unsigned long long mask = g.ballot(blocked);
+        if (mask) {
+            if (k == 0) minRow = ch * G + __builtin_ctzll(mask);
+            maxRow = ch * G + 63 - __builtin_clzll(mask);
+            k += __builtin_popcountll(mask);
+        }
+    }
+    r0.whole = ni * nj > 0 && !g.any(anyBelow);
+    r0.minRow = minRow;
+    r0.maxRow = maxRow;
+    return r0;
+}
+
 // checkFootholdUseCentroidMethod (cpp:1605-1997) given the row scan.  zCentre = mean height at the
 // centre (the whole-region-valid result reuses it, cpp:1687).
-template <int G>
-__device__ CentroidOut centroid_finish(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const Submap& s,
-                                       const CentroidScan& sc, float zCentre, const Grp<G>& g) {
+// checkFootholdUseCentroidMethod (cpp:1605-1997) given the row scan, in two halves: centroid_begin()
+// decides the case and ISSUES the loads of the result's foot disc; centroid_end() consumes them
+// after independent work (default-track height, spiral search) has overlapped their latency.
+// zCentre = mean height at the centre (the whole-region-valid result reuses it, cpp:1687).
+struct CentroidPending {
     CentroidOut o;
+    bool needDisc;
+    BBox rb;
+    DiscLoads dl;
+};
+template <int G>
+__device__ void centroid_begin(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const Submap& s,
+                               const CentroidScan& sc, float zCentre, const Grp<G>& g, CentroidPending& cp) {
+    CentroidOut& o = cp.o;
+    cp.needDisc = false;
     o.x = 0.0;
     o.y = 0.0;
     o.z = 0.0f;
@@ -532,7 +610,7 @@ __device__ CentroidOut centroid_finish(const DevMap& m, const PlanConsts& pc, co
     o.code = 5;
     if (!s.ok) {  // cpp:1628-1631
         o.code = 6;
-        return o;
+        return;
     }
     const int bottomRow = s.ni - 1, rightCol = s.nj - 1;
     const int minRow = sc.minRow, maxRow = sc.maxRow;
@@ -543,7 +621,7 @@ __device__ CentroidOut centroid_finish(const DevMap& m, const PlanConsts& pc, co
         o.row = c.ici;
         o.col = c.icj;
         o.code = 0;
-        return o;
+        return;
     }
     int newRow, newCol;
     if (minRow == 0 && maxRow != bottomRow) {  // case 1, cpp:1777-1786
@@ -564,7 +642,7 @@ __device__ CentroidOut centroid_finish(const DevMap& m, const PlanConsts& pc, co
         newCol = static_cast<int>(floor((rightCol + 0) * 0.5));
         o.code = 4;
     } else {
-        return o;  // first and last row blocked: no branch taken, result stays (0,0,0)
+        return;  // first and last row blocked: no branch taken, result stays (0,0,0)
     }
     // map.getPosition(newIndex) on the SUBMAP (cpp:1816), height on the full map (cpp:1820)
     o.x = cell_pos(s.baseX, m.g.res, newRow);
@@ -573,12 +651,18 @@ __device__ CentroidOut centroid_finish(const DevMap& m, const PlanConsts& pc, co
     const Box disc{o.x, o.y, pc.rf, pc.rf};
     Corners<G, 8> cr;
     cr.eval(m.g, g, disc, disc, disc, disc, 0x2u);
-    const BBox rb = cr.bbox(g, 0);
-    bool unused;
-    o.z = disc_pass_direct<G, false>(m, pc, o.x, o.y, rb, g, unused);
+    cp.rb = cr.bbox(g, 0);
     o.row = cr.get(g, 4);
     o.col = cr.get(g, 5);
-    return o;
+    disc_issue<G, false>(m, pc, o.x, o.y, cp.rb, g, cp.dl);
+    cp.needDisc = true;
+}
+template <int G>
+__device__ void centroid_end(const DevMap& m, const PlanConsts& pc, const Grp<G>& g, CentroidPending& cp) {
+    if (cp.needDisc) {
+        bool unused;
+        cp.o.z = disc_consume<G, false>(m, pc, cp.o.x, cp.o.y, cp.rb, g, cp.dl, unused);
+    }
 }
 
 struct NominalOut {
@@ -625,6 +709,10 @@ struct DefaultDisc {
     float z;
 };
 
+template <int G>
+__device__ void spiral_search(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head,
+                              const LegCtx& c, uint8_t* tile, const Grp<G>& g, float zCentre, NominalOut& no);
+
 // One leg: centroid method (cpp:1605-1997) + checkFoothold (cpp:2001-2036) around the same centre.
 // bb = CircleIterator box of the centre disc, s = getSubmap geometry of the centroid rectangle (both
 // from the corner lanes).  kCentroid=false skips the centroid track (open-loop fpe_search_legs).
@@ -638,20 +726,30 @@ __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLu
     c.nCand = lk.nCand;
     c.ti0 = c.ici - pc.tileH;
     c.tj0 = c.icj - pc.tileH;
-    // issue the centre-disc (and default-track disc) loads, overlap them with the centroid row scan
+    // software pipeline: (1) row loads of the centroid rectangle, (2) disc membership math and disc
+    // loads, (3) row counts, (4) centre disc -> default check and height, (5) centroid case + loads
+    // of its result disc, (6) default-track height, (7) spiral search if needed, (8) centroid height
+    RowLoads rl;
+    if (kCentroid) rows_issue(m, s, g, rl);
     DiscLoads dc;
     disc_issue<G, true>(m, pc, c.cx, c.cy, bb, g, dc);
     DiscLoads dd;
     if (dflt.want) disc_issue<G, false>(m, pc, dflt.x, dflt.y, dflt.bb, g, dd);
+    stamp(pc, c.cyc, 3);
     CentroidScan sc;
-    if (kCentroid) sc = centroid_scan(m, pc, s, g);
+    if (kCentroid) sc = rows_finish(m, pc, s, g, rl);
+    stamp(pc, c.cyc, 4);
     bool defaultOk = true;
     const float zCentre = disc_consume<G, true>(m, pc, c.cx, c.cy, bb, g, dc, defaultOk);  // cpp:2012 + cpp:2029
-    if (kCentroid) co = centroid_finish(m, pc, c, s, sc, zCentre, g);                        // cpp:818-821
+    stamp(pc, c.cyc, 5);
+    CentroidPending cp;
+    if (kCentroid) centroid_begin(m, pc, c, s, sc, zCentre, g, cp);                          // cpp:818-821
+    stamp(pc, c.cyc, 6);
     if (dflt.want) {
         bool unused;
         dflt.z = disc_consume<G, false>(m, pc, dflt.x, dflt.y, dflt.bb, g, dd, unused);     // cpp:2289-2301
     }
+    stamp(pc, c.cyc, 7);
     if (defaultOk) {
         no.valid = 1;
         no.source = 0;
@@ -660,8 +758,19 @@ __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLu
         no.x = c.cx;  // cpp:2016-2017
         no.y = c.cy;
         no.z = zCentre;
-        return;
+    } else {
+        spiral_search<G>(m, pc, lut, head, c, tile, g, zCentre, no);
     }
+    if (kCentroid) {
+        centroid_end(m, pc, g, cp);
+        co = cp.o;
+    }
+}
+
+// checkCandidateFoothold half of checkFoothold (cpp:2022-2029) once the default foothold has failed.
+template <int G>
+__device__ void spiral_search(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head,
+                              const LegCtx& c, uint8_t* tile, const Grp<G>& g, float zCentre, NominalOut& no) {
     nominal_invalid(no, c.cx, c.cy, 2);
     int wi = 0, wj = 0;
     bool found;
@@ -809,6 +918,7 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
             const unsigned mask = (gait == 1) ? (1u << ((walkOrder >> (2 * ph)) & 3)) : 0xFu;
             const bool active = (mask >> leg) & 1u;
 
+            stamp(pc, cyc, 0);
             // feet-polygon centres: group t computes track t (getPolygonCenter, cpp:2191, 2265)
             if (leg < 3 && g.sub == 0) {
                 double cx, cy;
@@ -817,6 +927,7 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
                 sh.ctr[leg][1] = cy;
             }
             pose_sync<G>();
+            stamp(pc, cyc, 1);
 
             if (active) {
                 // next default positions of this leg on the three tracks (cpp:2199-2213, 2270-2284)
@@ -848,6 +959,7 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
                 }
 
                 LegCtx c;
+                c.cyc = cyc;
                 c.cx = nx1;  // centre from the CENTROID track (cpp:861-862)
                 c.cy = ny;
                 c.nv = (polyKind == 0) ? 4 : 6;
@@ -882,6 +994,7 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
                     c.icj = cs.get(g, 13);
                     const bool rectWithin = cs.box_within(1);
                     const Submap sm = submap_from_corners(m.g, rbox, rectWithin, c.cx, c.cy);
+                    stamp(pc, cyc, 2);
                     DefaultDisc dflt;
                     dflt.want = out.default_next != nullptr && centre_usable(nx0, ny);
                     dflt.x = nx0;
@@ -891,6 +1004,7 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
                     search_leg<G, true>(m, pc, lut, head, c, lk, tile, g, bb, sm, dflt, no, co);
                     zDefault = dflt.z;
                     haveDbox = true;
+                    stamp(pc, cyc, 8);
                 }
                 if (out.default_next && !haveDbox) {  // cpp:2289-2301 (leg search skipped: radius / centre unusable)
                     if (!centre_usable(nx0, ny)) {
@@ -926,6 +1040,7 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
                 sh.valid[leg] = 1;  // non-swing legs do not vote
             }
             pose_sync<G>();
+            stamp(pc, cyc, 9);
             // footholdValidation_ = AND of the swing legs' flags (cpp:1323); commit or skip (cpp:1332-1576)
             const bool phaseOk = (sh.valid[0] & sh.valid[1] & sh.valid[2] & sh.valid[3]) != 0;
             if (phaseOk && active) {
@@ -936,6 +1051,7 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
             }
             pose_sync<G>();
             cycleOk = cycleOk && phaseOk;
+            stamp(pc, cyc, 10);
         }
         if (leg == 0 && g.sub == 0 && live && out.cycle_ok)
             out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = cycleOk ? 1 : 0;
@@ -979,6 +1095,7 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
     c.cx = qp->cx;
     c.cy = qp->cy;
     c.nv = nv;
+    c.cyc = 99;
     c.vx = sh.polyX[w];
     c.vy = sh.polyY[w];
     c.footDa = sh.footDa;
