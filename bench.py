@@ -123,26 +123,28 @@ def main():
 
     stream = torch.cuda.current_stream()
 
-    def step(ev=None):
-        if ev is not None:
-            ev[0].record(stream)
+    def step():
         planner.plan_device(d_poses.data_ptr(), B, n_cycles, d_nom.data_ptr(), d_cen.data_ptr(), d_def.data_ptr(),
                             d_ok.data_ptr(), d_st.data_ptr(), stream=stream.cuda_stream)
-        if ev is not None:
-            ev[1].record(stream)
         if world > 1:
             return fdist.all_gather_records(d_nom, B * world, n_cycles * 4 * rec)
         return d_nom
 
     for _ in range(args.warmup):
         step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events on the launch stream bracket the K launches of the timed region; at N=1 the region
+    # holds nothing but the K plan kernels, so elapsed/K is the mean launch duration (an upper bound
+    # of the kernel time: it includes the ~2 us dispatch gap between back-to-back launches).  At N>1
+    # the all-gather shares the stream, so a second, kernel-only pass measures the launch duration.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev0.record(stream)
     for k in range(args.steps):
-        gathered = step(events[k])
+        gathered = step()
+    ev1.record(stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -151,7 +153,16 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    if world > 1:
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record(stream)
+        for k in range(args.steps):
+            planner.plan_device(d_poses.data_ptr(), B, n_cycles, d_nom.data_ptr(), d_cen.data_ptr(), d_def.data_ptr(),
+                                d_ok.data_ptr(), d_st.data_ptr(), stream=stream.cuda_stream)
+        k1.record(stream)
+        torch.cuda.synchronize()
+        kernel_ms = k0.elapsed_time(k1) / args.steps
 
     footholds_per_step = 4 * n_cycles * B * world
     value = footholds_per_step * args.steps / elapsed
