@@ -48,6 +48,7 @@ struct PlanConsts {
     unsigned long long* trace;  // profiling-only: per-phase s_memtime stamps (FPE_TRACE_PTR); null in production
     int32_t nFoot;
     int32_t footRobust;
+    int32_t footReach;     // cells a foot disc can reach from its centre cell (max |offset|, or ceil(rf/res)+1)
     int8_t footDa[kMaxFootOffsets];
     int8_t footDb[kMaxFootOffsets];
 };

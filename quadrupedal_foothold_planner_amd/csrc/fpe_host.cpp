@@ -103,6 +103,7 @@ void derive_foot_offsets(float footRadius, const MapGeom& g, PlanConsts& c) {
     const int reach = static_cast<int>(std::ceil(rf / res)) + 1;
     c.nFoot = 0;
     c.footRobust = 1;
+    c.footReach = reach;  // bound of the literal bounding-box walk; tightened below when the table is valid
     if (reach > 100) {
         c.footRobust = 0;
         return;
@@ -126,6 +127,9 @@ void derive_foot_offsets(float footRadius, const MapGeom& g, PlanConsts& c) {
                 ++c.nFoot;
             }
         }
+    int mx = 0;
+    for (int k = 0; k < c.nFoot; ++k) mx = std::max(mx, std::max(std::abs(static_cast<int>(c.footDa[k])), std::abs(static_cast<int>(c.footDb[k]))));
+    c.footReach = mx;
 }
 
 void derive_constants(const fpe_params& p, const MapGeom& geom, float maxSearchRadius, PlanConsts& c) {
@@ -169,7 +173,10 @@ void derive_constants(const fpe_params& p, const MapGeom& geom, float maxSearchR
     const char* tr = std::getenv("FPE_TRACE_PTR");
     c.trace = tr ? reinterpret_cast<unsigned long long*>(std::strtoull(tr, nullptr, 0)) : nullptr;
     derive_foot_offsets(p.footRadius, geom, c);
-    if (std::getenv("FPE_LITERAL_DISCS")) c.footRobust = 0;  // test knob: force the literal bounding-box walk
+    if (std::getenv("FPE_LITERAL_DISCS")) {
+        c.footRobust = 0;
+        c.footReach = static_cast<int>(std::ceil(c.rf / resolution)) + 1;
+    }  // test knob: force the literal bounding-box walk
 }
 
 // globalFootholdPlan message bookkeeping: cpp:681-699 (stance entries), cpp:1378-1396 (valid

@@ -196,6 +196,8 @@ struct LegCtx {
     const double* vy;
     const int8_t* footDa;  // foot-disc offset table (LDS copy of PlanConsts::footDa/footDb)
     const int8_t* footDb;
+    bool rect;         // polygon is the reference rectangle: xlo/xhi/ylo/yhi hold its sides
+    double xlo, xhi, ylo, yhi;
 };
 
 __device__ __forceinline__ uint8_t tile_at(const uint8_t* tile, int W, const LegCtx& c, int i, int j) {
@@ -219,29 +221,63 @@ __device__ __forceinline__ uint8_t classify(const DevMap& m, const PlanConsts& p
     return f;
 }
 
-// Full spiral window, with the polygon test folded in (only when the spiral search runs).
-// checkCirclePolygonFoothold (cpp:2132-2138): a FINITE cell fails when it is below the candidate
-// threshold or its centre is outside the polygon; non-finite cells never fail.
+// ---- LDS staging of the spiral window (large foot discs) ---------------------------------------------------
+// The window around the search centre is staged into LDS as one flag byte per cell, with the
+// per-cell verdict of checkCirclePolygonFoothold (cpp:2132-2138) folded in: a FINITE cell fails when
+// it is below the candidate threshold or its centre is outside the search polygon; non-finite cells
+// never fail.  Staging is lazy by square annuli: the spiral visits rings outward and usually stops
+// after a few, so only the cells within reach of the rings examined so far are ever read from HBM.
+__device__ __forceinline__ bool cell_outside_polygon(const LegCtx& c, double px, double py) {
+    if (c.rect) {
+        // the reference's rectangle (getSearchPolygon, cpp:2496-2517; vertices LU,RU,RD,LD): PNPOLY
+        // reduces to these six comparisons on the same values — only the two vertical edges can
+        // straddle py, and their intersection abscissae are exactly xhi and xlo
+        const bool straddle = (c.ylo > py) != (c.yhi > py);
+        return !(straddle && ((px < c.xhi) != (px < c.xlo)));
+    }
+    return !polygon_inside_fast(c.vx, c.vy, c.nv, px, py);
+}
+
 template <int G>
-__device__ void stage_full_tile(const DevMap& m, const PlanConsts& pc, const LegCtx& c, uint8_t* tile, const Grp<G>& g) {
+__device__ void stage_rect_cells(const DevMap& m, const PlanConsts& pc, const LegCtx& c, uint8_t* tile, const Grp<G>& g,
+                                 int a0, int b0, int na, int nb) {  // tile-local rectangle [a0,a0+na) x [b0,b0+nb)
+    if (na <= 0 || nb <= 0) return;
     const int W = pc.tileW;
-    const int n = W * W;
+    const int n = na * nb;
+    const float nbInv = rcp_small(nb);
     for (int t = g.sub; t < n; t += G) {
-        const int a = static_cast<int>(fastdiv(static_cast<uint32_t>(t), pc.tileWMagic));
-        const int b = t - a * W;
+        int qa, qb;
+        divmod_small(t, nb, nbInv, qa, qb);
+        const int a = a0 + qa, b = b0 + qb;
         const int i = c.ti0 + a, j = c.tj0 + b;
         uint8_t f = classify(m, pc, i, j);
         if ((f & kFlagInMap) && (f & kFlagFinite)) {
             bool fail = (f & kFlagBelowCand) != 0;
-            if (!fail) {
-                const double px = cell_pos(m.g.baseX, m.g.res, i);
-                const double py = cell_pos(m.g.baseY, m.g.res, j);
-                fail = !polygon_inside_fast(c.vx, c.vy, c.nv, px, py);
-            }
+            if (!fail) fail = cell_outside_polygon(c, cell_pos(m.g.baseX, m.g.res, i), cell_pos(m.g.baseY, m.g.res, j));
             if (fail) f |= kFlagFail;
         }
-        tile[t] = f;
+        tile[a * W + b] = f;
     }
+}
+
+// Stage the cells whose Chebyshev distance d from the tile centre satisfies lo < d <= hi (lo = -1
+// stages the centre block too), as four bands of the square annulus.
+template <int G>
+__device__ void stage_annulus(const DevMap& m, const PlanConsts& pc, const LegCtx& c, uint8_t* tile, const Grp<G>& g,
+                              int lo, int hi) {
+    const int H = pc.tileH;
+    if (hi > H) hi = H;
+    if (hi <= lo) return;
+    const int o0 = H - hi, o1 = H + hi + 1;  // outer square [o0, o1)
+    if (lo < 0) {
+        stage_rect_cells(m, pc, c, tile, g, o0, o0, o1 - o0, o1 - o0);
+        return;
+    }
+    const int i0 = H - lo, i1 = H + lo + 1;  // inner square [i0, i1) already staged
+    stage_rect_cells(m, pc, c, tile, g, o0, o0, i0 - o0, o1 - o0);  // top band
+    stage_rect_cells(m, pc, c, tile, g, i1, o0, o1 - i1, o1 - o0);  // bottom band
+    stage_rect_cells(m, pc, c, tile, g, i0, o0, i1 - i0, i0 - o0);  // left band
+    stage_rect_cells(m, pc, c, tile, g, i0, i1, i1 - i0, o1 - i1);  // right band
 }
 
 // In-order f32 accumulation of getFootholdMeanHeight (cpp:2539-2545) over the visited lanes of one
@@ -272,11 +308,11 @@ __device__ __forceinline__ bool cell_fails_direct(const DevMap& m, const PlanCon
     const float v = m.trav[static_cast<size_t>(i) * m.g.cols + j];
     if (!__builtin_isfinite(v)) return false;
     if (v < pc.thrCandidate) return true;
-    return !polygon_inside_fast(c.vx, c.vy, c.nv, cell_pos(m.g.baseX, m.g.res, i), cell_pos(m.g.baseY, m.g.res, j));
+    return cell_outside_polygon(c, cell_pos(m.g.baseX, m.g.res, i), cell_pos(m.g.baseY, m.g.res, j));
 }
 
 // checkCirclePolygonFoothold (cpp:2117-2163) for the cell-centred disc of candidate (i, j), one
-// lane per candidate.  kTile: per-cell verdicts come from the LDS tile (stage_full_tile), else
+// lane per candidate.  kTile: per-cell verdicts come from the LDS tile (stage_annulus), else
 // they are evaluated on demand from the map (tiny discs: fewer cells than the tile has).
 // Disc membership: the host-proved offset table when pc.footRobust, else the literal
 // CircleIterator bounding-box walk in f64.
@@ -337,15 +373,16 @@ __device__ __forceinline__ LutHead load_lut_head(const SpiralLut& lut, const Grp
 
 template <int G, bool kTile>
 __device__ bool candidate_search_grp(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head,
-                                     const LegCtx& c, const uint8_t* tile, const Grp<G>& g, int& wi, int& wj) {
+                                     const LegCtx& c, uint8_t* tile, const Grp<G>& g, int& wi, int& wj) {
     const int M = c.nCand;
     int round = 0;
+    int staged = -1;  // Chebyshev radius of the tile staged so far (kTile)
     for (int base = 0; base < M; base += G, ++round) {
         const int k = base + g.sub;
         bool ok = false;
         int i = 0, j = 0;
+        int di = 0, dj = 0, r = c.nRings;
         if (k < M) {
-            int di, dj, r;
             if (round < kLutHeadRounds) {
                 const int e = round == 0 ? head.dij[0] : head.dij[1];
                 di = static_cast<int16_t>(e & 0xFFFF);
@@ -356,6 +393,16 @@ __device__ bool candidate_search_grp(const DevMap& m, const PlanConsts& pc, cons
                 dj = lut.dj[k];
                 r = lut.ring[k];
             }
+        }
+        if constexpr (kTile) {
+            // rings grow with rank: the last lane of the round holds the farthest ring it needs
+            const int need = g.bcast(r, G - 1) + pc.footReach;
+            if (need > staged) {
+                stage_annulus(m, pc, c, tile, g, staged, need);
+                staged = need;
+            }
+        }
+        if (k < M) {
             i = c.ici + di;
             j = c.icj + dj;
             ok = in_range(i, j, m.g.rows, m.g.cols);
@@ -379,7 +426,7 @@ __device__ bool candidate_search_grp(const DevMap& m, const PlanConsts& pc, cons
 // At small windows the cells a leg needs in the common case — the default disc and the centroid
 // rectangle, ~10^2 cells — are cheaper to read once straight from the cache hierarchy (lane = cell,
 // lane = row) than to stage through LDS first; the LDS tile is kept for the spiral window of
-// large foot discs (stage_full_tile).
+// large foot discs (stage_annulus).
 
 // One pass over a CircleIterator disc (centre c, bounding box bb), lanes = cells in row-major order:
 // getFootholdMeanHeight (cpp:2520-2554) and, when kCheck, checkDefaultFoothold (cpp:2039-2082):
@@ -778,7 +825,6 @@ __device__ void spiral_search(const DevMap& m, const PlanConsts& pc, const Spira
         // tiny foot discs: evaluate the few cells a candidate needs straight from the map
         found = candidate_search_grp<G, false>(m, pc, lut, head, c, tile, g, wi, wj);  // cpp:2022
     } else {
-        stage_full_tile(m, pc, c, tile, g);
         found = candidate_search_grp<G, true>(m, pc, lut, head, c, tile, g, wi, wj);
     }
     if (found) {
@@ -963,6 +1009,14 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
                 c.cx = nx1;  // centre from the CENTROID track (cpp:861-862)
                 c.cy = ny;
                 c.nv = (polyKind == 0) ? 4 : 6;
+                {
+                    const double r = static_cast<double>(Rf);
+                    c.rect = polyKind == 0;
+                    c.xhi = nx2 + r;        // vertices LU/RU x (cpp:2501-2503)
+                    c.xlo = nx2 - r;        // RD/LD x
+                    c.yhi = ny + 0.5 * r;   // LU/LD y
+                    c.ylo = ny - 0.5 * r;   // RU/RD y
+                }
                 c.vx = sh.polyX[leg];
                 c.vy = sh.polyY[leg];
                 c.footDa = sh.footDa;
@@ -1096,6 +1150,8 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
     c.cy = qp->cy;
     c.nv = nv;
     c.cyc = 99;
+    c.rect = false;
+    c.xlo = c.xhi = c.ylo = c.yhi = 0.0;
     c.vx = sh.polyX[w];
     c.vy = sh.polyY[w];
     c.footDa = sh.footDa;
