@@ -885,6 +885,155 @@ struct PoseShared {
     int8_t footDb[kMaxFootOffsets];
 };
 
+// Per-leg constants of a pose (do not change along the chain).
+struct LegStatic {
+    float Rf;       // search radius of this leg (fpe_pose override or fpe_params.searchRadius)
+    int polyKind;   // 0 reference rectangle, 1 hexagon
+    bool radiusOk;  // Rf within the radius the LDS tile was sized for
+    LegConst lk;
+    double biasX, biasY;  // defaultBias of the leg (cpp:403-421)
+};
+__device__ __forceinline__ LegStatic make_leg_static(const PlanConsts& pc, const fpe_pose* pp, int leg, double res,
+                                                     const SpiralLut& lut) {
+    LegStatic ls;
+    ls.Rf = pp->leg_search_radius[leg];
+    if (!(ls.Rf > 0.0f)) ls.Rf = pc.searchRadius;
+    ls.polyKind = pp->leg_polygon_kind[leg];
+    ls.radiusOk = ls.Rf <= pc.maxSearchRadius;
+    ls.lk = make_leg_const(ls.Rf, res, lut);
+    ls.biasX = pc.biasX[leg];
+    ls.biasY = pc.biasY[leg];
+    return ls;
+}
+
+// One swing leg of one phase: next default positions on the three tracks, search polygon, the leg
+// search, results to LDS (for the commit decision) and to HBM.
+template <int G>
+__device__ __forceinline__ void leg_phase(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head,
+                                          PoseShared& sh, uint8_t* tile, const Grp<G>& g, int leg, const LegStatic& ls,
+                                          double y0, double adjY, double advance, int cyc, int nCycles, int b, bool live,
+                                          const fpe_plan_out& out) {
+    const float Rf = ls.Rf;
+    const int polyKind = ls.polyKind;
+    const bool radiusOk = ls.radiusOk;
+    const LegConst& lk = ls.lk;
+    const double biasX = ls.biasX, biasY = ls.biasY;
+        // next default positions of this leg on the three tracks (cpp:2199-2213, 2270-2284)
+        const double Ny = y0 + adjY;                         // cpp:2201
+        const double nx0 = (sh.ctr[0][0] + advance) + biasX;  // cpp:2199, 2414
+        const double nx1 = (sh.ctr[1][0] + advance) + biasX;
+        const double nx2 = (sh.ctr[2][0] + advance) + biasX;
+        const double ny = Ny + biasY;                        // identical on the three tracks
+        // search polygon from the NOMINAL track (cpp:2235-2244, getSearchPolygon cpp:2496-2517)
+        if (g.sub == 0) {
+            const double r = static_cast<double>(Rf);
+            double* vx = sh.polyX[leg];
+            double* vy = sh.polyY[leg];
+            if (polyKind == 0) {
+                vx[0] = nx2 + r;  vy[0] = ny + 0.5 * r;
+                vx[1] = nx2 + r;  vy[1] = ny - 0.5 * r;
+                vx[2] = nx2 - r;  vy[2] = ny - 0.5 * r;
+                vx[3] = nx2 - r;  vy[3] = ny + 0.5 * r;
+            } else {
+                const double hx = 0.5 * r;
+                const double hy = (0.5 * r) * 0.8660254037844386;
+                vx[0] = nx2 + r;   vy[0] = ny;
+                vx[1] = nx2 + hx;  vy[1] = ny - hy;
+                vx[2] = nx2 - hx;  vy[2] = ny - hy;
+                vx[3] = nx2 - r;   vy[3] = ny;
+                vx[4] = nx2 - hx;  vy[4] = ny + hy;
+                vx[5] = nx2 + hx;  vy[5] = ny + hy;
+            }
+        }
+
+        LegCtx c;
+        c.cyc = cyc;
+        c.cx = nx1;  // centre from the CENTROID track (cpp:861-862)
+        c.cy = ny;
+        c.nv = (polyKind == 0) ? 4 : 6;
+        {
+            const double r = static_cast<double>(Rf);
+            c.rect = polyKind == 0;
+            c.xhi = nx2 + r;        // vertices LU/RU x (cpp:2501-2503)
+            c.xlo = nx2 - r;        // RD/LD x
+            c.yhi = ny + 0.5 * r;   // LU/LD y
+            c.ylo = ny - 0.5 * r;   // RU/RD y
+        }
+        c.vx = sh.polyX[leg];
+        c.vy = sh.polyY[leg];
+        c.footDa = sh.footDa;
+        c.footDb = sh.footDb;
+
+        NominalOut no;
+        CentroidOut co;
+        float zDefault = 0.0f;
+        BBox dbox;
+        bool haveDbox = false;
+        if (!radiusOk) {
+            nominal_invalid(no, c.cx, c.cy, 3);
+            co.x = co.y = 0.0; co.z = 0.0f; co.row = co.col = -1; co.code = 6;
+        } else if (!centre_usable(c.cx, c.cy)) {
+            nominal_invalid(no, c.cx, c.cy, 2);
+            co.x = co.y = 0.0; co.z = 0.0f; co.row = co.col = -1; co.code = 6;
+        } else {
+            // corner lanes: box 0 = centre foot disc, box 1 = centroid rectangle (half extents
+            // 0.5*lx, 0.5*ly: p -/+ (-0.5*l) == p +/- 0.5*l exactly), box 2 = default-track disc,
+            // box 3 = getIndex(centre) (zero half extent)
+            const Box b0{c.cx, c.cy, pc.rf, pc.rf}, b1{c.cx, c.cy, 0.5 * lk.lx, 0.5 * lk.ly};
+            const Box b2{nx0, ny, pc.rf, pc.rf};
+            Corners<G, 16> cs;
+            cs.eval(m.g, g, b0, b1, b2, b0, 0x8u);
+            const BBox bb = cs.bbox(g, 0);
+            const BBox rbox = cs.bbox(g, 1);
+            dbox = cs.bbox(g, 2);
+            c.ici = cs.get(g, 12);
+            c.icj = cs.get(g, 13);
+            const bool rectWithin = cs.box_within(1);
+            const Submap sm = submap_from_corners(m.g, rbox, rectWithin, c.cx, c.cy);
+            stamp(pc, cyc, 2);
+            DefaultDisc dflt;
+            dflt.want = out.default_next != nullptr && centre_usable(nx0, ny);
+            dflt.x = nx0;
+            dflt.y = ny;
+            dflt.bb = dbox;
+            dflt.z = static_cast<float>(static_cast<double>(0.0f) + pc.h);  // value when no cell is visited
+            search_leg<G, true>(m, pc, lut, head, c, lk, tile, g, bb, sm, dflt, no, co);
+            zDefault = dflt.z;
+            haveDbox = true;
+            stamp(pc, cyc, 8);
+        }
+        if (out.default_next && !haveDbox) {  // cpp:2289-2301 (leg search skipped: radius / centre unusable)
+            if (!centre_usable(nx0, ny)) {
+                zDefault = static_cast<float>(static_cast<double>(0.0f) + pc.h);  // no cell visited
+            } else {
+                dbox = circle_bbox_fast(m.g, nx0, ny, pc.rf);
+                bool unused;
+                zDefault = disc_pass_direct<G, false>(m, pc, nx0, ny, dbox, g, unused);
+            }
+        }
+        if (g.sub == 0) {
+            sh.valid[leg] = no.valid;
+            sh.nxt[0][leg][0] = nx0;   sh.nxt[0][leg][1] = ny;    sh.nxt[0][leg][2] = static_cast<double>(zDefault);
+            sh.nxt[1][leg][0] = co.x;  sh.nxt[1][leg][1] = co.y;  sh.nxt[1][leg][2] = static_cast<double>(co.z);
+            sh.nxt[2][leg][0] = no.x;  sh.nxt[2][leg][1] = no.y;  sh.nxt[2][leg][2] = static_cast<double>(no.z);
+            if (live) {
+                const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
+                if (out.nominal) store_foothold(out.nominal + o, no, leg, cyc);
+                if (out.centroid) {
+                    fpe_centroid_foothold cf;
+                    cf.x = co.x; cf.y = co.y; cf.z = co.z; cf.row = co.row; cf.col = co.col;
+                    cf.code = static_cast<uint8_t>(co.code); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
+                    out.centroid[o] = cf;
+                }
+                if (out.default_next) {
+                    out.default_next[o * 3 + 0] = nx0;
+                    out.default_next[o * 3 + 1] = ny;
+                    out.default_next[o * 3 + 2] = static_cast<double>(zDefault);
+                }
+            }
+        }
+}
+
 }  // namespace
 
 // ---- chained plan kernel ------------------------------------------------------------------------------
@@ -918,13 +1067,8 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
     const fpe_pose* pp = poses + b;
     const double x0 = pp->position[0], y0 = pp->position[1], z0 = pp->position[2];
     const int gait = pp->gait;
-    float Rf = pp->leg_search_radius[leg];
-    if (!(Rf > 0.0f)) Rf = pc.searchRadius;
-    const int polyKind = pp->leg_polygon_kind[leg];
-    const bool radiusOk = Rf <= pc.maxSearchRadius;
-    const LegConst lk = make_leg_const(Rf, m.g.res, lut);
+    const LegStatic ls = make_leg_static(pc, pp, leg, m.g.res, lut);
     const LutHead head = load_lut_head(lut, g);
-    const double biasX = pc.biasX[leg], biasY = pc.biasY[leg];
 
     for (int k = tid % kPoseThreads; k < pc.nFoot; k += kPoseThreads) {
         sh.footDa[k] = pc.footDa[k];
@@ -976,120 +1120,7 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
             stamp(pc, cyc, 1);
 
             if (active) {
-                // next default positions of this leg on the three tracks (cpp:2199-2213, 2270-2284)
-                const double Ny = y0 + adjY;                         // cpp:2201
-                const double nx0 = (sh.ctr[0][0] + advance) + biasX;  // cpp:2199, 2414
-                const double nx1 = (sh.ctr[1][0] + advance) + biasX;
-                const double nx2 = (sh.ctr[2][0] + advance) + biasX;
-                const double ny = Ny + biasY;                        // identical on the three tracks
-                // search polygon from the NOMINAL track (cpp:2235-2244, getSearchPolygon cpp:2496-2517)
-                if (g.sub == 0) {
-                    const double r = static_cast<double>(Rf);
-                    double* vx = sh.polyX[leg];
-                    double* vy = sh.polyY[leg];
-                    if (polyKind == 0) {
-                        vx[0] = nx2 + r;  vy[0] = ny + 0.5 * r;
-                        vx[1] = nx2 + r;  vy[1] = ny - 0.5 * r;
-                        vx[2] = nx2 - r;  vy[2] = ny - 0.5 * r;
-                        vx[3] = nx2 - r;  vy[3] = ny + 0.5 * r;
-                    } else {
-                        const double hx = 0.5 * r;
-                        const double hy = (0.5 * r) * 0.8660254037844386;
-                        vx[0] = nx2 + r;   vy[0] = ny;
-                        vx[1] = nx2 + hx;  vy[1] = ny - hy;
-                        vx[2] = nx2 - hx;  vy[2] = ny - hy;
-                        vx[3] = nx2 - r;   vy[3] = ny;
-                        vx[4] = nx2 - hx;  vy[4] = ny + hy;
-                        vx[5] = nx2 + hx;  vy[5] = ny + hy;
-                    }
-                }
-
-                LegCtx c;
-                c.cyc = cyc;
-                c.cx = nx1;  // centre from the CENTROID track (cpp:861-862)
-                c.cy = ny;
-                c.nv = (polyKind == 0) ? 4 : 6;
-                {
-                    const double r = static_cast<double>(Rf);
-                    c.rect = polyKind == 0;
-                    c.xhi = nx2 + r;        // vertices LU/RU x (cpp:2501-2503)
-                    c.xlo = nx2 - r;        // RD/LD x
-                    c.yhi = ny + 0.5 * r;   // LU/LD y
-                    c.ylo = ny - 0.5 * r;   // RU/RD y
-                }
-                c.vx = sh.polyX[leg];
-                c.vy = sh.polyY[leg];
-                c.footDa = sh.footDa;
-                c.footDb = sh.footDb;
-
-                NominalOut no;
-                CentroidOut co;
-                float zDefault = 0.0f;
-                BBox dbox;
-                bool haveDbox = false;
-                if (!radiusOk) {
-                    nominal_invalid(no, c.cx, c.cy, 3);
-                    co.x = co.y = 0.0; co.z = 0.0f; co.row = co.col = -1; co.code = 6;
-                } else if (!centre_usable(c.cx, c.cy)) {
-                    nominal_invalid(no, c.cx, c.cy, 2);
-                    co.x = co.y = 0.0; co.z = 0.0f; co.row = co.col = -1; co.code = 6;
-                } else {
-                    // corner lanes: box 0 = centre foot disc, box 1 = centroid rectangle (half extents
-                    // 0.5*lx, 0.5*ly: p -/+ (-0.5*l) == p +/- 0.5*l exactly), box 2 = default-track disc,
-                    // box 3 = getIndex(centre) (zero half extent)
-                    const Box b0{c.cx, c.cy, pc.rf, pc.rf}, b1{c.cx, c.cy, 0.5 * lk.lx, 0.5 * lk.ly};
-                    const Box b2{nx0, ny, pc.rf, pc.rf};
-                    Corners<G, 16> cs;
-                    cs.eval(m.g, g, b0, b1, b2, b0, 0x8u);
-                    const BBox bb = cs.bbox(g, 0);
-                    const BBox rbox = cs.bbox(g, 1);
-                    dbox = cs.bbox(g, 2);
-                    c.ici = cs.get(g, 12);
-                    c.icj = cs.get(g, 13);
-                    const bool rectWithin = cs.box_within(1);
-                    const Submap sm = submap_from_corners(m.g, rbox, rectWithin, c.cx, c.cy);
-                    stamp(pc, cyc, 2);
-                    DefaultDisc dflt;
-                    dflt.want = out.default_next != nullptr && centre_usable(nx0, ny);
-                    dflt.x = nx0;
-                    dflt.y = ny;
-                    dflt.bb = dbox;
-                    dflt.z = static_cast<float>(static_cast<double>(0.0f) + pc.h);  // value when no cell is visited
-                    search_leg<G, true>(m, pc, lut, head, c, lk, tile, g, bb, sm, dflt, no, co);
-                    zDefault = dflt.z;
-                    haveDbox = true;
-                    stamp(pc, cyc, 8);
-                }
-                if (out.default_next && !haveDbox) {  // cpp:2289-2301 (leg search skipped: radius / centre unusable)
-                    if (!centre_usable(nx0, ny)) {
-                        zDefault = static_cast<float>(static_cast<double>(0.0f) + pc.h);  // no cell visited
-                    } else {
-                        dbox = circle_bbox_fast(m.g, nx0, ny, pc.rf);
-                        bool unused;
-                        zDefault = disc_pass_direct<G, false>(m, pc, nx0, ny, dbox, g, unused);
-                    }
-                }
-                if (g.sub == 0) {
-                    sh.valid[leg] = no.valid;
-                    sh.nxt[0][leg][0] = nx0;   sh.nxt[0][leg][1] = ny;    sh.nxt[0][leg][2] = static_cast<double>(zDefault);
-                    sh.nxt[1][leg][0] = co.x;  sh.nxt[1][leg][1] = co.y;  sh.nxt[1][leg][2] = static_cast<double>(co.z);
-                    sh.nxt[2][leg][0] = no.x;  sh.nxt[2][leg][1] = no.y;  sh.nxt[2][leg][2] = static_cast<double>(no.z);
-                    if (live) {
-                        const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
-                        if (out.nominal) store_foothold(out.nominal + o, no, leg, cyc);
-                        if (out.centroid) {
-                            fpe_centroid_foothold cf;
-                            cf.x = co.x; cf.y = co.y; cf.z = co.z; cf.row = co.row; cf.col = co.col;
-                            cf.code = static_cast<uint8_t>(co.code); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
-                            out.centroid[o] = cf;
-                        }
-                        if (out.default_next) {
-                            out.default_next[o * 3 + 0] = nx0;
-                            out.default_next[o * 3 + 1] = ny;
-                            out.default_next[o * 3 + 2] = static_cast<double>(zDefault);
-                        }
-                    }
-                }
+                leg_phase<G>(m, pc, lut, head, sh, tile, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out);
             } else if (g.sub == 0) {
                 sh.valid[leg] = 1;  // non-swing legs do not vote
             }
@@ -1109,6 +1140,96 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
         }
         if (leg == 0 && g.sub == 0 && live && out.cycle_ok)
             out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = cycleOk ? 1 : 0;
+        adjY += pc.drift;  // cpp:1578
+    }
+}
+
+// ---- chained plan, sequential-legs form (large windows) ------------------------------------------------------
+// One wavefront per pose; the swing legs of a phase are searched one after the other, each with all
+// 64 lanes.  For large spiral windows (1 cm / 0.5 cm maps) a leg has enough cells and candidates to
+// fill a wavefront, the per-leg geometry becomes truly wave-uniform, there are no workgroup barriers
+// and — for the 4-phase walk gait, where only one leg swings per phase — no idle wavefronts.
+__global__ __launch_bounds__(64, 4) void plan_sequential_kernel(DevMap m, PlanConsts pc, SpiralLut lut,
+                                                                const fpe_pose* __restrict__ poses, int B, int nCycles,
+                                                                fpe_plan_out out) {
+    constexpr int G = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = static_cast<int>(threadIdx.x);
+    const Grp<G> g(tid);
+    PoseShared& sh = *reinterpret_cast<PoseShared*>(smem);
+    uint8_t* tile = smem + sizeof(PoseShared);
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const bool live = true;
+
+    const fpe_pose* pp = poses + b;
+    const double x0 = pp->position[0], y0 = pp->position[1], z0 = pp->position[2];
+    const int gait = pp->gait;
+    const LutHead head = load_lut_head(lut, g);
+    for (int k = tid; k < pc.nFoot; k += G) {
+        sh.footDa[k] = pc.footDa[k];
+        sh.footDb[k] = pc.footDb[k];
+    }
+    // initial stance (cpp:350-378) and first-gait shift (setFirstGait, cpp:2679-2699): lane = leg
+    if (tid < 4) {
+        const int leg = tid;
+        double sx = (leg == 0 || leg == 3) ? pc.LbHalf : -pc.LbHalf;
+        double sy = (leg <= 1) ? pc.WbHalfNeg : pc.WbHalfPos;
+        double sz = 0;
+        sx += x0;
+        sy += y0;
+        sz += z0;
+        if (out.stance) {
+            double* st = out.stance + (static_cast<size_t>(b) * 4 + leg) * 3;
+            st[0] = sx;
+            st[1] = sy;
+            st[2] = sz;
+        }
+        for (int t = 0; t < 3; ++t) {
+            sh.cur[t][leg][0] = sx - pc.stepHalf;
+            sh.cur[t][leg][1] = sy;
+            sh.cur[t][leg][2] = sz;
+        }
+    }
+    pose_sync<16>();
+
+    double adjY = 0.0;  // ajustedPose_[1], cpp:759
+    const int nPhases = (gait == 1) ? 4 : 1;
+    const double advance = (gait == 1) ? pc.stepQuarter : pc.step;
+    const int walkOrder = pc.RF_FIRST ? ((0) | (2 << 2) | (3 << 4) | (1 << 6)) : ((3) | (1 << 2) | (0 << 4) | (2 << 6));
+
+    for (int cyc = 0; cyc < nCycles; ++cyc) {
+        bool cycleOk = true;
+        for (int ph = 0; ph < nPhases; ++ph) {
+            const unsigned mask = (gait == 1) ? (1u << ((walkOrder >> (2 * ph)) & 3)) : 0xFu;
+            // feet-polygon centres: lane t computes track t (getPolygonCenter, cpp:2191, 2265)
+            if (tid < 3) {
+                double cx, cy;
+                polygon_center_xy(sh.cur[tid], cx, cy);
+                sh.ctr[tid][0] = cx;
+                sh.ctr[tid][1] = cy;
+            }
+            if (tid < 4) sh.valid[tid] = 1;  // non-swing legs do not vote
+            pose_sync<16>();
+            for (int leg = 0; leg < 4; ++leg) {
+                if (!((mask >> leg) & 1u)) continue;
+                const LegStatic ls = make_leg_static(pc, pp, leg, m.g.res, lut);
+                leg_phase<G>(m, pc, lut, head, sh, tile, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out);
+            }
+            pose_sync<16>();
+            // footholdValidation_ = AND of the swing legs' flags (cpp:1323); commit or skip (cpp:1332-1576)
+            const bool phaseOk = (sh.valid[0] & sh.valid[1] & sh.valid[2] & sh.valid[3]) != 0;
+            if (phaseOk && tid < 36) {
+                const int leg = tid / 9, e = tid - leg * 9;
+                if ((mask >> leg) & 1u) {
+                    const int t = e / 3, k = e - t * 3;
+                    sh.cur[t][leg][k] = sh.nxt[t][leg][k];
+                }
+            }
+            pose_sync<16>();
+            cycleOk = cycleOk && phaseOk;
+        }
+        if (tid == 0 && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = cycleOk ? 1 : 0;
         adjY += pc.drift;  // cpp:1578
     }
 }
@@ -1221,13 +1342,18 @@ static size_t tile_bytes(const PlanConsts& pc) { return static_cast<size_t>((pc.
 
 // lanes per leg for a tile of tileW^2 cells: small windows (2 cm maps) put a whole pose in one
 // wavefront; large windows give every leg its own wavefront
+// lanes per leg: 8 for small windows (two poses per wavefront); large windows use the sequential-legs
+// kernel (code 65: one wavefront per pose, 64 lanes per leg, legs in sequence).  64 = one wavefront per
+// leg, four per pose (kept for measurement).
 int plan_group_size(const PlanConsts& pc) {
-    if (pc.groupOverride == 4 || pc.groupOverride == 8 || pc.groupOverride == 16 || pc.groupOverride == 64)
+    if (pc.groupOverride == 4 || pc.groupOverride == 8 || pc.groupOverride == 16 || pc.groupOverride == 64 ||
+        pc.groupOverride == 65)
         return pc.groupOverride;
-    return (pc.tileW * pc.tileW <= 1024) ? 8 : 64;
+    return (pc.tileW * pc.tileW <= 1024) ? 8 : 65;
 }
 size_t plan_lds_bytes(const PlanConsts& pc) {
     const int G = plan_group_size(pc);
+    if (G == 65) return sizeof(PoseShared) + tile_bytes(pc);  // sequential legs share one tile
     const int ppb = G >= 16 ? 1 : 64 / (4 * G);  // poses per 64-thread block
     return ppb * (sizeof(PoseShared) + 4 * tile_bytes(pc));
 }
@@ -1237,7 +1363,9 @@ hipError_t launch_plan_chained(const DevMap& m, const PlanConsts& pc, const Spir
                                int B, int nCycles, const fpe_plan_out& d_out, hipStream_t stream) {
     const size_t lds = plan_lds_bytes(pc);
     const int G = plan_group_size(pc);
-    if (G == 4) {
+    if (G == 65) {
+        hipLaunchKernelGGL(plan_sequential_kernel, dim3(B), dim3(64), lds, stream, m, pc, lut, d_poses, B, nCycles, d_out);
+    } else if (G == 4) {
         hipLaunchKernelGGL(plan_chained_kernel<4>, dim3((B + 3) / 4), dim3(64), lds, stream, m, pc, lut, d_poses, B, nCycles, d_out);
     } else if (G == 8) {
         hipLaunchKernelGGL(plan_chained_kernel<8>, dim3((B + 1) / 2), dim3(64), lds, stream, m, pc, lut, d_poses, B, nCycles, d_out);
@@ -1274,6 +1402,9 @@ hipError_t set_max_lds(size_t planBytes, size_t searchBytes) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(planBytes));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_chained_kernel<64>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(planBytes));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_sequential_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(planBytes));
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(search_legs_kernel),

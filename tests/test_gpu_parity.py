@@ -57,7 +57,7 @@ def test_resolutions_and_radii(planner, res, R, rows):
     util.assert_plan_equal(eng, ora)
 
 
-@pytest.mark.parametrize("group", ["4", "8", "16", "64"])
+@pytest.mark.parametrize("group", ["4", "8", "16", "64", "65"])
 def test_both_lane_groupings_agree_with_the_oracle(planner, group, monkeypatch):
     """The chained kernel has two decompositions (16 lanes per leg = one wavefront per pose, 64 lanes
     per leg = one wavefront per leg); both must reproduce the oracle on 2 cm and 1 cm maps."""
