@@ -44,7 +44,6 @@ struct PlanConsts {
     // a spiral candidate), valid only when footRobust != 0: the host proved that no lattice offset
     // lies within rounding distance of the radius, so the f64 per-candidate bounding-box walk
     // visits exactly {candidate + offset} ∩ map (fpe_host.cpp::derive_foot_offsets).
-    int32_t debugSkip;     // profiling-only ablation mask (FPE_DEBUG_SKIP); 0 in production
     unsigned long long* trace;  // profiling-only: per-phase s_memtime stamps (FPE_TRACE_PTR); null in production
     int32_t nFoot;
     int32_t footRobust;

@@ -63,22 +63,15 @@ FPE_HD int index_of(double x, double org, double pos, double res) {
 // within 3.4e-16*|q| of the correctly rounded q = n / res, so trunc(q') == trunc(q) whenever q' is
 // farther than eps = 4.5e-16*|q'| from an integer; otherwise (exact ties such as cell-centre +
 // half-cell radii, or NaN) the true division decides.  Bit-identical to index_of by construction.
-// FPE_RARE_PATH(v): with -DFPE_RARE_BRANCH the rare exact path is kept a real branch; by default
-// hipcc if-converts it (the division is speculated).  Measured on MI355X: the speculated form is
-// ~2.5% faster for this kernel (0.1011 vs 0.1038 ms), so it is the default.
-#if defined(__HIP_DEVICE_COMPILE__) && defined(FPE_RARE_BRANCH)
-#define FPE_RARE_PATH(v) asm volatile("; rare exact path" : "+v"(v))
-#else
-#define FPE_RARE_PATH(v) (void)(v)
-#endif
+// (hipcc if-converts the rare branch below, i.e. the division is speculated; measured on MI355X
+// that straight-line form is ~2.5% faster for the plan kernel than keeping a real branch.)
 FPE_HD int index_of_fast(double x, double org, double pos, double res, double rinv) {
-    double n = (x - org) - pos;
+    const double n = (x - org) - pos;
     const double qf = n * rinv;
     double k = trunc(qf);
     const double fr = fabs(qf - k);
     const double eps = fabs(qf) * 4.5e-16 + 1e-290;
     if (__builtin_expect(!(fr > eps && fr < 1.0 - eps), 0)) {
-        FPE_RARE_PATH(n);
         k = trunc(n / res);
     }
     return -static_cast<int>(k);
@@ -214,11 +207,11 @@ FPE_HD bool polygon_inside_fast(const double* vx, const double* vy, int n, doubl
     int cross = 0;
     for (int i = 0, j = n - 1; i < n; j = i++) {
         if ((vy[i] > py) != (vy[j] > py)) {
-            double ex = vx[j] - vx[i];
+            const double ex = vx[j] - vx[i];
             const double t = py - vy[i];
             double xi = vx[i];
             if (!(ex == 0.0 && fabs(t) <= DBL_MAX)) {
-                FPE_RARE_PATH(ex);  // slanted edge: the literal intersection, division included
+                // slanted edge: the literal intersection, division included
                 xi = ex * t / (vy[j] - vy[i]) + vx[i];
             }
             if (px < xi) cross++;

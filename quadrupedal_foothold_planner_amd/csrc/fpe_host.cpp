@@ -168,8 +168,6 @@ void derive_constants(const fpe_params& p, const MapGeom& geom, float maxSearchR
     c.tileWMagic = fastdiv_magic(static_cast<uint32_t>(c.tileW));
     const char* grp = std::getenv("FPE_PLAN_GROUP");
     c.groupOverride = grp ? std::atoi(grp) : 0;
-    const char* skip = std::getenv("FPE_DEBUG_SKIP");
-    c.debugSkip = skip ? std::atoi(skip) : 0;
     const char* tr = std::getenv("FPE_TRACE_PTR");
     c.trace = tr ? reinterpret_cast<unsigned long long*>(std::strtoull(tr, nullptr, 0)) : nullptr;
     derive_foot_offsets(p.footRadius, geom, c);
