@@ -221,6 +221,32 @@ def main():
             "note": "latency/ALU bound; map is L2/Infinity-Cache resident (DESIGN.md)",
         },
     }
+    if rank == 0 and world == 1:
+        # map ingest: grid_map message layout (column-major, circular-buffer start
+        # index) -> canonical HBM layers, device-resident source; HBM-bound transpose, 2 layers
+        ir, ic = 4000, 4000
+        src_t = torch.rand(ic * ir, dtype=torch.float32, device=dev)
+        src_e = torch.rand(ic * ir, dtype=torch.float32, device=dev)
+        ing = FootholdPlanner(local_rank)
+        for _ in range(2):
+            ing.upload_map_device(src_t.data_ptr(), src_e.data_ptr(), ir, ic, 0.005, start_index=(1234, 321),
+                                  storage_order="col", stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        i0, i1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        i0.record(stream)
+        for _ in range(reps):
+            ing.upload_map_device(src_t.data_ptr(), src_e.data_ptr(), ir, ic, 0.005, start_index=(1234, 321),
+                                  storage_order="col", stream=stream.cuda_stream)
+        i1.record(stream)
+        torch.cuda.synchronize()
+        ing_ms = i0.elapsed_time(i1) / reps
+        ing_bytes = 2 * 2 * ir * ic * 4  # two layers, read + write
+        line["ingest"] = {"map": f"{ir}x{ic} f32 x 2 layers, column-major + start index (1234,321), device source",
+                          "ms": ing_ms, "GB/s": ing_bytes / (ing_ms * 1e-3) / 1e9, "bytes": ing_bytes,
+                          "note": "includes hipMalloc/hipFree of the snapshot buffers per upload"}
+        ing.close()
+        del src_t, src_e
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(trav, elev, res, params, poses, n_cycles, args.cpu_seconds)
     if rank == 0:

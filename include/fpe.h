@@ -182,6 +182,18 @@ int fpe_search_legs_device(fpe_handle h, const fpe_params* params, const fpe_leg
 int fpe_plan_service(fpe_handle h, const fpe_params* params, const double initial_position[3],
                      uint8_t gait_cycles, fpe_global_footholds* response);
 
+/* Same call, plus the other two result products the node publishes/logs; either
+ * extra pointer may be NULL.
+ *   centroid: content of global_footholds_centroid for THIS call (cpp:709-727 stance entries,
+ *             cpp:1444-1462 per valid cycle; the reference never clears that message between
+ *             calls, cpp:715 — appending across calls is left to the adapter);
+ *   default_footholds: rows of globalFootholdsResult_.defaultFootholds (cpp:666-671, 1344-1348):
+ *             (1 + gait_cycles_succeed') x 12 doubles = RF,RH,LH,LF x (x,y,z), stance row first, one row
+ *             per VALID cycle; *n_default_rows receives the number of rows (capacity 1 + gait_cycles). */
+int fpe_plan_service_ex(fpe_handle h, const fpe_params* params, const double initial_position[3],
+                        uint8_t gait_cycles, fpe_global_footholds* response, fpe_global_footholds* centroid,
+                        double* default_footholds, int32_t* n_default_rows);
+
 /* ---- host-side helpers (no GPU needed) -------------------------------------------------------- */
 /* SpiralIterator visiting order as index offsets (di,dj) for rings 0..n_rings (generateRing walk,
  * consumed from the back).  Writes min(count, max_cells) entries of (di, dj, ring); returns count. */

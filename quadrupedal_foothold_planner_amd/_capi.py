@@ -101,6 +101,7 @@ EXPORTED_SYMBOLS = [
     "fpe_search_legs",
     "fpe_search_legs_device",
     "fpe_plan_service",
+    "fpe_plan_service_ex",
     "fpe_spiral_offsets",
     "fpe_tile_halfwidth",
     "fpe_algorithmic_bytes_per_foothold",
@@ -146,6 +147,7 @@ def lib():
     L.fpe_search_legs.argtypes = [vp, vp, vp, i32, vp]
     L.fpe_search_legs_device.argtypes = [vp, vp, vp, i32, vp, vp]
     L.fpe_plan_service.argtypes = [vp, vp, vp, C.c_uint8, vp]
+    L.fpe_plan_service_ex.argtypes = [vp, vp, vp, C.c_uint8, vp, vp, vp, vp]
     L.fpe_spiral_offsets.argtypes = [i32, vp, i32]
     L.fpe_tile_halfwidth.argtypes = [f32, f32, f64]
     L.fpe_algorithmic_bytes_per_foothold.restype = f64

@@ -380,7 +380,14 @@ int fpe_search_legs(fpe_handle h, const fpe_params* params, const fpe_leg_query*
 
 int fpe_plan_service(fpe_handle h, const fpe_params* params, const double initial_position[3], uint8_t gait_cycles,
                      fpe_global_footholds* response) {
+    return fpe_plan_service_ex(h, params, initial_position, gait_cycles, response, nullptr, nullptr, nullptr);
+}
+
+int fpe_plan_service_ex(fpe_handle h, const fpe_params* params, const double initial_position[3], uint8_t gait_cycles,
+                        fpe_global_footholds* response, fpe_global_footholds* centroid, double* default_footholds,
+                        int32_t* n_default_rows) {
     if (!initial_position || !response) return fail(FPE_E_INVALID_ARG, "null argument");
+    if (default_footholds && !n_default_rows) return fail(FPE_E_INVALID_ARG, "n_default_rows is required with default_footholds");
     fpe_pose pose;
     std::memset(&pose, 0, sizeof(pose));
     pose.position[0] = initial_position[0];
@@ -388,6 +395,10 @@ int fpe_plan_service(fpe_handle h, const fpe_params* params, const double initia
     pose.position[2] = initial_position[2];
     const int N = gait_cycles;
     double stance[12];
+    std::vector<fpe_foothold> nominal(static_cast<size_t>(N) * 4);
+    std::vector<fpe_centroid_foothold> cen(static_cast<size_t>(N) * 4);
+    std::vector<double> dflt(static_cast<size_t>(N) * 12);
+    std::vector<uint8_t> ok(static_cast<size_t>(N));
     if (N == 0) {
         // the reference's loop body never runs (cpp:762); the stance comes from initialize()
         if (!h || !params) return fail(FPE_E_INVALID_ARG, "null handle or params");
@@ -402,19 +413,41 @@ int fpe_plan_service(fpe_handle h, const fpe_params* params, const double initia
             sz += pose.position[2];
             stance[l * 3] = sx; stance[l * 3 + 1] = sy; stance[l * 3 + 2] = sz;
         }
-        fpe::assemble_global_footholds(nullptr, nullptr, stance, 0, response);
-        return FPE_OK;
+    } else {
+        fpe_plan_out out;
+        std::memset(&out, 0, sizeof(out));
+        out.nominal = nominal.data();
+        out.cycle_ok = ok.data();
+        out.stance = stance;
+        if (centroid) out.centroid = cen.data();
+        if (default_footholds) out.default_next = dflt.data();
+        int rc = fpe_plan(h, params, &pose, 1, N, &out);
+        if (rc != FPE_OK) return rc;
     }
-    std::vector<fpe_foothold> nominal(static_cast<size_t>(N) * 4);
-    std::vector<uint8_t> ok(static_cast<size_t>(N));
-    fpe_plan_out out;
-    std::memset(&out, 0, sizeof(out));
-    out.nominal = nominal.data();
-    out.cycle_ok = ok.data();
-    out.stance = stance;
-    int rc = fpe_plan(h, params, &pose, 1, N, &out);
-    if (rc != FPE_OK) return rc;
     fpe::assemble_global_footholds(nominal.data(), ok.data(), stance, N, response);
+    if (centroid) {
+        // same bookkeeping with the centroid-track results (cpp:709-727, 1444-1462)
+        std::vector<fpe_foothold> asNominal(static_cast<size_t>(N) * 4);
+        for (size_t k = 0; k < asNominal.size(); ++k) {
+            std::memset(&asNominal[k], 0, sizeof(fpe_foothold));
+            asNominal[k].x = cen[k].x;
+            asNominal[k].y = cen[k].y;
+            asNominal[k].z = cen[k].z;
+        }
+        fpe::assemble_global_footholds(asNominal.data(), ok.data(), stance, N, centroid);
+    }
+    if (default_footholds) {
+        int rows = 0;
+        std::memcpy(default_footholds, stance, 12 * sizeof(double));  // cpp:666-671
+        rows = 1;
+        for (int g = 0; g < N; ++g)
+            if (ok[g]) {  // cpp:1344-1348: appended only for committed cycles
+                std::memcpy(default_footholds + static_cast<size_t>(rows) * 12, dflt.data() + static_cast<size_t>(g) * 12,
+                            12 * sizeof(double));
+                ++rows;
+            }
+        *n_default_rows = rows;
+    }
     return FPE_OK;
 }
 

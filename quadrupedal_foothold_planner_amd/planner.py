@@ -141,11 +141,8 @@ class FootholdPlanner:
                                                      C.c_void_p(d_out_ptr), C.c_void_p(stream or 0)))
 
     # ---- the service (globalFootholdPlan, cpp:539-1602): response content for one pose ---------------------
-    def globalFootholdPlan(self, gait_cycles, initial_position):
-        msg = np.zeros(1, dtype=GLOBAL_FOOTHOLDS_DTYPE)
-        pos = np.ascontiguousarray(initial_position, dtype=np.float64).reshape(3)
-        self._check(self._lib.fpe_plan_service(self._h, ptr(self.params), ptr(pos), int(gait_cycles) & 0xFF, ptr(msg)))
-        m = msg[0]
+    @staticmethod
+    def _msg(m):
         n = int(m["n_footholds"])
         return {
             "success": bool(m["success"]),
@@ -153,3 +150,21 @@ class FootholdPlanner:
             "gait_cycles_succeed": int(m["gait_cycles_succeed"]),
             "footholds": m["footholds"][:n].copy(),
         }
+
+    def globalFootholdPlan(self, gait_cycles, initial_position, all_tracks=False):
+        """Response content of the service; with all_tracks also the centroid message and the default-track
+        rows (global_footholds_centroid, globalFootholdsResult_.defaultFootholds)."""
+        msg = np.zeros(1, dtype=GLOBAL_FOOTHOLDS_DTYPE)
+        pos = np.ascontiguousarray(initial_position, dtype=np.float64).reshape(3)
+        if not all_tracks:
+            self._check(self._lib.fpe_plan_service(self._h, ptr(self.params), ptr(pos), int(gait_cycles) & 0xFF, ptr(msg)))
+            return self._msg(msg[0])
+        cen = np.zeros(1, dtype=GLOBAL_FOOTHOLDS_DTYPE)
+        dflt = np.zeros((1 + int(gait_cycles), 4, 3), dtype=np.float64)
+        nrows = C.c_int32(0)
+        self._check(self._lib.fpe_plan_service_ex(self._h, ptr(self.params), ptr(pos), int(gait_cycles) & 0xFF, ptr(msg),
+                                                  ptr(cen), ptr(dflt), C.cast(C.byref(nrows), C.c_void_p)))
+        out = self._msg(msg[0])
+        out["centroid"] = self._msg(cen[0])
+        out["default_footholds"] = dflt[: nrows.value].copy()
+        return out
