@@ -244,7 +244,7 @@ def main():
         ing_bytes = 2 * 2 * ir * ic * 4  # two layers, read + write
         line["ingest"] = {"map": f"{ir}x{ic} f32 x 2 layers, column-major + start index (1234,321), device source",
                           "ms": ing_ms, "GB/s": ing_bytes / (ing_ms * 1e-3) / 1e9, "bytes": ing_bytes,
-                          "note": "includes hipMalloc/hipFree of the snapshot buffers per upload"}
+                          "note": "canonicalise_layer_kernel x2 per upload, snapshot buffers recycled (no hipMalloc in steady state)"}
         ing.close()
         del src_t, src_e
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -46,13 +46,45 @@ int fail_hip(hipError_t e, const char* what) {
         if (e_ != hipSuccess) return fail_hip(e_, #call); \
     } while (0)
 
+// Layer buffers of retired snapshots are recycled instead of freed: a traversability map arrives
+// at 10-20 Hz and hipMalloc/hipFree (the latter a device-wide sync) would dominate the upload.
+// Reuse is safe in stream order: host-buffer plans are synchronous, and device-API callers order
+// uploads and plans on one stream (include/fpe.h).
+struct BufferPool {
+    std::mutex mu;
+    std::vector<std::pair<size_t, float*>> free;  // (floats, pointer)
+    float* take(size_t n) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t k = 0; k < free.size(); ++k)
+            if (free[k].first == n) {
+                float* p = free[k].second;
+                free.erase(free.begin() + static_cast<long>(k));
+                return p;
+            }
+        return nullptr;
+    }
+    void give(size_t n, float* p) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (free.size() >= 4) {  // keep at most two snapshots' worth
+            (void)hipFree(free.front().second);
+            free.erase(free.begin());
+        }
+        free.emplace_back(n, p);
+    }
+    ~BufferPool() {
+        for (auto& e : free) (void)hipFree(e.second);
+    }
+};
+
 struct MapSnapshot {
     fpe::MapGeom g;
+    size_t n = 0;
     float* d_trav = nullptr;
     float* d_elev = nullptr;
+    std::shared_ptr<BufferPool> pool;
     ~MapSnapshot() {
-        if (d_trav) (void)hipFree(d_trav);
-        if (d_elev) (void)hipFree(d_elev);
+        if (d_trav) pool ? pool->give(n, d_trav) : (void)hipFree(d_trav);
+        if (d_elev) pool ? pool->give(n, d_elev) : (void)hipFree(d_elev);
     }
 };
 
@@ -64,6 +96,7 @@ struct fpe_engine {
     int device = 0;
     std::mutex mu;
     std::shared_ptr<MapSnapshot> map;
+    std::shared_ptr<BufferPool> pool = std::make_shared<BufferPool>();
     int16_t* d_di = nullptr;
     int16_t* d_dj = nullptr;
     uint8_t* d_ring = nullptr;
@@ -129,8 +162,12 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
     const size_t n = static_cast<size_t>(desc->rows) * desc->cols;
     auto snap = std::make_shared<MapSnapshot>();
     snap->g = fpe::make_geom(desc->rows, desc->cols, desc->resolution, desc->position[0], desc->position[1]);
-    FPE_HIP(hipMalloc(reinterpret_cast<void**>(&snap->d_trav), n * sizeof(float)));
-    FPE_HIP(hipMalloc(reinterpret_cast<void**>(&snap->d_elev), n * sizeof(float)));
+    snap->n = n;
+    snap->pool = h->pool;
+    snap->d_trav = h->pool->take(n);
+    snap->d_elev = h->pool->take(n);
+    if (!snap->d_trav) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&snap->d_trav), n * sizeof(float)));
+    if (!snap->d_elev) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&snap->d_elev), n * sizeof(float)));
     const bool canonical = desc->storage_order == 1 && desc->start_index[0] == 0 && desc->start_index[1] == 0;
     const float* src[2] = {trav, elev};
     float* dst[2] = {snap->d_trav, snap->d_elev};

@@ -264,6 +264,32 @@ def test_service_message(planner):
     assert seen_fail, "the harsh map should make some cycles fail (commit/skip path)"
 
 
+@pytest.mark.parametrize("group", ["4", "8"])
+@pytest.mark.parametrize("B", [1, 2, 3, 5, 7])
+def test_ragged_batches_pad_the_last_wavefront(planner, group, B, monkeypatch):
+    """B not a multiple of the poses-per-wavefront (2 at 8 lanes per leg, 4 at 4): the padding poses of
+    the last wavefront must neither store nor disturb the live ones."""
+    monkeypatch.setenv("FPE_PLAN_GROUP", group)
+    set_params(planner)
+    trav, elev = synth.rough_map(300, 300, 0.02, seed=23, bad_frac=0.2)
+    poses = synth.poses_in_map(B, 6.0, 6.0, 5, 0.18, seed=24 + B, margin=0.7)
+    eng, ora = util.run_both(planner, trav, elev, 0.02, poses, 5)
+    util.assert_plan_equal(eng, ora)
+
+
+def test_maximum_gait_cycles_255(planner):
+    """uint8 gait_cycles (srv:5): 255 cycles, gait_cycle_id up to 254; trajectories leave the map at the end."""
+    set_params(planner)
+    trav, elev = synth.rough_map(400, 400, 0.02, seed=25)
+    poses = synth.poses_uniform(8, (-3.3, -3.0), (-1.0, 2.5), seed=26)
+    eng, ora = util.run_both(planner, trav, elev, 0.02, poses, 255)
+    util.assert_plan_equal(eng, ora)
+    assert eng["nominal"]["gait_cycle_id"][:, 254, :].tolist() == [[254] * 4] * 8
+    assert (eng["centroid"]["code"] == 6).any(), "late cycles run off the map: getSubmap must fail there"
+    msg = planner.globalFootholdPlan(255, poses["position"][0])
+    assert msg["gait_cycles"] == 255 and len(msg["footholds"]) == 4 + 4 * int(ora["cycle_ok"][0].sum())
+
+
 def test_service_all_tracks(planner):
     """N2: centroid message and default-track rows of the same call (cpp:1338-1348, 1444-1483)."""
     set_params(planner)
