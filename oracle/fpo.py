@@ -131,18 +131,20 @@ class OracleMap:
             pass
 
     # ---- chained plan -------------------------------------------------------------------------
-    def plan(self, params, poses, n_cycles, threads=1):
-        """params: PARAMS_DTYPE scalar array; poses: POSE_DTYPE array [B]."""
+    def plan(self, params, poses, n_cycles, threads=1, out=None):
+        """params: PARAMS_DTYPE scalar array; poses: POSE_DTYPE array [B].  `out` may be a dict of
+        preallocated arrays from a previous call (timing loops reuse it)."""
         params = np.ascontiguousarray(params, dtype=PARAMS_DTYPE).reshape(1)
         poses = np.ascontiguousarray(poses, dtype=POSE_DTYPE)
         B = poses.shape[0]
-        out = {
-            "nominal": np.zeros((B, n_cycles, 4), dtype=LEG_DTYPE),
-            "centroid": np.zeros((B, n_cycles, 4), dtype=CENTROID_DTYPE),
-            "default": np.zeros((B, n_cycles, 4, 3), dtype=np.float64),
-            "cycle_ok": np.zeros((B, n_cycles), dtype=np.uint8),
-            "stance": np.zeros((B, 4, 3), dtype=np.float64),
-        }
+        if out is None:
+            out = {
+                "nominal": np.zeros((B, n_cycles, 4), dtype=LEG_DTYPE),
+                "centroid": np.zeros((B, n_cycles, 4), dtype=CENTROID_DTYPE),
+                "default": np.zeros((B, n_cycles, 4, 3), dtype=np.float64),
+                "cycle_ok": np.zeros((B, n_cycles), dtype=np.uint8),
+                "stance": np.zeros((B, 4, 3), dtype=np.float64),
+            }
         rc = lib().fpo_plan(self._h, _ptr(params), _ptr(poses), B, n_cycles, threads, _ptr(out["nominal"]),
                             _ptr(out["centroid"]), _ptr(out["default"]), _ptr(out["cycle_ok"]), _ptr(out["stance"]))
         assert rc == 0
