@@ -196,6 +196,7 @@ struct LegCtx {
     const double* vy;
     const int8_t* footDa;  // foot-disc offset table (LDS copy of PlanConsts::footDa/footDb)
     const int8_t* footDb;
+    const int16_t* footOff;  // da * tileW + db of every table entry (LDS)
     bool rect;         // polygon is the reference rectangle: xlo/xhi/ylo/yhi hold its sides
     double xlo, xhi, ylo, yhi;
 };
@@ -297,6 +298,44 @@ __device__ __forceinline__ void accumulate_heights(const Grp<G>& g, bool vis, fl
     }
 }
 
+// Large discs (G = 64): the visited values of a round are compacted into LDS scratch in lane order
+// (= CircleIterator order) and summed afterwards by reading them back four at a time — the f32
+// additions stay strictly sequential, only the cross-lane traffic is batched.
+struct OrderedSum {
+    float* scratch;  // >= (cells of the disc bounding box) floats, 16-byte aligned; null: ballot loop
+    int n;
+};
+template <int G>
+__device__ __forceinline__ void ordered_push(const Grp<G>& g, OrderedSum& os, bool vis, float v) {
+    const unsigned long long mask = g.ballot(vis);
+    const int rank = __builtin_popcountll(mask & ((1ull << g.sub) - 1ull));
+    if (vis) os.scratch[os.n + rank] = v;
+    os.n += __builtin_popcountll(mask);
+}
+__device__ __forceinline__ void ordered_finish(const OrderedSum& os, float& sum, float& last, int& cnt) {
+    int t = 0;
+    for (; t + 4 <= os.n; t += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(os.scratch + t);
+        const float e4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            last = e4[u];
+            if (e4[u] < 10) {  // cpp:2539
+                cnt++;
+                sum = sum + e4[u];
+            }
+        }
+    }
+    for (; t < os.n; ++t) {
+        const float e = os.scratch[t];
+        last = e;
+        if (e < 10) {
+            cnt++;
+            sum = sum + e;
+        }
+    }
+}
+
 __device__ __forceinline__ float finish_mean(float sum, float last, int cnt, double h) {
     const float mean = (cnt != 0) ? (sum / cnt) : last;       // cpp:2547-2551
     return static_cast<float>(static_cast<double>(mean) + h);  // cpp:2553 (float + double)
@@ -323,11 +362,26 @@ __device__ __forceinline__ bool candidate_disc_ok(const DevMap& m, const PlanCon
         if (pc.nFoot == 1) {  // the disc is the candidate's own cell (e.g. rf 0.02 on a 2 cm map)
             return kTile ? (tile_at(tile, pc.tileW, c, i, j) & kFlagFail) == 0 : !cell_fails_direct(m, pc, c, i, j);
         }
+        if (kTile) {
+            // every cell a disc can touch has been staged (stage_annulus keeps ring + footReach ahead of the
+            // candidates; cells outside the map carry flag 0), so the disc is a branch-free OR over the
+            // precomputed tile displacements of the offset table, eight independent LDS reads per trip
+            const uint8_t* p = tile + (i - c.ti0) * pc.tileW + (j - c.tj0);
+            unsigned acc = 0;
+            int k = 0;
+            for (; k + 8 <= pc.nFoot; k += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc |= p[c.footOff[k + u]];
+                if (acc & kFlagFail) return false;  // early exit at chunk granularity: a round whose candidates all
+                                                    // fail stays short, a clean disc still reads 8 cells per trip
+            }
+            for (; k < pc.nFoot; ++k) acc |= p[c.footOff[k]];
+            return (acc & kFlagFail) == 0;  // the candidate's own cell (offset 0,0) is always visited
+        }
         for (int k = 0; k < pc.nFoot; ++k) {
             const int qi = i + c.footDa[k], qj = j + c.footDb[k];
             if (!in_range(qi, qj, m.g.rows, m.g.cols)) continue;
-            const bool fail = kTile ? (tile_at(tile, pc.tileW, c, qi, qj) & kFlagFail) != 0 : cell_fails_direct(m, pc, c, qi, qj);
-            if (fail) return false;
+            if (cell_fails_direct(m, pc, c, qi, qj)) return false;
         }
         return true;  // the candidate's own cell (offset 0,0) is always visited
     }
@@ -433,12 +487,13 @@ __device__ bool candidate_search_grp(const DevMap& m, const PlanConsts& pc, cons
 // valid iff >= 1 cell visited and no finite visited cell is below defaultFootholdThreshold_.
 template <int G, bool kCheck>
 __device__ __forceinline__ float disc_pass_direct(const DevMap& m, const PlanConsts& pc, double cx, double cy,
-                                                  const BBox& bb, const Grp<G>& g, bool& defaultOk) {
+                                                  const BBox& bb, const Grp<G>& g, bool& defaultOk, float* scratch) {
     const int nb = bb.ni * bb.nj;
     const float njInv = rcp_small(bb.nj);
     float sum = 0.0f, last = 0.0f;
     int cnt = 0;
     bool any = false, fail = false;
+    OrderedSum os{(G == 64) ? scratch : nullptr, 0};
     for (int base = 0; base < nb; base += G) {
         const int t = base + g.sub;
         bool vis = false;
@@ -459,8 +514,10 @@ __device__ __forceinline__ float disc_pass_direct(const DevMap& m, const PlanCon
             }
         }
         any |= vis;
-        accumulate_heights(g, vis, v, sum, last, cnt);
+        if (os.scratch) ordered_push(g, os, vis, v);
+        else accumulate_heights(g, vis, v, sum, last, cnt);
     }
+    if (os.scratch) ordered_finish(os, sum, last, cnt);
     if (kCheck) defaultOk = g.any(any) && !g.any(fail);
     return finish_mean(sum, last, cnt, pc.h);
 }
@@ -504,18 +561,21 @@ __device__ __forceinline__ void disc_issue(const DevMap& m, const PlanConsts& pc
 }
 template <int G, bool kCheck>
 __device__ __forceinline__ float disc_consume(const DevMap& m, const PlanConsts& pc, double cx, double cy, const BBox& bb,
-                                              const Grp<G>& g, const DiscLoads& d, bool& defaultOk) {
-    if (!d.pipelined) return disc_pass_direct<G, kCheck>(m, pc, cx, cy, bb, g, defaultOk);
+                                              const Grp<G>& g, const DiscLoads& d, bool& defaultOk, float* scratch) {
+    if (!d.pipelined) return disc_pass_direct<G, kCheck>(m, pc, cx, cy, bb, g, defaultOk, scratch);
     float sum = 0.0f, last = 0.0f;
     int cnt = 0;
     bool any = false, fail = false;
+    OrderedSum os{(G == 64) ? scratch : nullptr, 0};
 #pragma unroll
     for (int r = 0; r < kDiscRounds; ++r) {
         const float v = __builtin_isfinite(d.e[r]) ? d.e[r] : 0.0f;                                 // cpp:2532-2537
         if (kCheck && d.vis[r] && __builtin_isfinite(d.t[r]) && d.t[r] < pc.thrDefault) fail = true;  // cpp:2055-2057
         any |= d.vis[r];
-        accumulate_heights(g, d.vis[r], v, sum, last, cnt);
+        if (os.scratch) ordered_push(g, os, d.vis[r], v);
+        else accumulate_heights(g, d.vis[r], v, sum, last, cnt);
     }
+    if (os.scratch) ordered_finish(os, sum, last, cnt);
     if (kCheck) defaultOk = g.any(any) && !g.any(fail);
     return finish_mean(sum, last, cnt, pc.h);
 }
@@ -705,10 +765,10 @@ __device__ void centroid_begin(const DevMap& m, const PlanConsts& pc, const LegC
     cp.needDisc = true;
 }
 template <int G>
-__device__ void centroid_end(const DevMap& m, const PlanConsts& pc, const Grp<G>& g, CentroidPending& cp) {
+__device__ void centroid_end(const DevMap& m, const PlanConsts& pc, const Grp<G>& g, CentroidPending& cp, float* scratch) {
     if (cp.needDisc) {
         bool unused;
-        cp.o.z = disc_consume<G, false>(m, pc, cp.o.x, cp.o.y, cp.rb, g, cp.dl, unused);
+        cp.o.z = disc_consume<G, false>(m, pc, cp.o.x, cp.o.y, cp.rb, g, cp.dl, unused, scratch);
     }
 }
 
@@ -787,14 +847,15 @@ __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLu
     if (kCentroid) sc = rows_finish(m, pc, s, g, rl);
     stamp(pc, c.cyc, 4);
     bool defaultOk = true;
-    const float zCentre = disc_consume<G, true>(m, pc, c.cx, c.cy, bb, g, dc, defaultOk);  // cpp:2012 + cpp:2029
+    float* scratch = reinterpret_cast<float*>(tile);  // the tile is idle outside the spiral search
+    const float zCentre = disc_consume<G, true>(m, pc, c.cx, c.cy, bb, g, dc, defaultOk, scratch);  // cpp:2012 + cpp:2029
     stamp(pc, c.cyc, 5);
     CentroidPending cp;
     if (kCentroid) centroid_begin(m, pc, c, s, sc, zCentre, g, cp);                          // cpp:818-821
     stamp(pc, c.cyc, 6);
     if (dflt.want) {
         bool unused;
-        dflt.z = disc_consume<G, false>(m, pc, dflt.x, dflt.y, dflt.bb, g, dd, unused);     // cpp:2289-2301
+        dflt.z = disc_consume<G, false>(m, pc, dflt.x, dflt.y, dflt.bb, g, dd, unused, scratch);  // cpp:2289-2301
     }
     stamp(pc, c.cyc, 7);
     if (defaultOk) {
@@ -809,7 +870,7 @@ __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLu
         spiral_search<G>(m, pc, lut, head, c, tile, g, zCentre, no);
     }
     if (kCentroid) {
-        centroid_end(m, pc, g, cp);
+        centroid_end(m, pc, g, cp, scratch);
         co = cp.o;
     }
 }
@@ -883,6 +944,7 @@ struct PoseShared {
     int pad[4];
     int8_t footDa[kMaxFootOffsets];
     int8_t footDb[kMaxFootOffsets];
+    int16_t footOff[kMaxFootOffsets];
 };
 
 // Per-leg constants of a pose (do not change along the chain).
@@ -963,6 +1025,7 @@ __device__ __forceinline__ void leg_phase(const DevMap& m, const PlanConsts& pc,
         c.vy = sh.polyY[leg];
         c.footDa = sh.footDa;
         c.footDb = sh.footDb;
+        c.footOff = sh.footOff;
 
         NominalOut no;
         CentroidOut co;
@@ -1008,7 +1071,7 @@ __device__ __forceinline__ void leg_phase(const DevMap& m, const PlanConsts& pc,
             } else {
                 dbox = circle_bbox_fast(m.g, nx0, ny, pc.rf);
                 bool unused;
-                zDefault = disc_pass_direct<G, false>(m, pc, nx0, ny, dbox, g, unused);
+                zDefault = disc_pass_direct<G, false>(m, pc, nx0, ny, dbox, g, unused, reinterpret_cast<float*>(tile));
             }
         }
         if (g.sub == 0) {
@@ -1073,6 +1136,7 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
     for (int k = tid % kPoseThreads; k < pc.nFoot; k += kPoseThreads) {
         sh.footDa[k] = pc.footDa[k];
         sh.footDb[k] = pc.footDb[k];
+        sh.footOff[k] = static_cast<int16_t>(pc.footDa[k] * pc.tileW + pc.footDb[k]);
     }
     // initial stance (cpp:350-378) and first-gait shift (setFirstGait, cpp:2679-2699)
     if (g.sub == 0) {
@@ -1169,6 +1233,7 @@ __global__ __launch_bounds__(64, 4) void plan_sequential_kernel(DevMap m, PlanCo
     for (int k = tid; k < pc.nFoot; k += G) {
         sh.footDa[k] = pc.footDa[k];
         sh.footDb[k] = pc.footDb[k];
+        sh.footOff[k] = static_cast<int16_t>(pc.footDa[k] * pc.tileW + pc.footDb[k]);
     }
     // initial stance (cpp:350-378) and first-gait shift (setFirstGait, cpp:2679-2699): lane = leg
     if (tid < 4) {
@@ -1240,6 +1305,7 @@ struct QueryShared {
     double polyY[4][8];
     int8_t footDa[kMaxFootOffsets];
     int8_t footDb[kMaxFootOffsets];
+    int16_t footOff[kMaxFootOffsets];
 };
 
 __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts pc, SpiralLut lut,
@@ -1260,6 +1326,7 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
     for (int k = g.sub; k < pc.nFoot; k += 64) {  // every wavefront writes the same bytes, then reads its own writes
         sh.footDa[k] = pc.footDa[k];
         sh.footDb[k] = pc.footDb[k];
+        sh.footOff[k] = static_cast<int16_t>(pc.footDa[k] * pc.tileW + pc.footDb[k]);
     }
     if (g.sub < 8) {
         sh.polyX[w][g.sub] = g.sub < nv ? qp->vx[g.sub] : 0.0;
@@ -1277,6 +1344,7 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
     c.vy = sh.polyY[w];
     c.footDa = sh.footDa;
     c.footDb = sh.footDb;
+    c.footOff = sh.footOff;
     NominalOut no;
     CentroidOut co;
     if (!centre_usable(c.cx, c.cy)) {
