@@ -1,0 +1,87 @@
+"""Randomised differential test: engine (through the C ABI) vs the oracle over random parameters,
+map geometries/positions, thresholds, gaits, polygon kinds, per-leg radii, hostile cells, lattice-
+aligned poses, poses outside the map, every lane grouping and the literal-disc fallback.
+FPE_FUZZ_CASES (default 120) sets the number of cases; the same generator ran 3000 cases clean
+during round 1 (sources 0/1/2 and all seven centroid codes each hit >10^5 times)."""
+import os
+
+import numpy as np
+import pytest
+
+from quadrupedal_foothold_planner_amd import _capi, synth
+from quadrupedal_foothold_planner_amd.planner import FootholdPlanner, FpeError
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def make_case(seed):
+    rng = np.random.default_rng(seed)
+    res = float(rng.choice([0.02, 0.02, 0.01, 0.005, 0.03, 0.025, 0.04, 0.0125]))
+    rows, cols = int(rng.integers(150, 420)), int(rng.integers(150, 420))
+    pos = (float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5))) if rng.random() < 0.5 else (0.0, 0.0)
+    p = _capi.params_yaml()
+    scale = res / 0.02
+    p["footRadius"] = np.float32(rng.choice([0.02, 0.03, 0.015, 0.025, 0.04]) * (scale if rng.random() < 0.5 else 1.0))
+    p["searchRadius"] = np.float32(rng.uniform(0.05, 0.16) * max(1.0, scale * 0.8))
+    p["defaultFootholdThreshold"] = np.float32(rng.uniform(0.5, 0.95))
+    p["candidateFootholdThreshold"] = np.float32(rng.uniform(0.3, 0.9))
+    p["stepLength"] = np.float32(rng.uniform(0.08, 0.22))
+    p["skew"] = np.float32(rng.uniform(0.0, 0.08))
+    p["RF_FIRST"] = int(rng.integers(0, 2))
+    p["h"] = float(rng.choice([0.01, 0.0, 0.05]))
+    p["lateralDrift"] = float(rng.choice([-0.007, 0.0, 0.004]))
+    if rng.random() < 0.3:
+        p["length"], p["width"], p["l1"] = np.float32(0.3), np.float32(0.12), np.float32(0.03)
+    trav, elev = synth.rough_map(rows, cols, res, seed=int(rng.integers(1 << 30)), position=pos,
+                                 nan_frac=float(rng.choice([0.0, 0.005, 0.05])),
+                                 bad_frac=float(rng.choice([0.02, 0.1, 0.3, 0.5])),
+                                 stair_period=float(rng.choice([2.4, 1.1, 0.7])))
+    if rng.random() < 0.2:
+        trav[rng.random(trav.shape) < 0.01] = -np.inf
+        elev[rng.random(elev.shape) < 0.02] = 12.0
+    B, N = 48, int(rng.integers(2, 7))
+    side_x, side_y = rows * res, cols * res
+    xs = rng.uniform(pos[0] - 0.5 * side_x - 0.3, pos[0] + 0.5 * side_x + 0.3, B)
+    ys = rng.uniform(pos[1] - 0.5 * side_y - 0.3, pos[1] + 0.5 * side_y + 0.3, B)
+    if rng.random() < 0.3:  # lattice-aligned poses: exact ties in the index arithmetic
+        xs, ys = np.round(xs / res) * res, np.round(ys / res) * res
+    poses = np.zeros(B, dtype=_capi.POSE_DTYPE)
+    poses["position"][:, 0], poses["position"][:, 1] = xs, ys
+    poses["position"][:, 2] = rng.uniform(-0.2, 0.2, B)
+    if rng.random() < 0.5:
+        poses["gait"] = rng.integers(0, 2, B)
+        poses["leg_polygon_kind"] = rng.integers(0, 2, (B, 4))
+        if rng.random() < 0.5:
+            poses["leg_search_radius"] = rng.uniform(0.04, float(p["searchRadius"][0]), (B, 4)).astype(np.float32)
+    group = str(rng.choice(["0", "4", "8", "16", "64", "65"]))
+    literal = rng.random() < 0.15
+    return dict(res=res, pos=pos, params=p, trav=trav, elev=elev, poses=poses, n=N, group=group, literal=literal)
+
+
+def test_random_differential_campaign(monkeypatch):
+    planner = FootholdPlanner(0)
+    n_cases = int(os.environ.get("FPE_FUZZ_CASES", "120"))
+    src = np.zeros(4, np.int64)
+    codes = np.zeros(7, np.int64)
+    for k in range(n_cases):
+        c = make_case(20000 + k)
+        monkeypatch.setenv("FPE_PLAN_GROUP", c["group"])
+        if c["literal"]:
+            monkeypatch.setenv("FPE_LITERAL_DISCS", "1")
+        else:
+            monkeypatch.delenv("FPE_LITERAL_DISCS", raising=False)
+        planner.params = c["params"]
+        try:
+            eng, ora = util.run_both(planner, c["trav"], c["elev"], c["res"], c["poses"], c["n"], position=c["pos"], threads=8)
+        except FpeError as e:
+            assert e.code == _capi.FPE_E_UNSUPPORTED, e
+            continue
+        try:
+            util.assert_plan_equal(eng, ora)
+        except AssertionError as e:
+            raise AssertionError(f"case seed {20000 + k} (res {c['res']}, group {c['group']}, literal {c['literal']}): {e}")
+        src += np.bincount(eng["nominal"]["source"].ravel(), minlength=4)[:4]
+        codes += np.bincount(eng["centroid"]["code"].ravel(), minlength=7)[:7]
+    planner.close()
+    assert (src[:3] > 0).all() and (codes > 0).all(), (src, codes)
