@@ -84,6 +84,8 @@ def lib():
         L.fpo_map_destroy.argtypes = [C.c_void_p]
         L.fpo_plan.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
         L.fpo_search_legs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.fpo_plan_as_written.restype = C.c_ulonglong
+        L.fpo_plan_as_written.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.fpo_centroid_method.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_float, C.c_void_p]
         L.fpo_mean_height.restype = C.c_float
         L.fpo_mean_height.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_float, C.c_double]
@@ -149,6 +151,15 @@ class OracleMap:
                             _ptr(out["centroid"]), _ptr(out["default"]), _ptr(out["cycle_ok"]), _ptr(out["stance"]))
         assert rc == 0
         return out
+
+    def plan_as_written(self, params, poses, n_cycles):
+        """Same results as plan(); additionally performs the reference's by-value whole-map copies
+        (cost emulation, see fpo_planner.hpp).  Returns (nominal, number_of_map_copies)."""
+        params = np.ascontiguousarray(params, dtype=PARAMS_DTYPE).reshape(1)
+        poses = np.ascontiguousarray(poses, dtype=POSE_DTYPE)
+        nominal = np.zeros((poses.shape[0], n_cycles, 4), dtype=LEG_DTYPE)
+        n = lib().fpo_plan_as_written(self._h, _ptr(params), _ptr(poses), poses.shape[0], n_cycles, _ptr(nominal))
+        return nominal, int(n)
 
     def search_legs(self, params, queries):
         params = np.ascontiguousarray(params, dtype=PARAMS_DTYPE).reshape(1)

@@ -230,6 +230,17 @@ void fpo_constants(const Params* p, double* out /*[14]*/) {
     for (int l = 0; l < 4; ++l) { out[3 + l] = c.biasX[l]; out[7 + l] = c.biasY[l]; }
     out[11] = c.stepHalf; out[12] = c.step; out[13] = c.stepQuarter;
 }
+// as-written cost emulation: single-threaded plan with by-value map copies; returns the copy count
+unsigned long long fpo_plan_as_written(const void* mapHandle, const Params* params, const PoseSpec* poses, int B, int nCycles,
+                                       fpo_leg* nominal) {
+    const GridMap& map = *static_cast<const GridMap*>(mapHandle);
+    setEmulateByValueCopies(true);
+    planRange(map, *params, poses, 0, B, nCycles, nominal, nullptr, nullptr, nullptr, nullptr);
+    const unsigned long long n = byValueCopyCount();
+    setEmulateByValueCopies(false);
+    return n;
+}
+
 int fpo_sizeof(int which) {
     switch (which) {
         case 0: return (int)sizeof(Params);

@@ -6,6 +6,20 @@
 
 namespace fpo {
 
+// ---- by-value copy emulation (see fpo_planner.hpp) ----------------------------------------------
+static thread_local bool g_emulateCopies = false;
+static thread_local unsigned long long g_copyCount = 0;
+static thread_local std::vector<float> g_sinkTrav, g_sinkElev;
+void setEmulateByValueCopies(bool on) { g_emulateCopies = on; g_copyCount = 0; }
+unsigned long long byValueCopyCount() { return g_copyCount; }
+static inline void byValueCopy(const GridMap& map) {
+    if (!g_emulateCopies) return;
+    g_sinkTrav = map.trav;  // deep copy of each layer, as GridMap's copy constructor does
+    g_sinkElev = map.elev;
+    asm volatile("" ::"r"(g_sinkTrav.data()), "r"(g_sinkElev.data()) : "memory");
+    ++g_copyCount;
+}
+
 // initialize(), cpp:340-421.  lengthBase/widthBase are FLOAT members (hpp:666-667); widthBase is
 // computed in f32 (cpp:341); every later use promotes the float to double first.
 Constants makeConstants(const Params& p) {
@@ -43,6 +57,7 @@ Constants makeConstants(const Params& p) {
 // cpp:2039-2082.  false iff the disc is empty or a FINITE cell is below the threshold; NaN cells
 // are ignored; `validation = true` closes every iteration (cpp:2078).
 bool checkDefaultFoothold(const GridMap& map, const Vec2& center, float footRadius, const Params& p) {
+    byValueCopy(map);  // hpp:110 / cpp:2012
     bool validation = false;
     for (CircleIterator it(map, center, footRadius); !it.isPastEnd(); ++it) {
         const float v = map.travAt(*it);
@@ -60,6 +75,7 @@ bool checkDefaultFoothold(const GridMap& map, const Vec2& center, float footRadi
 // cpp:2117-2163.
 bool checkCirclePolygonFoothold(const GridMap& map, const Vec2& center, float footRadius,
                                 const Polygon& polygon, const Params& p) {
+    byValueCopy(map);  // hpp:140 / cpp:2100: one whole-map copy per spiral candidate
     bool validation = false;
     for (CircleIterator it(map, center, footRadius); !it.isPastEnd(); ++it) {
         const float v = map.travAt(*it);
@@ -79,6 +95,7 @@ bool checkCirclePolygonFoothold(const GridMap& map, const Vec2& center, float fo
 // cpp:2085-2114: first valid cell in SpiralIterator order.
 bool checkCandidateFoothold(const GridMap& map, const Vec2& spiralCenter, float footRadius,
                             float searchRadius, const Polygon& polygon, const Params& p, LegResult& out) {
+    byValueCopy(map);  // hpp:124 / cpp:2022
     bool validation = false;
     for (SpiralIterator it(map, spiralCenter, searchRadius); !it.isPastEnd(); ++it) {
         Vec2 footCenter{0, 0};
@@ -107,6 +124,7 @@ static bool centreUsable(const Vec2& c) { return std::fabs(c.x) <= 1e6 && std::f
 // cpp:2520-2554.  f32 sequential sum in CircleIterator (row-major bbox) order; NaN -> 0.0 and
 // counted; values >= 10 skipped; empty count -> last iHeight; "+ h" in f64, returned as float.
 float getFootholdMeanHeight(const GridMap& map, const Vec2& center, float radius, double h) {
+    byValueCopy(map);  // hpp:262 / cpp:2029, 2292-2301, 1687, 1820
     float iHeight = 0.0, meanHeight = 0.0;
     int i = 0;
     if (!centreUsable(center)) return static_cast<float>(meanHeight + h);
@@ -133,6 +151,8 @@ float getFootholdMeanHeight(const GridMap& map, const Vec2& center, float radius
 // cpp:2001-2036.  z is measured at the DEFAULT centre even when a candidate was chosen (cpp:2029).
 void checkFoothold(const GridMap& map, const Vec2& center, float footRadius, float searchRadius,
                    const Polygon& polygon, const Params& p, LegResult& out) {
+    byValueCopy(map);  // cpp:863-869: std::thread(&checkFoothold, this, gridmap_, ...) copies the argument
+    byValueCopy(map);  // ... and checkFoothold receives it by value again (hpp:94)
     out = LegResult();
     if (!centreUsable(center)) {  // oracle-defined, see centreUsable
         out.x = center.x;

@@ -101,4 +101,11 @@ struct PlanOutput {
 void planGlobalFootholds(const GridMap& map, const Params& p, const PoseSpec& pose, int nCycles,
                          PlanOutput& out);
 
+// "As-written" cost EMULATION: the reference passes grid_map::GridMap BY
+// VALUE (hpp:94,110,124,140,262,288), i.e. deep-copies every layer at each of those call sites.  When
+// enabled, the oracle performs an equivalent copy of its two layers at the same sites (results are
+// unchanged).  It is an emulation of the reference's copy traffic, not a measurement of the reference.
+void setEmulateByValueCopies(bool on);
+unsigned long long byValueCopyCount();
+
 }  // namespace fpo

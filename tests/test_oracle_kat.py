@@ -220,3 +220,17 @@ def test_invalid_cycle_does_not_advance_but_drift_applies():
     # centre x identical every cycle (no advance); y moves by -0.007 per cycle
     assert nom[0, 0]["x"] == nom[1, 0]["x"] == nom[2, 0]["x"]
     assert nom[1, 0]["y"] - nom[0, 0]["y"] == pytest.approx(-0.007, abs=1e-15)
+
+
+def test_as_written_emulation_changes_cost_not_results():
+    """The by-value copy emulation must leave every result untouched."""
+    p = yaml_params()
+    rng = np.random.default_rng(3)
+    trav = rng.uniform(0.4, 1.0, size=(120, 120)).astype(np.float32)
+    m = fpo.OracleMap(trav, np.zeros((120, 120), np.float32), 0.02)
+    poses = oracle_poses([[-0.6, 0.1, 0.0], [-0.5, -0.3, 0.0]])
+    ref = m.plan(p, poses, 4)["nominal"]
+    nom, copies = m.plan_as_written(p, poses, 4)
+    assert nom.tobytes() == ref.tobytes()
+    assert copies >= 2 * 4 * 4 * 4  # at least 4 copies per checkFoothold call (cpp:863-869, 2012, 2029)
+    assert m.plan(p, poses, 4)["nominal"].tobytes() == ref.tobytes()  # emulation switched off again
