@@ -77,19 +77,6 @@ FPE_HD int index_of_fast(double x, double org, double pos, double res, double ri
     return -static_cast<int>(k);
 }
 
-// The prediction half of index_of_fast: returns -(int)trunc(n * rinv) and reports whether the true
-// division must decide (callers then branch wave-uniformly to index_of, keeping the division off
-// the common path entirely).
-FPE_HD int index_predict(double x, double org, double pos, double rinv, bool& ambiguous) {
-    const double n = (x - org) - pos;
-    const double qf = n * rinv;
-    const double k = trunc(qf);
-    const double fr = fabs(qf - k);
-    const double eps = fabs(qf) * 4.5e-16 + 1e-290;
-    ambiguous = !(fr > eps && fr < 1.0 - eps);
-    return -static_cast<int>(k);
-}
-
 // checkIfPositionWithinMap, one axis: t = -((position - mapPosition) - offset); 0 <= t < length.
 FPE_HD bool within_axis(double x, double org, double pos, double len) {
     const double t = -((x - pos) - org);
