@@ -4,6 +4,7 @@
 // There is NO CPU compute path: without a usable GPU every compute entry point fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -76,6 +77,70 @@ struct BufferPool {
     }
 };
 
+// Per-call resources of the host-buffer entry points (stream, one device arena, one pinned host
+// arena), recycled across calls: a plan_global_footholds call must not pay for hipMalloc /
+// hipStreamCreate (3.6 ms per call before this pool, ~0.1 ms after).  Concurrent calls each take
+// their own context.
+struct CallCtx {
+    hipStream_t stream = nullptr;
+    unsigned char* dev = nullptr;
+    size_t devCap = 0;
+    unsigned char* pinned = nullptr;
+    size_t pinCap = 0;
+    ~CallCtx() {
+        if (dev) (void)hipFree(dev);
+        if (pinned) (void)hipHostFree(pinned);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    hipError_t reserve(size_t bytes) {
+        if (!stream) {
+            hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+            if (e != hipSuccess) return e;
+        }
+        if (bytes > devCap) {
+            if (dev) (void)hipFree(dev);
+            dev = nullptr;
+            devCap = 0;
+            const size_t cap = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&dev), cap);
+            if (e != hipSuccess) return e;
+            devCap = cap;
+        }
+        if (bytes > pinCap) {
+            if (pinned) (void)hipHostFree(pinned);
+            pinned = nullptr;
+            pinCap = 0;
+            const size_t cap = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+            hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&pinned), cap, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+            pinCap = cap;
+        }
+        return hipSuccess;
+    }
+};
+struct CtxPool {
+    std::mutex mu;
+    std::vector<std::unique_ptr<CallCtx>> free;
+    std::unique_ptr<CallCtx> take() {
+        std::lock_guard<std::mutex> lk(mu);
+        if (free.empty()) return std::unique_ptr<CallCtx>(new CallCtx());
+        std::unique_ptr<CallCtx> c = std::move(free.back());
+        free.pop_back();
+        return c;
+    }
+    void give(std::unique_ptr<CallCtx> c) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (free.size() < 8) free.push_back(std::move(c));
+    }
+};
+struct CtxLease {  // returns the context to the pool on every exit path
+    CtxPool& pool;
+    std::unique_ptr<CallCtx> ctx;
+    explicit CtxLease(CtxPool& p) : pool(p), ctx(p.take()) {}
+    ~CtxLease() { pool.give(std::move(ctx)); }
+};
+inline size_t align256(size_t n) { return (n + 255) & ~static_cast<size_t>(255); }
+
 struct MapSnapshot {
     fpe::MapGeom g;
     size_t n = 0;
@@ -97,6 +162,7 @@ struct fpe_engine {
     std::mutex mu;
     std::shared_ptr<MapSnapshot> map;
     std::shared_ptr<BufferPool> pool = std::make_shared<BufferPool>();
+    CtxPool ctxPool;
     int16_t* d_di = nullptr;
     int16_t* d_dj = nullptr;
     uint8_t* d_ring = nullptr;
@@ -328,38 +394,46 @@ int fpe_plan(fpe_handle h, const fpe_params* params, const fpe_pose* poses, int3
     int rc = prepare_call(h, params, maxRadius, snap, pc, planLds, searchLds);
     if (rc != FPE_OK) return rc;
 
+    // one device arena + one pinned arena: [poses | nominal | centroid | default | cycle_ok | stance]
     const size_t nRec = static_cast<size_t>(B) * n_cycles * 4;
-    struct Scratch {  // per-call device buffers + stream (plans may run concurrently)
-        hipStream_t stream = nullptr;
-        void* p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        ~Scratch() {
-            for (void* q : p)
-                if (q) (void)hipFree(q);
-            if (stream) (void)hipStreamDestroy(stream);
-        }
-    } s;
-    FPE_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-    FPE_HIP(hipMalloc(&s.p[0], static_cast<size_t>(B) * sizeof(fpe_pose)));
-    FPE_HIP(hipMemcpyAsync(s.p[0], poses, static_cast<size_t>(B) * sizeof(fpe_pose), hipMemcpyHostToDevice, s.stream));
+    const size_t szPose = align256(static_cast<size_t>(B) * sizeof(fpe_pose));
+    const size_t szNom = out->nominal ? align256(nRec * sizeof(fpe_foothold)) : 0;
+    const size_t szCen = out->centroid ? align256(nRec * sizeof(fpe_centroid_foothold)) : 0;
+    const size_t szDef = out->default_next ? align256(nRec * 3 * sizeof(double)) : 0;
+    const size_t szOk = out->cycle_ok ? align256(static_cast<size_t>(B) * n_cycles) : 0;
+    const size_t szSt = out->stance ? align256(static_cast<size_t>(B) * 12 * sizeof(double)) : 0;
+    const size_t total = szPose + szNom + szCen + szDef + szOk + szSt;
+    CtxLease lease(h->ctxPool);
+    CallCtx& cx = *lease.ctx;
+    FPE_HIP(cx.reserve(total));
+    unsigned char* dp = cx.dev;
+    unsigned char* hp = cx.pinned;
+    std::memcpy(hp, poses, static_cast<size_t>(B) * sizeof(fpe_pose));
+    FPE_HIP(hipMemcpyAsync(dp, hp, static_cast<size_t>(B) * sizeof(fpe_pose), hipMemcpyHostToDevice, cx.stream));
+    size_t off = szPose;
+    const size_t oNom = off; off += szNom;
+    const size_t oCen = off; off += szCen;
+    const size_t oDef = off; off += szDef;
+    const size_t oOk = off; off += szOk;
+    const size_t oSt = off;
     fpe_plan_out d;
     std::memset(&d, 0, sizeof(d));
-    if (out->nominal) { FPE_HIP(hipMalloc(&s.p[1], nRec * sizeof(fpe_foothold))); d.nominal = static_cast<fpe_foothold*>(s.p[1]); }
-    if (out->centroid) { FPE_HIP(hipMalloc(&s.p[2], nRec * sizeof(fpe_centroid_foothold))); d.centroid = static_cast<fpe_centroid_foothold*>(s.p[2]); }
-    if (out->default_next) { FPE_HIP(hipMalloc(&s.p[3], nRec * 3 * sizeof(double))); d.default_next = static_cast<double*>(s.p[3]); }
-    if (out->cycle_ok) { FPE_HIP(hipMalloc(&s.p[4], static_cast<size_t>(B) * n_cycles)); d.cycle_ok = static_cast<uint8_t*>(s.p[4]); }
-    if (out->stance) { FPE_HIP(hipMalloc(&s.p[5], static_cast<size_t>(B) * 12 * sizeof(double))); d.stance = static_cast<double*>(s.p[5]); }
-    // walk-gait poses leave the records of non-swing phases untouched only if a cycle is skipped;
-    // zero the buffers so every record is defined
-    if (d.nominal) FPE_HIP(hipMemsetAsync(d.nominal, 0, nRec * sizeof(fpe_foothold), s.stream));
-    if (d.centroid) FPE_HIP(hipMemsetAsync(d.centroid, 0, nRec * sizeof(fpe_centroid_foothold), s.stream));
-    if (d.default_next) FPE_HIP(hipMemsetAsync(d.default_next, 0, nRec * 3 * sizeof(double), s.stream));
-    FPE_HIP(fpe::launch_plan_chained(dev_map(*snap), pc, h->lut(), static_cast<const fpe_pose*>(s.p[0]), B, n_cycles, d, s.stream));
-    if (out->nominal) FPE_HIP(hipMemcpyAsync(out->nominal, d.nominal, nRec * sizeof(fpe_foothold), hipMemcpyDeviceToHost, s.stream));
-    if (out->centroid) FPE_HIP(hipMemcpyAsync(out->centroid, d.centroid, nRec * sizeof(fpe_centroid_foothold), hipMemcpyDeviceToHost, s.stream));
-    if (out->default_next) FPE_HIP(hipMemcpyAsync(out->default_next, d.default_next, nRec * 3 * sizeof(double), hipMemcpyDeviceToHost, s.stream));
-    if (out->cycle_ok) FPE_HIP(hipMemcpyAsync(out->cycle_ok, d.cycle_ok, static_cast<size_t>(B) * n_cycles, hipMemcpyDeviceToHost, s.stream));
-    if (out->stance) FPE_HIP(hipMemcpyAsync(out->stance, d.stance, static_cast<size_t>(B) * 12 * sizeof(double), hipMemcpyDeviceToHost, s.stream));
-    FPE_HIP(hipStreamSynchronize(s.stream));
+    if (out->nominal) d.nominal = reinterpret_cast<fpe_foothold*>(dp + oNom);
+    if (out->centroid) d.centroid = reinterpret_cast<fpe_centroid_foothold*>(dp + oCen);
+    if (out->default_next) d.default_next = reinterpret_cast<double*>(dp + oDef);
+    if (out->cycle_ok) d.cycle_ok = dp + oOk;
+    if (out->stance) d.stance = reinterpret_cast<double*>(dp + oSt);
+    // every (pose, cycle, leg) record is written by the kernel (trot: all legs each cycle; walk: each
+    // leg in its phase), so the buffers need no clearing
+    FPE_HIP(fpe::launch_plan_chained(dev_map(*snap), pc, h->lut(), reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, d, cx.stream));
+    if (total > szPose)  // results: one D2H copy of the whole result arena into pinned memory
+        FPE_HIP(hipMemcpyAsync(hp + szPose, dp + szPose, total - szPose, hipMemcpyDeviceToHost, cx.stream));
+    FPE_HIP(hipStreamSynchronize(cx.stream));
+    if (out->nominal) std::memcpy(out->nominal, hp + oNom, nRec * sizeof(fpe_foothold));
+    if (out->centroid) std::memcpy(out->centroid, hp + oCen, nRec * sizeof(fpe_centroid_foothold));
+    if (out->default_next) std::memcpy(out->default_next, hp + oDef, nRec * 3 * sizeof(double));
+    if (out->cycle_ok) std::memcpy(out->cycle_ok, hp + oOk, static_cast<size_t>(B) * n_cycles);
+    if (out->stance) std::memcpy(out->stance, hp + oSt, static_cast<size_t>(B) * 12 * sizeof(double));
     return FPE_OK;
 }
 
@@ -395,23 +469,18 @@ int fpe_search_legs(fpe_handle h, const fpe_params* params, const fpe_leg_query*
     size_t planLds, searchLds;
     int rc = prepare_call(h, params, maxRadius, snap, pc, planLds, searchLds);
     if (rc != FPE_OK) return rc;
-    struct Scratch {
-        hipStream_t stream = nullptr;
-        void* p[2] = {nullptr, nullptr};
-        ~Scratch() {
-            for (void* q : p)
-                if (q) (void)hipFree(q);
-            if (stream) (void)hipStreamDestroy(stream);
-        }
-    } s;
-    FPE_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-    FPE_HIP(hipMalloc(&s.p[0], static_cast<size_t>(n) * sizeof(fpe_leg_query)));
-    FPE_HIP(hipMalloc(&s.p[1], static_cast<size_t>(n) * sizeof(fpe_foothold)));
-    FPE_HIP(hipMemcpyAsync(s.p[0], queries, static_cast<size_t>(n) * sizeof(fpe_leg_query), hipMemcpyHostToDevice, s.stream));
-    FPE_HIP(fpe::launch_search_legs(dev_map(*snap), pc, h->lut(), static_cast<const fpe_leg_query*>(s.p[0]), n,
-                                    static_cast<fpe_foothold*>(s.p[1]), s.stream));
-    FPE_HIP(hipMemcpyAsync(out, s.p[1], static_cast<size_t>(n) * sizeof(fpe_foothold), hipMemcpyDeviceToHost, s.stream));
-    FPE_HIP(hipStreamSynchronize(s.stream));
+    const size_t szQ = align256(static_cast<size_t>(n) * sizeof(fpe_leg_query));
+    const size_t szO = align256(static_cast<size_t>(n) * sizeof(fpe_foothold));
+    CtxLease lease(h->ctxPool);
+    CallCtx& cx = *lease.ctx;
+    FPE_HIP(cx.reserve(szQ + szO));
+    std::memcpy(cx.pinned, queries, static_cast<size_t>(n) * sizeof(fpe_leg_query));
+    FPE_HIP(hipMemcpyAsync(cx.dev, cx.pinned, static_cast<size_t>(n) * sizeof(fpe_leg_query), hipMemcpyHostToDevice, cx.stream));
+    FPE_HIP(fpe::launch_search_legs(dev_map(*snap), pc, h->lut(), reinterpret_cast<const fpe_leg_query*>(cx.dev), n,
+                                    reinterpret_cast<fpe_foothold*>(cx.dev + szQ), cx.stream));
+    FPE_HIP(hipMemcpyAsync(cx.pinned + szQ, cx.dev + szQ, static_cast<size_t>(n) * sizeof(fpe_foothold), hipMemcpyDeviceToHost, cx.stream));
+    FPE_HIP(hipStreamSynchronize(cx.stream));
+    std::memcpy(out, cx.pinned + szQ, static_cast<size_t>(n) * sizeof(fpe_foothold));
     return FPE_OK;
 }
 
