@@ -313,28 +313,35 @@ __device__ __forceinline__ void ordered_push(const Grp<G>& g, OrderedSum& os, bo
     if (vis) os.scratch[os.n + rank] = v;
     os.n += __builtin_popcountll(mask);
 }
+__device__ __forceinline__ void ordered_step(float e, float& sum, float& last, int& cnt) {
+    last = e;
+    if (e < 10) {  // cpp:2539
+        cnt++;
+        sum = sum + e;
+    }
+}
 __device__ __forceinline__ void ordered_finish(const OrderedSum& os, float& sum, float& last, int& cnt) {
     int t = 0;
-    for (; t + 4 <= os.n; t += 4) {
-        const float4 q = *reinterpret_cast<const float4*>(os.scratch + t);
-        const float e4[4] = {q.x, q.y, q.z, q.w};
+    for (; t + 16 <= os.n; t += 16) {  // large discs: four independent 16-byte reads, then 16 dependent adds
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const float4*>(os.scratch + t + 4 * u);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            last = e4[u];
-            if (e4[u] < 10) {  // cpp:2539
-                cnt++;
-                sum = sum + e4[u];
-            }
+            ordered_step(q[u].x, sum, last, cnt);
+            ordered_step(q[u].y, sum, last, cnt);
+            ordered_step(q[u].z, sum, last, cnt);
+            ordered_step(q[u].w, sum, last, cnt);
         }
     }
-    for (; t < os.n; ++t) {
-        const float e = os.scratch[t];
-        last = e;
-        if (e < 10) {
-            cnt++;
-            sum = sum + e;
-        }
+    for (; t + 4 <= os.n; t += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(os.scratch + t);
+        ordered_step(q.x, sum, last, cnt);
+        ordered_step(q.y, sum, last, cnt);
+        ordered_step(q.z, sum, last, cnt);
+        ordered_step(q.w, sum, last, cnt);
     }
+    for (; t < os.n; ++t) ordered_step(os.scratch[t], sum, last, cnt);
 }
 
 __device__ __forceinline__ float finish_mean(float sum, float last, int cnt, double h) {
@@ -432,26 +439,42 @@ __device__ bool candidate_search_grp(const DevMap& m, const PlanConsts& pc, cons
     const int M = c.nCand;
     int round = 0;
     int staged = -1;  // Chebyshev radius of the tile staged so far (kTile)
+    // rank-table entries of the NEXT round are loaded while the current round is evaluated (from the
+    // last register-held round on; searches that end earlier never touch the table)
+    int nDi = 0, nDj = 0, nR = c.nRings;
     for (int base = 0; base < M; base += G, ++round) {
         const int k = base + g.sub;
         bool ok = false;
         int i = 0, j = 0;
         int di = 0, dj = 0, r = c.nRings;
-        if (k < M) {
-            if (round < kLutHeadRounds) {
+        if (round < kLutHeadRounds) {
+            if (k < M) {
                 const int e = round == 0 ? head.dij[0] : head.dij[1];
                 di = static_cast<int16_t>(e & 0xFFFF);
                 dj = e >> 16;
                 r = round == 0 ? head.ring[0] : head.ring[1];
-            } else {
-                di = lut.di[k];
-                dj = lut.dj[k];
-                r = lut.ring[k];
+            }
+        } else {
+            di = nDi;
+            dj = nDj;
+            r = nR;
+        }
+        if (round + 1 >= kLutHeadRounds) {
+            const int kn = k + G;
+            nR = c.nRings;
+            if (kn < M) {
+                nDi = lut.di[kn];
+                nDj = lut.dj[kn];
+                nR = lut.ring[kn];
             }
         }
         if constexpr (kTile) {
-            // rings grow with rank: the last lane of the round holds the farthest ring it needs
-            const int need = g.bcast(r, G - 1) + pc.footReach;
+            // rings grow with rank: the last lane of the round holds the farthest ring it needs.  The
+            // staged radius grows geometrically (x1.5) so that a long search needs O(log) staging steps
+            // while a short one never stages much more than it reads (measured against per-round and
+            // all-at-once staging on cfg-3/4/5).
+            int need = g.bcast(r, G - 1) + pc.footReach;
+            if (need > staged && staged >= 0) need = max(need, min(pc.tileH, staged + max(2, staged / 2)));
             if (need > staged) {
                 stage_annulus(m, pc, c, tile, g, staged, need);
                 staged = need;
