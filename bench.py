@@ -282,6 +282,31 @@ def main():
                           "note": "canonicalise_layer_kernel x2 per upload, snapshot buffers recycled (no hipMalloc in steady state)"}
         ing.close()
         del src_t, src_e
+    if rank == 0 and world == 1:
+        # open-loop mode: one independent checkFoothold query per (leg, cycle, pose) unit —
+        # the step's 4*N*B units as fpe_search_legs_device queries with the reference rectangle polygon
+        nq = 4 * n_cycles * B
+        rng = np.random.default_rng(7)
+        q = np.zeros(nq, dtype=_capi.QUERY_DTYPE)
+        half_x, half_y = 0.5 * rows * res - 0.5, 0.5 * cols * res - 0.5
+        q["cx"], q["cy"] = rng.uniform(-half_x, half_x, nq), rng.uniform(-half_y, half_y, nq)
+        q["search_radius"], q["n_vertices"] = np.float32(R), 4
+        Rd = float(np.float32(R))
+        q["vx"][:, :4] = q["cx"][:, None] + np.array([Rd, Rd, -Rd, -Rd])
+        q["vy"][:, :4] = q["cy"][:, None] + 0.5 * np.array([Rd, -Rd, -Rd, Rd])
+        d_q = torch.from_numpy(q.view(np.uint8).reshape(-1)).to(dev)
+        d_qo = torch.zeros(nq * rec, dtype=torch.uint8, device=dev)
+        for _ in range(2):
+            planner.search_legs_device(d_q.data_ptr(), nq, d_qo.data_ptr(), stream=stream.cuda_stream)
+        q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        q0.record(stream)
+        for _ in range(10):
+            planner.search_legs_device(d_q.data_ptr(), nq, d_qo.data_ptr(), stream=stream.cuda_stream)
+        q1.record(stream)
+        torch.cuda.synchronize()
+        ol_ms = q0.elapsed_time(q1) / 10
+        line["open_loop"] = {"queries": nq, "ms": ol_ms, "footholds_per_s": nq / (ol_ms * 1e-3),
+                             "note": "search_legs_kernel: independent checkFoothold queries (no centroid/default track, no chain)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(trav, elev, res, params, poses, n_cycles, args.cpu_seconds)
     if rank == 0:
