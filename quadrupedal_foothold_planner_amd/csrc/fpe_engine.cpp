@@ -232,8 +232,9 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
     snap->pool = h->pool;
     snap->d_trav = h->pool->take(n);
     snap->d_elev = h->pool->take(n);
-    if (!snap->d_trav) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&snap->d_trav), n * sizeof(float)));
-    if (!snap->d_elev) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&snap->d_elev), n * sizeof(float)));
+    // + 32 B tail padding: the row scan reads whole 16-byte groups (fpe_kernels.hip::rows_issue)
+    if (!snap->d_trav) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&snap->d_trav), n * sizeof(float) + 32));
+    if (!snap->d_elev) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&snap->d_elev), n * sizeof(float) + 32));
     const bool canonical = desc->storage_order == 1 && desc->start_index[0] == 0 && desc->start_index[1] == 0;
     const float* src[2] = {trav, elev};
     float* dst[2] = {snap->d_trav, snap->d_elev};

@@ -681,8 +681,13 @@ __device__ __forceinline__ void rows_issue(const DevMap& m, const Submap& s, con
     for (int ch = 0; ch < kRowChunks; ++ch) {
         const int r = min(ch * G + g.sub, s.ni - 1);  // clamped: idle lanes re-read the last row
         const float* rowp = m.trav + static_cast<size_t>(s.i0 + r) * m.g.cols + s.j0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) rl.v[ch][u] = rowp[min(u, s.nj - 1)];
+        // two 16-byte loads per row (4-byte aligned; columns >= nj are never counted, and the layer
+        // allocation carries 32 B of tail padding so the over-read of the last row stays in bounds)
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        const f4u a = *reinterpret_cast<const f4u*>(rowp);
+        const f4u b = *reinterpret_cast<const f4u*>(rowp + 4);
+        rl.v[ch][0] = a.x; rl.v[ch][1] = a.y; rl.v[ch][2] = a.z; rl.v[ch][3] = a.w;
+        rl.v[ch][4] = b.x; rl.v[ch][5] = b.y; rl.v[ch][6] = b.z; rl.v[ch][7] = b.w;
     }
 }
 template <int G>
