@@ -196,6 +196,25 @@ int fpe_plan_service_ex(fpe_handle h, const fpe_params* params, const double ini
                         uint8_t gait_cycles, fpe_global_footholds* response, fpe_global_footholds* centroid,
                         double* default_footholds, int32_t* n_default_rows);
 
+/* Evaluation products of one track of a service call:
+ *   feet_center_path: poses of nominal_feet_center_path / centroid_feet_center_path (cpp:231-232,
+ *             1410, 1477): getPolygonCenter of the track's CURRENT feet, one per planned cycle whether
+ *             or not it commits (getFootholdSearchGridMap, cpp:2191-2196);
+ *   feet_distance / cog_speed: footholdsKPI_ (hpp:732-745), two entries per COMMITTED cycle
+ *             (getHipDistance cpp:2571-2584, getCogSpeed cpp:2587-2623 with gaitCycle_ = 1.0, cpp:332). */
+typedef struct fpe_track_report {
+    int32_t n_path; /* = gait_cycles */
+    int32_t n_kpi;  /* = 2 x committed cycles */
+    double feet_center_path[255][3];
+    double feet_distance[2 * 255];
+    double cog_speed[2 * 255];
+} fpe_track_report;
+/* fpe_plan_service_ex plus the per-track reports; every pointer after `response` may be NULL. */
+int fpe_plan_service_report(fpe_handle h, const fpe_params* params, const double initial_position[3],
+                            uint8_t gait_cycles, fpe_global_footholds* response, fpe_global_footholds* centroid,
+                            double* default_footholds, int32_t* n_default_rows, fpe_track_report* nominal_report,
+                            fpe_track_report* centroid_report);
+
 /* ---- host-side helpers (no GPU needed) -------------------------------------------------------- */
 /* SpiralIterator visiting order as index offsets (di,dj) for rings 0..n_rings (generateRing walk,
  * consumed from the back).  Writes min(count, max_cells) entries of (di, dj, ring); returns count. */

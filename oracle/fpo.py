@@ -86,6 +86,7 @@ def lib():
         L.fpo_search_legs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.fpo_plan_as_written.restype = C.c_ulonglong
         L.fpo_plan_as_written.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.fpo_plan_products.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7
         L.fpo_centroid_method.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_float, C.c_void_p]
         L.fpo_mean_height.restype = C.c_float
         L.fpo_mean_height.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_float, C.c_double]
@@ -160,6 +161,23 @@ class OracleMap:
         nominal = np.zeros((poses.shape[0], n_cycles, 4), dtype=LEG_DTYPE)
         n = lib().fpo_plan_as_written(self._h, _ptr(params), _ptr(poses), poses.shape[0], n_cycles, _ptr(nominal))
         return nominal, int(n)
+
+    def plan_products(self, params, pose, n_cycles):
+        """Feet-centre paths and KPIs of one trot plan: {"centroid"|"nominal": {"path", "feet_distance", "cog_speed"}}."""
+        params = np.ascontiguousarray(params, dtype=PARAMS_DTYPE).reshape(1)
+        pose = np.ascontiguousarray(pose, dtype=POSE_DTYPE).reshape(1)
+        n = max(int(n_cycles), 1)
+        path = [np.zeros((n, 3)), np.zeros((n, 3))]
+        dist = [np.zeros(2 * n), np.zeros(2 * n)]
+        speed = [np.zeros(2 * n), np.zeros(2 * n)]
+        counts = np.zeros(4, dtype=np.int32)
+        lib().fpo_plan_products(self._h, _ptr(params), _ptr(pose), int(n_cycles), _ptr(path[0]), _ptr(path[1]), _ptr(dist[0]),
+                                _ptr(dist[1]), _ptr(speed[0]), _ptr(speed[1]), _ptr(counts))
+        out = {}
+        for k, name in enumerate(("centroid", "nominal")):
+            out[name] = {"path": path[k][: counts[2 * k]].copy(), "feet_distance": dist[k][: counts[2 * k + 1]].copy(),
+                         "cog_speed": speed[k][: counts[2 * k + 1]].copy()}
+        return out
 
     def search_legs(self, params, queries):
         params = np.ascontiguousarray(params, dtype=PARAMS_DTYPE).reshape(1)

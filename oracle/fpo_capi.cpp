@@ -129,6 +129,32 @@ int fpo_plan(const void* mapHandle, const Params* params, const PoseSpec* poses,
     return 0;
 }
 
+// Evaluation products of ONE trot plan: per track k (0 centroid, 1 nominal)
+//   path[k]: up to nCycles x 3 doubles, dist[k] / speed[k]: up to 2*nCycles doubles; counts[k] = {nPath, nKpi}.
+int fpo_plan_products(const void* mapHandle, const Params* params, const PoseSpec* pose, int nCycles, double* path0,
+                      double* path1, double* dist0, double* dist1, double* speed0, double* speed1, int32_t* counts) {
+    const GridMap& map = *static_cast<const GridMap*>(mapHandle);
+    PlanOutput out;
+    planGlobalFootholds(map, *params, *pose, nCycles, out);
+    double* path[2] = {path0, path1};
+    double* dist[2] = {dist0, dist1};
+    double* speed[2] = {speed0, speed1};
+    for (int k = 0; k < 2; ++k) {
+        counts[2 * k] = (int32_t)out.feetCenterPath[k].size();
+        counts[2 * k + 1] = (int32_t)out.feetDistance[k].size();
+        for (size_t i = 0; i < out.feetCenterPath[k].size(); ++i) {
+            path[k][3 * i] = out.feetCenterPath[k][i].x;
+            path[k][3 * i + 1] = out.feetCenterPath[k][i].y;
+            path[k][3 * i + 2] = out.feetCenterPath[k][i].z;
+        }
+        for (size_t i = 0; i < out.feetDistance[k].size(); ++i) {
+            dist[k][i] = out.feetDistance[k][i];
+            speed[k][i] = out.cogSpeed[k][i];
+        }
+    }
+    return 0;
+}
+
 // n independent checkFoothold calls (cpp:2001) with arbitrary polygons.
 int fpo_search_legs(const void* mapHandle, const Params* params, const fpo_query* q, int n, fpo_leg* out) {
     const GridMap& map = *static_cast<const GridMap*>(mapHandle);

@@ -329,6 +329,34 @@ Polygon getSearchPolygon(const Point3& center, float radius, int kind) {
     return polygon;
 }
 
+// getHipDistance, cpp:2571-2584: x distance of each diagonal pair.
+void getHipDistance(const Point3 result[4], std::vector<double>& feetDistance) {
+    double feetDistance1, feetDistance2;
+    feetDistance1 = (result[RF].x - result[LH].x);
+    feetDistance.push_back(feetDistance1);
+    feetDistance2 = (result[LF].x - result[RH].x);
+    feetDistance.push_back(feetDistance2);
+}
+
+// getCogSpeed, cpp:2587-2623: the two half-cycle COG displacements over 0.5*gaitCycle_ (gaitCycle_ = 1.0, cpp:332).
+void getCogSpeed(const Point3 result[4], const Point3 current[4], int RF_FIRST, std::vector<double>& cogSpeed) {
+    const double gaitCycle = 1.0;
+    double feetCenter1, feetCenter2, feetCenter3;
+    if (RF_FIRST) {
+        feetCenter1 = (current[RF].x + current[LH].x) / 2;
+        feetCenter2 = (result[LF].x + result[RH].x) / 2;
+        feetCenter3 = (result[RF].x + result[LH].x) / 2;
+    } else {
+        feetCenter1 = (current[LF].x + current[RH].x) / 2;
+        feetCenter2 = (result[RF].x + result[LH].x) / 2;
+        feetCenter3 = (result[LF].x + result[RH].x) / 2;
+    }
+    double cogMovedDistance1 = feetCenter2 - feetCenter1;
+    double cogMovedDistance2 = feetCenter3 - feetCenter2;
+    cogSpeed.push_back(cogMovedDistance1 / (0.5 * gaitCycle));
+    cogSpeed.push_back(cogMovedDistance2 / (0.5 * gaitCycle));
+}
+
 // globalFootholdPlan, cpp:539-1602, for one initial pose.  Tracks: 0 default, 1 centroid, 2 nominal.
 // A gait cycle is a sequence of phases, each with a set of swing legs and a centre advance:
 //   trot (reference): ONE phase, all four legs, advance stepLength_ (cpp:762-1579);
@@ -343,6 +371,11 @@ void planGlobalFootholds(const GridMap& map, const Params& p, const PoseSpec& ps
     out.centroid.assign((size_t)nCycles * 4, CentroidResult());
     out.defaultNext.assign((size_t)nCycles * 4, Point3());
     out.cycleOk.assign((size_t)nCycles, 0);
+    for (int k = 0; k < 2; ++k) {  // cpp:606-611, 635-636
+        out.feetCenterPath[k].clear();
+        out.feetDistance[k].clear();
+        out.cogSpeed[k].clear();
+    }
 
     // cpp:350-378: initial stance = hip rectangle + initialPose_
     const double sx[4] = {c.LbHalf, -c.LbHalf, -c.LbHalf, c.LbHalf};
@@ -382,6 +415,7 @@ void planGlobalFootholds(const GridMap& map, const Params& p, const PoseSpec& ps
             for (int t = 0; t < 3; ++t) {
                 // getDefaultFootholds cpp:2265-2284 / getFootholdSearchGridMap cpp:2191-2213
                 Point3 C = getPolygonCenter(cur[t][RF], cur[t][RH], cur[t][LH], cur[t][LF]);
+                if (t >= 1 && ps.gait == 0) out.feetCenterPath[t - 1].push_back(C);  // cpp:2194-2196
                 Point3 N;
                 N.x = C.x + advance;              // cpp:2199 / 2270
                 N.y = pose[1] + ajustedPoseY;     // cpp:2201 / 2272
@@ -410,6 +444,17 @@ void planGlobalFootholds(const GridMap& map, const Params& p, const PoseSpec& ps
                 out.nominal[(size_t)g * 4 + l] = nom[l];
                 out.centroid[(size_t)g * 4 + l] = cen[l];
                 out.defaultNext[(size_t)g * 4 + l] = next[0][l];
+            }
+            if (phaseOk && ps.gait == 0) {  // KPIs use the track's current feet BEFORE the commit
+                Point3 nomP[4], cenP[4];
+                for (int l = 0; l < 4; ++l) {
+                    nomP[l].x = nom[l].x; nomP[l].y = nom[l].y; nomP[l].z = nom[l].z;
+                    cenP[l].x = cen[l].x; cenP[l].y = cen[l].y; cenP[l].z = cen[l].z;
+                }
+                getHipDistance(nomP, out.feetDistance[1]);               // cpp:1357
+                getCogSpeed(nomP, cur[2], p.RF_FIRST, out.cogSpeed[1]);  // cpp:1366
+                getHipDistance(cenP, out.feetDistance[0]);               // cpp:1422
+                getCogSpeed(cenP, cur[1], p.RF_FIRST, out.cogSpeed[0]);  // cpp:1430
             }
             if (phaseOk) {  // cpp:1332-1483: commit every track
                 for (int l = 0; l < 4; ++l) {

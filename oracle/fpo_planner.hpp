@@ -88,6 +88,8 @@ void checkFootholdUseCentroidMethod(const GridMap& map, const Vec2& defaultFooth
                                     const Params& p, CentroidResult& out);
 Point3 getPolygonCenter(const Point3& rf, const Point3& rh, const Point3& lh, const Point3& lf);
 Polygon getSearchPolygon(const Point3& center, float radius, int kind = 0);
+void getHipDistance(const Point3 result[4], std::vector<double>& feetDistance);
+void getCogSpeed(const Point3 result[4], const Point3 current[4], int RF_FIRST, std::vector<double>& cogSpeed);
 
 // --- the chained plan for ONE initial pose (globalFootholdPlan, cpp:539-1602) --------------------
 struct PlanOutput {
@@ -97,6 +99,14 @@ struct PlanOutput {
     std::vector<Point3> defaultNext;  // default-track next positions with z (cpp:774-781)
     std::vector<uint8_t> cycleOk;     // footholdValidation_ per cycle (cpp:1323)
     Point3 stance[4];                 // RF/RH/LH/LF_initialPosition_ (cpp:350-378)
+    // Evaluation products of the centroid ([0]) and nominal ([1]) tracks (trot only):
+    //   feetCenterPath: one pose per planned cycle = getPolygonCenter of the track's CURRENT feet,
+    //                   pushed in getFootholdSearchGridMap whether or not the cycle commits (cpp:2191-2196);
+    //   feetDistance / cogSpeed: two entries per COMMITTED cycle (getHipDistance cpp:2571-2584,
+    //                   getCogSpeed cpp:2587-2623; called at cpp:1357-1368 and cpp:1422-1432).
+    std::vector<Point3> feetCenterPath[2];
+    std::vector<double> feetDistance[2];
+    std::vector<double> cogSpeed[2];
 };
 void planGlobalFootholds(const GridMap& map, const Params& p, const PoseSpec& pose, int nCycles,
                          PlanOutput& out);

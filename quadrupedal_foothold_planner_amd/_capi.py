@@ -63,6 +63,13 @@ GLOBAL_FOOTHOLDS_DTYPE = np.dtype(
 )
 
 
+TRACK_REPORT_DTYPE = np.dtype(
+    [("n_path", "<i4"), ("n_kpi", "<i4"), ("feet_center_path", "<f8", (255, 3)), ("feet_distance", "<f8", (510,)),
+     ("cog_speed", "<f8", (510,))],
+    align=True,
+)
+
+
 class MapDesc(C.Structure):
     _fields_ = [
         ("rows", C.c_int32),
@@ -102,6 +109,7 @@ EXPORTED_SYMBOLS = [
     "fpe_search_legs_device",
     "fpe_plan_service",
     "fpe_plan_service_ex",
+    "fpe_plan_service_report",
     "fpe_spiral_offsets",
     "fpe_tile_halfwidth",
     "fpe_algorithmic_bytes_per_foothold",
@@ -148,6 +156,7 @@ def lib():
     L.fpe_search_legs_device.argtypes = [vp, vp, vp, i32, vp, vp]
     L.fpe_plan_service.argtypes = [vp, vp, vp, C.c_uint8, vp]
     L.fpe_plan_service_ex.argtypes = [vp, vp, vp, C.c_uint8, vp, vp, vp, vp]
+    L.fpe_plan_service_report.argtypes = [vp, vp, vp, C.c_uint8, vp, vp, vp, vp, vp, vp]
     L.fpe_spiral_offsets.argtypes = [i32, vp, i32]
     L.fpe_tile_halfwidth.argtypes = [f32, f32, f64]
     L.fpe_algorithmic_bytes_per_foothold.restype = f64

@@ -493,6 +493,13 @@ int fpe_plan_service(fpe_handle h, const fpe_params* params, const double initia
 int fpe_plan_service_ex(fpe_handle h, const fpe_params* params, const double initial_position[3], uint8_t gait_cycles,
                         fpe_global_footholds* response, fpe_global_footholds* centroid, double* default_footholds,
                         int32_t* n_default_rows) {
+    return fpe_plan_service_report(h, params, initial_position, gait_cycles, response, centroid, default_footholds,
+                                   n_default_rows, nullptr, nullptr);
+}
+
+int fpe_plan_service_report(fpe_handle h, const fpe_params* params, const double initial_position[3], uint8_t gait_cycles,
+                            fpe_global_footholds* response, fpe_global_footholds* centroid, double* default_footholds,
+                            int32_t* n_default_rows, fpe_track_report* nominal_report, fpe_track_report* centroid_report) {
     if (!initial_position || !response) return fail(FPE_E_INVALID_ARG, "null argument");
     if (default_footholds && !n_default_rows) return fail(FPE_E_INVALID_ARG, "n_default_rows is required with default_footholds");
     fpe_pose pose;
@@ -526,7 +533,7 @@ int fpe_plan_service_ex(fpe_handle h, const fpe_params* params, const double ini
         out.nominal = nominal.data();
         out.cycle_ok = ok.data();
         out.stance = stance;
-        if (centroid) out.centroid = cen.data();
+        if (centroid || centroid_report) out.centroid = cen.data();
         if (default_footholds) out.default_next = dflt.data();
         int rc = fpe_plan(h, params, &pose, 1, N, &out);
         if (rc != FPE_OK) return rc;
@@ -542,6 +549,26 @@ int fpe_plan_service_ex(fpe_handle h, const fpe_params* params, const double ini
             asNominal[k].z = cen[k].z;
         }
         fpe::assemble_global_footholds(asNominal.data(), ok.data(), stance, N, centroid);
+    }
+    if (nominal_report || centroid_report) {
+        if (!params) return fail(FPE_E_INVALID_ARG, "null params");
+        std::vector<double> xyz(static_cast<size_t>(N) * 12);
+        if (nominal_report) {
+            for (size_t k = 0; k < static_cast<size_t>(N) * 4; ++k) {
+                xyz[k * 3] = nominal[k].x;
+                xyz[k * 3 + 1] = nominal[k].y;
+                xyz[k * 3 + 2] = static_cast<double>(nominal[k].z);
+            }
+            fpe::assemble_track_report(xyz.data(), ok.data(), stance, N, *params, nominal_report);
+        }
+        if (centroid_report) {
+            for (size_t k = 0; k < static_cast<size_t>(N) * 4; ++k) {
+                xyz[k * 3] = cen[k].x;
+                xyz[k * 3 + 1] = cen[k].y;
+                xyz[k * 3 + 2] = static_cast<double>(cen[k].z);
+            }
+            fpe::assemble_track_report(xyz.data(), ok.data(), stance, N, *params, centroid_report);
+        }
     }
     if (default_footholds) {
         int rows = 0;

@@ -214,6 +214,65 @@ void assemble_global_footholds(const fpe_foothold* nominal, const uint8_t* cycle
     msg->n_footholds = n;
 }
 
+// getPolygonCenter (cpp:2421-2463) on the host, with z (= mean of the four z, cpp:2459-2461).
+static void polygon_center_host(const double feet[4][3], double out[3]) {
+    const double x1 = feet[0][0], y1 = feet[0][1];
+    double x2 = feet[1][0], y2 = feet[1][1];
+    double sum_x = 0, sum_y = 0, sum_s = 0;
+    for (int i = 1; i <= 2; i++) {
+        const double x3 = feet[i + 1][0], y3 = feet[i + 1][1];
+        const double s = ((x2 - x1) * (y3 - y1) - (x3 - x1) * (y2 - y1)) / 2.0;
+        sum_x += (x1 + x2 + x3) * s;
+        sum_y += (y1 + y2 + y3) * s;
+        sum_s += s;
+        x2 = x3;
+        y2 = y3;
+    }
+    out[0] = sum_x / sum_s / 3.0;
+    out[1] = sum_y / sum_s / 3.0;
+    out[2] = (feet[0][2] + feet[1][2] + feet[2][2] + feet[3][2]) / 4.0;
+}
+
+// Feet-centre path and KPIs of one track, rebuilt from the kernel's per-cycle results: the track's
+// current feet start at the stance shifted by -stepLength_/2 (setFirstGait, cpp:2679-2699) and take the
+// results of every committed cycle (cpp:1413-1416 / 1480-1483).
+void assemble_track_report(const double* resultXYZ /*[nCycles][4][3]*/, const uint8_t* cycleOk, const double* stance,
+                           int nCycles, const fpe_params& params, fpe_track_report* rep) {
+    std::memset(rep, 0, sizeof(*rep));
+    const double stepHalf = static_cast<double>(params.stepLength / 2);
+    double cur[4][3];
+    for (int l = 0; l < 4; ++l) {
+        cur[l][0] = stance[l * 3 + 0] - stepHalf;
+        cur[l][1] = stance[l * 3 + 1];
+        cur[l][2] = stance[l * 3 + 2];
+    }
+    enum { RF = 0, RH = 1, LH = 2, LF = 3 };
+    const double gaitCycle = 1.0;  // cpp:332
+    for (int g = 0; g < nCycles; ++g) {
+        polygon_center_host(cur, rep->feet_center_path[rep->n_path++]);
+        if (!cycleOk[g]) continue;
+        const double(*r)[3] = reinterpret_cast<const double(*)[3]>(resultXYZ + static_cast<size_t>(g) * 12);
+        rep->feet_distance[rep->n_kpi] = r[RF][0] - r[LH][0];
+        rep->feet_distance[rep->n_kpi + 1] = r[LF][0] - r[RH][0];
+        double c1, c2, c3;
+        if (params.RF_FIRST) {
+            c1 = (cur[RF][0] + cur[LH][0]) / 2;
+            c2 = (r[LF][0] + r[RH][0]) / 2;
+            c3 = (r[RF][0] + r[LH][0]) / 2;
+        } else {
+            c1 = (cur[LF][0] + cur[RH][0]) / 2;
+            c2 = (r[RF][0] + r[LH][0]) / 2;
+            c3 = (r[LF][0] + r[RH][0]) / 2;
+        }
+        const double d1 = c2 - c1, d2 = c3 - c2;
+        rep->cog_speed[rep->n_kpi] = d1 / (0.5 * gaitCycle);
+        rep->cog_speed[rep->n_kpi + 1] = d2 / (0.5 * gaitCycle);
+        rep->n_kpi += 2;
+        for (int l = 0; l < 4; ++l)
+            for (int k = 0; k < 3; ++k) cur[l][k] = r[l][k];
+    }
+}
+
 }  // namespace fpe
 
 // ---- C ABI: host-only entry points -----------------------------------------------------------------

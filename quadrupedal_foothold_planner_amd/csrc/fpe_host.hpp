@@ -40,5 +40,7 @@ int validate_params(const fpe_params& p);
 // GlobalFootholds message content from one pose's plan outputs (cpp:591-699, 1378-1396, 1574).
 void assemble_global_footholds(const fpe_foothold* nominal, const uint8_t* cycleOk, const double* stance,
                                int nCycles, fpe_global_footholds* msg);
+void assemble_track_report(const double* resultXYZ, const uint8_t* cycleOk, const double* stance, int nCycles,
+                           const fpe_params& params, fpe_track_report* rep);
 
 }  // namespace fpe

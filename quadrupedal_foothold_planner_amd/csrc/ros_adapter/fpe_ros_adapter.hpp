@@ -9,10 +9,15 @@
 #ifdef FPE_WITH_ROS
 
 #include <foothold_planner_msgs/GlobalFootholds.h>
+#include <geometry_msgs/PoseStamped.h>
 #include <grid_map_core/GridMap.hpp>
+#include <nav_msgs/Path.h>
 
+#include <algorithm>
+#include <array>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "fpe.h"
 
@@ -66,12 +71,70 @@ public:
         return true;
     }
 
+    // Same call with every product the node publishes or logs for the nominal and centroid tracks
+    // (SURVEY.md §8(f) N2).  `centroidMsg` is APPENDED to, as the reference never clears it between
+    // calls (cpp:715); the paths are cleared first (cpp:635-636); the KPI vectors are the members of
+    // footholdsKPI_ (hpp:732-745; cleared at cpp:606-611).
+    bool planAllTracks(const fpe_params& params, const double initialPose[3], uint8_t gaitCycles,
+                       foothold_planner_msgs::GlobalFootholds& msg, foothold_planner_msgs::GlobalFootholds& centroidMsg,
+                       std::vector<std::array<double, 12>>& defaultFootholds, nav_msgs::Path& nominalFeetCenterPath,
+                       nav_msgs::Path& centroidFeetCenterPath, std::vector<double>& cogSpeedNominal,
+                       std::vector<double>& feetDistanceNominal, std::vector<double>& cogSpeedCentroid,
+                       std::vector<double>& feetDistanceCentroid) {
+        std::vector<double> rows(static_cast<size_t>(1 + gaitCycles) * 12);
+        int32_t nRows = 0;
+        if (fpe_plan_service_report(h_, &params, initialPose, gaitCycles, &resp_, &cen_, rows.data(), &nRows, &repNominal_,
+                                    &repCentroid_) != FPE_OK)
+            return false;
+        fill(resp_, msg, true);
+        fill(cen_, centroidMsg, false);
+        defaultFootholds.clear();  // cpp:601
+        for (int r = 0; r < nRows; ++r) {
+            std::array<double, 12> row;
+            std::copy(rows.begin() + r * 12, rows.begin() + (r + 1) * 12, row.begin());
+            defaultFootholds.push_back(row);
+        }
+        fillPath(repNominal_, nominalFeetCenterPath);
+        fillPath(repCentroid_, centroidFeetCenterPath);
+        cogSpeedNominal.assign(repNominal_.cog_speed, repNominal_.cog_speed + repNominal_.n_kpi);
+        feetDistanceNominal.assign(repNominal_.feet_distance, repNominal_.feet_distance + repNominal_.n_kpi);
+        cogSpeedCentroid.assign(repCentroid_.cog_speed, repCentroid_.cog_speed + repCentroid_.n_kpi);
+        feetDistanceCentroid.assign(repCentroid_.feet_distance, repCentroid_.feet_distance + repCentroid_.n_kpi);
+        return true;
+    }
+
     const char* lastError() const { return fpe_last_error(h_); }
     fpe_handle handle() const { return h_; }
 
 private:
+    static void fill(const fpe_global_footholds& r, foothold_planner_msgs::GlobalFootholds& msg, bool clear) {
+        msg.success = r.success;
+        msg.gait_cycles = r.gait_cycles;
+        msg.gait_cycles_succeed = r.gait_cycles_succeed;
+        if (clear) msg.footholds.clear();
+        for (int k = 0; k < r.n_footholds; ++k) {
+            foothold_planner_msgs::Foothold f;
+            f.point.x = r.footholds[k].x;
+            f.point.y = r.footholds[k].y;
+            f.point.z = r.footholds[k].z;
+            f.foot_id = r.footholds[k].foot_id;
+            f.gait_cycle_id = r.footholds[k].gait_cycle_id;
+            msg.footholds.push_back(f);
+        }
+    }
+    static void fillPath(const fpe_track_report& rep, nav_msgs::Path& path) {
+        path.poses.clear();
+        for (int k = 0; k < rep.n_path; ++k) {
+            geometry_msgs::PoseStamped p;  // cpp:2194-2196: only pose.position is set
+            p.pose.position.x = rep.feet_center_path[k][0];
+            p.pose.position.y = rep.feet_center_path[k][1];
+            p.pose.position.z = rep.feet_center_path[k][2];
+            path.poses.push_back(p);
+        }
+    }
     fpe_handle h_ = nullptr;
-    fpe_global_footholds resp_;
+    fpe_global_footholds resp_, cen_;
+    fpe_track_report repNominal_, repCentroid_;
 };
 
 }  // namespace fpe_ros

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _capi
 from ._capi import (CENTROID_DTYPE, FOOTHOLD_DTYPE, GLOBAL_FOOTHOLDS_DTYPE, POSE_DTYPE, PARAMS_DTYPE, QUERY_DTYPE,
-                    EngineUnavailable, MapDesc, PlanOut, ptr)
+                    TRACK_REPORT_DTYPE, EngineUnavailable, MapDesc, PlanOut, ptr)
 
 
 class FpeError(RuntimeError):
@@ -151,9 +151,16 @@ class FootholdPlanner:
             "footholds": m["footholds"][:n].copy(),
         }
 
+    @staticmethod
+    def _report(r):
+        return {"path": r["feet_center_path"][: int(r["n_path"])].copy(),
+                "feet_distance": r["feet_distance"][: int(r["n_kpi"])].copy(),
+                "cog_speed": r["cog_speed"][: int(r["n_kpi"])].copy()}
+
     def globalFootholdPlan(self, gait_cycles, initial_position, all_tracks=False):
-        """Response content of the service; with all_tracks also the centroid message and the default-track
-        rows (global_footholds_centroid, globalFootholdsResult_.defaultFootholds)."""
+        """Response content of the service; with all_tracks also the centroid message, the default-track
+        rows (global_footholds_centroid, globalFootholdsResult_.defaultFootholds), and per track the
+        feet-centre path and KPIs (nominal/centroid_feet_center_path, footholdsKPI_)."""
         msg = np.zeros(1, dtype=GLOBAL_FOOTHOLDS_DTYPE)
         pos = np.ascontiguousarray(initial_position, dtype=np.float64).reshape(3)
         if not all_tracks:
@@ -162,9 +169,13 @@ class FootholdPlanner:
         cen = np.zeros(1, dtype=GLOBAL_FOOTHOLDS_DTYPE)
         dflt = np.zeros((1 + int(gait_cycles), 4, 3), dtype=np.float64)
         nrows = C.c_int32(0)
-        self._check(self._lib.fpe_plan_service_ex(self._h, ptr(self.params), ptr(pos), int(gait_cycles) & 0xFF, ptr(msg),
-                                                  ptr(cen), ptr(dflt), C.cast(C.byref(nrows), C.c_void_p)))
+        rep = np.zeros(2, dtype=TRACK_REPORT_DTYPE)
+        self._check(self._lib.fpe_plan_service_report(self._h, ptr(self.params), ptr(pos), int(gait_cycles) & 0xFF, ptr(msg),
+                                                      ptr(cen), ptr(dflt), C.cast(C.byref(nrows), C.c_void_p),
+                                                      ptr(rep[0:1]), ptr(rep[1:2])))
         out = self._msg(msg[0])
         out["centroid"] = self._msg(cen[0])
         out["default_footholds"] = dflt[: nrows.value].copy()
+        out["report"] = self._report(rep[0])
+        out["centroid"]["report"] = self._report(rep[1])
         return out

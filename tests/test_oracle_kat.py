@@ -222,6 +222,38 @@ def test_invalid_cycle_does_not_advance_but_drift_applies():
     assert nom[1, 0]["y"] - nom[0, 0]["y"] == pytest.approx(-0.007, abs=1e-15)
 
 
+def test_track_reports_closed_form_on_flat_and_blocked_maps():
+    # flat map: every cycle commits; the feet polygon is a trapezoid whose centre advances by stepLength_,
+    # getCogSpeed cpp:2587-2623 with gaitCycle_ = 1.0 -> speed = 2 * distance per half cycle
+    p = yaml_params()
+    s = 0.18000000715255737
+    lb2, k = 0.21934999525547028, 0.03999999910593033
+    out = flat(400, 400, 0.02).plan_products(p, oracle_poses([[-0.21, -1.87, 0.0]]), 8)
+    for name in ("nominal", "centroid"):
+        r = out[name]
+        assert r["path"].shape == (8, 3) and len(r["feet_distance"]) == 16 == len(r["cog_speed"])
+        assert np.allclose(r["path"][:, 0], -0.21 - s / 2 + s * np.arange(8), atol=1e-12)
+        # the stance is a rectangle (centre = pose); the planned feet form a trapezoid whose area centroid sits
+        # wb2*k/(3*lb2) towards its long (left) side; the drift of cycle g shows in the path of cycle g+1
+        yoff = 0.12449999898672104 * k / (3 * lb2)
+        assert np.allclose(r["path"][0, 1], -1.87, atol=1e-12)
+        assert np.allclose(r["path"][1:, 1], -1.87 + yoff - 0.007 * np.arange(7), atol=1e-12)
+        assert r["path"][0, 2] == 0.0 and np.allclose(r["path"][1:, 2], 0.009999999776482582, atol=0)
+        # RF_FIRST = false (yaml): RF.x - LH.x = (lb2-k) - (-lb2-k) = 2 lb2; LF.x - RH.x = (lb2+k) - (-lb2+k) = 2 lb2
+        assert np.allclose(r["feet_distance"], 2 * lb2, atol=1e-12)
+        # pair midpoints: (RF+LH)/2 = centre - k, (LF+RH)/2 = centre + k; the stance pair sits at the centre
+        assert np.allclose(r["cog_speed"][0], 2 * (s - k), atol=1e-12)
+        assert np.allclose(r["cog_speed"][2::2], 2 * (s - 2 * k), atol=1e-12)
+        assert np.allclose(r["cog_speed"][1::2], 2 * (2 * k), atol=1e-12)
+    # blocked world: no cycle commits -> no KPI entries, the path repeats the first centre (cpp:2194-2196 runs anyway)
+    rows = cols = 200
+    m = fpo.OracleMap(np.full((rows, cols), 0.1, np.float32), np.zeros((rows, cols), np.float32), 0.02)
+    out = m.plan_products(p, oracle_poses([[-1.0, 0.0, 0.0]]), 3)
+    for name in ("nominal", "centroid"):
+        assert len(out[name]["cog_speed"]) == 0 and out[name]["path"].shape == (3, 3)
+        assert (out[name]["path"] == out[name]["path"][0]).all()
+
+
 def test_as_written_emulation_changes_cost_not_results():
     """The by-value copy emulation must leave every result untouched."""
     p = yaml_params()
