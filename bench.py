@@ -4,7 +4,8 @@
 A "step" = one pass of the hot path over one batch: fpe_plan_device on B poses x N cycles x 4
 legs with the map and the poses already resident in HBM, every product of the three tracks
 written (nominal, centroid, default, cycle flags, stance); at N>1 GPUs the step also contains the
-RCCL all-gather of the selected (nominal) footholds, as north_star names it.  Weak scaling: every
+RCCL all-gather of the selected (nominal) footholds, as north_star names it — issued asynchronously so
+that it overlaps the next step's plan kernel (double-buffered; all gathers complete inside the timed region).  Weak scaling: every
 rank plans its own B poses (a contiguous shard of the global seeded list of N*B poses).
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per foothold (SURVEY.md
@@ -157,16 +158,25 @@ def main():
     d_st = torch.zeros(B * 12, dtype=torch.float64, device=dev)
 
     stream = torch.cuda.current_stream()
+    # N>1: the all-gather of step k (RCCL, its own stream) overlaps the plan kernel of step k+1; two
+    # foothold blocks are cycled (quadrupedal_foothold_planner_amd.dist.FootholdExchange).  Every step's
+    # footholds are gathered on every rank; the timed region ends after the last gather has completed.
+    ex = fdist.FootholdExchange(n_rec * rec, dev) if world > 1 else None
+    step_no = [0]
 
     def step():
-        planner.plan_device(d_poses.data_ptr(), B, n_cycles, d_nom.data_ptr(), d_cen.data_ptr(), d_def.data_ptr(),
+        k = step_no[0]
+        step_no[0] += 1
+        nom = ex.acquire(k) if ex else d_nom
+        planner.plan_device(d_poses.data_ptr(), B, n_cycles, nom.data_ptr(), d_cen.data_ptr(), d_def.data_ptr(),
                             d_ok.data_ptr(), d_st.data_ptr(), stream=stream.cuda_stream)
-        if world > 1:
-            return fdist.all_gather_records(d_nom, B * world, n_cycles * 4 * rec)
-        return d_nom
+        if ex:
+            ex.gather(k)
 
     for _ in range(args.warmup):
         step()
+    if ex:
+        ex.drain()
     # HIP events on the launch stream bracket the K launches of the timed region; at N=1 the region
     # holds nothing but the K plan kernels, so elapsed/K is the mean launch duration (an upper bound
     # of the kernel time: it includes the ~2 us dispatch gap between back-to-back launches).  At N>1
@@ -178,7 +188,9 @@ def main():
     t0 = time.perf_counter()
     ev0.record(stream)
     for k in range(args.steps):
-        gathered = step()
+        step()
+    if ex:
+        ex.drain()  # the stream waits for the in-flight all-gathers
     ev1.record(stream)
     torch.cuda.synchronize()
     if world > 1:
@@ -208,7 +220,12 @@ def main():
 
     # sanity: the last step's results are real (not a skipped/cached launch)
     ok_frac = float(d_ok.float().mean().item())
-    valid_frac = float(torch.from_numpy(np.frombuffer(d_nom.cpu().numpy().tobytes(), dtype=_capi.FOOTHOLD_DTYPE)["valid"].copy()).float().mean())
+    last_nom = ex.local[(step_no[0] - 1) % ex.depth] if ex else d_nom
+    valid_frac = float(torch.from_numpy(np.frombuffer(last_nom.cpu().numpy().tobytes(), dtype=_capi.FOOTHOLD_DTYPE)["valid"].copy()).float().mean())
+    if ex:
+        # the gathered block of the last step holds this rank's shard at its rank offset
+        g = ex.result(step_no[0] - 1)
+        assert torch.equal(g[rank * n_rec * rec:(rank + 1) * n_rec * rec], last_nom), "all-gather lost this rank's footholds"
 
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -241,7 +258,7 @@ def main():
             "generator": synth.GENERATOR_VERSION,
             "cycle_ok_fraction": ok_frac,
             "valid_leg_fraction": valid_frac,
-            "exchange": "all_gather of nominal footholds (RCCL)" if world > 1 else "none",
+            "exchange": "all_gather of nominal footholds (RCCL), every step, overlapped with the next step's plan kernel" if world > 1 else "none",
         },
         "roofline": {
             "bound": "hbm",

@@ -344,6 +344,29 @@ __device__ __forceinline__ void ordered_finish(const OrderedSum& os, float& sum,
     for (; t < os.n; ++t) ordered_step(os.scratch[t], sum, last, cnt);
 }
 
+// Sequential f32 sum of one value per lane over the lanes of a group, in lane order, computed
+// redundantly by every lane: lane k's value arrives by ds_swizzle (bit mode: keep the group bits of
+// the lane id, force the low bits to k — no LDS memory, no VALU), so a round costs G dependent
+// v_add_f32 and nothing else.  Lanes that must not contribute pass -0.0f: s + (-0.0f) == s bit for
+// bit for every s (round-to-nearest), which keeps the reference's add order over the visited cells.
+template <int G, int K>
+__device__ __forceinline__ float grp_lane_value(float v) {
+    static_assert(G <= 32, "ds_swizzle bit mode permutes within 32 lanes");
+    constexpr int pattern = ((~(G - 1)) & 0x1F) | (K << 5);
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), pattern));
+}
+template <int G, int K = 0>
+struct SeqSum {
+    static __device__ __forceinline__ float run(float s, float x) {
+        s = s + grp_lane_value<G, K>(x);
+        return SeqSum<G, K + 1>::run(s, x);
+    }
+};
+template <int G>
+struct SeqSum<G, G> {
+    static __device__ __forceinline__ float run(float s, float) { return s; }
+};
+
 __device__ __forceinline__ float finish_mean(float sum, float last, int cnt, double h) {
     const float mean = (cnt != 0) ? (sum / cnt) : last;       // cpp:2547-2551
     return static_cast<float>(static_cast<double>(mean) + h);  // cpp:2553 (float + double)
@@ -590,6 +613,30 @@ __device__ __forceinline__ float disc_consume(const DevMap& m, const PlanConsts&
     float sum = 0.0f, last = 0.0f;
     int cnt = 0;
     bool any = false, fail = false;
+    if constexpr (G <= 16) {
+        // small discs: no compaction at all — G dependent adds per round on swizzled lane values
+        unsigned long long visMask[kDiscRounds];
+        float v[kDiscRounds];
+#pragma unroll
+        for (int r = 0; r < kDiscRounds; ++r) {
+            v[r] = __builtin_isfinite(d.e[r]) ? d.e[r] : 0.0f;                                          // cpp:2532-2537
+            if (kCheck && d.vis[r] && __builtin_isfinite(d.t[r]) && d.t[r] < pc.thrDefault) fail = true;  // cpp:2055-2057
+            const bool inc = d.vis[r] && v[r] < 10;                                                     // cpp:2539
+            visMask[r] = g.ballot(d.vis[r]);
+            cnt += __builtin_popcountll(g.ballot(inc));
+            if (r == 0 || __ballot(d.vis[r]) != 0ull) sum = SeqSum<G>::run(sum, inc ? v[r] : -0.0f);
+        }
+        if (__ballot(cnt == 0 && (visMask[0] | visMask[1]) != 0ull) != 0ull) {
+            // every visited value was >= 10: the mean falls back to the LAST visited value (cpp:2547-2551)
+            const bool hi = visMask[kDiscRounds - 1] != 0ull;
+            const unsigned long long mk = hi ? visMask[kDiscRounds - 1] : visMask[0];
+            const int l = mk ? 63 - __builtin_clzll(mk) : 0;
+            const float l1 = g.bcast(v[kDiscRounds - 1], l), l0 = g.bcast(v[0], l);
+            if (mk) last = hi ? l1 : l0;
+        }
+        if (kCheck) defaultOk = (visMask[0] | visMask[1]) != 0ull && !g.any(fail);
+        return finish_mean(sum, last, cnt, pc.h);
+    }
     OrderedSum os{scratch, 0};
 #pragma unroll
     for (int r = 0; r < kDiscRounds; ++r) {

@@ -57,6 +57,59 @@ def all_gather_records(local, total_poses, pose_bytes):
     return torch.cat(parts)
 
 
+class FootholdExchange:
+    """Pipelined form of all_gather_records for a stream of plans with equal shards: the all-gather of
+    plan k runs on the collective's own stream (async_op) while plan k+1 is computed, so a step costs
+    max(plan, exchange) instead of their sum.  `depth` result blocks are cycled; a block is handed out
+    again only after the all-gather that read it has completed (stream-ordered wait, no host sync on
+    RCCL).  xGMI is point-to-point, so the 4 MB-per-rank exchange of the headline step is of the same
+    order as the 60 us plan kernel: hiding it is what keeps weak scaling flat.
+
+        ex = FootholdExchange(local_bytes, device)
+        for k in range(steps):
+            buf = ex.acquire(k)          # device block the plan of step k writes its footholds into
+            plan(..., buf.data_ptr())
+            ex.gather(k)                 # asynchronous all-gather of that block
+        all_footholds = ex.result(steps - 1)   # [world * local_bytes], waits for that step only
+        ex.drain()
+    """
+
+    def __init__(self, local_bytes, device, depth=2):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.depth = depth
+        self.local = [torch.zeros(local_bytes, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.out = [torch.empty(local_bytes * self.world, dtype=torch.uint8, device=device) if self.world > 1 else None
+                    for _ in range(depth)]
+        self.work = [None] * depth
+
+    def acquire(self, k):
+        slot = k % self.depth
+        if self.work[slot] is not None:
+            self.work[slot].wait()
+            self.work[slot] = None
+        return self.local[slot]
+
+    def gather(self, k):
+        slot = k % self.depth
+        if self.world > 1:
+            self.work[slot] = dist.all_gather_into_tensor(self.out[slot], self.local[slot], async_op=True)
+
+    def result(self, k):
+        slot = k % self.depth
+        if self.world == 1:
+            return self.local[slot]
+        if self.work[slot] is not None:
+            self.work[slot].wait()
+            self.work[slot] = None
+        return self.out[slot]
+
+    def drain(self):
+        for slot in range(self.depth):
+            if self.work[slot] is not None:
+                self.work[slot].wait()
+                self.work[slot] = None
+
+
 def records_to_numpy(t, n_cycles, dtype=FOOTHOLD_DTYPE):
     a = t.detach().cpu().numpy().view(dtype)
     return a.reshape(-1, n_cycles, 4)

@@ -52,6 +52,46 @@ def test_sharded_plan_all_gather_equals_unsharded(tmp_path, B):
     assert open(tmp_path / "result").read() == "ok"
 
 
+def _pipelined_worker(rank, world, port, B, n_cycles, steps, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import fpo
+    from quadrupedal_foothold_planner_amd import dist as fdist
+    from quadrupedal_foothold_planner_amd import synth
+    from tests.conftest import yaml_params
+    from tests.util import to_oracle_poses
+
+    trav, elev = synth.rough_map(160, 160, 0.02, seed=3)
+    omap = fpo.OracleMap(trav, elev, 0.02)
+    lo, hi = fdist.shard_range(B, rank, world)
+    local_bytes = (hi - lo) * n_cycles * 4 * fpo.LEG_DTYPE.itemsize
+    ex = fdist.FootholdExchange(local_bytes, torch.device("cpu"))
+    ok = True
+    expected = []
+    for k in range(steps):  # a different pose list per step: a stale or overwritten block would show
+        poses = synth.poses_in_map(B, 3.2, 3.2, n_cycles, 0.18, seed=40 + k, margin=0.65)
+        buf = ex.acquire(k)
+        out = omap.plan(yaml_params(), to_oracle_poses(poses[lo:hi]), n_cycles)
+        buf.copy_(torch.from_numpy(np.ascontiguousarray(out["nominal"]).view(np.uint8).reshape(-1)))
+        ex.gather(k)
+        expected.append(np.ascontiguousarray(omap.plan(yaml_params(), to_oracle_poses(poses), n_cycles)["nominal"]).tobytes())
+        if k >= 1:  # read step k-1 while step k's exchange is in flight
+            ok &= ex.result(k - 1).numpy().tobytes() == expected[k - 1]
+    ok &= ex.result(steps - 1).numpy().tobytes() == expected[steps - 1]
+    ex.drain()
+    open(os.path.join(tmpdir, f"result{rank}"), "w").write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_exchange_overlaps_without_mixing_steps(tmp_path):
+    port = 29500 + (os.getpid() + 977) % 2000
+    mp.spawn(_pipelined_worker, args=(2, port, 32, 3, 5, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "result0").read() == "ok" and open(tmp_path / "result1").read() == "ok"
+
+
 def test_shard_ranges_partition_exactly():
     from quadrupedal_foothold_planner_amd import dist as fdist
 
