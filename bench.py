@@ -123,10 +123,18 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    # debugging aid for 1-GPU boxes: FPE_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo for
+    # the collectives (RCCL refuses two ranks on one device); never set by the driver
+    share = os.environ.get("FPE_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     # ---- workload --------------------------------------------------------------------------------
