@@ -989,31 +989,30 @@ __device__ __forceinline__ void store_foothold(fpe_foothold* dst, const NominalO
     *dst = f;
 }
 
-// getPolygonCenter (cpp:2421-2463): feet[leg][xyz] in LDS; x and y only (z of the centre is never
-// used downstream: getDefaultFootholdNext zeroes it, cpp:2411-2418).
-__device__ __forceinline__ void polygon_center_xy(const double (*feet)[3], double& ox, double& oy) {
+// getPolygonCenter (cpp:2421-2463): feet[leg][xyz] in LDS.  Only the centre's x is computed: the next
+// centre takes y from initialPose_/ajustedPose_ (cpp:2201, 2272) and getDefaultFootholdNext zeroes z
+// (cpp:2411-2418), so the y and z of the centre never reach a result (two f64 divisions saved per track).
+__device__ __forceinline__ double polygon_center_x(const double (*feet)[3]) {
     const double x1 = feet[0][0], y1 = feet[0][1];
     double x2 = feet[1][0], y2 = feet[1][1];
-    double sum_x = 0, sum_y = 0, sum_s = 0;
+    double sum_x = 0, sum_s = 0;
 #pragma unroll
     for (int i = 1; i <= 2; i++) {
         const double x3 = feet[i + 1][0], y3 = feet[i + 1][1];  // i=1: LH, i=2: LF
         const double s = ((x2 - x1) * (y3 - y1) - (x3 - x1) * (y2 - y1)) / 2.0;
         sum_x += (x1 + x2 + x3) * s;
-        sum_y += (y1 + y2 + y3) * s;
         sum_s += s;
         x2 = x3;
         y2 = y3;
     }
-    ox = sum_x / sum_s / 3.0;
-    oy = sum_y / sum_s / 3.0;
+    return sum_x / sum_s / 3.0;
 }
 
 // LDS of one pose (all offsets multiples of 16).
 struct PoseShared {
     double cur[3][4][3];  // current feet of the default / centroid / nominal tracks (cpp:1338, 1413, 1480)
     double nxt[3][4][3];  // this phase's results per track
-    double ctr[3][2];     // feet-polygon centre of each track for this phase
+    double ctr[4];        // x of the feet-polygon centre of each track for this phase ([3] pads to 16 B)
     double polyX[4][8];   // search polygon vertices per leg
     double polyY[4][8];
     int valid[4];
@@ -1058,9 +1057,9 @@ __device__ __forceinline__ void leg_phase(const DevMap& m, const PlanConsts& pc,
     const double biasX = ls.biasX, biasY = ls.biasY;
         // next default positions of this leg on the three tracks (cpp:2199-2213, 2270-2284)
         const double Ny = y0 + adjY;                         // cpp:2201
-        const double nx0 = (sh.ctr[0][0] + advance) + biasX;  // cpp:2199, 2414
-        const double nx1 = (sh.ctr[1][0] + advance) + biasX;
-        const double nx2 = (sh.ctr[2][0] + advance) + biasX;
+        const double nx0 = (sh.ctr[0] + advance) + biasX;  // cpp:2199, 2414
+        const double nx1 = (sh.ctr[1] + advance) + biasX;
+        const double nx2 = (sh.ctr[2] + advance) + biasX;
         const double ny = Ny + biasY;                        // identical on the three tracks
         // search polygon from the NOMINAL track (cpp:2235-2244, getSearchPolygon cpp:2496-2517)
         if (g.sub == 0) {
@@ -1251,10 +1250,7 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
             stamp(pc, cyc, 0);
             // feet-polygon centres: group t computes track t (getPolygonCenter, cpp:2191, 2265)
             if (leg < 3 && g.sub == 0) {
-                double cx, cy;
-                polygon_center_xy(sh.cur[leg], cx, cy);
-                sh.ctr[leg][0] = cx;
-                sh.ctr[leg][1] = cy;
+                sh.ctr[leg] = polygon_center_x(sh.cur[leg]);
             }
             pose_sync<G>();
             stamp(pc, cyc, 1);
@@ -1345,10 +1341,7 @@ __global__ __launch_bounds__(64, 4) void plan_sequential_kernel(DevMap m, PlanCo
             const unsigned mask = (gait == 1) ? (1u << ((walkOrder >> (2 * ph)) & 3)) : 0xFu;
             // feet-polygon centres: lane t computes track t (getPolygonCenter, cpp:2191, 2265)
             if (tid < 3) {
-                double cx, cy;
-                polygon_center_xy(sh.cur[tid], cx, cy);
-                sh.ctr[tid][0] = cx;
-                sh.ctr[tid][1] = cy;
+                sh.ctr[tid] = polygon_center_x(sh.cur[tid]);
             }
             if (tid < 4) sh.valid[tid] = 1;  // non-swing legs do not vote
             pose_sync<16>();
