@@ -75,7 +75,8 @@ __device__ __forceinline__ void divmod_small(int t, int d, float dinv, int& q, i
         r -= d;
     }
 }
-__device__ __forceinline__ float rcp_small(int d) { return __frcp_rn(static_cast<float>(d)); }
+// v_rcp_f32 (1 ulp) is enough: with t < 2^22 the estimate t * dinv is within 1 of t / d, which the fix-up absorbs
+__device__ __forceinline__ float rcp_small(int d) { return __builtin_amdgcn_rcpf(static_cast<float>(d)); }
 
 // Pose-level synchronisation: a pose owns one wavefront when G < 64 (LDS operations of a wavefront
 // are executed in order, so only the compiler must not reorder) and four wavefronts when G = 64.
@@ -146,13 +147,24 @@ struct Corners {
             within |= bits << (p * L);
         }
     }
-    __device__ __forceinline__ int get(const Grp<G>& g, int id) const { return g.bcast(idx[id / L], id % L); }
-    __device__ __forceinline__ BBox bbox(const Grp<G>& g, int q) const {
+    // Quantity ID as seen by every lane of the group.  Groups of <= 32 lanes read it with ds_swizzle (bit mode:
+    // keep the group bits of the lane id, force the low bits to ID % L): no LDS memory and no address VALU.
+    template <int ID>
+    __device__ __forceinline__ int get(const Grp<G>& g) const {
+        if constexpr (G <= 32) {
+            constexpr int pattern = ((~(G - 1)) & 0x1F) | ((ID % L) << 5);
+            return __builtin_amdgcn_ds_swizzle(idx[ID / L], pattern);
+        } else {
+            return g.bcast(idx[ID / L], ID % L);
+        }
+    }
+    template <int Q>
+    __device__ __forceinline__ BBox bbox(const Grp<G>& g) const {
         BBox b;
-        b.i0 = get(g, 4 * q + 0);
-        b.j0 = get(g, 4 * q + 1);
-        b.ni = get(g, 4 * q + 2) - b.i0 + 1;
-        b.nj = get(g, 4 * q + 3) - b.j0 + 1;
+        b.i0 = get<4 * Q + 0>(g);
+        b.j0 = get<4 * Q + 1>(g);
+        b.ni = get<4 * Q + 2>(g) - b.i0 + 1;
+        b.nj = get<4 * Q + 3>(g) - b.j0 + 1;
         return b;
     }
     __device__ __forceinline__ bool box_within(int q) const { return ((within >> (4 * q)) & 0xFu) == 0xFu; }
@@ -834,9 +846,9 @@ __device__ void centroid_begin(const DevMap& m, const PlanConsts& pc, const LegC
     const Box disc{o.x, o.y, pc.rf, pc.rf};
     Corners<G, 8> cr;
     cr.eval(m.g, g, disc, disc, disc, disc, 0x2u);
-    cp.rb = cr.bbox(g, 0);
-    o.row = cr.get(g, 4);
-    o.col = cr.get(g, 5);
+    cp.rb = cr.template bbox<0>(g);
+    o.row = cr.template get<4>(g);
+    o.col = cr.template get<5>(g);
     disc_issue<G, false>(m, pc, o.x, o.y, cp.rb, g, cp.dl);
     cp.needDisc = true;
 }
@@ -1121,11 +1133,11 @@ __device__ __forceinline__ void leg_phase(const DevMap& m, const PlanConsts& pc,
             const Box b2{nx0, ny, pc.rf, pc.rf};
             Corners<G, 16> cs;
             cs.eval(m.g, g, b0, b1, b2, b0, 0x8u);
-            const BBox bb = cs.bbox(g, 0);
-            const BBox rbox = cs.bbox(g, 1);
-            dbox = cs.bbox(g, 2);
-            c.ici = cs.get(g, 12);
-            c.icj = cs.get(g, 13);
+            const BBox bb = cs.template bbox<0>(g);
+            const BBox rbox = cs.template bbox<1>(g);
+            dbox = cs.template bbox<2>(g);
+            c.ici = cs.template get<12>(g);
+            c.icj = cs.template get<13>(g);
             const bool rectWithin = cs.box_within(1);
             const Submap sm = submap_from_corners(m.g, rbox, rectWithin, c.cx, c.cy);
             stamp(pc, cyc, 2);
@@ -1424,9 +1436,9 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
         const Box b0{c.cx, c.cy, pc.rf, pc.rf};
         Corners<64, 8> cs;
         cs.eval(m.g, g, b0, b0, b0, b0, 0x2u);  // quantities 4,5 = getIndex(centre)
-        const BBox bb = cs.bbox(g, 0);
-        c.ici = cs.get(g, 4);
-        c.icj = cs.get(g, 5);
+        const BBox bb = cs.template bbox<0>(g);
+        c.ici = cs.template get<4>(g);
+        c.icj = cs.template get<5>(g);
         Submap sm;
         sm.ok = false;
         DefaultDisc dflt;
