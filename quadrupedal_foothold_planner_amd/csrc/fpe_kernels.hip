@@ -104,18 +104,11 @@ struct CornerVal {
     int idx;      // getIndexFromPosition of the bounded corner on this lane's axis
     bool within;  // checkIfPositionWithinMap of the bounded corner on this lane's axis
 };
-// Quantity `id` = box (id >> 2) & 3, corner/axis id & 3.  A box whose bit is set in rawBoxMask is a
+// Quantity k (0 top-left x, 1 top-left y, 2 bottom-right x, 3 bottom-right y) of one box.  raw: the box is a
 // plain getIndexFromPosition of its centre (no boundPositionToRange), e.g. getIndex(search centre).
-__device__ __forceinline__ CornerVal corner_quantity(const MapGeom& g, int id, const Box& b0, const Box& b1,
-                                                     const Box& b2, const Box& b3, unsigned rawBoxMask) {
-    const int q = (id >> 2) & 3, k = id & 3;
+__device__ __forceinline__ CornerVal corner_quantity(const MapGeom& g, int k, const Box& b, bool raw) {
     const bool isY = (k & 1) != 0, isBR = (k & 2) != 0;
-    const bool raw = ((rawBoxMask >> q) & 1u) != 0;
-    const double cx = q == 0 ? b0.cx : (q == 1 ? b1.cx : (q == 2 ? b2.cx : b3.cx));
-    const double cy = q == 0 ? b0.cy : (q == 1 ? b1.cy : (q == 2 ? b2.cy : b3.cy));
-    const double hx = q == 0 ? b0.hx : (q == 1 ? b1.hx : (q == 2 ? b2.hx : b3.hx));
-    const double hy = q == 0 ? b0.hy : (q == 1 ? b1.hy : (q == 2 ? b2.hy : b3.hy));
-    const double c = isY ? cy : cx, h = isY ? hy : hx;
+    const double c = isY ? b.cy : b.cx, h = isY ? b.hy : b.hx;
     const double org = isY ? g.orgY : g.orgX, pos = isY ? g.posY : g.posX, len = isY ? g.lenY : g.lenX;
     const double v = isBR ? c - h : c + h;
     const double bnd = raw ? c : bound_axis(v, org, pos, len);
@@ -124,6 +117,14 @@ __device__ __forceinline__ CornerVal corner_quantity(const MapGeom& g, int id, c
     // faster here than either a per-lane or a wave-uniform branch (0.0766 vs 0.0783 ms per launch)
     r.idx = index_of_fast(bnd, org, pos, g.res, g.rinv);
     r.within = raw || within_axis(bnd, org, pos, len);
+    return r;
+}
+__device__ __forceinline__ Box pick_box(bool second, const Box& a, const Box& b) {
+    Box r;
+    r.cx = second ? b.cx : a.cx;
+    r.cy = second ? b.cy : a.cy;
+    r.hx = second ? b.hx : a.hx;
+    r.hy = second ? b.hy : a.hy;
     return r;
 }
 
@@ -135,13 +136,32 @@ struct Corners {
     int idx[P];
     unsigned within;                                      // bit id = within flag of quantity id
 
+    // Quantity id = box (id >> 2) & 3, corner/axis id & 3; a box whose bit is set in rawBoxMask is raw.  Pass p
+    // covers the L/4 boxes starting at p*L/4, so a lane chooses among 1, 2 or 4 boxes — never more than it must.
     __device__ __forceinline__ void eval(const MapGeom& mg, const Grp<G>& g, const Box& b0, const Box& b1, const Box& b2,
                                          const Box& b3, unsigned rawBoxMask) {
         within = 0u;
+        const int lane = g.sub & (L - 1);
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const int id = (p * L + (g.sub & (L - 1))) & (NQ - 1);
-            const CornerVal cv = corner_quantity(mg, id, b0, b1, b2, b3, rawBoxMask);
+            Box b;
+            bool raw;
+            if constexpr (L == 4) {
+                const int q = p & 3;
+                b = q == 0 ? b0 : (q == 1 ? b1 : (q == 2 ? b2 : b3));
+                raw = ((rawBoxMask >> q) & 1u) != 0;
+            } else if constexpr (L == 8) {
+                const bool second = (lane & 4) != 0;
+                const bool upper = ((2 * p) & 3) >= 2;
+                b = upper ? pick_box(second, b2, b3) : pick_box(second, b0, b1);
+                const unsigned two = (rawBoxMask >> ((2 * p) & 3)) & 3u;
+                raw = second ? (two & 2u) != 0 : (two & 1u) != 0;
+            } else {
+                const int q = (lane >> 2) & 3;
+                b = pick_box((q & 2) != 0, pick_box((q & 1) != 0, b0, b1), pick_box((q & 1) != 0, b2, b3));
+                raw = ((rawBoxMask >> q) & 1u) != 0;
+            }
+            const CornerVal cv = corner_quantity(mg, lane & 3, b, raw);
             idx[p] = cv.idx;
             const unsigned bits = static_cast<unsigned>(g.ballot(cv.within)) & ((1u << L) - 1u);
             within |= bits << (p * L);
@@ -627,26 +647,28 @@ __device__ __forceinline__ float disc_consume(const DevMap& m, const PlanConsts&
     bool any = false, fail = false;
     if constexpr (G <= 16) {
         // small discs: no compaction at all — G dependent adds per round on swizzled lane values
-        unsigned long long visMask[kDiscRounds];
         float v[kDiscRounds];
+        bool anyVis = false;
 #pragma unroll
         for (int r = 0; r < kDiscRounds; ++r) {
             v[r] = __builtin_isfinite(d.e[r]) ? d.e[r] : 0.0f;                                          // cpp:2532-2537
             if (kCheck && d.vis[r] && __builtin_isfinite(d.t[r]) && d.t[r] < pc.thrDefault) fail = true;  // cpp:2055-2057
             const bool inc = d.vis[r] && v[r] < 10;                                                     // cpp:2539
-            visMask[r] = g.ballot(d.vis[r]);
+            anyVis |= d.vis[r];
             cnt += __builtin_popcountll(g.ballot(inc));
             if (r == 0 || __ballot(d.vis[r]) != 0ull) sum = SeqSum<G>::run(sum, inc ? v[r] : -0.0f);
         }
-        if (__ballot(cnt == 0 && (visMask[0] | visMask[1]) != 0ull) != 0ull) {
+        const bool groupVis = g.any(anyVis);
+        if (__ballot(cnt == 0 && groupVis) != 0ull) {
             // every visited value was >= 10: the mean falls back to the LAST visited value (cpp:2547-2551)
-            const bool hi = visMask[kDiscRounds - 1] != 0ull;
-            const unsigned long long mk = hi ? visMask[kDiscRounds - 1] : visMask[0];
+            const unsigned long long m1 = g.ballot(d.vis[kDiscRounds - 1]), m0 = g.ballot(d.vis[0]);
+            const bool hi = m1 != 0ull;
+            const unsigned long long mk = hi ? m1 : m0;
             const int l = mk ? 63 - __builtin_clzll(mk) : 0;
             const float l1 = g.bcast(v[kDiscRounds - 1], l), l0 = g.bcast(v[0], l);
             if (mk) last = hi ? l1 : l0;
         }
-        if (kCheck) defaultOk = (visMask[0] | visMask[1]) != 0ull && !g.any(fail);
+        if (kCheck) defaultOk = groupVis && !g.any(fail);
         return finish_mean(sum, last, cnt, pc.h);
     }
     OrderedSum os{scratch, 0};
