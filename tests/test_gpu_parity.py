@@ -356,3 +356,68 @@ def test_errors_are_codes_not_crashes(planner):
     with pytest.raises(FpeError) as e:
         planner.plan(make_poses([[np.nan, 0, 0]]), 2)
     assert e.value.code == _capi.FPE_E_INVALID_ARG
+
+
+def test_concurrent_uploads_and_plans_see_whole_snapshots(planner):
+    """SURVEY 8(b) threading row: the reference runs gridmapCallback and the service handler on an
+    AsyncSpinner thread pool with no locking (hpp:535, cpp:506).  Here fpe_upload_map and fpe_plan /
+    fpe_plan_service are called from different threads at once (ctypes drops the GIL): every plan must
+    equal the oracle's plan on ONE of the two maps being swapped — never a mixture, never an error."""
+    import threading
+
+    set_params(planner)
+    maps = [synth.rough_map(300, 300, 0.02, seed=61, bad_frac=0.1), synth.rough_map(300, 300, 0.02, seed=62, bad_frac=0.25)]
+    poses = synth.poses_in_map(48, 6.0, 6.0, 6, 0.18, seed=63, margin=0.7)
+    want = []
+    for trav, elev in maps:
+        o = fpo.OracleMap(trav, elev, 0.02).plan(util.to_oracle_params(planner.params), util.to_oracle_poses(poses), 6, threads=4)
+        want.append(o)
+    assert not np.array_equal(want[0]["nominal"]["row"], want[1]["nominal"]["row"]), "the two maps must plan differently"
+    planner.gridmapCallback(maps[0][0], maps[0][1], 0.02)
+    stop = threading.Event()
+    errors, seen = [], [0, 0]
+
+    def uploader():
+        k = 0
+        try:
+            while not stop.is_set():
+                k += 1
+                planner.gridmapCallback(maps[k & 1][0], maps[k & 1][1], 0.02)
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    def client(service):
+        try:
+            for it in range(60):
+                if service:
+                    msg = planner.globalFootholdPlan(6, poses["position"][it % 48])
+                    b = it % 48
+                    hits = []
+                    for m in (0, 1):
+                        ok = want[m]["cycle_ok"][b].astype(bool)
+                        ref = want[m]["nominal"][b][ok].reshape(-1)
+                        f = msg["footholds"][4:]
+                        hits.append(len(f) == len(ref) and np.array_equal(f["x"], ref["x"]) and np.array_equal(f["y"], ref["y"]))
+                    if not any(hits):
+                        errors.append(f"service call {it}: response matches neither map")
+                else:
+                    eng = planner.plan(poses, 6, products=("nominal", "cycle_ok"))
+                    which = [m for m in (0, 1) if np.array_equal(eng["nominal"]["row"], want[m]["nominal"]["row"])
+                             and np.array_equal(eng["nominal"]["x"], want[m]["nominal"]["x"])
+                             and np.array_equal(eng["cycle_ok"], want[m]["cycle_ok"])]
+                    if not which:
+                        errors.append(f"plan {it}: result is a mixture of snapshots")
+                    else:
+                        seen[which[0]] += 1
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    ths = [threading.Thread(target=uploader)] + [threading.Thread(target=client, args=(s,)) for s in (False, False, True)]
+    for t in ths:
+        t.start()
+    for t in ths[1:]:
+        t.join()
+    stop.set()
+    ths[0].join()
+    assert not errors, errors[:3]
+    assert seen[0] + seen[1] == 120
