@@ -37,6 +37,18 @@ __device__ __forceinline__ void stamp(const PlanConsts& pc, int cyc, int point) 
 #endif
 }
 
+__device__ __forceinline__ void stamp_value(const PlanConsts& pc, int cyc, int point, long long v) {
+#ifdef FPE_TRACE
+    if (pc.trace && blockIdx.x < 256 && cyc < 8 && threadIdx.x == 0)
+        pc.trace[(static_cast<size_t>(blockIdx.x) * 8 + cyc) * 16 + point] = v;
+#else
+    (void)pc;
+    (void)cyc;
+    (void)point;
+    (void)v;
+#endif
+}
+
 // A search centre must be finite and of sane magnitude.  The reference has no such test: a
 // non-finite centre (reachable once the centroid track has committed its "no case" (0,0,0)
 // results, cpp:1777-1944, and the feet polygon degenerates) sends NaN through
@@ -271,9 +283,58 @@ __device__ __forceinline__ bool cell_outside_polygon(const LegCtx& c, double px,
     return !polygon_inside_fast(c.vx, c.vy, c.nv, px, py);
 }
 
+// LDS of one spiral window: tileW^2 flag bytes (rounded to 16), then two doubles per tile column — the
+// abscissae at which the search polygon's boundary crosses that column (column_crossings).
+__host__ __device__ __forceinline__ int tile_flag_bytes(const PlanConsts& pc) { return (pc.tileW * pc.tileW + 15) & ~15; }
+__host__ __device__ __forceinline__ int tile_total_bytes(const PlanConsts& pc) { return tile_flag_bytes(pc) + pc.tileW * 16; }
+
+// PNPOLY (Polygon::isInside, cpp:2138) counts, for a cell centre (px, py), the edges that straddle py and
+// whose intersection abscissa xi = (vx[j]-vx[i])*(py-vy[i])/(vy[j]-vy[i]) + vx[i] lies beyond px.  py and
+// therefore every xi depend on the tile COLUMN only, so they are evaluated once per column (same
+// expressions, same operands) instead of once per cell: with at most two crossings per column — any convex
+// polygon, in particular the reference rectangle and the hexagon — a cell is inside iff
+// (px < X0) != (px < X1), a missing crossing being -inf.  Returns false when some column has more than two
+// crossings (non-convex open-loop polygons): the caller then keeps the per-cell evaluation.
+template <int G>
+__device__ bool column_crossings(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const Grp<G>& g, double* colX) {
+    const double ninf = -__builtin_huge_val();
+    bool over = false;
+    for (int b = g.sub; b < pc.tileW; b += G) {
+        const double py = cell_pos(m.g.baseY, m.g.res, c.tj0 + b);
+        double X0 = ninf, X1 = ninf;
+        if (c.rect) {
+            // getSearchPolygon's rectangle (cpp:2496-2517): only the two vertical edges can straddle, and their
+            // intersection abscissae are exactly xhi and xlo (see cell_outside_polygon)
+            if ((c.ylo > py) != (c.yhi > py)) {
+                X0 = c.xhi;
+                X1 = c.xlo;
+            }
+        } else {
+            int n = 0;
+            for (int i = 0, j = c.nv - 1; i < c.nv; j = i++) {
+                if ((c.vy[i] > py) != (c.vy[j] > py)) {
+                    const double ex = c.vx[j] - c.vx[i];
+                    const double t = py - c.vy[i];
+                    double xi = c.vx[i];
+                    if (!(ex == 0.0 && fabs(t) <= DBL_MAX)) xi = ex * t / (c.vy[j] - c.vy[i]) + c.vx[i];  // polygon_inside_fast
+                    if (n == 0) X0 = xi;
+                    else if (n == 1) X1 = xi;
+                    ++n;
+                }
+            }
+            over |= n > 2;
+        }
+        colX[2 * b] = X0;
+        colX[2 * b + 1] = X1;
+    }
+    return !g.any(over);
+}
+
+// Band-by-band staging (small lane groups: few cells per band, and the merged walk below costs the 8-lane
+// kernel registers on its common path — measured 60.1 vs 62.9 us per headline launch).
 template <int G>
 __device__ void stage_rect_cells(const DevMap& m, const PlanConsts& pc, const LegCtx& c, uint8_t* tile, const Grp<G>& g,
-                                 int a0, int b0, int na, int nb) {  // tile-local rectangle [a0,a0+na) x [b0,b0+nb)
+                                 int a0, int b0, int na, int nb, const double* colX) {  // tile-local rectangle [a0,a0+na) x [b0,b0+nb)
     if (na <= 0 || nb <= 0) return;
     const int W = pc.tileW;
     const int n = na * nb;
@@ -286,7 +347,15 @@ __device__ void stage_rect_cells(const DevMap& m, const PlanConsts& pc, const Le
         uint8_t f = classify(m, pc, i, j);
         if ((f & kFlagInMap) && (f & kFlagFinite)) {
             bool fail = (f & kFlagBelowCand) != 0;
-            if (!fail) fail = cell_outside_polygon(c, cell_pos(m.g.baseX, m.g.res, i), cell_pos(m.g.baseY, m.g.res, j));
+            if (!fail) {
+                const double px = cell_pos(m.g.baseX, m.g.res, i);
+                if (colX) {
+                    const double2 X = *reinterpret_cast<const double2*>(colX + 2 * b);
+                    fail = !((px < X.x) != (px < X.y));
+                } else {
+                    fail = cell_outside_polygon(c, px, cell_pos(m.g.baseY, m.g.res, j));
+                }
+            }
             if (fail) f |= kFlagFail;
         }
         tile[a * W + b] = f;
@@ -296,21 +365,107 @@ __device__ void stage_rect_cells(const DevMap& m, const PlanConsts& pc, const Le
 // Stage the cells whose Chebyshev distance d from the tile centre satisfies lo < d <= hi (lo = -1
 // stages the centre block too), as four bands of the square annulus.
 template <int G>
-__device__ void stage_annulus(const DevMap& m, const PlanConsts& pc, const LegCtx& c, uint8_t* tile, const Grp<G>& g,
-                              int lo, int hi) {
+__device__ void stage_annulus_bands(const DevMap& m, const PlanConsts& pc, const LegCtx& c, uint8_t* tile, const Grp<G>& g,
+                              int lo, int hi, const double* colX) {
     const int H = pc.tileH;
     if (hi > H) hi = H;
     if (hi <= lo) return;
     const int o0 = H - hi, o1 = H + hi + 1;  // outer square [o0, o1)
     if (lo < 0) {
-        stage_rect_cells(m, pc, c, tile, g, o0, o0, o1 - o0, o1 - o0);
+        stage_rect_cells(m, pc, c, tile, g, o0, o0, o1 - o0, o1 - o0, colX);
         return;
     }
     const int i0 = H - lo, i1 = H + lo + 1;  // inner square [i0, i1) already staged
-    stage_rect_cells(m, pc, c, tile, g, o0, o0, i0 - o0, o1 - o0);  // top band
-    stage_rect_cells(m, pc, c, tile, g, i1, o0, o1 - i1, o1 - o0);  // bottom band
-    stage_rect_cells(m, pc, c, tile, g, i0, o0, i1 - i0, i0 - o0);  // left band
-    stage_rect_cells(m, pc, c, tile, g, i0, i1, i1 - i0, o1 - i1);  // right band
+    stage_rect_cells(m, pc, c, tile, g, o0, o0, i0 - o0, o1 - o0, colX);  // top band
+    stage_rect_cells(m, pc, c, tile, g, i1, o0, o1 - i1, o1 - o0, colX);  // bottom band
+    stage_rect_cells(m, pc, c, tile, g, i0, o0, i1 - i0, i0 - o0, colX);  // left band
+    stage_rect_cells(m, pc, c, tile, g, i0, i1, i1 - i0, o1 - i1, colX);  // right band
+}
+
+
+// Stage the cells whose Chebyshev distance d from the tile centre satisfies lo < d <= hi (lo = -1 stages
+// the centre block too).  The square annulus is ONE index space — top band, bottom band, then the left and
+// right bands row by row — walked by all lanes with 2-4 independent loads in flight per lane:
+// the staging of a large window is a chain of cache round trips, so what matters is how many of them
+// overlap, not the arithmetic (cfg-5: 20 k of the 25 k clocks of a spiral search were staging waits).
+template <int G>
+__device__ void stage_annulus(const DevMap& m, const PlanConsts& pc, const LegCtx& c, uint8_t* tile, const Grp<G>& g,
+                              int lo, int hi, bool useColX) {
+    const double* colX = reinterpret_cast<const double*>(tile + tile_flag_bytes(pc));
+    if constexpr (G < 64) {
+        stage_annulus_bands(m, pc, c, tile, g, lo, hi, nullptr);
+        return;
+    }
+    constexpr int kStageUnroll = 4;  // loads in flight per lane
+    const int H = pc.tileH;
+    if (hi > H) hi = H;
+    if (hi <= lo) return;
+    const int W = pc.tileW;
+    const int o0 = H - hi, Wo = 2 * hi + 1;             // outer square [o0, o0 + Wo)
+    const bool whole = lo < 0;
+    const int i0 = whole ? o0 : H - lo;                 // inner square [i0, i0 + Wi) is already staged
+    const int Wi = whole ? 0 : 2 * lo + 1;
+    const int band = i0 - o0;                           // thickness of the annulus
+    const int nTop = whole ? Wo * Wo : band * Wo;       // whole square: everything is "top band"
+    const int nBot = whole ? 0 : band * Wo;
+    const int sideW = 2 * band;
+    const int nSide = whole ? 0 : Wi * sideW;
+    const int N = nTop + nBot + nSide;
+    const float woInv = rcp_small(Wo), swInv = rcp_small(sideW > 0 ? sideW : 1);
+    for (int base = 0; base < N; base += G * kStageUnroll) {
+        int a[kStageUnroll], b[kStageUnroll];
+        float v[kStageUnroll];
+        bool live[kStageUnroll], inMap[kStageUnroll];
+#pragma unroll
+        for (int u = 0; u < kStageUnroll; ++u) {
+            const int t = base + u * G + g.sub;
+            live[u] = t < N;
+            inMap[u] = false;
+            v[u] = 0.0f;
+            a[u] = b[u] = 0;
+            if (live[u]) {
+                int qa, qb;
+                if (t < nTop + nBot) {
+                    const bool bottom = t >= nTop;
+                    divmod_small(bottom ? t - nTop : t, Wo, woInv, qa, qb);
+                    a[u] = (bottom ? i0 + Wi : o0) + qa;
+                    b[u] = o0 + qb;
+                } else {
+                    divmod_small(t - nTop - nBot, sideW, swInv, qa, qb);
+                    a[u] = i0 + qa;
+                    b[u] = qb < band ? o0 + qb : i0 + Wi + (qb - band);
+                }
+                const int ci = c.ti0 + a[u], cj = c.tj0 + b[u];
+                inMap[u] = in_range(ci, cj, m.g.rows, m.g.cols);
+                if (inMap[u]) v[u] = m.trav[static_cast<size_t>(ci) * m.g.cols + cj];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kStageUnroll; ++u) {
+            if (!live[u]) continue;
+            uint8_t f = 0;
+            if (inMap[u]) {
+                f = kFlagInMap;
+                if (v[u] < pc.thrDefault) f |= kFlagBelowDef;
+                if (v[u] < pc.thrCandidate) f |= kFlagBelowCand;
+                if (__builtin_isfinite(v[u])) {
+                    f |= kFlagFinite;
+                    bool fail = (f & kFlagBelowCand) != 0;
+                    if (!fail) {
+                        const double px = cell_pos(m.g.baseX, m.g.res, c.ti0 + a[u]);
+                        if (G == 64 && useColX) {
+                            const double2 X = *reinterpret_cast<const double2*>(colX + 2 * b[u]);
+                            fail = !((px < X.x) != (px < X.y));
+                        } else {
+                            fail = cell_outside_polygon(c, px, cell_pos(m.g.baseY, m.g.res, c.tj0 + b[u]));
+                        }
+                    }
+                    if (fail) f |= kFlagFail;
+                }
+            }
+            tile[a[u] * W + b[u]] = f;
+        }
+    }
 }
 
 // In-order f32 accumulation of getFootholdMeanHeight (cpp:2539-2545) over the visited lanes of one
@@ -494,9 +649,13 @@ __device__ bool candidate_search_grp(const DevMap& m, const PlanConsts& pc, cons
     const int M = c.nCand;
     int round = 0;
     int staged = -1;  // Chebyshev radius of the tile staged so far (kTile)
+    bool useColX = false;
     // rank-table entries of the NEXT round are loaded while the current round is evaluated (from the
     // last register-held round on; searches that end earlier never touch the table)
     int nDi = 0, nDj = 0, nR = c.nRings;
+#ifdef FPE_TRACE
+    long long traceStage = 0;
+#endif
     for (int base = 0; base < M; base += G, ++round) {
         const int k = base + g.sub;
         bool ok = false;
@@ -531,8 +690,21 @@ __device__ bool candidate_search_grp(const DevMap& m, const PlanConsts& pc, cons
             int need = g.bcast(r, G - 1) + pc.footReach;
             if (need > staged && staged >= 0) need = max(need, min(pc.tileH, staged + max(2, staged / 2)));
             if (need > staged) {
-                stage_annulus(m, pc, c, tile, g, staged, need);
+#ifdef FPE_TRACE
+                const long long t0 = __builtin_readcyclecounter();
+#endif
+                if (G == 64 && staged < 0 && !c.rect) {  // the rectangle's own test is six compares: nothing to precompute
+                    useColX = column_crossings(m, pc, c, g, reinterpret_cast<double*>(tile + tile_flag_bytes(pc)));
+                    // the crossings are read by other lanes of the group (a group never spans wavefronts, and the
+                    // LDS operations of a wavefront execute in order: only the compiler must not reorder)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                stage_annulus(m, pc, c, tile, g, staged, need, useColX);
                 staged = need;
+#ifdef FPE_TRACE
+                traceStage += __builtin_readcyclecounter() - t0;
+#endif
             }
         }
         if (k < M) {
@@ -549,9 +721,17 @@ __device__ bool candidate_search_grp(const DevMap& m, const PlanConsts& pc, cons
             const int l = __builtin_ctzll(mask);
             wi = g.bcast(i, l);
             wj = g.bcast(j, l);
+#ifdef FPE_TRACE
+            stamp_value(pc, c.cyc, 11, traceStage);
+            stamp_value(pc, c.cyc, 12, round + 1);
+#endif
             return true;
         }
     }
+#ifdef FPE_TRACE
+    stamp_value(pc, c.cyc, 11, traceStage);
+    stamp_value(pc, c.cyc, 12, round);
+#endif
     return false;
 }
 
@@ -1226,7 +1406,7 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
     const int slot = tid / kPoseThreads;
     const int leg = (tid / G) & 3;
     const Grp<G> g(tid);
-    const int tileBytes = (pc.tileW * pc.tileW + 15) & ~15;
+    const int tileBytes = tile_total_bytes(pc);
     const size_t poseBytes = sizeof(PoseShared) + 4 * static_cast<size_t>(tileBytes);
     unsigned char* base = smem + static_cast<size_t>(slot) * poseBytes;
     PoseShared& sh = *reinterpret_cast<PoseShared*>(base);
@@ -1421,7 +1601,7 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
     const Grp<64> g(tid);
     const int q = blockIdx.x * 4 + w;
     if (q >= n) return;
-    const int tileBytes = (pc.tileW * pc.tileW + 15) & ~15;
+    const int tileBytes = tile_total_bytes(pc);
     uint8_t* tile = smem + sizeof(QueryShared) + static_cast<size_t>(w) * tileBytes;
 
     const fpe_leg_query* qp = queries + q;
@@ -1509,7 +1689,7 @@ __global__ __launch_bounds__(256) void canonicalise_layer_kernel(const float* __
 }
 
 // ---- launch wrappers (called from fpe_engine.cpp) ---------------------------------------------------------
-static size_t tile_bytes(const PlanConsts& pc) { return static_cast<size_t>((pc.tileW * pc.tileW + 15) & ~15); }
+static size_t tile_bytes(const PlanConsts& pc) { return static_cast<size_t>(tile_total_bytes(pc)); }
 
 // lanes per leg for a tile of tileW^2 cells: small windows (2 cm maps) put a whole pose in one
 // wavefront; large windows give every leg its own wavefront

@@ -197,6 +197,37 @@ def test_open_loop_checkFoothold_with_arbitrary_polygons(planner):
     assert (eng["source"] == 1).sum() > 20
 
 
+@pytest.mark.parametrize("res,rows", [(0.01, 700), (0.005, 900)])
+def test_open_loop_polygons_on_the_staged_window_path(planner, res, rows):
+    """Fine maps: the spiral window is staged through LDS and the polygon test runs per tile column
+    (column_crossings): convex polygons take the two-crossing form, star-shaped (non-convex) ones have
+    columns with four or more crossings and must fall back to the per-cell PNPOLY — both against the oracle."""
+    set_params(planner)
+    trav, elev = synth.rough_map(rows, rows, res, seed=73, bad_frac=0.15)
+    planner.gridmapCallback(trav, elev, res)
+    rng = np.random.default_rng(74)
+    n = 700
+    half = 0.5 * rows * res - 0.4
+    q = np.zeros(n, dtype=_capi.QUERY_DTYPE)
+    q["cx"] = rng.uniform(-half, half, n)
+    q["cy"] = rng.uniform(-half, half, n)
+    q["search_radius"] = rng.choice(np.array([0.06, 0.1, 0.15], np.float32), n)
+    for k in range(n):
+        nv = int(rng.integers(3, 9))
+        q["n_vertices"][k] = nv
+        ang = np.sort(rng.uniform(0, 2 * np.pi, nv))
+        convex = k % 2 == 0
+        rad = np.full(nv, rng.uniform(0.08, 0.2)) if convex else rng.uniform(0.03, 0.2, nv)
+        q["vx"][k, :nv] = q["cx"][k] + rng.uniform(-0.03, 0.03) + rad * np.cos(ang)
+        q["vy"][k, :nv] = q["cy"][k] + rng.uniform(-0.03, 0.03) + rad * np.sin(ang)
+    planner.set_max_leg_search_radius(0.15)
+    eng = planner.checkFoothold(q)
+    planner.set_max_leg_search_radius(0.0)
+    ora = fpo.OracleMap(trav, elev, res).search_legs(util.to_oracle_params(planner.params), util.to_oracle_queries(q))
+    util.assert_nominal_equal(eng, ora, "checkFoothold")
+    assert (eng["source"] == 1).sum() > 20 and (eng["source"] == 2).sum() > 5
+
+
 def test_single_blocked_cell_kat_on_gpu(planner):
     set_params(planner)
     trav = np.ones((200, 200), np.float32)
