@@ -169,16 +169,17 @@ def main():
     # N>1: the all-gather of step k (RCCL, its own stream) overlaps the plan kernel of step k+1; two
     # foothold blocks are cycled (quadrupedal_foothold_planner_amd.dist.FootholdExchange).  Every step's
     # footholds are gathered on every rank; the timed region ends after the last gather has completed.
-    ex = fdist.FootholdExchange(n_rec * rec, dev) if world > 1 else None
+    sel = fdist.SELECTED_DTYPE.itemsize  # 16 B exchange record: grid index + z + flags
+    ex = fdist.FootholdExchange(n_rec * sel, dev) if world > 1 else None
     step_no = [0]
 
     def step():
         k = step_no[0]
         step_no[0] += 1
-        nom = ex.acquire(k) if ex else d_nom
-        planner.plan_device(d_poses.data_ptr(), B, n_cycles, nom.data_ptr(), d_cen.data_ptr(), d_def.data_ptr(),
+        planner.plan_device(d_poses.data_ptr(), B, n_cycles, d_nom.data_ptr(), d_cen.data_ptr(), d_def.data_ptr(),
                             d_ok.data_ptr(), d_st.data_ptr(), stream=stream.cuda_stream)
         if ex:
+            fdist.pack_selected(d_nom, out=ex.acquire(k))  # same stream: ordered after the plan, before the next one
             ex.gather(k)
 
     for _ in range(args.warmup):
@@ -228,12 +229,14 @@ def main():
 
     # sanity: the last step's results are real (not a skipped/cached launch)
     ok_frac = float(d_ok.float().mean().item())
-    last_nom = ex.local[(step_no[0] - 1) % ex.depth] if ex else d_nom
-    valid_frac = float(torch.from_numpy(np.frombuffer(last_nom.cpu().numpy().tobytes(), dtype=_capi.FOOTHOLD_DTYPE)["valid"].copy()).float().mean())
+    nom_host = np.frombuffer(d_nom.cpu().numpy().tobytes(), dtype=_capi.FOOTHOLD_DTYPE)
+    valid_frac = float(nom_host["valid"].mean())
     if ex:
-        # the gathered block of the last step holds this rank's shard at its rank offset
-        g = ex.result(step_no[0] - 1)
-        assert torch.equal(g[rank * n_rec * rec:(rank + 1) * n_rec * rec], last_nom), "all-gather lost this rank's footholds"
+        # the gathered block of the last step holds this rank's selected footholds at its rank offset
+        g = ex.result(step_no[0] - 1)[rank * n_rec * sel:(rank + 1) * n_rec * sel]
+        mine = np.frombuffer(g.cpu().numpy().tobytes(), dtype=fdist.SELECTED_DTYPE)
+        for f in ("row", "col", "z", "valid", "source", "foot_id", "gait_cycle_id"):
+            assert np.array_equal(mine[f], nom_host[f]), f"all-gather lost this rank's footholds ({f})"
 
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -266,7 +269,7 @@ def main():
             "generator": synth.GENERATOR_VERSION,
             "cycle_ok_fraction": ok_frac,
             "valid_leg_fraction": valid_frac,
-            "exchange": "all_gather of nominal footholds (RCCL), every step, overlapped with the next step's plan kernel" if world > 1 else "none",
+            "exchange": "all_gather of the selected footholds (16 B records: grid index, z, flags; RCCL), every step, overlapped with the next step's plan kernel" if world > 1 else "none",
         },
         "roofline": {
             "bound": "hbm",

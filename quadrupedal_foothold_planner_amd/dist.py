@@ -57,6 +57,28 @@ def all_gather_records(local, total_poses, pose_bytes):
     return torch.cat(parts)
 
 
+# The exchange record of a selected foothold (16 B per foothold): what north_star asks every
+# rank to end up with — the chosen grid index and the height — plus the flag bytes.  It is words 0, 1, 6, 7 of the
+# 32-byte fpe_foothold (row, col | z | valid, source, foot_id, gait_cycle_id); x and y stay with the owning rank.
+SELECTED_DTYPE = np.dtype(
+    [("row", "<i4"), ("col", "<i4"), ("z", "<f4"), ("valid", "u1"), ("source", "u1"), ("foot_id", "u1"), ("gait_cycle_id", "u1")]
+)
+_SELECT_WORDS = {}
+
+
+def pack_selected(records_u8, out=None):
+    """fpe_foothold records (uint8 tensor, 32 B each) -> SELECTED_DTYPE records (uint8 tensor, 16 B each), one
+    index_select on the records' stream; `out` (uint8, half the size) is written in place when given."""
+    w = records_u8.view(torch.int32).view(-1, 8)
+    key = str(records_u8.device)
+    if key not in _SELECT_WORDS:
+        _SELECT_WORDS[key] = torch.tensor([0, 1, 6, 7], dtype=torch.int64, device=records_u8.device)
+    if out is None:
+        return torch.index_select(w, 1, _SELECT_WORDS[key]).view(torch.uint8).view(-1)
+    torch.index_select(w, 1, _SELECT_WORDS[key], out=out.view(torch.int32).view(-1, 4))
+    return out
+
+
 class FootholdExchange:
     """Pipelined form of all_gather_records for a stream of plans with equal shards: the all-gather of
     plan k runs on the collective's own stream (async_op) while plan k+1 is computed, so a step costs

@@ -66,17 +66,25 @@ def _pipelined_worker(rank, world, port, B, n_cycles, steps, tmpdir):
     trav, elev = synth.rough_map(160, 160, 0.02, seed=3)
     omap = fpo.OracleMap(trav, elev, 0.02)
     lo, hi = fdist.shard_range(B, rank, world)
-    local_bytes = (hi - lo) * n_cycles * 4 * fpo.LEG_DTYPE.itemsize
+    local_bytes = (hi - lo) * n_cycles * 4 * fdist.SELECTED_DTYPE.itemsize  # the 16 B exchange records
     ex = fdist.FootholdExchange(local_bytes, torch.device("cpu"))
+
+    def selected(nominal):  # what pack_selected must produce, field by field
+        o = np.zeros(nominal.size, dtype=fdist.SELECTED_DTYPE)
+        flat = nominal.reshape(-1)
+        for f in ("row", "col", "z", "valid", "source"):
+            o[f] = flat[f]
+        return o.tobytes()
+
     ok = True
     expected = []
     for k in range(steps):  # a different pose list per step: a stale or overwritten block would show
         poses = synth.poses_in_map(B, 3.2, 3.2, n_cycles, 0.18, seed=40 + k, margin=0.65)
         buf = ex.acquire(k)
         out = omap.plan(yaml_params(), to_oracle_poses(poses[lo:hi]), n_cycles)
-        buf.copy_(torch.from_numpy(np.ascontiguousarray(out["nominal"]).view(np.uint8).reshape(-1)))
+        fdist.pack_selected(torch.from_numpy(np.ascontiguousarray(out["nominal"]).view(np.uint8).reshape(-1)), out=buf)
         ex.gather(k)
-        expected.append(np.ascontiguousarray(omap.plan(yaml_params(), to_oracle_poses(poses), n_cycles)["nominal"]).tobytes())
+        expected.append(selected(omap.plan(yaml_params(), to_oracle_poses(poses), n_cycles)["nominal"]))
         if k >= 1:  # read step k-1 while step k's exchange is in flight
             ok &= ex.result(k - 1).numpy().tobytes() == expected[k - 1]
     ok &= ex.result(steps - 1).numpy().tobytes() == expected[steps - 1]
