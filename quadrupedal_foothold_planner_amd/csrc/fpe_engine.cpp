@@ -66,7 +66,7 @@ struct BufferPool {
     }
     void give(size_t n, float* p) {
         std::lock_guard<std::mutex> lk(mu);
-        if (free.size() >= 4) {  // keep at most two snapshots' worth
+        if (free.size() >= 6) {  // keep at most two snapshots' worth plus the upload staging layer
             (void)hipFree(free.front().second);
             free.erase(free.begin());
         }
@@ -238,8 +238,21 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
     const bool canonical = desc->storage_order == 1 && desc->start_index[0] == 0 && desc->start_index[1] == 0;
     const float* src[2] = {trav, elev};
     float* dst[2] = {snap->d_trav, snap->d_elev};
-    float* staging = nullptr;
-    if (!srcOnDevice && !canonical) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&staging), n * sizeof(float)));
+    // staging layer of a host upload in message layout: recycled like the snapshot layers (a 10-20 Hz map stream
+    // must not hipMalloc/hipFree per message), and returned to the pool on every exit path
+    struct Staging {
+        std::shared_ptr<BufferPool> pool;
+        size_t n;
+        float* p = nullptr;
+        ~Staging() {
+            if (p) pool->give(n, p);
+        }
+    } stagingGuard{h->pool, n};
+    float*& staging = stagingGuard.p;
+    if (!srcOnDevice && !canonical) {
+        staging = h->pool->take(n);
+        if (!staging) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&staging), n * sizeof(float) + 32));
+    }
     for (int l = 0; l < 2; ++l) {
         if (canonical) {
             FPE_HIP(hipMemcpyAsync(dst[l], src[l], n * sizeof(float),
@@ -255,7 +268,6 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
         }
         if (!srcOnDevice) FPE_HIP(hipStreamSynchronize(stream));  // host buffers may be freed on return
     }
-    if (staging) FPE_HIP(hipFree(staging));
     {
         std::lock_guard<std::mutex> lk(h->mu);
         h->map = snap;  // readers holding the old snapshot keep it alive until they finish
