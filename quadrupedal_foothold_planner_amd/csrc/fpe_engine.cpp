@@ -280,7 +280,7 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
 
 extern "C" {
 
-const char* fpe_version(void) { return "fpe 0.1.0 (gfx950, wave64; one workgroup per pose, one wavefront per leg)"; }
+const char* fpe_version(void) { return "fpe 0.2.0 (gfx950, wave64; 8 lanes per leg and two poses per wavefront, one wavefront per pose for large windows)"; }
 
 const char* fpe_last_error(fpe_handle) { return g_err.c_str(); }
 

