@@ -452,3 +452,18 @@ def test_concurrent_uploads_and_plans_see_whole_snapshots(planner):
     ths[0].join()
     assert not errors, errors[:3]
     assert seen[0] + seen[1] == 120
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (2, 3), (5, 5), (7, 9), (16, 4), (33, 17)])
+@pytest.mark.parametrize("res", [0.02, 0.005])
+def test_tiny_maps_smaller_than_every_window(planner, rows, cols, res):
+    """Maps smaller than the search window, the centroid rectangle and even one 16-byte row group: every
+    iterator is clamped to the map (or fails like getSubmap does) exactly as in the oracle."""
+    set_params(planner)
+    rng = np.random.default_rng(rows * 100 + cols)
+    trav = rng.uniform(0.5, 1.0, (rows, cols)).astype(np.float32)
+    elev = rng.uniform(-0.1, 0.1, (rows, cols)).astype(np.float32)
+    poses = make_poses(np.column_stack([rng.uniform(-0.6, 0.3, 24), rng.uniform(-0.3, 0.3, 24), np.zeros(24)]))
+    poses["gait"] = rng.integers(0, 2, 24)
+    eng, ora = util.run_both(planner, trav, elev, res, poses, 4)
+    util.assert_plan_equal(eng, ora)
