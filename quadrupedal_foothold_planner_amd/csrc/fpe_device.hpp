@@ -48,6 +48,10 @@ struct PlanConsts {
     int32_t nFoot;
     int32_t footRobust;
     int32_t footReach;     // cells a foot disc can reach from its centre cell (max |offset|, or ceil(rf/res)+1)
+    // foot radius >= 0.9 * resolution: the middle cell of an UNCLAMPED 3x3 CircleIterator bounding box is inside the
+    // disc whatever the (continuous) centre — proof in fpe_host.cpp::derive_constants — so the 8-lane kernel walks
+    // the other eight cells in one round and takes the middle one for granted (disc_issue / disc_consume)
+    int32_t midCellInside;
     int8_t footDa[kMaxFootOffsets];
     int8_t footDb[kMaxFootOffsets];
 };

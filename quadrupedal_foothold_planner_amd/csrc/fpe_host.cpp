@@ -171,7 +171,15 @@ void derive_constants(const fpe_params& p, const MapGeom& geom, float maxSearchR
     const char* tr = std::getenv("FPE_TRACE_PTR");
     c.trace = tr ? reinterpret_cast<unsigned long long*>(std::strtoull(tr, nullptr, 0)) : nullptr;
     derive_foot_offsets(p.footRadius, geom, c);
+    // Middle cell of an unclamped 3x3 CircleIterator box.  The box rows are i0 = index(cx + r) .. i0 + 2 =
+    // index(cx - r) (findSubmapParameters); cell i covers (x_i - res/2, x_i + res/2], so cx + r <= x_m + 1.5 res and
+    // cx - r >= x_m - 1.5 res for the middle row's centre x_m, i.e. |cx - x_m| <= 1.5 res - r, and likewise in y.
+    // With r >= 0.9 res the middle cell's squared distance is <= 2 (0.6 res)^2 = 0.72 res^2 < 0.81 res^2 <= r^2: an 11 %
+    // margin against rounding errors of order 1e-9 m (|coordinates| <= 1e6), so the reference's f64 test
+    // dx*dx + dy*dy <= r^2 is true for that cell without evaluating it.
+    c.midCellInside = (c.rf >= 0.9 * resolution) ? 1 : 0;
     if (std::getenv("FPE_LITERAL_DISCS")) {
+        c.midCellInside = 0;
         c.footRobust = 0;
         c.footReach = static_cast<int>(std::ceil(c.rf / resolution)) + 1;
     }  // test knob: force the literal bounding-box walk

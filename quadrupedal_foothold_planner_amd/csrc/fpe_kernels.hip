@@ -542,15 +542,15 @@ __device__ __forceinline__ float grp_lane_value(float v) {
     constexpr int pattern = ((~(G - 1)) & 0x1F) | (K << 5);
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), pattern));
 }
-template <int G, int K = 0>
+template <int G, int K = 0, int End = G>  // lanes K .. End-1 of the group, in order
 struct SeqSum {
     static __device__ __forceinline__ float run(float s, float x) {
         s = s + grp_lane_value<G, K>(x);
-        return SeqSum<G, K + 1>::run(s, x);
+        return SeqSum<G, K + 1, End>::run(s, x);
     }
 };
-template <int G>
-struct SeqSum<G, G> {
+template <int G, int End>
+struct SeqSum<G, End, End> {
     static __device__ __forceinline__ float run(float s, float) { return s; }
 };
 
@@ -791,11 +791,44 @@ struct DiscLoads {
     float t[kDiscRounds];  // traversability (centre disc only)
     bool vis[kDiscRounds];
     bool pipelined;
+    bool mid;              // 3x3 form: round 0 holds cells 0-3 and 5-8, the middle cell is eMid / tMid
+    float eMid, tMid;
 };
 template <int G, bool kCheck>
 __device__ __forceinline__ void disc_issue(const DevMap& m, const PlanConsts& pc, double cx, double cy, const BBox& bb,
                                            const Grp<G>& g, DiscLoads& d) {
     const int nb = bb.ni * bb.nj;
+    d.mid = false;
+    d.eMid = d.tMid = 0.0f;
+    if constexpr (G == 8) {
+        // The usual disc of a 2 cm map is a 3x3 box: nine cells on eight lanes would cost a second round of
+        // membership arithmetic for one cell.  The middle cell is inside the disc by construction
+        // (PlanConsts::midCellInside), so the eight lanes take the other eight cells and every lane loads the
+        // middle one without testing it.  The choice is made per wavefront: all its active legs must qualify.
+        // "Unclamped": boundPositionToRange moves an outside corner onto the map edge, i.e. into the first or last
+        // row / column — a box that stays clear of those was not clamped (and lies inside the map).
+        const bool ok3 = pc.midCellInside != 0 && bb.ni == 3 && bb.nj == 3 && bb.i0 >= 1 && bb.j0 >= 1 &&
+                         bb.i0 + 4 <= m.g.rows && bb.j0 + 4 <= m.g.cols;
+        if (__ballot(!ok3) == 0ull) {
+            d.mid = true;
+            d.pipelined = true;
+            const int t = g.sub + (g.sub >= 4 ? 1 : 0);
+            const int a = t >= 6 ? 2 : (t >= 3 ? 1 : 0);
+            const int i = bb.i0 + a, j = bb.j0 + (t - 3 * a);
+            d.vis[0] = cell_in_disc(m.g, i, j, cx, cy, pc.rf2);  // the unclamped box lies inside the map
+            d.vis[1] = false;
+            d.e[0] = d.e[1] = d.t[0] = d.t[1] = 0.0f;
+            const size_t offM = static_cast<size_t>(bb.i0 + 1) * m.g.cols + (bb.j0 + 1);
+            d.eMid = m.elev[offM];
+            if (kCheck) d.tMid = m.trav[offM];
+            if (d.vis[0]) {
+                const size_t off = static_cast<size_t>(i) * m.g.cols + j;
+                d.e[0] = m.elev[off];
+                if (kCheck) d.t[0] = m.trav[off];
+            }
+            return;
+        }
+    }
     d.pipelined = nb <= kDiscRounds * G;
     if (!d.pipelined) return;
     const float njInv = rcp_small(bb.nj);
@@ -825,6 +858,32 @@ __device__ __forceinline__ float disc_consume(const DevMap& m, const PlanConsts&
     float sum = 0.0f, last = 0.0f;
     int cnt = 0;
     bool any = false, fail = false;
+    if constexpr (G == 8) {
+        if (d.mid) {  // wave-uniform (disc_issue): cells 0-3 = lanes 0-3, the middle cell, cells 5-8 = lanes 4-7
+            const float v0 = __builtin_isfinite(d.e[0]) ? d.e[0] : 0.0f;  // cpp:2532-2537
+            const float vm = __builtin_isfinite(d.eMid) ? d.eMid : 0.0f;
+            if (kCheck) {  // cpp:2055-2057
+                fail = (d.vis[0] && __builtin_isfinite(d.t[0]) && d.t[0] < pc.thrDefault) ||
+                       (__builtin_isfinite(d.tMid) && d.tMid < pc.thrDefault);
+            }
+            const bool inc0 = d.vis[0] && v0 < 10, incM = vm < 10;  // cpp:2539
+            cnt = __builtin_popcountll(g.ballot(inc0)) + (incM ? 1 : 0);
+            const float x0 = inc0 ? v0 : -0.0f;
+            sum = SeqSum<G, 0, 4>::run(sum, x0);
+            sum = sum + (incM ? vm : -0.0f);
+            sum = SeqSum<G, 4, 8>::run(sum, x0);
+            if (__ballot(cnt == 0) != 0ull) {
+                // every visited value was >= 10: the mean falls back to the LAST visited value (cpp:2547-2551) —
+                // the highest visited lane of cells 5-8, else the middle cell
+                const unsigned long long mv = g.ballot(d.vis[0]) >> 4;
+                const int l = mv ? 4 + (63 - __builtin_clzll(mv)) : 0;
+                const float lv = g.bcast(v0, l);
+                last = mv ? lv : vm;
+            }
+            if (kCheck) defaultOk = !g.any(fail);  // the middle cell is always visited
+            return finish_mean(sum, last, cnt, pc.h);
+        }
+    }
     if constexpr (G <= 16) {
         // small discs: no compaction at all — G dependent adds per round on swizzled lane values
         float v[kDiscRounds];
