@@ -467,3 +467,22 @@ def test_tiny_maps_smaller_than_every_window(planner, rows, cols, res):
     poses["gait"] = rng.integers(0, 2, 24)
     eng, ora = util.run_both(planner, trav, elev, res, poses, 4)
     util.assert_plan_equal(eng, ora)
+
+
+@pytest.mark.parametrize("ratio", [0.85, 0.9001, 0.95, 1.0, 1.2, 1.45])
+def test_foot_radius_ratios_around_the_middle_cell_shortcut(planner, ratio):
+    """footRadius / resolution from just below to well above 0.9: from 0.9 on, the 8-lane kernel takes the middle cell
+    of an unclamped 3x3 disc box for granted (PlanConsts::midCellInside).  Lattice-aligned and random poses, border
+    poses (clamped boxes fall back to the generic walk), default hits and spiral candidates — all against the oracle."""
+    res = 0.02
+    set_params(planner, footRadius=np.float32(ratio * res))
+    trav, elev = synth.rough_map(260, 260, res, seed=int(ratio * 1000), bad_frac=0.12)
+    rng = np.random.default_rng(int(ratio * 977))
+    xs = rng.uniform(-2.9, 2.0, 160)
+    ys = rng.uniform(-2.9, 2.9, 160)
+    xs[:40], ys[:40] = np.round(xs[:40] / res) * res, np.round(ys[:40] / res) * res          # cell corners / centres
+    xs[40:60], ys[40:60] = np.round(xs[40:60] / res) * res + 0.5 * res, ys[40:60]              # half-cell offsets
+    poses = make_poses(np.column_stack([xs, ys, np.zeros(160)]))
+    eng, ora = util.run_both(planner, trav, elev, res, poses, 5, threads=8)
+    util.assert_plan_equal(eng, ora)
+    set_params(planner)
