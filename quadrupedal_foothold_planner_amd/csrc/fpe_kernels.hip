@@ -18,6 +18,8 @@
 // -ffp-contract=off.  Reference citations: "cpp:" = foothold_planner/src/FootholdPlanner.cpp.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "fpe_device.hpp"
 
 namespace fpe {
@@ -794,7 +796,12 @@ struct DiscLoads {
     bool mid;              // 3x3 form: round 0 holds cells 0-3 and 5-8, the middle cell is eMid / tMid
     float eMid, tMid;
 };
-template <int G, bool kCheck>
+// kMid: kernel variant for foot radii in [0.9, 1] x resolution, where every unclamped disc box is 3x3: the
+// generic two-round issue is not compiled in at all (a wavefront with a clamped or smaller box takes the direct
+// pass at consume time).  Besides the instructions, this removes the generic path's load destinations from the
+// hot region: with both forms present the compiler's s_waitcnt insertion has to assume those loads pending at the
+// join and stalls the 3x3 form on the row loads issued just before it (measured: 56.2 -> 53.7 us per launch).
+template <int G, bool kCheck, bool kMid = false>
 __device__ __forceinline__ void disc_issue(const DevMap& m, const PlanConsts& pc, double cx, double cy, const BBox& bb,
                                            const Grp<G>& g, DiscLoads& d) {
     const int nb = bb.ni * bb.nj;
@@ -826,6 +833,12 @@ __device__ __forceinline__ void disc_issue(const DevMap& m, const PlanConsts& pc
                 d.e[0] = m.elev[off];
                 if (kCheck) d.t[0] = m.trav[off];
             }
+            return;
+        }
+        if constexpr (kMid) {
+            d.pipelined = false;  // rare (map border): disc_consume runs the direct pass
+            d.vis[0] = d.vis[1] = false;
+            d.e[0] = d.e[1] = d.t[0] = d.t[1] = 0.0f;
             return;
         }
     }
@@ -1053,7 +1066,7 @@ struct CentroidPending {
     BBox rb;
     DiscLoads dl;
 };
-template <int G>
+template <int G, bool kMid = false>
 __device__ void centroid_begin(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const Submap& s,
                                const CentroidScan& sc, float zCentre, const Grp<G>& g, CentroidPending& cp) {
     CentroidOut& o = cp.o;
@@ -1110,7 +1123,7 @@ __device__ void centroid_begin(const DevMap& m, const PlanConsts& pc, const LegC
     cp.rb = cr.template bbox<0>(g);
     o.row = cr.template get<4>(g);
     o.col = cr.template get<5>(g);
-    disc_issue<G, false>(m, pc, o.x, o.y, cp.rb, g, cp.dl);
+    disc_issue<G, false, kMid>(m, pc, o.x, o.y, cp.rb, g, cp.dl);
     cp.needDisc = true;
 }
 template <int G>
@@ -1172,7 +1185,7 @@ __device__ void spiral_search(const DevMap& m, const PlanConsts& pc, const Spira
 // One leg: centroid method (cpp:1605-1997) + checkFoothold (cpp:2001-2036) around the same centre.
 // bb = CircleIterator box of the centre disc, s = getSubmap geometry of the centroid rectangle (both
 // from the corner lanes).  kCentroid=false skips the centroid track (open-loop fpe_search_legs).
-template <int G, bool kCentroid>
+template <int G, bool kCentroid, bool kMid = false>
 __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head, LegCtx& c,
                            const LegConst& lk,
                            uint8_t* tile, const Grp<G>& g, const BBox& bb, const Submap& s, DefaultDisc& dflt,
@@ -1188,9 +1201,9 @@ __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLu
     RowLoads rl;
     if (kCentroid) rows_issue(m, s, g, rl);
     DiscLoads dc;
-    disc_issue<G, true>(m, pc, c.cx, c.cy, bb, g, dc);
+    disc_issue<G, true, kMid>(m, pc, c.cx, c.cy, bb, g, dc);
     DiscLoads dd;
-    if (dflt.want) disc_issue<G, false>(m, pc, dflt.x, dflt.y, dflt.bb, g, dd);
+    if (dflt.want) disc_issue<G, false, kMid>(m, pc, dflt.x, dflt.y, dflt.bb, g, dd);
     stamp(pc, c.cyc, 3);
     CentroidScan sc;
     if (kCentroid) sc = rows_finish(m, pc, s, g, rl);
@@ -1200,7 +1213,7 @@ __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLu
     const float zCentre = disc_consume<G, true>(m, pc, c.cx, c.cy, bb, g, dc, defaultOk, scratch);  // cpp:2012 + cpp:2029
     stamp(pc, c.cyc, 5);
     CentroidPending cp;
-    if (kCentroid) centroid_begin(m, pc, c, s, sc, zCentre, g, cp);                          // cpp:818-821
+    if (kCentroid) centroid_begin<G, kMid>(m, pc, c, s, sc, zCentre, g, cp);                          // cpp:818-821
     stamp(pc, c.cyc, 6);
     if (dflt.want) {
         bool unused;
@@ -1318,7 +1331,7 @@ __device__ __forceinline__ LegStatic make_leg_static(const PlanConsts& pc, const
 
 // One swing leg of one phase: next default positions on the three tracks, search polygon, the leg
 // search, results to LDS (for the commit decision) and to HBM.
-template <int G>
+template <int G, bool kMid = false>
 __device__ __forceinline__ void leg_phase(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head,
                                           PoseShared& sh, uint8_t* tile, const Grp<G>& g, int leg, const LegStatic& ls,
                                           double y0, double adjY, double advance, int cyc, int nCycles, int b, bool live,
@@ -1408,7 +1421,7 @@ __device__ __forceinline__ void leg_phase(const DevMap& m, const PlanConsts& pc,
             dflt.y = ny;
             dflt.bb = dbox;
             dflt.z = static_cast<float>(static_cast<double>(0.0f) + pc.h);  // value when no cell is visited
-            search_leg<G, true>(m, pc, lut, head, c, lk, tile, g, bb, sm, dflt, no, co);
+            search_leg<G, true, kMid>(m, pc, lut, head, c, lk, tile, g, bb, sm, dflt, no, co);
             zDefault = dflt.z;
             haveDbox = true;
             stamp(pc, cyc, 8);
@@ -1453,7 +1466,7 @@ __device__ __forceinline__ void leg_phase(const DevMap& m, const PlanConsts& pc,
 #ifndef FPE_MINWAVES
 #define FPE_MINWAVES 4
 #endif
-template <int G>
+template <int G, bool kMid = false>
 __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MINWAVES : 2)) void plan_chained_kernel(DevMap m, PlanConsts pc, SpiralLut lut,
                                                                            const fpe_pose* __restrict__ poses, int B,
                                                                            int nCycles, fpe_plan_out out) {
@@ -1529,7 +1542,7 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
             stamp(pc, cyc, 1);
 
             if (active) {
-                leg_phase<G>(m, pc, lut, head, sh, tile, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out);
+                leg_phase<G, kMid>(m, pc, lut, head, sh, tile, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out);
             } else if (g.sub == 0) {
                 sh.valid[leg] = 1;  // non-swing legs do not vote
             }
@@ -1775,6 +1788,13 @@ size_t plan_lds_bytes(const PlanConsts& pc) {
 }
 size_t search_lds_bytes(const PlanConsts& pc) { return sizeof(QueryShared) + 4 * tile_bytes(pc); }
 
+// The 3x3-only variant of the 8-lane kernel: foot radius in [0.9, 1] x resolution (a disc box then spans at most
+// three cells per axis), e.g. the reference's yaml footRadius 0.02 on a 2 cm map.  FPE_NO_MID_VARIANT=1 keeps the
+// generic kernel (tests run both).
+static bool mid_variant(const PlanConsts& pc, double res) {
+    return pc.midCellInside != 0 && pc.rf <= res && std::getenv("FPE_NO_MID_VARIANT") == nullptr;
+}
+
 hipError_t launch_plan_chained(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const fpe_pose* d_poses,
                                int B, int nCycles, const fpe_plan_out& d_out, hipStream_t stream) {
     const size_t lds = plan_lds_bytes(pc);
@@ -1783,6 +1803,8 @@ hipError_t launch_plan_chained(const DevMap& m, const PlanConsts& pc, const Spir
         hipLaunchKernelGGL(plan_sequential_kernel, dim3(B), dim3(64), lds, stream, m, pc, lut, d_poses, B, nCycles, d_out);
     } else if (G == 4) {
         hipLaunchKernelGGL(plan_chained_kernel<4>, dim3((B + 3) / 4), dim3(64), lds, stream, m, pc, lut, d_poses, B, nCycles, d_out);
+    } else if (G == 8 && mid_variant(pc, m.g.res)) {
+        hipLaunchKernelGGL((plan_chained_kernel<8, true>), dim3((B + 1) / 2), dim3(64), lds, stream, m, pc, lut, d_poses, B, nCycles, d_out);
     } else if (G == 8) {
         hipLaunchKernelGGL(plan_chained_kernel<8>, dim3((B + 1) / 2), dim3(64), lds, stream, m, pc, lut, d_poses, B, nCycles, d_out);
     } else if (G == 16) {
@@ -1812,6 +1834,9 @@ hipError_t set_max_lds(size_t planBytes, size_t searchBytes) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(planBytes));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_chained_kernel<8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(planBytes));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_chained_kernel<8, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(planBytes));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_chained_kernel<4>),

@@ -486,3 +486,19 @@ def test_foot_radius_ratios_around_the_middle_cell_shortcut(planner, ratio):
     eng, ora = util.run_both(planner, trav, elev, res, poses, 5, threads=8)
     util.assert_plan_equal(eng, ora)
     set_params(planner)
+
+
+def test_generic_and_3x3_only_kernel_variants_agree(planner, monkeypatch):
+    """foot radius in [0.9, 1] x resolution launches the 3x3-only variant of the 8-lane kernel (no generic disc issue
+    compiled in; clamped boxes at the map border take the direct pass).  FPE_NO_MID_VARIANT=1 forces the generic
+    kernel: both must reproduce the oracle on a map whose border is inside the pose range."""
+    set_params(planner)
+    trav, elev = synth.rough_map(220, 220, 0.02, seed=81, bad_frac=0.15)
+    rng = np.random.default_rng(82)
+    poses = make_poses(np.column_stack([rng.uniform(-2.4, 2.3, 200), rng.uniform(-2.3, 2.3, 200), np.zeros(200)]))
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("FPE_NO_MID_VARIANT", env)
+        eng, ora = util.run_both(planner, trav, elev, 0.02, poses, 6, threads=8)
+        util.assert_plan_equal(eng, ora)
+    assert (eng["nominal"]["valid"] == 0).any() and (eng["centroid"]["code"] == 6).any(), "poses must reach the border"
