@@ -787,7 +787,9 @@ __device__ __forceinline__ float disc_pass_direct(const DevMap& m, const PlanCon
 // membership and issues the loads of up to kDiscRounds*G cells; disc_consume() runs after other
 // independent work (the centroid row scan) has overlapped their latency.  Larger discs fall back to
 // the single-phase pass inside disc_consume().
-constexpr int kDiscRounds = 2;
+constexpr int kDiscRounds = 4;  // up to 32 cells on 8 lanes: the 5x5 boxes of a 1 cm map stay pipelined
+template <int G>
+__device__ __forceinline__ constexpr int disc_rounds() { return G >= 64 ? 2 : kDiscRounds; }  // 64 lanes: 2 x 64 cells
 struct DiscLoads {
     float e[kDiscRounds];  // elevation of this lane's cell in round r
     float t[kDiscRounds];  // traversability (centre disc only)
@@ -822,9 +824,12 @@ __device__ __forceinline__ void disc_issue(const DevMap& m, const PlanConsts& pc
             const int t = g.sub + (g.sub >= 4 ? 1 : 0);
             const int a = t >= 6 ? 2 : (t >= 3 ? 1 : 0);
             const int i = bb.i0 + a, j = bb.j0 + (t - 3 * a);
+#pragma unroll
+            for (int r = 0; r < kDiscRounds; ++r) {
+                d.vis[r] = false;
+                d.e[r] = d.t[r] = 0.0f;
+            }
             d.vis[0] = cell_in_disc(m.g, i, j, cx, cy, pc.rf2);  // the unclamped box lies inside the map
-            d.vis[1] = false;
-            d.e[0] = d.e[1] = d.t[0] = d.t[1] = 0.0f;
             const size_t offM = static_cast<size_t>(bb.i0 + 1) * m.g.cols + (bb.j0 + 1);
             d.eMid = m.elev[offM];
             if (kCheck) d.tMid = m.trav[offM];
@@ -837,16 +842,19 @@ __device__ __forceinline__ void disc_issue(const DevMap& m, const PlanConsts& pc
         }
         if constexpr (kMid) {
             d.pipelined = false;  // rare (map border): disc_consume runs the direct pass
-            d.vis[0] = d.vis[1] = false;
-            d.e[0] = d.e[1] = d.t[0] = d.t[1] = 0.0f;
+#pragma unroll
+            for (int r = 0; r < kDiscRounds; ++r) {
+                d.vis[r] = false;
+                d.e[r] = d.t[r] = 0.0f;
+            }
             return;
         }
     }
-    d.pipelined = nb <= kDiscRounds * G;
+    d.pipelined = nb <= disc_rounds<G>() * G;
     if (!d.pipelined) return;
     const float njInv = rcp_small(bb.nj);
 #pragma unroll
-    for (int r = 0; r < kDiscRounds; ++r) {
+    for (int r = 0; r < disc_rounds<G>(); ++r) {
         const int t = r * G + g.sub;
         d.vis[r] = false;
         d.e[r] = 0.0f;
@@ -902,7 +910,7 @@ __device__ __forceinline__ float disc_consume(const DevMap& m, const PlanConsts&
         float v[kDiscRounds];
         bool anyVis = false;
 #pragma unroll
-        for (int r = 0; r < kDiscRounds; ++r) {
+        for (int r = 0; r < disc_rounds<G>(); ++r) {
             v[r] = __builtin_isfinite(d.e[r]) ? d.e[r] : 0.0f;                                          // cpp:2532-2537
             if (kCheck && d.vis[r] && __builtin_isfinite(d.t[r]) && d.t[r] < pc.thrDefault) fail = true;  // cpp:2055-2057
             const bool inc = d.vis[r] && v[r] < 10;                                                     // cpp:2539
@@ -913,19 +921,29 @@ __device__ __forceinline__ float disc_consume(const DevMap& m, const PlanConsts&
         const bool groupVis = g.any(anyVis);
         if (__ballot(cnt == 0 && groupVis) != 0ull) {
             // every visited value was >= 10: the mean falls back to the LAST visited value (cpp:2547-2551)
-            const unsigned long long m1 = g.ballot(d.vis[kDiscRounds - 1]), m0 = g.ballot(d.vis[0]);
-            const bool hi = m1 != 0ull;
-            const unsigned long long mk = hi ? m1 : m0;
+            unsigned long long mk = 0ull;
+            int lastRound = 0;
+#pragma unroll
+            for (int r = 0; r < disc_rounds<G>(); ++r) {
+                const unsigned long long mr = g.ballot(d.vis[r]);
+                if (mr) {
+                    mk = mr;
+                    lastRound = r;
+                }
+            }
             const int l = mk ? 63 - __builtin_clzll(mk) : 0;
-            const float l1 = g.bcast(v[kDiscRounds - 1], l), l0 = g.bcast(v[0], l);
-            if (mk) last = hi ? l1 : l0;
+#pragma unroll
+            for (int r = 0; r < disc_rounds<G>(); ++r) {
+                const float lv = g.bcast(v[r], l);
+                if (mk && r == lastRound) last = lv;
+            }
         }
         if (kCheck) defaultOk = groupVis && !g.any(fail);
         return finish_mean(sum, last, cnt, pc.h);
     }
     OrderedSum os{scratch, 0};
 #pragma unroll
-    for (int r = 0; r < kDiscRounds; ++r) {
+    for (int r = 0; r < disc_rounds<G>(); ++r) {
         const float v = __builtin_isfinite(d.e[r]) ? d.e[r] : 0.0f;                                 // cpp:2532-2537
         if (kCheck && d.vis[r] && __builtin_isfinite(d.t[r]) && d.t[r] < pc.thrDefault) fail = true;  // cpp:2055-2057
         any |= d.vis[r];
