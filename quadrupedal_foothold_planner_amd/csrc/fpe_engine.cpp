@@ -154,6 +154,7 @@ struct MapSnapshot {
 };
 
 constexpr size_t kMaxLdsBytes = 160 * 1024;
+constexpr size_t kLayerPadBytes = 128;  // >= kRowOverreadBytes of fpe_kernels.hip (96)
 constexpr size_t kZeroCopyBytes = 64 * 1024;  // fpe_plan calls up to this size run on the pinned arena directly
 
 }  // namespace
@@ -233,9 +234,9 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
     snap->pool = h->pool;
     snap->d_trav = h->pool->take(n);
     snap->d_elev = h->pool->take(n);
-    // + 32 B tail padding: the row scan reads whole 16-byte groups (fpe_kernels.hip::rows_issue)
-    if (!snap->d_trav) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&snap->d_trav), n * sizeof(float) + 32));
-    if (!snap->d_elev) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&snap->d_elev), n * sizeof(float) + 32));
+    // tail padding: the row scan reads whole 16-byte groups, up to 96 B per row (fpe_kernels.hip::rows_issue)
+    if (!snap->d_trav) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&snap->d_trav), n * sizeof(float) + kLayerPadBytes));
+    if (!snap->d_elev) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&snap->d_elev), n * sizeof(float) + kLayerPadBytes));
     const bool canonical = desc->storage_order == 1 && desc->start_index[0] == 0 && desc->start_index[1] == 0;
     const float* src[2] = {trav, elev};
     float* dst[2] = {snap->d_trav, snap->d_elev};
@@ -252,7 +253,7 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
     float*& staging = stagingGuard.p;
     if (!srcOnDevice && !canonical) {
         staging = h->pool->take(n);
-        if (!staging) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&staging), n * sizeof(float) + 32));
+        if (!staging) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&staging), n * sizeof(float) + kLayerPadBytes));
     }
     for (int l = 0; l < 2; ++l) {
         if (canonical) {

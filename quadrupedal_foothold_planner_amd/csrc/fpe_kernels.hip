@@ -256,18 +256,6 @@ __device__ __forceinline__ uint8_t tile_at(const uint8_t* tile, int W, const Leg
     return tile[a * W + b];
 }
 
-__device__ __forceinline__ uint8_t classify(const DevMap& m, const PlanConsts& pc, int i, int j) {
-    uint8_t f = 0;
-    if (in_range(i, j, m.g.rows, m.g.cols)) {
-        const float v = m.trav[static_cast<size_t>(i) * m.g.cols + j];
-        f = kFlagInMap;
-        if (__builtin_isfinite(v)) f |= kFlagFinite;
-        if (v < pc.thrDefault) f |= kFlagBelowDef;
-        if (v < pc.thrCandidate) f |= kFlagBelowCand;
-    }
-    return f;
-}
-
 // ---- LDS staging of the spiral window (large foot discs) ---------------------------------------------------
 // The window around the search centre is staged into LDS as one flag byte per cell, with the
 // per-cell verdict of checkCirclePolygonFoothold (cpp:2132-2138) folded in: a FINITE cell fails when
@@ -332,59 +320,6 @@ __device__ bool column_crossings(const DevMap& m, const PlanConsts& pc, const Le
     return !g.any(over);
 }
 
-// Band-by-band staging (small lane groups: few cells per band, and the merged walk below costs the 8-lane
-// kernel registers on its common path — measured 60.1 vs 62.9 us per headline launch).
-template <int G>
-__device__ void stage_rect_cells(const DevMap& m, const PlanConsts& pc, const LegCtx& c, uint8_t* tile, const Grp<G>& g,
-                                 int a0, int b0, int na, int nb, const double* colX) {  // tile-local rectangle [a0,a0+na) x [b0,b0+nb)
-    if (na <= 0 || nb <= 0) return;
-    const int W = pc.tileW;
-    const int n = na * nb;
-    const float nbInv = rcp_small(nb);
-    for (int t = g.sub; t < n; t += G) {
-        int qa, qb;
-        divmod_small(t, nb, nbInv, qa, qb);
-        const int a = a0 + qa, b = b0 + qb;
-        const int i = c.ti0 + a, j = c.tj0 + b;
-        uint8_t f = classify(m, pc, i, j);
-        if ((f & kFlagInMap) && (f & kFlagFinite)) {
-            bool fail = (f & kFlagBelowCand) != 0;
-            if (!fail) {
-                const double px = cell_pos(m.g.baseX, m.g.res, i);
-                if (colX) {
-                    const double2 X = *reinterpret_cast<const double2*>(colX + 2 * b);
-                    fail = !((px < X.x) != (px < X.y));
-                } else {
-                    fail = cell_outside_polygon(c, px, cell_pos(m.g.baseY, m.g.res, j));
-                }
-            }
-            if (fail) f |= kFlagFail;
-        }
-        tile[a * W + b] = f;
-    }
-}
-
-// Stage the cells whose Chebyshev distance d from the tile centre satisfies lo < d <= hi (lo = -1
-// stages the centre block too), as four bands of the square annulus.
-template <int G>
-__device__ void stage_annulus_bands(const DevMap& m, const PlanConsts& pc, const LegCtx& c, uint8_t* tile, const Grp<G>& g,
-                              int lo, int hi, const double* colX) {
-    const int H = pc.tileH;
-    if (hi > H) hi = H;
-    if (hi <= lo) return;
-    const int o0 = H - hi, o1 = H + hi + 1;  // outer square [o0, o1)
-    if (lo < 0) {
-        stage_rect_cells(m, pc, c, tile, g, o0, o0, o1 - o0, o1 - o0, colX);
-        return;
-    }
-    const int i0 = H - lo, i1 = H + lo + 1;  // inner square [i0, i1) already staged
-    stage_rect_cells(m, pc, c, tile, g, o0, o0, i0 - o0, o1 - o0, colX);  // top band
-    stage_rect_cells(m, pc, c, tile, g, i1, o0, o1 - i1, o1 - o0, colX);  // bottom band
-    stage_rect_cells(m, pc, c, tile, g, i0, o0, i1 - i0, i0 - o0, colX);  // left band
-    stage_rect_cells(m, pc, c, tile, g, i0, i1, i1 - i0, o1 - i1, colX);  // right band
-}
-
-
 // Stage the cells whose Chebyshev distance d from the tile centre satisfies lo < d <= hi (lo = -1 stages
 // the centre block too).  The square annulus is ONE index space — top band, bottom band, then the left and
 // right bands row by row — walked by all lanes with 2-4 independent loads in flight per lane:
@@ -394,10 +329,6 @@ template <int G>
 __device__ void stage_annulus(const DevMap& m, const PlanConsts& pc, const LegCtx& c, uint8_t* tile, const Grp<G>& g,
                               int lo, int hi, bool useColX) {
     const double* colX = reinterpret_cast<const double*>(tile + tile_flag_bytes(pc));
-    if constexpr (G < 64) {
-        stage_annulus_bands(m, pc, c, tile, g, lo, hi, nullptr);
-        return;
-    }
     constexpr int kStageUnroll = 4;  // loads in flight per lane
     const int H = pc.tileH;
     if (hi > H) hi = H;
@@ -455,7 +386,7 @@ __device__ void stage_annulus(const DevMap& m, const PlanConsts& pc, const LegCt
                     bool fail = (f & kFlagBelowCand) != 0;
                     if (!fail) {
                         const double px = cell_pos(m.g.baseX, m.g.res, c.ti0 + a[u]);
-                        if (G == 64 && useColX) {
+                        if (useColX) {
                             const double2 X = *reinterpret_cast<const double2*>(colX + 2 * b[u]);
                             fail = !((px < X.x) != (px < X.y));
                         } else {
@@ -695,7 +626,7 @@ __device__ bool candidate_search_grp(const DevMap& m, const PlanConsts& pc, cons
 #ifdef FPE_TRACE
                 const long long t0 = __builtin_readcyclecounter();
 #endif
-                if (G == 64 && staged < 0 && !c.rect) {  // the rectangle's own test is six compares: nothing to precompute
+                if (staged < 0 && !c.rect) {  // the rectangle's own test is six compares: nothing to precompute
                     useColX = column_crossings(m, pc, c, g, reinterpret_cast<double*>(tile + tile_flag_bytes(pc)));
                     // the crossings are read by other lanes of the group (a group never spans wavefronts, and the
                     // LDS operations of a wavefront execute in order: only the compiler must not reorder)
@@ -1016,46 +947,66 @@ __device__ CentroidScan centroid_scan(const DevMap& m, const PlanConsts& pc, con
     return r0;
 }
 
-// Two-phase form of centroid_scan: rows_issue() starts the loads of up to kRowChunks*G rows x 8
-// columns right after the corner arithmetic; rows_finish() counts after the disc membership math
-// has overlapped their latency.  Larger rectangles fall back to centroid_scan().
-constexpr int kRowChunks = 2;
+// Two-phase form of centroid_scan: rows_issue() starts the loads of up to CH*G rows x 4*C4 columns right after
+// the corner arithmetic; rows_finish() counts after the disc membership math has overlapped their latency.
+// Larger rectangles fall back to centroid_scan().  The shape is a property of the kernel variant: the 3x3-only
+// 8-lane kernel scans the 11x6 rectangle of a 2 cm map (2 chunks x 8 columns), the generic small-group kernels
+// up to 24 rows x 12 columns (21x11 at 1 cm / R 0.1), the 64-lane kernels up to 64 rows x 24 columns (41x21 at 0.5 cm).
+template <int CH, int C4>
 struct RowLoads {
-    float v[kRowChunks][8];
+    float v[CH][4 * C4];
     bool pipelined;
+    bool small;  // wave-uniform: every active leg's rectangle fits 2 chunks x 8 columns (the 11x6 of a 2 cm map)
 };
-template <int G>
-__device__ __forceinline__ void rows_issue(const DevMap& m, const Submap& s, const Grp<G>& g, RowLoads& rl) {
-    rl.pipelined = s.ok && s.ni <= kRowChunks * G && s.nj <= 8;
+template <int G, bool kMid>
+struct RowShape {
+    static constexpr int CH = (G >= 64) ? 1 : (kMid ? 2 : 3);
+    static constexpr int C4 = (G >= 64) ? 6 : (kMid ? 2 : 3);
+    typedef RowLoads<CH, C4> Loads;
+};
+constexpr int kRowOverreadBytes = 6 * 16;  // widest row read (C4 = 6); the layers carry this much tail padding
+template <int G, int CH, int C4>
+__device__ __forceinline__ void rows_issue(const DevMap& m, const Submap& s, const Grp<G>& g, RowLoads<CH, C4>& rl) {
+    rl.pipelined = s.ok && s.ni <= CH * G && s.nj <= 4 * C4;
+    rl.small = (CH > 2 || C4 > 2) && __ballot(!(s.ni <= 2 * G && s.nj <= 8)) == 0ull;
     if (!rl.pipelined) return;
 #pragma unroll
-    for (int ch = 0; ch < kRowChunks; ++ch) {
+    for (int ch = 0; ch < CH; ++ch) {
+        if (ch >= 2 && rl.small) continue;
         const int r = min(ch * G + g.sub, s.ni - 1);  // clamped: idle lanes re-read the last row
         const float* rowp = m.trav + static_cast<size_t>(s.i0 + r) * m.g.cols + s.j0;
-        // two 16-byte loads per row (4-byte aligned; columns >= nj are never counted, and the layer
-        // allocation carries 32 B of tail padding so the over-read of the last row stays in bounds)
+        // 16-byte loads at 4-byte alignment; columns >= nj are never counted, and the layer allocation carries
+        // kRowOverreadBytes of tail padding so the over-read of the last row stays in bounds
         typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-        const f4u a = *reinterpret_cast<const f4u*>(rowp);
-        const f4u b = *reinterpret_cast<const f4u*>(rowp + 4);
-        rl.v[ch][0] = a.x; rl.v[ch][1] = a.y; rl.v[ch][2] = a.z; rl.v[ch][3] = a.w;
-        rl.v[ch][4] = b.x; rl.v[ch][5] = b.y; rl.v[ch][6] = b.z; rl.v[ch][7] = b.w;
+#pragma unroll
+        for (int q = 0; q < C4; ++q) {
+            if (q >= 2 && rl.small) continue;
+            const f4u a = *reinterpret_cast<const f4u*>(rowp + 4 * q);
+            rl.v[ch][4 * q + 0] = a.x;
+            rl.v[ch][4 * q + 1] = a.y;
+            rl.v[ch][4 * q + 2] = a.z;
+            rl.v[ch][4 * q + 3] = a.w;
+        }
     }
 }
-template <int G>
+template <int G, int CH, int C4>
 __device__ __forceinline__ CentroidScan rows_finish(const DevMap& m, const PlanConsts& pc, const Submap& s,
-                                                    const Grp<G>& g, const RowLoads& rl) {
+                                                    const Grp<G>& g, const RowLoads<CH, C4>& rl) {
     if (!rl.pipelined) return centroid_scan(m, pc, s, g);
     CentroidScan r0;
     const int ni = s.ni, nj = s.nj, rightCol = nj - 1;
     bool anyBelow = false;
     int minRow = 0, maxRow = 0, k = 0;
 #pragma unroll
-    for (int ch = 0; ch < kRowChunks; ++ch) {
+    for (int ch = 0; ch < CH; ++ch) {
+        if (ch >= 2 && rl.small) continue;
         const int r = ch * G + g.sub;
         int cnt = 0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 4 * C4; ++u) {
+            if (u >= 8 && rl.small) continue;
             if (u < nj && rl.v[ch][u] < pc.thrDefault) ++cnt;  // raw `<`, NaN passes (cpp:1653, 1736)
+        }
         const bool live = r < ni;
         anyBelow |= live && cnt > 0;
         const bool blocked = live && cnt > ((rightCol + 1) * 0.5);  // cpp:1743
@@ -1196,7 +1147,7 @@ struct DefaultDisc {
     float z;
 };
 
-template <int G>
+template <int G, bool kMid>
 __device__ void spiral_search(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head,
                               const LegCtx& c, uint8_t* tile, const Grp<G>& g, float zCentre, NominalOut& no);
 
@@ -1216,7 +1167,7 @@ __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLu
     // software pipeline: (1) row loads of the centroid rectangle, (2) disc membership math and disc
     // loads, (3) row counts, (4) centre disc -> default check and height, (5) centroid case + loads
     // of its result disc, (6) default-track height, (7) spiral search if needed, (8) centroid height
-    RowLoads rl;
+    typename RowShape<G, kMid>::Loads rl;
     if (kCentroid) rows_issue(m, s, g, rl);
     DiscLoads dc;
     disc_issue<G, true, kMid>(m, pc, c.cx, c.cy, bb, g, dc);
@@ -1247,7 +1198,7 @@ __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLu
         no.y = c.cy;
         no.z = zCentre;
     } else {
-        spiral_search<G>(m, pc, lut, head, c, tile, g, zCentre, no);
+        spiral_search<G, kMid>(m, pc, lut, head, c, tile, g, zCentre, no);
     }
     if (kCentroid) {
         centroid_end(m, pc, g, cp, scratch);
@@ -1256,13 +1207,13 @@ __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLu
 }
 
 // checkCandidateFoothold half of checkFoothold (cpp:2022-2029) once the default foothold has failed.
-template <int G>
+template <int G, bool kMid>
 __device__ void spiral_search(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head,
                               const LegCtx& c, uint8_t* tile, const Grp<G>& g, float zCentre, NominalOut& no) {
     nominal_invalid(no, c.cx, c.cy, 2);
     int wi = 0, wj = 0;
     bool found;
-    if (pc.footRobust && pc.nFoot <= kOnDemandMaxFoot) {
+    if (kMid || (pc.footRobust && pc.nFoot <= kOnDemandMaxFoot)) {  // the 3x3-only variant is launched for such discs only
         // tiny foot discs: evaluate the few cells a candidate needs straight from the map
         found = candidate_search_grp<G, false>(m, pc, lut, head, c, tile, g, wi, wj);  // cpp:2022
     } else {
@@ -1807,10 +1758,12 @@ size_t plan_lds_bytes(const PlanConsts& pc) {
 size_t search_lds_bytes(const PlanConsts& pc) { return sizeof(QueryShared) + 4 * tile_bytes(pc); }
 
 // The 3x3-only variant of the 8-lane kernel: foot radius in [0.9, 1] x resolution (a disc box then spans at most
-// three cells per axis), e.g. the reference's yaml footRadius 0.02 on a 2 cm map.  FPE_NO_MID_VARIANT=1 keeps the
+// three cells per axis) with a host-proved candidate foot disc of at most four cells (no LDS window: the staged
+// spiral path is not compiled into it), e.g. the reference's yaml footRadius 0.02 on a 2 cm map.  FPE_NO_MID_VARIANT=1 keeps the
 // generic kernel (tests run both).
 static bool mid_variant(const PlanConsts& pc, double res) {
-    return pc.midCellInside != 0 && pc.rf <= res && std::getenv("FPE_NO_MID_VARIANT") == nullptr;
+    return pc.midCellInside != 0 && pc.rf <= res && pc.footRobust != 0 && pc.nFoot <= kOnDemandMaxFoot &&
+           std::getenv("FPE_NO_MID_VARIANT") == nullptr;
 }
 
 hipError_t launch_plan_chained(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const fpe_pose* d_poses,
