@@ -51,6 +51,12 @@ __device__ __forceinline__ void stamp_value(const PlanConsts& pc, int cyc, int p
 #endif
 }
 
+// Keep a (wave-uniform) value in a vector register: the empty asm hides its uniformity from the compiler.
+__device__ __forceinline__ double in_vgpr(double x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // A search centre must be finite and of sane magnitude.  The reference has no such test: a
 // non-finite centre (reachable once the centroid track has committed its "no case" (0,0,0)
 // results, cpp:1777-1944, and the feet polygon degenerates) sends NaN through
@@ -1436,9 +1442,25 @@ __device__ __forceinline__ void leg_phase(const DevMap& m, const PlanConsts& pc,
 #define FPE_MINWAVES 4
 #endif
 template <int G, bool kMid = false>
-__global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MINWAVES : 2)) void plan_chained_kernel(DevMap m, PlanConsts pc, SpiralLut lut,
+__global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MINWAVES : 2)) void plan_chained_kernel(DevMap mArg, PlanConsts pc, SpiralLut lut,
                                                                            const fpe_pose* __restrict__ poses, int B,
                                                                            int nCycles, fpe_plan_out out) {
+    // The map geometry is wave-uniform and would live in 20 scalar registers; this kernel needs more uniform
+    // state than the 102 SGPRs hold, and every spilled SGPR costs a v_readlane (+ wait states) per use.  The
+    // doubles are only ever operands of vector f64 arithmetic, so they are parked in VGPRs instead.
+    DevMap m = mArg;
+    if constexpr (G <= 16) {
+        m.g.res = in_vgpr(m.g.res);
+        m.g.rinv = in_vgpr(m.g.rinv);
+        m.g.lenX = in_vgpr(m.g.lenX);
+        m.g.lenY = in_vgpr(m.g.lenY);
+        m.g.posX = in_vgpr(m.g.posX);
+        m.g.posY = in_vgpr(m.g.posY);
+        m.g.orgX = in_vgpr(m.g.orgX);
+        m.g.orgY = in_vgpr(m.g.orgY);
+        m.g.baseX = in_vgpr(m.g.baseX);
+        m.g.baseY = in_vgpr(m.g.baseY);
+    }
     constexpr int kPoseThreads = 4 * G;
     constexpr int kBlock = (G == 64) ? 256 : 64;
     constexpr int kPPB = kBlock / kPoseThreads;
