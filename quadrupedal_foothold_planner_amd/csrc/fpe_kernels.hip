@@ -730,7 +730,7 @@ __device__ __forceinline__ constexpr int disc_rounds() { return G >= 64 ? 2 : kD
 struct DiscLoads {
     float e[kDiscRounds];  // elevation of this lane's cell in round r
     float t[kDiscRounds];  // traversability (centre disc only)
-    bool vis[kDiscRounds];
+    int vis[kDiscRounds];  // 0/1, deliberately an int: a long-lived lane mask would occupy (and spill) a scalar register pair
     bool pipelined;
     bool mid;              // 3x3 form: round 0 holds cells 0-3 and 5-8, the middle cell is eMid / tMid
     float eMid, tMid;
@@ -766,7 +766,7 @@ __device__ __forceinline__ void disc_issue(const DevMap& m, const PlanConsts& pc
                 d.vis[r] = false;
                 d.e[r] = d.t[r] = 0.0f;
             }
-            d.vis[0] = cell_in_disc(m.g, i, j, cx, cy, pc.rf2);  // the unclamped box lies inside the map
+            d.vis[0] = cell_in_disc(m.g, i, j, cx, cy, pc.rf2) ? 1 : 0;  // the unclamped box lies inside the map
             const size_t offM = static_cast<size_t>(bb.i0 + 1) * m.g.cols + (bb.j0 + 1);
             d.eMid = m.elev[offM];
             if (kCheck) d.tMid = m.trav[offM];
@@ -1037,7 +1037,7 @@ __device__ __forceinline__ CentroidScan rows_finish(const DevMap& m, const PlanC
 // zCentre = mean height at the centre (the whole-region-valid result reuses it, cpp:1687).
 struct CentroidPending {
     CentroidOut o;
-    bool needDisc;
+    int needDisc;  // 0/1 (int on purpose, see DiscLoads::vis)
     BBox rb;
     DiscLoads dl;
 };
@@ -1045,7 +1045,7 @@ template <int G, bool kMid = false>
 __device__ void centroid_begin(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const Submap& s,
                                const CentroidScan& sc, float zCentre, const Grp<G>& g, CentroidPending& cp) {
     CentroidOut& o = cp.o;
-    cp.needDisc = false;
+    cp.needDisc = 0;
     o.x = 0.0;
     o.y = 0.0;
     o.z = 0.0f;
@@ -1099,11 +1099,11 @@ __device__ void centroid_begin(const DevMap& m, const PlanConsts& pc, const LegC
     o.row = cr.template get<4>(g);
     o.col = cr.template get<5>(g);
     disc_issue<G, false, kMid>(m, pc, o.x, o.y, cp.rb, g, cp.dl);
-    cp.needDisc = true;
+    cp.needDisc = 1;
 }
 template <int G>
 __device__ void centroid_end(const DevMap& m, const PlanConsts& pc, const Grp<G>& g, CentroidPending& cp, float* scratch) {
-    if (cp.needDisc) {
+    if (cp.needDisc != 0) {
         bool unused;
         cp.o.z = disc_consume<G, false>(m, pc, cp.o.x, cp.o.y, cp.rb, g, cp.dl, unused, scratch);
     }
@@ -1147,7 +1147,7 @@ __device__ __forceinline__ LegConst make_leg_const(float Rf, double res, const S
 
 // Default-track mean height request (getDefaultFootholds, cpp:2289-2301) riding along with a leg search.
 struct DefaultDisc {
-    bool want;
+    int want;  // 0/1 (int on purpose, see DiscLoads::vis)
     double x, y;
     BBox bb;
     float z;
@@ -1178,7 +1178,7 @@ __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLu
     DiscLoads dc;
     disc_issue<G, true, kMid>(m, pc, c.cx, c.cy, bb, g, dc);
     DiscLoads dd;
-    if (dflt.want) disc_issue<G, false, kMid>(m, pc, dflt.x, dflt.y, dflt.bb, g, dd);
+    if (dflt.want != 0) disc_issue<G, false, kMid>(m, pc, dflt.x, dflt.y, dflt.bb, g, dd);
     stamp(pc, c.cyc, 3);
     CentroidScan sc;
     if (kCentroid) sc = rows_finish(m, pc, s, g, rl);
@@ -1190,7 +1190,7 @@ __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLu
     CentroidPending cp;
     if (kCentroid) centroid_begin<G, kMid>(m, pc, c, s, sc, zCentre, g, cp);                          // cpp:818-821
     stamp(pc, c.cyc, 6);
-    if (dflt.want) {
+    if (dflt.want != 0) {
         bool unused;
         dflt.z = disc_consume<G, false>(m, pc, dflt.x, dflt.y, dflt.bb, g, dd, unused, scratch);  // cpp:2289-2301
     }
@@ -1391,7 +1391,7 @@ __device__ __forceinline__ void leg_phase(const DevMap& m, const PlanConsts& pc,
             const Submap sm = submap_from_corners(m.g, rbox, rectWithin, c.cx, c.cy);
             stamp(pc, cyc, 2);
             DefaultDisc dflt;
-            dflt.want = out.default_next != nullptr && centre_usable(nx0, ny);
+            dflt.want = (out.default_next != nullptr && centre_usable(nx0, ny)) ? 1 : 0;
             dflt.x = nx0;
             dflt.y = ny;
             dflt.bb = dbox;
@@ -1713,7 +1713,7 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
         Submap sm;
         sm.ok = false;
         DefaultDisc dflt;
-        dflt.want = false;
+        dflt.want = 0;
         search_leg<64, false>(m, pc, lut, head, c, lk, tile, g, bb, sm, dflt, no, co);
     } else {
         nominal_invalid(no, c.cx, c.cy, 3);
