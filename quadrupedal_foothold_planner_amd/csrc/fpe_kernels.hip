@@ -1306,11 +1306,18 @@ __device__ __forceinline__ LegStatic make_leg_static(const PlanConsts& pc, const
 
 // One swing leg of one phase: next default positions on the three tracks, search polygon, the leg
 // search, results to LDS (for the commit decision) and to HBM.
-template <int G, bool kMid = false>
+// What a leg hands to the commit step: the next positions of the three tracks and its validity.
+struct LegCommit {
+    double v[3][3];  // [track][xyz]
+    int valid;
+};
+// kDirect: the results stay in registers (LegCommit) for a commit decided by wave ballot (a pose lives in one
+// wavefront); otherwise they are staged in PoseShared::nxt / valid for the LDS commit of the multi-wave forms.
+template <int G, bool kMid = false, bool kDirect = false>
 __device__ __forceinline__ void leg_phase(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head,
                                           PoseShared& sh, uint8_t* tile, const Grp<G>& g, int leg, const LegStatic& ls,
                                           double y0, double adjY, double advance, int cyc, int nCycles, int b, bool live,
-                                          const fpe_plan_out& out) {
+                                          const fpe_plan_out& out, LegCommit* lc = nullptr) {
     const float Rf = ls.Rf;
     const int polyKind = ls.polyKind;
     const bool radiusOk = ls.radiusOk;
@@ -1410,11 +1417,19 @@ __device__ __forceinline__ void leg_phase(const DevMap& m, const PlanConsts& pc,
                 zDefault = disc_pass_direct<G, false>(m, pc, nx0, ny, dbox, g, unused, reinterpret_cast<float*>(tile));
             }
         }
+        if constexpr (kDirect) {
+            lc->valid = no.valid;
+            lc->v[0][0] = nx0;   lc->v[0][1] = ny;    lc->v[0][2] = static_cast<double>(zDefault);
+            lc->v[1][0] = co.x;  lc->v[1][1] = co.y;  lc->v[1][2] = static_cast<double>(co.z);
+            lc->v[2][0] = no.x;  lc->v[2][1] = no.y;  lc->v[2][2] = static_cast<double>(no.z);
+        }
         if (g.sub == 0) {
-            sh.valid[leg] = no.valid;
-            sh.nxt[0][leg][0] = nx0;   sh.nxt[0][leg][1] = ny;    sh.nxt[0][leg][2] = static_cast<double>(zDefault);
-            sh.nxt[1][leg][0] = co.x;  sh.nxt[1][leg][1] = co.y;  sh.nxt[1][leg][2] = static_cast<double>(co.z);
-            sh.nxt[2][leg][0] = no.x;  sh.nxt[2][leg][1] = no.y;  sh.nxt[2][leg][2] = static_cast<double>(no.z);
+            if constexpr (!kDirect) {
+                sh.valid[leg] = no.valid;
+                sh.nxt[0][leg][0] = nx0;   sh.nxt[0][leg][1] = ny;    sh.nxt[0][leg][2] = static_cast<double>(zDefault);
+                sh.nxt[1][leg][0] = co.x;  sh.nxt[1][leg][1] = co.y;  sh.nxt[1][leg][2] = static_cast<double>(co.z);
+                sh.nxt[2][leg][0] = no.x;  sh.nxt[2][leg][1] = no.y;  sh.nxt[2][leg][2] = static_cast<double>(no.z);
+            }
             if (live) {
                 const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
                 if (out.nominal) store_foothold(out.nominal + o, no, leg, cyc);
@@ -1532,19 +1547,40 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
             pose_sync<G>();
             stamp(pc, cyc, 1);
 
-            if (active) {
-                leg_phase<G, kMid>(m, pc, lut, head, sh, tile, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out);
-            } else if (g.sub == 0) {
-                sh.valid[leg] = 1;  // non-swing legs do not vote
-            }
-            pose_sync<G>();
-            stamp(pc, cyc, 9);
-            // footholdValidation_ = AND of the swing legs' flags (cpp:1323); commit or skip (cpp:1332-1576)
-            const bool phaseOk = (sh.valid[0] & sh.valid[1] & sh.valid[2] & sh.valid[3]) != 0;
-            if (phaseOk && active) {
-                for (int e = g.sub; e < 9; e += G) {
-                    const int t = e / 3, k = e - t * 3;
-                    sh.cur[t][leg][k] = sh.nxt[t][leg][k];
+            bool phaseOk;
+            if constexpr (G <= 16) {
+                // a pose lives in one wavefront: footholdValidation_ (cpp:1323) is a ballot over its lanes and the
+                // committed positions go from registers straight to PoseShared::cur (cpp:1332-1576)
+                LegCommit lc;
+                lc.valid = 1;  // non-swing legs do not vote
+                if (active) {
+                    leg_phase<G, kMid, true>(m, pc, lut, head, sh, tile, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out, &lc);
+                }
+                stamp(pc, cyc, 9);
+                constexpr int kPoseLanes = 4 * G;
+                const unsigned long long poseMask = (kPoseLanes == 64) ? ~0ull : (((1ull << (kPoseLanes & 63)) - 1ull) << (slot * kPoseLanes));
+                phaseOk = (__ballot(lc.valid == 0) & poseMask) == 0ull;
+                if (phaseOk && active && g.sub == 0) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) sh.cur[t][leg][k] = lc.v[t][k];
+                }
+            } else {
+                if (active) {
+                    leg_phase<G, kMid>(m, pc, lut, head, sh, tile, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out);
+                } else if (g.sub == 0) {
+                    sh.valid[leg] = 1;  // non-swing legs do not vote
+                }
+                pose_sync<G>();
+                stamp(pc, cyc, 9);
+                // footholdValidation_ = AND of the swing legs' flags (cpp:1323); commit or skip (cpp:1332-1576)
+                phaseOk = (sh.valid[0] & sh.valid[1] & sh.valid[2] & sh.valid[3]) != 0;
+                if (phaseOk && active) {
+                    for (int e = g.sub; e < 9; e += G) {
+                        const int t = e / 3, k = e - t * 3;
+                        sh.cur[t][leg][k] = sh.nxt[t][leg][k];
+                    }
                 }
             }
             pose_sync<G>();
