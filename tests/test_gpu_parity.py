@@ -502,3 +502,24 @@ def test_generic_and_3x3_only_kernel_variants_agree(planner, monkeypatch):
         eng, ora = util.run_both(planner, trav, elev, 0.02, poses, 6, threads=8)
         util.assert_plan_equal(eng, ora)
     assert (eng["nominal"]["valid"] == 0).any() and (eng["centroid"]["code"] == 6).any(), "poses must reach the border"
+
+
+def test_map_stream_with_changing_sizes_recycles_buffers_correctly(planner):
+    """A stream of maps of different sizes and layouts through one engine: snapshot layers and the upload staging layer
+    are recycled by size (BufferPool); every plan must see exactly the map uploaded last."""
+    set_params(planner)
+    rng = np.random.default_rng(101)
+    shapes = [(120, 160), (200, 150), (120, 160), (90, 90), (200, 150), (120, 160), (300, 80), (90, 90)]
+    for k, (rows, cols) in enumerate(shapes * 2):
+        trav, elev = synth.rough_map(rows, cols, 0.02, seed=200 + k, bad_frac=0.15)
+        poses = synth.poses_in_map(16, rows * 0.02, cols * 0.02, 3, 0.18, seed=300 + k, margin=0.45)
+        if k % 2:  # grid_map message layout: column-major with a circular-buffer start index
+            si, sj = int(rng.integers(0, rows)), int(rng.integers(0, cols))
+            msg_t = np.ascontiguousarray(np.roll(trav, (si, sj), axis=(0, 1)).T)
+            msg_e = np.ascontiguousarray(np.roll(elev, (si, sj), axis=(0, 1)).T)
+            planner.gridmapCallback(msg_t, msg_e, 0.02, start_index=(si, sj), storage_order="col")
+        else:
+            planner.gridmapCallback(trav, elev, 0.02)
+        eng = planner.plan(poses, 3)
+        ora = fpo.OracleMap(trav, elev, 0.02).plan(util.to_oracle_params(planner.params), util.to_oracle_poses(poses), 3)
+        util.assert_plan_equal(eng, ora)
