@@ -334,7 +334,9 @@ def main():
         torch.cuda.synchronize()
         ol_ms = q0.elapsed_time(q1) / 10
         line["open_loop"] = {"queries": nq, "ms": ol_ms, "footholds_per_s": nq / (ol_ms * 1e-3),
-                             "note": "search_legs_kernel: independent checkFoothold queries (no centroid/default track, no chain)"}
+                             "roofline_frac": alg_bytes * nq / (ol_ms * 1e-3) / 1e9 / peak,
+                             "note": "search_legs_kernel: independent checkFoothold queries (no centroid/default track, no chain); "
+                                     "roofline_frac uses the same algorithmic bytes per foothold against the 8 TB/s peak"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(trav, elev, res, params, poses, n_cycles, args.cpu_seconds)
     if rank == 0:

@@ -1688,38 +1688,43 @@ __global__ __launch_bounds__(64, 4) void plan_sequential_kernel(DevMap m, PlanCo
 }
 
 // ---- open-loop per-leg search: one wavefront per checkFoothold call (hpp:94-100) ----------------------
+constexpr int kMaxQueriesPerBlock = 32;  // 256 threads / 8 lanes per query
 struct QueryShared {
-    double polyX[4][8];
-    double polyY[4][8];
+    double polyX[kMaxQueriesPerBlock][8];
+    double polyY[kMaxQueriesPerBlock][8];
     int8_t footDa[kMaxFootOffsets];
     int8_t footDb[kMaxFootOffsets];
     int16_t footOff[kMaxFootOffsets];
 };
 
+// G lanes per query (8 for windows of <= 1024 cells, like the chained plan; else a whole wavefront), 256 / G queries
+// per workgroup.
+template <int G>
 __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts pc, SpiralLut lut,
                                                            const fpe_leg_query* __restrict__ queries, int n,
                                                            fpe_foothold* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     QueryShared& sh = *reinterpret_cast<QueryShared*>(smem);
     const int tid = static_cast<int>(threadIdx.x);
-    const int w = tid >> 6;
-    const Grp<64> g(tid);
-    const int q = blockIdx.x * 4 + w;
-    if (q >= n) return;
+    const int w = tid / G;
+    const Grp<G> g(tid);
+    const int q = blockIdx.x * (256 / G) + w;
     const int tileBytes = tile_total_bytes(pc);
     uint8_t* tile = smem + sizeof(QueryShared) + static_cast<size_t>(w) * tileBytes;
-
-    const fpe_leg_query* qp = queries + q;
-    const int nv = qp->n_vertices;
-    for (int k = g.sub; k < pc.nFoot; k += 64) {  // every wavefront writes the same bytes, then reads its own writes
+    for (int k = tid & 63; k < pc.nFoot; k += 64) {  // every wavefront writes the same bytes, then reads its own writes
         sh.footDa[k] = pc.footDa[k];
         sh.footDb[k] = pc.footDb[k];
         sh.footOff[k] = static_cast<int16_t>(pc.footDa[k] * pc.tileW + pc.footDb[k]);
     }
+    if (q >= n) return;
+
+    const fpe_leg_query* qp = queries + q;
+    const int nv = qp->n_vertices;
     if (g.sub < 8) {
         sh.polyX[w][g.sub] = g.sub < nv ? qp->vx[g.sub] : 0.0;
         sh.polyY[w][g.sub] = g.sub < nv ? qp->vy[g.sub] : 0.0;
     }
+    pose_sync<16>();  // the vertices are read by the other lanes of the group (same wavefront)
     const float Rf = qp->search_radius;
     LegCtx c;
     c.cx = qp->cx;
@@ -1741,7 +1746,7 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
         const LegConst lk = make_leg_const(Rf, m.g.res, lut);
         const LutHead head = load_lut_head(lut, g);
         const Box b0{c.cx, c.cy, pc.rf, pc.rf};
-        Corners<64, 8> cs;
+        Corners<G, 8> cs;
         cs.eval(m.g, g, b0, b0, b0, b0, 0x2u);  // quantities 4,5 = getIndex(centre)
         const BBox bb = cs.template bbox<0>(g);
         c.ici = cs.template get<4>(g);
@@ -1750,7 +1755,7 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
         sm.ok = false;
         DefaultDisc dflt;
         dflt.want = 0;
-        search_leg<64, false>(m, pc, lut, head, c, lk, tile, g, bb, sm, dflt, no, co);
+        search_leg<G, false>(m, pc, lut, head, c, lk, tile, g, bb, sm, dflt, no, co);
     } else {
         nominal_invalid(no, c.cx, c.cy, 3);
     }
@@ -1813,7 +1818,10 @@ size_t plan_lds_bytes(const PlanConsts& pc) {
     const int ppb = G >= 16 ? 1 : 64 / (4 * G);  // poses per 64-thread block
     return ppb * (sizeof(PoseShared) + 4 * tile_bytes(pc));
 }
-size_t search_lds_bytes(const PlanConsts& pc) { return sizeof(QueryShared) + 4 * tile_bytes(pc); }
+static int search_group_size(const PlanConsts& pc) { return (pc.tileW * pc.tileW <= 1024 && pc.groupOverride != 64) ? 8 : 64; }
+size_t search_lds_bytes(const PlanConsts& pc) {
+    return sizeof(QueryShared) + static_cast<size_t>(256 / search_group_size(pc)) * tile_bytes(pc);
+}
 
 // The 3x3-only variant of the 8-lane kernel: foot radius in [0.9, 1] x resolution (a disc box then spans at most
 // three cells per axis) with a host-proved candidate foot disc of at most four cells (no LDS window: the staged
@@ -1847,7 +1855,10 @@ hipError_t launch_plan_chained(const DevMap& m, const PlanConsts& pc, const Spir
 hipError_t launch_search_legs(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const fpe_leg_query* d_q,
                               int n, fpe_foothold* d_out, hipStream_t stream) {
     const size_t lds = search_lds_bytes(pc);
-    hipLaunchKernelGGL(search_legs_kernel, dim3((n + 3) / 4), dim3(256), lds, stream, m, pc, lut, d_q, n, d_out);
+    if (search_group_size(pc) == 8)
+        hipLaunchKernelGGL(search_legs_kernel<8>, dim3((n + 31) / 32), dim3(256), lds, stream, m, pc, lut, d_q, n, d_out);
+    else
+        hipLaunchKernelGGL(search_legs_kernel<64>, dim3((n + 3) / 4), dim3(256), lds, stream, m, pc, lut, d_q, n, d_out);
     return hipGetLastError();
 }
 
@@ -1877,7 +1888,10 @@ hipError_t set_max_lds(size_t planBytes, size_t searchBytes) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_sequential_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(planBytes));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(search_legs_kernel),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_legs_kernel<8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(searchBytes));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(search_legs_kernel<64>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(searchBytes));
 }
 
