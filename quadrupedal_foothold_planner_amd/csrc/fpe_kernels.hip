@@ -1699,7 +1699,7 @@ struct QueryShared {
 
 // G lanes per query (8 for windows of <= 1024 cells, like the chained plan; else a whole wavefront), 256 / G queries
 // per workgroup.
-template <int G>
+template <int G, bool kMid = false>
 __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts pc, SpiralLut lut,
                                                            const fpe_leg_query* __restrict__ queries, int n,
                                                            fpe_foothold* __restrict__ out) {
@@ -1755,7 +1755,7 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
         sm.ok = false;
         DefaultDisc dflt;
         dflt.want = 0;
-        search_leg<G, false>(m, pc, lut, head, c, lk, tile, g, bb, sm, dflt, no, co);
+        search_leg<G, false, kMid>(m, pc, lut, head, c, lk, tile, g, bb, sm, dflt, no, co);
     } else {
         nominal_invalid(no, c.cx, c.cy, 3);
     }
@@ -1855,7 +1855,9 @@ hipError_t launch_plan_chained(const DevMap& m, const PlanConsts& pc, const Spir
 hipError_t launch_search_legs(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const fpe_leg_query* d_q,
                               int n, fpe_foothold* d_out, hipStream_t stream) {
     const size_t lds = search_lds_bytes(pc);
-    if (search_group_size(pc) == 8)
+    if (search_group_size(pc) == 8 && mid_variant(pc, m.g.res))
+        hipLaunchKernelGGL((search_legs_kernel<8, true>), dim3((n + 31) / 32), dim3(256), lds, stream, m, pc, lut, d_q, n, d_out);
+    else if (search_group_size(pc) == 8)
         hipLaunchKernelGGL(search_legs_kernel<8>, dim3((n + 31) / 32), dim3(256), lds, stream, m, pc, lut, d_q, n, d_out);
     else
         hipLaunchKernelGGL(search_legs_kernel<64>, dim3((n + 3) / 4), dim3(256), lds, stream, m, pc, lut, d_q, n, d_out);
@@ -1889,6 +1891,9 @@ hipError_t set_max_lds(size_t planBytes, size_t searchBytes) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(planBytes));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_legs_kernel<8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(searchBytes));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_legs_kernel<8, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(searchBytes));
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(search_legs_kernel<64>),
