@@ -809,7 +809,7 @@ __device__ __forceinline__ void disc_issue(const DevMap& m, const PlanConsts& pc
         }
     }
 }
-template <int G, bool kCheck>
+template <int G, bool kCheck, bool kMid = false>
 __device__ __forceinline__ float disc_consume(const DevMap& m, const PlanConsts& pc, double cx, double cy, const BBox& bb,
                                               const Grp<G>& g, const DiscLoads& d, bool& defaultOk, float* scratch) {
     if (!d.pipelined) return disc_pass_direct<G, kCheck>(m, pc, cx, cy, bb, g, defaultOk, scratch);
@@ -840,6 +840,9 @@ __device__ __forceinline__ float disc_consume(const DevMap& m, const PlanConsts&
             }
             if (kCheck) defaultOk = !g.any(fail);  // the middle cell is always visited
             return finish_mean(sum, last, cnt, pc.h);
+        }
+        if constexpr (kMid) {  // the 3x3-only variant issues nothing else (disc_issue): rounds 1.. are never loaded
+            __builtin_unreachable();
         }
     }
     if constexpr (G <= 16) {
@@ -1101,11 +1104,11 @@ __device__ void centroid_begin(const DevMap& m, const PlanConsts& pc, const LegC
     disc_issue<G, false, kMid>(m, pc, o.x, o.y, cp.rb, g, cp.dl);
     cp.needDisc = 1;
 }
-template <int G>
+template <int G, bool kMid = false>
 __device__ void centroid_end(const DevMap& m, const PlanConsts& pc, const Grp<G>& g, CentroidPending& cp, float* scratch) {
     if (cp.needDisc != 0) {
         bool unused;
-        cp.o.z = disc_consume<G, false>(m, pc, cp.o.x, cp.o.y, cp.rb, g, cp.dl, unused, scratch);
+        cp.o.z = disc_consume<G, false, kMid>(m, pc, cp.o.x, cp.o.y, cp.rb, g, cp.dl, unused, scratch);
     }
 }
 
@@ -1185,14 +1188,14 @@ __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLu
     stamp(pc, c.cyc, 4);
     bool defaultOk = true;
     float* scratch = reinterpret_cast<float*>(tile);  // the tile is idle outside the spiral search
-    const float zCentre = disc_consume<G, true>(m, pc, c.cx, c.cy, bb, g, dc, defaultOk, scratch);  // cpp:2012 + cpp:2029
+    const float zCentre = disc_consume<G, true, kMid>(m, pc, c.cx, c.cy, bb, g, dc, defaultOk, scratch);  // cpp:2012 + cpp:2029
     stamp(pc, c.cyc, 5);
     CentroidPending cp;
     if (kCentroid) centroid_begin<G, kMid>(m, pc, c, s, sc, zCentre, g, cp);                          // cpp:818-821
     stamp(pc, c.cyc, 6);
     if (dflt.want != 0) {
         bool unused;
-        dflt.z = disc_consume<G, false>(m, pc, dflt.x, dflt.y, dflt.bb, g, dd, unused, scratch);  // cpp:2289-2301
+        dflt.z = disc_consume<G, false, kMid>(m, pc, dflt.x, dflt.y, dflt.bb, g, dd, unused, scratch);  // cpp:2289-2301
     }
     stamp(pc, c.cyc, 7);
     if (defaultOk) {
@@ -1207,7 +1210,7 @@ __device__ void search_leg(const DevMap& m, const PlanConsts& pc, const SpiralLu
         spiral_search<G, kMid>(m, pc, lut, head, c, tile, g, zCentre, no);
     }
     if (kCentroid) {
-        centroid_end(m, pc, g, cp, scratch);
+        centroid_end<G, kMid>(m, pc, g, cp, scratch);
         co = cp.o;
     }
 }
