@@ -523,3 +523,21 @@ def test_map_stream_with_changing_sizes_recycles_buffers_correctly(planner):
         eng = planner.plan(poses, 3)
         ora = fpo.OracleMap(trav, elev, 0.02).plan(util.to_oracle_params(planner.params), util.to_oracle_poses(poses), 3)
         util.assert_plan_equal(eng, ora)
+
+
+@pytest.mark.parametrize("n", [1, 5, 31, 32, 33, 257])
+def test_open_loop_ragged_query_counts(planner, n):
+    """fpe_search_legs plans 32 queries per workgroup on small windows (8 lanes each): counts that do not fill the last
+    workgroup or wavefront must neither read nor write beyond the arrays."""
+    set_params(planner)
+    trav, elev = synth.rough_map(200, 200, 0.02, seed=121, bad_frac=0.2)
+    planner.gridmapCallback(trav, elev, 0.02)
+    rng = np.random.default_rng(122 + n)
+    q = np.zeros(n, dtype=_capi.QUERY_DTYPE)
+    q["cx"], q["cy"] = rng.uniform(-1.9, 1.9, n), rng.uniform(-1.9, 1.9, n)
+    q["search_radius"], q["n_vertices"] = np.float32(0.1), 4
+    q["vx"][:, :4] = q["cx"][:, None] + np.array([0.1, 0.1, -0.1, -0.1])
+    q["vy"][:, :4] = q["cy"][:, None] + np.array([0.05, -0.05, -0.05, 0.05])
+    eng = planner.checkFoothold(q)
+    ora = fpo.OracleMap(trav, elev, 0.02).search_legs(util.to_oracle_params(planner.params), util.to_oracle_queries(q))
+    util.assert_nominal_equal(eng, ora, "checkFoothold")
