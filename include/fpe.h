@@ -33,7 +33,9 @@ enum fpe_status {
     FPE_E_HIP = -3,         /* a HIP runtime call failed; fpe_last_error() has the text */
     FPE_E_NO_DEVICE = -4,   /* no usable gfx950 device / HIP code object not loadable */
     FPE_E_UNSUPPORTED = -5, /* search radius / foot radius too large for the on-chip tile */
-    FPE_E_NOMEM = -6
+    FPE_E_NOMEM = -6,
+    FPE_E_SERVICE_FALSE = -7 /* the reference's service handler returns false for this request:
+                                getGaitCycleSearchGridMap's getSubmap failed (cpp:920-934, 2345-2349) */
 };
 
 /* ROS parameters of the path, with the reference's member types (readParameters cpp:248-314;
@@ -102,6 +104,21 @@ typedef struct fpe_centroid_foothold {
     uint8_t pad[3];
 } fpe_centroid_foothold;
 
+/* The exchange record of a selected (nominal) foothold, 16 bytes: the chosen grid index, the height
+ * and the flag bytes of the nominal record; x / y stay with the rank that planned the pose.  This is what
+ * the multi-GPU all-gather moves. */
+typedef struct fpe_selected_foothold {
+    int32_t row, col;
+    float z;
+    uint8_t valid, source, foot_id, gait_cycle_id;
+} fpe_selected_foothold;
+
+/* fpe_plan_out.pose_status bits */
+#define FPE_POSE_OPT_SUBMAP_FAILED 1u /* getGaitCycleSearchGridMap (cpp:2307-2349) fails in the FIRST gait cycle:
+                                         getSubmap(next feet centre, isos_.length x isos_.width) — the reference's
+                                         service handler returns false there (cpp:920-934).  Exact for cycle 0
+                                         only: from cycle 1 on the opt track's feet depend on NLopt (not rebuilt). */
+
 /* Output buffers of a chained plan; any pointer may be NULL (that product is skipped).
  * Index convention: record (b, g, leg) at ((b * n_cycles) + g) * 4 + leg. */
 typedef struct fpe_plan_out {
@@ -110,6 +127,8 @@ typedef struct fpe_plan_out {
     double* default_next;            /* [B * n_cycles * 4 * 3] default track x,y,z (cpp:1344-1347) */
     uint8_t* cycle_ok;               /* [B * n_cycles] footholdValidation_ per cycle (cpp:1323) */
     double* stance;                  /* [B * 4 * 3] RF/RH/LH/LF_initialPosition_ (cpp:350-378) */
+    fpe_selected_foothold* selected; /* [B * n_cycles * 4] 16-byte form of `nominal` (multi-GPU exchange record) */
+    uint8_t* pose_status;            /* [B] FPE_POSE_* bits */
 } fpe_plan_out;
 
 /* One open-loop checkFoothold call (hpp:94-100) with an arbitrary polygon (grid_map::Polygon). */
@@ -143,6 +162,13 @@ typedef struct fpe_global_footholds {
 /* One engine per process per GPU (device_id = LOCAL_RANK under torch.distributed). */
 int fpe_create(int device_id, fpe_handle* out);
 int fpe_destroy(fpe_handle h);
+/* Build-defined tuning / test knobs of one engine (never read from the environment per call; the
+ * environment variables FPE_PLAN_GROUP, FPE_LITERAL_DISCS, FPE_NO_MID_VARIANT, FPE_NO_BITS only seed the
+ * defaults once, in fpe_create).  Keys: "plan_group" (0 automatic; 4/8/16/64 lanes per leg, 65 = one
+ * wavefront per pose), "literal_discs" (1: force the literal CircleIterator walk), "no_mid_variant"
+ * (1: never launch the 3x3-only kernel variants), "no_bits" (1: never launch the bit-window kernels).
+ * Not thread-safe against concurrent plan calls on the same engine. */
+int fpe_set_tuning(fpe_handle h, const char* key, int32_t value);
 const char* fpe_last_error(fpe_handle h); /* thread-local text of the last failure on this thread */
 const char* fpe_version(void);
 
@@ -180,7 +206,10 @@ int fpe_search_legs(fpe_handle h, const fpe_params* params, const fpe_leg_query*
 int fpe_search_legs_device(fpe_handle h, const fpe_params* params, const fpe_leg_query* d_queries, int32_t n,
                            fpe_foothold* d_out, void* stream);
 
-/* ---- service-shaped call: one pose, response content of plan_global_footholds (cpp:539-1602) -- */
+/* ---- service-shaped call: one pose, response content of plan_global_footholds (cpp:539-1602) --
+ * Returns FPE_E_SERVICE_FALSE (response zeroed) where the reference's handler returns false because
+ * getGaitCycleSearchGridMap fails in the first gait cycle (cpp:920-934): the next feet centre lies off
+ * the map.  Later cycles of that gate depend on the NLopt opt track, which is not rebuilt. */
 int fpe_plan_service(fpe_handle h, const fpe_params* params, const double initial_position[3],
                      uint8_t gait_cycles, fpe_global_footholds* response);
 
@@ -188,7 +217,10 @@ int fpe_plan_service(fpe_handle h, const fpe_params* params, const double initia
  * extra pointer may be NULL.
  *   centroid: content of global_footholds_centroid for THIS call (cpp:709-727 stance entries,
  *             cpp:1444-1462 per valid cycle; the reference never clears that message between
- *             calls, cpp:715 — appending across calls is left to the adapter);
+ *             calls, cpp:715 — appending across calls is left to the adapter).  Its bookkeeping is NOT
+ *             the nominal one: success = 1 iff any cycle committed (set false once at cpp:711, true at
+ *             cpp:1446, never cleared by a later failed cycle — cpp:1574 touches the nominal message
+ *             only), gait_cycles_succeed = last committed cycle + 1, gait_cycles is never written (0);
  *   default_footholds: rows of globalFootholdsResult_.defaultFootholds (cpp:666-671, 1344-1348):
  *             (1 + gait_cycles_succeed') x 12 doubles = RF,RH,LH,LF x (x,y,z), stance row first, one row
  *             per VALID cycle; *n_default_rows receives the number of rows (capacity 1 + gait_cycles). */

@@ -84,6 +84,7 @@ def lib():
         L.fpo_map_destroy.argtypes = [C.c_void_p]
         L.fpo_plan.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
         L.fpo_search_legs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.fpo_pose_status.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.fpo_plan_as_written.restype = C.c_ulonglong
         L.fpo_plan_as_written.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.fpo_plan_products.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7
@@ -151,6 +152,14 @@ class OracleMap:
         rc = lib().fpo_plan(self._h, _ptr(params), _ptr(poses), B, n_cycles, threads, _ptr(out["nominal"]),
                             _ptr(out["centroid"]), _ptr(out["default"]), _ptr(out["cycle_ok"]), _ptr(out["stance"]))
         assert rc == 0
+        return out
+
+    def pose_status(self, params, poses):
+        """bit 0 per pose: getGaitCycleSearchGridMap fails in the first gait cycle (the service returns false, cpp:931-934)."""
+        params = np.ascontiguousarray(params, dtype=PARAMS_DTYPE).reshape(1)
+        poses = np.ascontiguousarray(poses, dtype=POSE_DTYPE)
+        out = np.zeros(poses.shape[0], dtype=np.uint8)
+        lib().fpo_pose_status(self._h, _ptr(params), _ptr(poses), poses.shape[0], _ptr(out))
         return out
 
     def plan_as_written(self, params, poses, n_cycles):

@@ -129,6 +129,26 @@ int fpo_plan(const void* mapHandle, const Params* params, const PoseSpec* poses,
     return 0;
 }
 
+// status[b] bit 0: getGaitCycleSearchGridMap fails in the first gait cycle of pose b (service returns false)
+int fpo_pose_status(const void* mapHandle, const Params* params, const PoseSpec* poses, int B, uint8_t* status) {
+    const GridMap& map = *static_cast<const GridMap*>(mapHandle);
+    const Constants c = makeConstants(*params);
+    for (int b = 0; b < B; ++b) {
+        const double sx[4] = {c.LbHalf, -c.LbHalf, -c.LbHalf, c.LbHalf};
+        const double sy[4] = {c.WbHalfNeg, c.WbHalfNeg, c.WbHalfPos, c.WbHalfPos};
+        Point3 cur[4];
+        for (int l = 0; l < 4; ++l) {  // stance (cpp:350-378) then setFirstGait (cpp:2693)
+            Point3 s;
+            s.x = sx[l]; s.y = sy[l]; s.z = 0;
+            s.x += poses[b].pose[0]; s.y += poses[b].pose[1]; s.z += poses[b].pose[2];
+            cur[l] = s;
+            cur[l].x = s.x - c.stepHalf;
+        }
+        status[b] = getGaitCycleSearchGridMap(map, *params, cur, poses[b].pose[1], 0.0) ? 0 : 1;
+    }
+    return 0;
+}
+
 // Evaluation products of ONE trot plan: per track k (0 centroid, 1 nominal)
 //   path[k]: up to nCycles x 3 doubles, dist[k] / speed[k]: up to 2*nCycles doubles; counts[k] = {nPath, nKpi}.
 int fpo_plan_products(const void* mapHandle, const Params* params, const PoseSpec* pose, int nCycles, double* path0,

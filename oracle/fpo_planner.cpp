@@ -305,6 +305,31 @@ Point3 getPolygonCenter(const Point3& rf, const Point3& rh, const Point3& lh, co
     return c;
 }
 
+// cpp:2307-2349, the part that decides the return value: getSubmap of isos_.length x isos_.width around the
+// next feet centre.  isos_ (cpp:384-394, hpp:677-697): longEdge = lengthBase + skew*2 evaluated in f32
+// (hpp:666, 683) and stored in a double; footSearchRect_.length = searchRadius_*2 / .width = searchRadius_
+// are f32 values stored in doubles (hpp:700-701); isos_.length / .width are sums of doubles.
+bool getGaitCycleSearchGridMap(const GridMap& gridmap, const Params& prm, const Point3 cur[4], double initialPoseY,
+                               double ajustedPoseY) {
+    const Point3 feetCenter = getPolygonCenter(cur[RF], cur[RH], cur[LH], cur[LF]);  // cpp:2322
+    Vec2 p;
+    p.x = feetCenter.x + prm.stepLength;    // cpp:2327
+    p.y = initialPoseY + ajustedPoseY;      // cpp:2329
+    if (!centreUsable(p)) return false;     // oracle-defined, see centreUsable
+    const float lengthBase = prm.length;                // cpp:340
+    const float widthBase = prm.width + prm.l1 * 2;     // cpp:341
+    const double longEdge = lengthBase + prm.skew * 2;  // cpp:391 (f32 sum, promoted on assignment)
+    const double shortEdge = widthBase;                 // cpp:392
+    const double rectLength = prm.searchRadius * 2;     // cpp:384
+    const double rectWidth = prm.searchRadius;          // cpp:385
+    Vec2 rect;
+    rect.x = longEdge + rectLength;  // cpp:393, 2340
+    rect.y = shortEdge + rectWidth;  // cpp:394, 2341
+    bool isSuccess = false;
+    (void)gridmap.getSubmap(p, rect, isSuccess);  // cpp:2345
+    return isSuccess;                             // cpp:2347-2349
+}
+
 // cpp:2496-2517 (kind 0).  Vertex order LU, RU, RD, LD; `radius` is float, promoted per use.
 // kind 1 (build-defined, App. E): flattened hexagon with the same x extent and y half-extent
 // 0.5*r*kHexH, all vertices from products of doubles so host and device agree bit for bit.
@@ -398,6 +423,8 @@ void planGlobalFootholds(const GridMap& map, const Params& p, const PoseSpec& ps
             cur[t][l].x = out.stance[l].x - c.stepHalf;
         }
     double ajustedPoseY = 0.0;  // cpp:759
+    // opt track, first cycle (cpp:916-934): its current feet are the shifted stance too (cpp:582-588)
+    out.optGate0Failed = (nCycles > 0 && !getGaitCycleSearchGridMap(map, p, cur[0], pose[1], ajustedPoseY)) ? 1 : 0;
 
     static const int walkOrderLF[4] = {LF, RH, RF, LH};
     static const int walkOrderRF[4] = {RF, LH, LF, RH};

@@ -87,6 +87,8 @@ void checkFoothold(const GridMap& map, const Vec2& center, float footRadius, flo
 void checkFootholdUseCentroidMethod(const GridMap& map, const Vec2& defaultFoothold, float searchRadius,
                                     const Params& p, CentroidResult& out);
 Point3 getPolygonCenter(const Point3& rf, const Point3& rh, const Point3& lh, const Point3& lf);
+bool getGaitCycleSearchGridMap(const GridMap& gridmap, const Params& p, const Point3 optCurrent[4], double initialPoseY,
+                               double ajustedPoseY);
 Polygon getSearchPolygon(const Point3& center, float radius, int kind = 0);
 void getHipDistance(const Point3 result[4], std::vector<double>& feetDistance);
 void getCogSpeed(const Point3 result[4], const Point3 current[4], int RF_FIRST, std::vector<double>& cogSpeed);
@@ -99,6 +101,9 @@ struct PlanOutput {
     std::vector<Point3> defaultNext;  // default-track next positions with z (cpp:774-781)
     std::vector<uint8_t> cycleOk;     // footholdValidation_ per cycle (cpp:1323)
     Point3 stance[4];                 // RF/RH/LH/LF_initialPosition_ (cpp:350-378)
+    // getGaitCycleSearchGridMap (cpp:2307-2349) fails in the FIRST gait cycle => the reference's service handler
+    // returns false (cpp:920-934).  Only cycle 0 is restated: later cycles use the NLopt track's feet.
+    uint8_t optGate0Failed = 0;
     // Evaluation products of the centroid ([0]) and nominal ([1]) tracks (trot only):
     //   feetCenterPath: one pose per planned cycle = getPolygonCenter of the track's CURRENT feet,
     //                   pushed in getFootholdSearchGridMap whether or not the cycle commits (cpp:2191-2196);

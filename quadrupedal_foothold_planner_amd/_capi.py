@@ -14,6 +14,8 @@ FPE_E_HIP = -3
 FPE_E_NO_DEVICE = -4
 FPE_E_UNSUPPORTED = -5
 FPE_E_NOMEM = -6
+FPE_E_SERVICE_FALSE = -7
+FPE_POSE_OPT_SUBMAP_FAILED = 1
 
 MAX_POLYGON_VERTICES = 8
 
@@ -45,6 +47,11 @@ FOOTHOLD_DTYPE = np.dtype(
 )
 CENTROID_DTYPE = np.dtype(
     [("x", "<f8"), ("y", "<f8"), ("z", "<f4"), ("row", "<i4"), ("col", "<i4"), ("code", "u1"), ("pad", "u1", (3,))],
+    align=True,
+)
+# fpe_selected_foothold: the 16-byte multi-GPU exchange record
+SELECTED_DTYPE = np.dtype(
+    [("row", "<i4"), ("col", "<i4"), ("z", "<f4"), ("valid", "u1"), ("source", "u1"), ("foot_id", "u1"), ("gait_cycle_id", "u1")],
     align=True,
 )
 QUERY_DTYPE = np.dtype(
@@ -88,6 +95,8 @@ class PlanOut(C.Structure):
         ("default_next", C.c_void_p),
         ("cycle_ok", C.c_void_p),
         ("stance", C.c_void_p),
+        ("selected", C.c_void_p),
+        ("pose_status", C.c_void_p),
     ]
 
 
@@ -103,6 +112,7 @@ EXPORTED_SYMBOLS = [
     "fpe_upload_map_device",
     "fpe_map_info",
     "fpe_set_max_leg_search_radius",
+    "fpe_set_tuning",
     "fpe_plan",
     "fpe_plan_device",
     "fpe_search_legs",
@@ -130,10 +140,8 @@ def lib():
     try:
         # FPE_LIB: load a specific prebuilt engine (kernel-variant A/B runs); default = in-tree libfpe.so
         path = os.environ.get("FPE_LIB") or _build.build_engine()
-    except Exception as e:  # hipcc missing or compile error: fail loudly, never fall back
-        if not os.path.exists(_build.LIB_PATH):
-            raise EngineUnavailable(f"cannot build libfpe.so: {e}") from e
-        path = _build.LIB_PATH
+    except Exception as e:  # hipcc missing or compile error: fail loudly — never load a stale library instead
+        raise EngineUnavailable(f"cannot build libfpe.so: {e}") from e
     try:
         L = C.CDLL(path)
     except OSError as e:
@@ -150,6 +158,7 @@ def lib():
     L.fpe_upload_map_device.argtypes = [vp, C.POINTER(MapDesc), vp, vp, vp]
     L.fpe_map_info.argtypes = [vp, C.POINTER(MapDesc)]
     L.fpe_set_max_leg_search_radius.argtypes = [vp, f32]
+    L.fpe_set_tuning.argtypes = [vp, C.c_char_p, i32]
     L.fpe_plan.argtypes = [vp, vp, vp, i32, i32, C.POINTER(PlanOut)]
     L.fpe_plan_device.argtypes = [vp, vp, vp, i32, i32, C.POINTER(PlanOut), vp]
     L.fpe_search_legs.argtypes = [vp, vp, vp, i32, vp]

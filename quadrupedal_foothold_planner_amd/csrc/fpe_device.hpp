@@ -2,6 +2,8 @@
 #pragma once
 #include <cstdint>
 
+#include <hip/hip_runtime.h>
+
 #include "../../include/fpe.h"
 #include "fpe_gridmath.hpp"
 
@@ -28,6 +30,14 @@ constexpr int kMaxFootOffsets = 128;
 
 // Per-call constants derived on the host from fpe_params with the reference's typing
 // (initialize(), cpp:340-421; fpe_host.cpp::derive_constants).
+// Engine-level tuning / test knobs (fpe_set_tuning); seeded once from the environment in fpe_create.
+struct Tuning {
+    int32_t planGroup = 0;
+    int32_t literalDiscs = 0;
+    int32_t noMidVariant = 0;
+    int32_t noBits = 0;
+};
+
 struct PlanConsts {
     float footRadius, thrDefault, thrCandidate, searchRadius;
     double rf, rf2;  // double(footRadius), pow(rf, 2)
@@ -39,12 +49,16 @@ struct PlanConsts {
     int32_t tileH, tileW;  // LDS tile half-width / width in cells
     uint32_t tileWMagic;   // fastdiv magic of tileW
     float maxSearchRadius; // radius the tile was sized for
-    int32_t groupOverride; // 0 = automatic lanes-per-leg; 16 / 64 force it (tuning knob FPE_PLAN_GROUP)
+    int32_t groupOverride; // 0 = automatic lanes-per-leg; 4 / 8 / 16 / 64 / 65 force it (fpe_set_tuning "plan_group")
+    int32_t noMidVariant;  // fpe_set_tuning "no_mid_variant": never launch the 3x3-only kernel variants
+    int32_t noBits;        // fpe_set_tuning "no_bits": never launch the bit-window kernels
+    // getGaitCycleSearchGridMap's submap (cpp:2339-2345): isos_.length x isos_.width (cpp:384-394)
+    double isosLen, isosWid;
     // Cell offsets of a CELL-CENTRED foot disc (checkCirclePolygonFoothold's CircleIterator around
     // a spiral candidate), valid only when footRobust != 0: the host proved that no lattice offset
     // lies within rounding distance of the radius, so the f64 per-candidate bounding-box walk
     // visits exactly {candidate + offset} ∩ map (fpe_host.cpp::derive_foot_offsets).
-    unsigned long long* trace;  // profiling-only: per-phase s_memtime stamps (FPE_TRACE_PTR); null in production
+    unsigned long long* trace;  // profiling-only (-DFPE_TRACE builds): per-phase s_memtime stamps; null in production
     int32_t nFoot;
     int32_t footRobust;
     int32_t footReach;     // cells a foot disc can reach from its centre cell (max |offset|, or ceil(rf/res)+1)
@@ -54,6 +68,18 @@ struct PlanConsts {
     int32_t midCellInside;
     int8_t footDa[kMaxFootOffsets];
     int8_t footDb[kMaxFootOffsets];
+};
+
+// Bit planes of one map snapshot for one (defaultFootholdThreshold, candidateFootholdThreshold) pair
+// (fpe_bits.hpp).  One uint4 per 32 columns of a row: x = D  (trav < thrDefault, raw compare: NaN 0, -inf 1),
+// y = Df (finite && trav < thrDefault), z = C (finite && trav < thrCandidate), w = F (finite); bit b of a word =
+// column 32 * word + b.  Rows -1 and `rows`, kBitPadW word groups left of column 0 and everything right of the last
+// column are zero ("not in the map"), so a window hanging over the map edge reads zeros without a bounds test.
+constexpr int kBitPadW = 4;
+struct BitMap {
+    const uint4* words;  // [(rows + 2) * strideW]; group of (row i, word w) at (i + 1) * strideW + w + kBitPadW
+    int32_t strideW;     // nw + 2 * kBitPadW
+    int32_t nw;          // ceil(cols / 32)
 };
 
 // Tile flag bits (one byte per cell in LDS).

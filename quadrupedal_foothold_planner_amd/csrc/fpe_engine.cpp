@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -27,6 +28,13 @@ hipError_t launch_canonicalise(const float* d_src, float* d_dst, int rows, int c
 hipError_t set_max_lds(size_t planBytes, size_t searchBytes);
 size_t plan_lds_bytes(const PlanConsts& pc);
 size_t search_lds_bytes(const PlanConsts& pc);
+// bit-window path (fpe_bits.hip part of fpe_kernels.hip)
+size_t bitmap_words(int rows, int cols, int* strideW, int* nw);
+hipError_t launch_build_bitmap(const float* d_trav, int rows, int cols, float thrDefault, float thrCandidate,
+                               uint32_t* d_words, hipStream_t stream);
+bool bits_supported(const PlanConsts& pc, const MapGeom& g);
+hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut,
+                            const fpe_pose* d_poses, int B, int nCycles, const fpe_plan_out& d_out, hipStream_t stream);
 }  // namespace fpe
 
 namespace {
@@ -49,11 +57,11 @@ int fail_hip(hipError_t e, const char* what) {
 
 // Layer buffers of retired snapshots are recycled instead of freed: a traversability map arrives
 // at 10-20 Hz and hipMalloc/hipFree (the latter a device-wide sync) would dominate the upload.
-// Reuse is safe in stream order: host-buffer plans are synchronous, and device-API callers order
-// uploads and plans on one stream (include/fpe.h).
+// A buffer reaches the pool only from ~MapSnapshot, i.e. after the upload that filled it and every
+// recorded asynchronous reader have completed (events), so a taker may write it on any stream.
 struct BufferPool {
     std::mutex mu;
-    std::vector<std::pair<size_t, float*>> free;  // (floats, pointer)
+    std::vector<std::pair<size_t, float*>> free;  // (4-byte units, pointer)
     float* take(size_t n) {
         std::lock_guard<std::mutex> lk(mu);
         for (size_t k = 0; k < free.size(); ++k)
@@ -65,12 +73,16 @@ struct BufferPool {
         return nullptr;
     }
     void give(size_t n, float* p) {
-        std::lock_guard<std::mutex> lk(mu);
-        if (free.size() >= 6) {  // keep at most two snapshots' worth plus the upload staging layer
-            (void)hipFree(free.front().second);
-            free.erase(free.begin());
+        float* drop = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (free.size() >= 10) {  // two snapshots' worth (layers + bit planes) plus the upload staging layer
+                drop = free.front().second;
+                free.erase(free.begin());
+            }
+            free.emplace_back(n, p);
         }
-        free.emplace_back(n, p);
+        if (drop) (void)hipFree(drop);
     }
     ~BufferPool() {
         for (auto& e : free) (void)hipFree(e.second);
@@ -141,13 +153,67 @@ struct CtxLease {  // returns the context to the pool on every exit path
 };
 inline size_t align256(size_t n) { return (n + 255) & ~static_cast<size_t>(255); }
 
+// Bit planes of a snapshot for one (defaultFootholdThreshold, candidateFootholdThreshold) pair, built lazily by
+// the first plan that needs them (one HBM-bound pass over the traversability layer) and kept with the snapshot.
+struct MaskSet {
+    float thrD = 0.0f, thrC = 0.0f;
+    uint32_t* d_words = nullptr;
+    size_t n = 0;  // in 4-byte units (BufferPool size key)
+    int strideW = 0, nw = 0;
+    hipEvent_t ready = nullptr;
+};
+
 struct MapSnapshot {
     fpe::MapGeom g;
     size_t n = 0;
     float* d_trav = nullptr;
     float* d_elev = nullptr;
     std::shared_ptr<BufferPool> pool;
+    // `ready` is recorded on the uploading stream after the copy / canonicalise work; every consumer stream waits
+    // on it before its first kernel (a no-op once the upload has completed).  `uses` are events recorded by
+    // asynchronous consumers (fpe_plan_device / fpe_search_legs_device) after their launch: the layer buffers are
+    // recycled only behind them.
+    hipEvent_t ready = nullptr;
+    std::mutex mu;
+    std::vector<std::pair<hipStream_t, hipEvent_t>> uses;
+    std::vector<MaskSet> masks;
+
+    hipError_t wait_ready(hipStream_t s) const { return ready ? hipStreamWaitEvent(s, ready, 0) : hipSuccess; }
+    // "last use on stream s": one event per consumer stream, re-recorded by every launch on that stream
+    hipError_t note_use(hipStream_t s) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& u : uses)
+            if (u.first == s) return hipEventRecord(u.second, s);
+        hipEvent_t ev;
+        hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        e = hipEventRecord(ev, s);
+        if (e != hipSuccess) {
+            (void)hipEventDestroy(ev);
+            return e;
+        }
+        uses.emplace_back(s, ev);
+        return hipSuccess;
+    }
     ~MapSnapshot() {
+        // A buffer goes back to the pool only after the upload and every recorded asynchronous use have
+        // completed.  A snapshot is retired once per map message (10-20 Hz), never in the per-plan path, and the
+        // events have usually completed long before.
+        for (auto& u : uses) {
+            (void)hipEventSynchronize(u.second);
+            (void)hipEventDestroy(u.second);
+        }
+        if (ready) {
+            (void)hipEventSynchronize(ready);
+            (void)hipEventDestroy(ready);
+        }
+        for (MaskSet& ms : masks) {
+            if (ms.ready) {
+                (void)hipEventSynchronize(ms.ready);
+                (void)hipEventDestroy(ms.ready);
+            }
+            if (ms.d_words) pool ? pool->give(ms.n, reinterpret_cast<float*>(ms.d_words)) : (void)hipFree(ms.d_words);
+        }
         if (d_trav) pool ? pool->give(n, d_trav) : (void)hipFree(d_trav);
         if (d_elev) pool ? pool->give(n, d_elev) : (void)hipFree(d_elev);
     }
@@ -171,38 +237,88 @@ struct fpe_engine {
     int32_t* d_ringStart = nullptr;
     int maxRing = 0;
     float maxLegSearchRadius = 0.0f;  // fpe_set_max_leg_search_radius
-    size_t ldsConfigured = 0;
+    fpe::Tuning tuning;               // fpe_set_tuning; seeded from the environment once, in fpe_create
 
     fpe::SpiralLut lut() const { return fpe::SpiralLut{d_di, d_dj, d_ring, d_ringStart, maxRing}; }
 };
 
 namespace {
 
-int prepare_call(fpe_engine* h, const fpe_params* params, float maxRadius, std::shared_ptr<MapSnapshot>& snap,
-                 fpe::PlanConsts& pc, size_t& planLds, size_t& searchLds) {
+// Device allocation in 4-byte units with the tail padding every pooled buffer carries (the row scan reads whole
+// 16-byte groups past the end of a layer, fpe_kernels.hip::rows_issue), so any pooled buffer can serve any role.
+hipError_t alloc_units(BufferPool& pool, size_t n, float** out) {
+    *out = pool.take(n);
+    if (*out) return hipSuccess;
+    return hipMalloc(reinterpret_cast<void**>(out), n * sizeof(float) + kLayerPadBytes);
+}
+
+// What one launch needs besides the constants: the snapshot, and (bit-window path) its bit planes.
+struct CallPlan {
+    std::shared_ptr<MapSnapshot> snap;
+    fpe::PlanConsts pc;
+    size_t planLds = 0, searchLds = 0;
+    bool useBits = false;
+    fpe::BitMap bits{nullptr, 0, 0};
+    hipEvent_t bitsReady = nullptr;
+};
+
+int prepare_call(fpe_engine* h, const fpe_params* params, float maxRadius, CallPlan& cp, hipStream_t stream, bool wantBits) {
     if (!h || !params) return fail(FPE_E_INVALID_ARG, "null handle or params");
     int rc = fpe::validate_params(*params);
     if (rc != FPE_OK) return fail(rc, "non-finite or negative parameter");
+    fpe::Tuning tuning;
     {
         std::lock_guard<std::mutex> lk(h->mu);
-        snap = h->map;
+        cp.snap = h->map;
         maxRadius = std::max(maxRadius, std::max(params->searchRadius, h->maxLegSearchRadius));
+        tuning = h->tuning;
     }
-    if (!snap) return fail(FPE_E_NO_MAP, "no map uploaded");
-    fpe::derive_constants(*params, snap->g, maxRadius, pc);
-    if (fpe::spiral_rings(maxRadius, snap->g.res) > h->maxRing)
+    if (!cp.snap) return fail(FPE_E_NO_MAP, "no map uploaded");
+    MapSnapshot& snap = *cp.snap;
+    fpe::PlanConsts& pc = cp.pc;
+    fpe::derive_constants(*params, snap.g, maxRadius, tuning, pc);
+    if (fpe::spiral_rings(maxRadius, snap.g.res) > h->maxRing)
         return fail(FPE_E_UNSUPPORTED, "search radius needs more spiral rings than the rank table holds");
-    planLds = fpe::plan_lds_bytes(pc);
-    searchLds = fpe::search_lds_bytes(pc);
-    if (planLds > kMaxLdsBytes || searchLds > kMaxLdsBytes)
+    cp.planLds = fpe::plan_lds_bytes(pc);
+    cp.searchLds = fpe::search_lds_bytes(pc);
+    if (cp.planLds > kMaxLdsBytes || cp.searchLds > kMaxLdsBytes)
         return fail(FPE_E_UNSUPPORTED, "search/foot radius too large for the 160 KiB LDS tile");
     FPE_HIP(hipSetDevice(h->device));
-    if (std::max(planLds, searchLds) > 48 * 1024) {
-        std::lock_guard<std::mutex> lk(h->mu);
-        if (std::max(planLds, searchLds) > h->ldsConfigured) {
-            FPE_HIP(fpe::set_max_lds(planLds, searchLds));
-            h->ldsConfigured = std::max(planLds, searchLds);
+    FPE_HIP(snap.wait_ready(stream));
+    cp.useBits = wantBits && fpe::bits_supported(pc, snap.g);
+    if (cp.useBits) {
+        std::lock_guard<std::mutex> lk(snap.mu);
+        MaskSet* found = nullptr;
+        for (MaskSet& ms : snap.masks)
+            if (std::memcmp(&ms.thrD, &pc.thrDefault, 4) == 0 && std::memcmp(&ms.thrC, &pc.thrCandidate, 4) == 0) found = &ms;
+        if (!found && snap.masks.size() >= 4) {
+            // more threshold pairs than a snapshot keeps planes for (sets are never evicted while the snapshot
+            // lives: another call may be reading them): this call runs the direct kernels
+            cp.useBits = false;
+            return FPE_OK;
         }
+        if (!found) {
+            MaskSet ms;
+            ms.thrD = pc.thrDefault;
+            ms.thrC = pc.thrCandidate;
+            ms.n = fpe::bitmap_words(snap.g.rows, snap.g.cols, &ms.strideW, &ms.nw);
+            float* buf = nullptr;
+            FPE_HIP(alloc_units(*snap.pool, ms.n, &buf));
+            ms.d_words = reinterpret_cast<uint32_t*>(buf);
+            hipError_t e = fpe::launch_build_bitmap(snap.d_trav, snap.g.rows, snap.g.cols, pc.thrDefault, pc.thrCandidate,
+                                                    ms.d_words, stream);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ms.ready, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(ms.ready, stream);
+            if (e != hipSuccess) {
+                snap.pool->give(ms.n, buf);
+                return fail_hip(e, "bit-plane build");
+            }
+            snap.masks.push_back(ms);
+            found = &snap.masks.back();
+        }
+        cp.bits = fpe::BitMap{reinterpret_cast<const uint4*>(found->d_words), found->strideW, found->nw};
+        cp.bitsReady = found->ready;
+        FPE_HIP(hipStreamWaitEvent(stream, cp.bitsReady, 0));
     }
     return FPE_OK;
 }
@@ -232,11 +348,8 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
     snap->g = fpe::make_geom(desc->rows, desc->cols, desc->resolution, desc->position[0], desc->position[1]);
     snap->n = n;
     snap->pool = h->pool;
-    snap->d_trav = h->pool->take(n);
-    snap->d_elev = h->pool->take(n);
-    // tail padding: the row scan reads whole 16-byte groups, up to 96 B per row (fpe_kernels.hip::rows_issue)
-    if (!snap->d_trav) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&snap->d_trav), n * sizeof(float) + kLayerPadBytes));
-    if (!snap->d_elev) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&snap->d_elev), n * sizeof(float) + kLayerPadBytes));
+    FPE_HIP(alloc_units(*h->pool, n, &snap->d_trav));
+    FPE_HIP(alloc_units(*h->pool, n, &snap->d_elev));
     const bool canonical = desc->storage_order == 1 && desc->start_index[0] == 0 && desc->start_index[1] == 0;
     const float* src[2] = {trav, elev};
     float* dst[2] = {snap->d_trav, snap->d_elev};
@@ -252,8 +365,7 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
     } stagingGuard{h->pool, n};
     float*& staging = stagingGuard.p;
     if (!srcOnDevice && !canonical) {
-        staging = h->pool->take(n);
-        if (!staging) FPE_HIP(hipMalloc(reinterpret_cast<void**>(&staging), n * sizeof(float) + kLayerPadBytes));
+        FPE_HIP(alloc_units(*h->pool, n, &staging));
     }
     for (int l = 0; l < 2; ++l) {
         if (canonical) {
@@ -270,10 +382,17 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
         }
         if (!srcOnDevice) FPE_HIP(hipStreamSynchronize(stream));  // host buffers may be freed on return
     }
+    // consumers on other streams wait for this event before their first kernel (device-source uploads are
+    // asynchronous; host-source uploads have been synchronised above, the event is then already complete)
+    FPE_HIP(hipEventCreateWithFlags(&snap->ready, hipEventDisableTiming));
+    FPE_HIP(hipEventRecord(snap->ready, stream));
+    std::shared_ptr<MapSnapshot> old;
     {
         std::lock_guard<std::mutex> lk(h->mu);
+        old = std::move(h->map);
         h->map = snap;  // readers holding the old snapshot keep it alive until they finish
     }
+    old.reset();  // outside the engine lock: ~MapSnapshot may wait for the old snapshot's last asynchronous readers
     return FPE_OK;
 }
 
@@ -300,6 +419,11 @@ int fpe_create(int device_id, fpe_handle* out) {
     fpe_engine* h = new (std::nothrow) fpe_engine();
     if (!h) return fail(FPE_E_NOMEM, "out of host memory");
     h->device = device_id;
+    // tuning defaults: the environment is read HERE, once per engine — never in the per-call path
+    if (const char* v = std::getenv("FPE_PLAN_GROUP")) h->tuning.planGroup = std::atoi(v);
+    if (std::getenv("FPE_LITERAL_DISCS")) h->tuning.literalDiscs = 1;
+    if (std::getenv("FPE_NO_MID_VARIANT")) h->tuning.noMidVariant = 1;
+    if (std::getenv("FPE_NO_BITS")) h->tuning.noBits = 1;
     fpe::SpiralTable t;
     fpe::build_spiral_table(fpe::kMaxRings, t);
     h->maxRing = t.maxRing;
@@ -321,6 +445,9 @@ int fpe_create(int device_id, fpe_handle* out) {
     FPE_HIP_C(hipMemcpy(h->d_dj, t.dj.data(), n * sizeof(int16_t), hipMemcpyHostToDevice));
     FPE_HIP_C(hipMemcpy(h->d_ring, t.ring.data(), n * sizeof(uint8_t), hipMemcpyHostToDevice));
     FPE_HIP_C(hipMemcpy(h->d_ringStart, t.ringStart.data(), t.ringStart.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    // every kernel may use the whole 160 KiB of LDS: set once per process and device, never lowered again (a
+    // second engine on the same device sets the same value)
+    FPE_HIP_C(fpe::set_max_lds(kMaxLdsBytes, kMaxLdsBytes));
 #undef FPE_HIP_C
     *out = h;
     return FPE_OK;
@@ -336,6 +463,18 @@ int fpe_destroy(fpe_handle h) {
     if (h->d_ringStart) (void)hipFree(h->d_ringStart);
     h->map.reset();
     delete h;
+    return FPE_OK;
+}
+
+int fpe_set_tuning(fpe_handle h, const char* key, int32_t value) {
+    if (!h || !key) return fail(FPE_E_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    const std::string k(key);
+    if (k == "plan_group") h->tuning.planGroup = value;
+    else if (k == "literal_discs") h->tuning.literalDiscs = value ? 1 : 0;
+    else if (k == "no_mid_variant") h->tuning.noMidVariant = value ? 1 : 0;
+    else if (k == "no_bits") h->tuning.noBits = value ? 1 : 0;
+    else return fail(FPE_E_INVALID_ARG, "unknown tuning key: " + k);
     return FPE_OK;
 }
 
@@ -373,17 +512,28 @@ int fpe_map_info(fpe_handle h, fpe_map_desc* out) {
     return FPE_OK;
 }
 
+// One chained-plan launch on `stream`: the bit-window kernels when the snapshot's bit planes apply, else the direct ones.
+static int launch_plan(fpe_engine* h, const CallPlan& cp, const fpe_pose* d_poses, int32_t B, int32_t n_cycles,
+                       const fpe_plan_out& d_out, hipStream_t stream) {
+    if (cp.useBits)
+        FPE_HIP(fpe::launch_plan_bits(dev_map(*cp.snap), cp.bits, cp.pc, h->lut(), d_poses, B, n_cycles, d_out, stream));
+    else
+        FPE_HIP(fpe::launch_plan_chained(dev_map(*cp.snap), cp.pc, h->lut(), d_poses, B, n_cycles, d_out, stream));
+    return FPE_OK;
+}
+
 int fpe_plan_device(fpe_handle h, const fpe_params* params, const fpe_pose* d_poses, int32_t B, int32_t n_cycles,
                     const fpe_plan_out* d_out, void* stream) {
     if (!d_poses || !d_out) return fail(FPE_E_INVALID_ARG, "null argument");
     if (B <= 0 || n_cycles <= 0 || n_cycles > 255) return fail(FPE_E_INVALID_ARG, "B and n_cycles must be in [1, ..] / [1, 255]");
-    std::shared_ptr<MapSnapshot> snap;
-    fpe::PlanConsts pc;
-    size_t planLds, searchLds;
-    int rc = prepare_call(h, params, 0.0f, snap, pc, planLds, searchLds);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    CallPlan cp;
+    int rc = prepare_call(h, params, 0.0f, cp, st, true);
     if (rc != FPE_OK) return rc;
-    FPE_HIP(fpe::launch_plan_chained(dev_map(*snap), pc, h->lut(), d_poses, B, n_cycles, *d_out,
-                                     static_cast<hipStream_t>(stream)));
+    rc = launch_plan(h, cp, d_poses, B, n_cycles, *d_out, st);
+    if (rc != FPE_OK) return rc;
+    // the launch is asynchronous: the snapshot's buffers must not be recycled before it has completed
+    FPE_HIP(cp.snap->note_use(st));
     return FPE_OK;
 }
 
@@ -403,13 +553,7 @@ int fpe_plan(fpe_handle h, const fpe_params* params, const fpe_pose* poses, int3
                 return fail(FPE_E_INVALID_ARG, "unknown polygon kind");
         }
     }
-    std::shared_ptr<MapSnapshot> snap;
-    fpe::PlanConsts pc;
-    size_t planLds, searchLds;
-    int rc = prepare_call(h, params, maxRadius, snap, pc, planLds, searchLds);
-    if (rc != FPE_OK) return rc;
-
-    // one device arena + one pinned arena: [poses | nominal | centroid | default | cycle_ok | stance]
+    // one device arena + one pinned arena: [poses | nominal | centroid | default | cycle_ok | stance | selected | status]
     const size_t nRec = static_cast<size_t>(B) * n_cycles * 4;
     const size_t szPose = align256(static_cast<size_t>(B) * sizeof(fpe_pose));
     const size_t szNom = out->nominal ? align256(nRec * sizeof(fpe_foothold)) : 0;
@@ -417,10 +561,17 @@ int fpe_plan(fpe_handle h, const fpe_params* params, const fpe_pose* poses, int3
     const size_t szDef = out->default_next ? align256(nRec * 3 * sizeof(double)) : 0;
     const size_t szOk = out->cycle_ok ? align256(static_cast<size_t>(B) * n_cycles) : 0;
     const size_t szSt = out->stance ? align256(static_cast<size_t>(B) * 12 * sizeof(double)) : 0;
-    const size_t total = szPose + szNom + szCen + szDef + szOk + szSt;
+    const size_t szSel = out->selected ? align256(nRec * sizeof(fpe_selected_foothold)) : 0;
+    const size_t szPs = out->pose_status ? align256(static_cast<size_t>(B)) : 0;
+    const size_t total = szPose + szNom + szCen + szDef + szOk + szSt + szSel + szPs;
+    if (!h) return fail(FPE_E_INVALID_ARG, "null handle or params");
     CtxLease lease(h->ctxPool);
     CallCtx& cx = *lease.ctx;
+    FPE_HIP(hipSetDevice(h->device));
     FPE_HIP(cx.reserve(total));
+    CallPlan cp;
+    int rc = prepare_call(h, params, maxRadius, cp, cx.stream, true);
+    if (rc != FPE_OK) return rc;
     unsigned char* dp = cx.dev;
     unsigned char* hp = cx.pinned;
     std::memcpy(hp, poses, static_cast<size_t>(B) * sizeof(fpe_pose));
@@ -440,7 +591,9 @@ int fpe_plan(fpe_handle h, const fpe_params* params, const fpe_pose* poses, int3
     const size_t oCen = off; off += szCen;
     const size_t oDef = off; off += szDef;
     const size_t oOk = off; off += szOk;
-    const size_t oSt = off;
+    const size_t oSt = off; off += szSt;
+    const size_t oSel = off; off += szSel;
+    const size_t oPs = off;
     fpe_plan_out d;
     std::memset(&d, 0, sizeof(d));
     if (out->nominal) d.nominal = reinterpret_cast<fpe_foothold*>(dp + oNom);
@@ -448,9 +601,12 @@ int fpe_plan(fpe_handle h, const fpe_params* params, const fpe_pose* poses, int3
     if (out->default_next) d.default_next = reinterpret_cast<double*>(dp + oDef);
     if (out->cycle_ok) d.cycle_ok = dp + oOk;
     if (out->stance) d.stance = reinterpret_cast<double*>(dp + oSt);
+    if (out->selected) d.selected = reinterpret_cast<fpe_selected_foothold*>(dp + oSel);
+    if (out->pose_status) d.pose_status = dp + oPs;
     // every (pose, cycle, leg) record is written by the kernel (trot: all legs each cycle; walk: each
     // leg in its phase), so the buffers need no clearing
-    FPE_HIP(fpe::launch_plan_chained(dev_map(*snap), pc, h->lut(), reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, d, cx.stream));
+    rc = launch_plan(h, cp, reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, d, cx.stream);
+    if (rc != FPE_OK) return rc;
     if (total > szPose && !zeroCopy)  // results: one D2H copy of the whole result arena into pinned memory
         FPE_HIP(hipMemcpyAsync(hp + szPose, dp + szPose, total - szPose, hipMemcpyDeviceToHost, cx.stream));
     FPE_HIP(hipStreamSynchronize(cx.stream));
@@ -459,6 +615,8 @@ int fpe_plan(fpe_handle h, const fpe_params* params, const fpe_pose* poses, int3
     if (out->default_next) std::memcpy(out->default_next, hp + oDef, nRec * 3 * sizeof(double));
     if (out->cycle_ok) std::memcpy(out->cycle_ok, hp + oOk, static_cast<size_t>(B) * n_cycles);
     if (out->stance) std::memcpy(out->stance, hp + oSt, static_cast<size_t>(B) * 12 * sizeof(double));
+    if (out->selected) std::memcpy(out->selected, hp + oSel, nRec * sizeof(fpe_selected_foothold));
+    if (out->pose_status) std::memcpy(out->pose_status, hp + oPs, static_cast<size_t>(B));
     return FPE_OK;
 }
 
@@ -466,12 +624,12 @@ int fpe_search_legs_device(fpe_handle h, const fpe_params* params, const fpe_leg
                            fpe_foothold* d_out, void* stream) {
     if (!d_queries || !d_out) return fail(FPE_E_INVALID_ARG, "null argument");
     if (n <= 0) return fail(FPE_E_INVALID_ARG, "n must be positive");
-    std::shared_ptr<MapSnapshot> snap;
-    fpe::PlanConsts pc;
-    size_t planLds, searchLds;
-    int rc = prepare_call(h, params, 0.0f, snap, pc, planLds, searchLds);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    CallPlan cp;
+    int rc = prepare_call(h, params, 0.0f, cp, st, false);
     if (rc != FPE_OK) return rc;
-    FPE_HIP(fpe::launch_search_legs(dev_map(*snap), pc, h->lut(), d_queries, n, d_out, static_cast<hipStream_t>(stream)));
+    FPE_HIP(fpe::launch_search_legs(dev_map(*cp.snap), cp.pc, h->lut(), d_queries, n, d_out, st));
+    FPE_HIP(cp.snap->note_use(st));
     return FPE_OK;
 }
 
@@ -489,19 +647,19 @@ int fpe_search_legs(fpe_handle h, const fpe_params* params, const fpe_leg_query*
             return fail(FPE_E_INVALID_ARG, "too many polygon vertices");
         maxRadius = std::max(maxRadius, queries[k].search_radius);
     }
-    std::shared_ptr<MapSnapshot> snap;
-    fpe::PlanConsts pc;
-    size_t planLds, searchLds;
-    int rc = prepare_call(h, params, maxRadius, snap, pc, planLds, searchLds);
-    if (rc != FPE_OK) return rc;
+    if (!h) return fail(FPE_E_INVALID_ARG, "null handle or params");
     const size_t szQ = align256(static_cast<size_t>(n) * sizeof(fpe_leg_query));
     const size_t szO = align256(static_cast<size_t>(n) * sizeof(fpe_foothold));
     CtxLease lease(h->ctxPool);
     CallCtx& cx = *lease.ctx;
+    FPE_HIP(hipSetDevice(h->device));
     FPE_HIP(cx.reserve(szQ + szO));
+    CallPlan cp;
+    int rc = prepare_call(h, params, maxRadius, cp, cx.stream, false);
+    if (rc != FPE_OK) return rc;
     std::memcpy(cx.pinned, queries, static_cast<size_t>(n) * sizeof(fpe_leg_query));
     FPE_HIP(hipMemcpyAsync(cx.dev, cx.pinned, static_cast<size_t>(n) * sizeof(fpe_leg_query), hipMemcpyHostToDevice, cx.stream));
-    FPE_HIP(fpe::launch_search_legs(dev_map(*snap), pc, h->lut(), reinterpret_cast<const fpe_leg_query*>(cx.dev), n,
+    FPE_HIP(fpe::launch_search_legs(dev_map(*cp.snap), cp.pc, h->lut(), reinterpret_cast<const fpe_leg_query*>(cx.dev), n,
                                     reinterpret_cast<fpe_foothold*>(cx.dev + szQ), cx.stream));
     FPE_HIP(hipMemcpyAsync(cx.pinned + szQ, cx.dev + szQ, static_cast<size_t>(n) * sizeof(fpe_foothold), hipMemcpyDeviceToHost, cx.stream));
     FPE_HIP(hipStreamSynchronize(cx.stream));
@@ -541,7 +699,7 @@ int fpe_plan_service_report(fpe_handle h, const fpe_params* params, const double
         // the reference's loop body never runs (cpp:762); the stance comes from initialize()
         if (!h || !params) return fail(FPE_E_INVALID_ARG, "null handle or params");
         fpe::PlanConsts pc;
-        fpe::derive_constants(*params, fpe::make_geom(1, 1, 1.0, 0.0, 0.0), params->searchRadius, pc);
+        fpe::derive_constants(*params, fpe::make_geom(1, 1, 1.0, 0.0, 0.0), params->searchRadius, fpe::Tuning(), pc);
         for (int l = 0; l < 4; ++l) {
             double sx = (l == 0 || l == 3) ? pc.LbHalf : -pc.LbHalf;
             double sy = (l <= 1) ? pc.WbHalfNeg : pc.WbHalfPos;
@@ -557,23 +715,26 @@ int fpe_plan_service_report(fpe_handle h, const fpe_params* params, const double
         out.nominal = nominal.data();
         out.cycle_ok = ok.data();
         out.stance = stance;
+        uint8_t poseStatus = 0;
+        out.pose_status = &poseStatus;
         if (centroid || centroid_report) out.centroid = cen.data();
         if (default_footholds) out.default_next = dflt.data();
         int rc = fpe_plan(h, params, &pose, 1, N, &out);
         if (rc != FPE_OK) return rc;
+        if (poseStatus & FPE_POSE_OPT_SUBMAP_FAILED) {
+            // getGaitCycleSearchGridMap fails in the first gait cycle: the reference's handler logs "Failed to get
+            // gait-cycle search gridmap." and returns false before anything is appended beyond the stance
+            // (cpp:920-934); the ROS response is never assigned (cpp:1588 is not reached)
+            std::memset(response, 0, sizeof(*response));
+            if (centroid) std::memset(centroid, 0, sizeof(*centroid));
+            if (n_default_rows) *n_default_rows = 0;
+            if (nominal_report) std::memset(nominal_report, 0, sizeof(*nominal_report));
+            if (centroid_report) std::memset(centroid_report, 0, sizeof(*centroid_report));
+            return fail(FPE_E_SERVICE_FALSE, "getGaitCycleSearchGridMap: getSubmap failed in the first gait cycle (cpp:931-934)");
+        }
     }
     fpe::assemble_global_footholds(nominal.data(), ok.data(), stance, N, response);
-    if (centroid) {
-        // same bookkeeping with the centroid-track results (cpp:709-727, 1444-1462)
-        std::vector<fpe_foothold> asNominal(static_cast<size_t>(N) * 4);
-        for (size_t k = 0; k < asNominal.size(); ++k) {
-            std::memset(&asNominal[k], 0, sizeof(fpe_foothold));
-            asNominal[k].x = cen[k].x;
-            asNominal[k].y = cen[k].y;
-            asNominal[k].z = cen[k].z;
-        }
-        fpe::assemble_global_footholds(asNominal.data(), ok.data(), stance, N, centroid);
-    }
+    if (centroid) fpe::assemble_centroid_footholds(cen.data(), ok.data(), stance, N, centroid);
     if (nominal_report || centroid_report) {
         if (!params) return fail(FPE_E_INVALID_ARG, "null params");
         std::vector<double> xyz(static_cast<size_t>(N) * 12);

@@ -132,7 +132,7 @@ void derive_foot_offsets(float footRadius, const MapGeom& g, PlanConsts& c) {
     c.footReach = mx;
 }
 
-void derive_constants(const fpe_params& p, const MapGeom& geom, float maxSearchRadius, PlanConsts& c) {
+void derive_constants(const fpe_params& p, const MapGeom& geom, float maxSearchRadius, const Tuning& tuning, PlanConsts& c) {
     const double resolution = geom.res;
     std::memset(&c, 0, sizeof(c));
     c.footRadius = p.footRadius;
@@ -164,12 +164,34 @@ void derive_constants(const fpe_params& p, const MapGeom& geom, float maxSearchR
     c.RF_FIRST = p.RF_FIRST ? 1 : 0;
     c.maxSearchRadius = maxSearchRadius;
     c.tileH = tile_halfwidth(maxSearchRadius, p.footRadius, resolution);
+    {
+        // the per-leg LDS tile (tileW^2 flag bytes + 16 tileW of column crossings, fpe_kernels.hip::tile_total_bytes)
+        // doubles as float scratch of the ordered height sums, one float per visited cell of a foot-disc bounding
+        // box of up to (2 ceil(rf/res) + 2)^2 cells: a foot radius much larger than the search radius must not
+        // overrun it, so the tile grows until the scratch fits
+        const double boxSide = 2.0 * std::ceil(c.rf / resolution) + 2.0;
+        const double scratch = 4.0 * boxSide * boxSide;
+        while (static_cast<double>(2 * c.tileH + 1) * (2 * c.tileH + 1) + 16.0 * (2 * c.tileH + 1) < scratch && c.tileH < 4096) ++c.tileH;
+    }
     c.tileW = 2 * c.tileH + 1;
     c.tileWMagic = fastdiv_magic(static_cast<uint32_t>(c.tileW));
-    const char* grp = std::getenv("FPE_PLAN_GROUP");
-    c.groupOverride = grp ? std::atoi(grp) : 0;
-    const char* tr = std::getenv("FPE_TRACE_PTR");
-    c.trace = tr ? reinterpret_cast<unsigned long long*>(std::strtoull(tr, nullptr, 0)) : nullptr;
+    c.groupOverride = tuning.planGroup;
+    c.noMidVariant = tuning.noMidVariant;
+    c.noBits = tuning.noBits;
+    c.trace = nullptr;
+#ifdef FPE_TRACE  // profiling builds only (scratch/trace.py); the shipped library never reads the environment per call
+    if (const char* tr = std::getenv("FPE_TRACE_PTR")) c.trace = reinterpret_cast<unsigned long long*>(std::strtoull(tr, nullptr, 0));
+#endif
+    // isos_ (cpp:384-394): longEdge = lengthBase + skew*2 in f32 (hpp:666, 683), promoted on assignment to the
+    // double member (hpp:679); footSearchRect_.length = searchRadius_*2 and .width = searchRadius_ are f32 values
+    // stored in doubles (hpp:700-701); the sums are f64
+    {
+        const float longEdgeF = lengthBase + p.skew * 2;
+        const double longEdge = longEdgeF, shortEdge = widthBase;
+        const double rectLen = p.searchRadius * 2, rectWid = p.searchRadius;
+        c.isosLen = longEdge + rectLen;
+        c.isosWid = shortEdge + rectWid;
+    }
     derive_foot_offsets(p.footRadius, geom, c);
     // Middle cell of an unclamped 3x3 CircleIterator box.  The box rows are i0 = index(cx + r) .. i0 + 2 =
     // index(cx - r) (findSubmapParameters); cell i covers (x_i - res/2, x_i + res/2], so cx + r <= x_m + 1.5 res and
@@ -178,7 +200,7 @@ void derive_constants(const fpe_params& p, const MapGeom& geom, float maxSearchR
     // margin against rounding errors of order 1e-9 m (|coordinates| <= 1e6), so the reference's f64 test
     // dx*dx + dy*dy <= r^2 is true for that cell without evaluating it.
     c.midCellInside = (c.rf >= 0.9 * resolution) ? 1 : 0;
-    if (std::getenv("FPE_LITERAL_DISCS")) {
+    if (tuning.literalDiscs) {
         c.midCellInside = 0;
         c.footRobust = 0;
         c.footReach = static_cast<int>(std::ceil(c.rf / resolution)) + 1;
@@ -217,6 +239,38 @@ void assemble_global_footholds(const fpe_foothold* nominal, const uint8_t* cycle
             }
         } else {
             msg->success = 0;
+        }
+    }
+    msg->n_footholds = n;
+}
+
+// centroidGlobalFootholdsMsg_ (cpp:709-727, 1444-1462).  Unlike the nominal message its `success` is set false
+// once per call (cpp:711) and true on every committed cycle (cpp:1446) — a failed cycle never clears it again
+// (cpp:1574 touches nominalGlobalFootholdsMsg_ only) — and its `gait_cycles` field is never written (stays 0).
+void assemble_centroid_footholds(const fpe_centroid_foothold* cen, const uint8_t* cycleOk, const double* stance,
+                                 int nCycles, fpe_global_footholds* msg) {
+    std::memset(msg, 0, sizeof(*msg));
+    int n = 0;
+    for (int l = 0; l < 4; ++l) {
+        fpe_msg_foothold& f = msg->footholds[n++];
+        f.x = stance[l * 3 + 0];
+        f.y = stance[l * 3 + 1];
+        f.z = stance[l * 3 + 2];
+        f.foot_id = static_cast<uint8_t>(l);
+        f.gait_cycle_id = 0;
+    }
+    for (int g = 0; g < nCycles; ++g) {
+        if (!cycleOk[g]) continue;
+        msg->gait_cycles_succeed = static_cast<uint8_t>(g + 1);  // cpp:1445
+        msg->success = 1;                                        // cpp:1446
+        for (int l = 0; l < 4; ++l) {
+            const fpe_centroid_foothold& s = cen[g * 4 + l];
+            fpe_msg_foothold& f = msg->footholds[n++];
+            f.x = s.x;
+            f.y = s.y;
+            f.z = static_cast<double>(s.z);
+            f.foot_id = static_cast<uint8_t>(l);
+            f.gait_cycle_id = static_cast<uint8_t>(g);
         }
     }
     msg->n_footholds = n;

@@ -22,7 +22,7 @@ struct SpiralTable {
 void build_spiral_table(int nRings, SpiralTable& out);
 
 // initialize() constants with the reference's float/double typing (cpp:340-421, 2693).
-void derive_constants(const fpe_params& p, const MapGeom& g, float maxSearchRadius, PlanConsts& out);
+void derive_constants(const fpe_params& p, const MapGeom& g, float maxSearchRadius, const Tuning& tuning, PlanConsts& out);
 
 // Offsets of a cell-centred disc of radius double(footRadius) and the proof that they are
 // rounding-robust on this map (see PlanConsts::footRobust).
@@ -40,6 +40,9 @@ int validate_params(const fpe_params& p);
 // GlobalFootholds message content from one pose's plan outputs (cpp:591-699, 1378-1396, 1574).
 void assemble_global_footholds(const fpe_foothold* nominal, const uint8_t* cycleOk, const double* stance,
                                int nCycles, fpe_global_footholds* msg);
+// centroidGlobalFootholdsMsg_ content of one call (cpp:709-727, 1444-1462): its own bookkeeping, not the nominal one
+void assemble_centroid_footholds(const fpe_centroid_foothold* centroid, const uint8_t* cycleOk, const double* stance,
+                                 int nCycles, fpe_global_footholds* msg);
 void assemble_track_report(const double* resultXYZ, const uint8_t* cycleOk, const double* stance, int nCycles,
                            const fpe_params& params, fpe_track_report* rep);
 

@@ -3,22 +3,21 @@
 // Work decomposition.  A body pose is one chain of gait cycles (globalFootholdPlan, cpp:762-1579);
 // inside a cycle the four legs are independent (the reference's 4 std::thread(checkFoothold),
 // cpp:863-909).  A leg is searched by a GROUP of G lanes (template parameter):
-//   G = 16: one wavefront per pose, lanes 16*l..16*l+15 = leg l — the per-leg f64 geometry of the
-//           four legs runs as ONE vector instruction stream and the cross-leg exchange never
-//           leaves the wavefront (default for small tiles, e.g. 2 cm maps);
-//   G = 64: one workgroup of 4 wavefronts per pose, wavefront w = leg w (large tiles: 1 cm / 0.5 cm
-//           maps with 10^2..10^3 spiral candidates per leg).
-// Each group stages the traversability window it needs into LDS as one flag byte per cell (first
-// the region of the default disc + centroid rectangle; the full spiral window only when the
-// default foothold fails), then evaluates the default disc, the spiral candidates (rank table +
-// ballot = argmin of SpiralIterator rank), the centroid rectangle and the mean heights.
+//   G = 8 : two poses per wavefront, lanes 8*l..8*l+7 of a pose's half = leg l; 64-thread workgroups, no
+//           block barriers — the default for windows of <= 1024 cells (2 cm maps, 1 cm maps at R 0.1);
+//   G = 64: plan_sequential_kernel, one wavefront per pose, the swing legs of a phase searched one after the
+//           other with all 64 lanes — large windows (1 cm at R 0.15, 0.5 cm maps);
+//   G = 4 / 16 and the four-wavefronts-per-pose form of G = 64 exist for measurement (fpe_set_tuning "plan_group").
+// Direct kernels (this file's first part) read the f32 layers themselves: the default disc and the centroid
+// rectangle straight through L1/L2, the spiral window of large foot discs staged into LDS as flag bytes.
+// Bit-window kernels (second part, fpe_bits.hpp) read per-snapshot bit planes instead — one 32/64/96-bit row mask
+// per window row and lane — and touch the f32 elevation layer only for the mean heights.
+// Spiral candidates: lane = SpiralIterator rank, lowest set ballot bit = argmin of rank.
 // No MFMA: nothing here is a contraction.
 //
 // All geometry is f64 in the reference's expression order (fpe_gridmath.hpp); compile with
 // -ffp-contract=off.  Reference citations: "cpp:" = foothold_planner/src/FootholdPlanner.cpp.
 #include <hip/hip_runtime.h>
-
-#include <cstdlib>
 
 #include "fpe_device.hpp"
 
@@ -1272,6 +1271,17 @@ __device__ __forceinline__ double polygon_center_x(const double (*feet)[3]) {
     return sum_x / sum_s / 3.0;
 }
 
+// getGaitCycleSearchGridMap (cpp:2307-2349) in the FIRST gait cycle: the opt track's current feet are the shifted
+// stance like every other track's (setFirstGait, cpp:582-588), so the next feet centre is (centre.x + stepLength_,
+// initialPose_[1] + 0) and the gate is getSubmap(centre, isos_.length x isos_.width) succeeding (cpp:2345-2349).
+// Later cycles depend on the NLopt results and are not evaluated.
+__device__ __forceinline__ uint8_t opt_gate_cycle0(const MapGeom& g, const PlanConsts& pc, double ctrX, double y0) {
+    const double px = ctrX + pc.step;  // cpp:2327
+    const double py = y0 + 0.0;        // cpp:2329 with ajustedPose_[1] = 0 (cpp:759)
+    const bool ok = centre_usable(px, py) && submap_info(g, px, py, pc.isosLen, pc.isosWid).ok;
+    return ok ? 0 : static_cast<uint8_t>(FPE_POSE_OPT_SUBMAP_FAILED);
+}
+
 // LDS of one pose (all offsets multiples of 16).
 struct PoseShared {
     double cur[3][4][3];  // current feet of the default / centroid / nominal tracks (cpp:1338, 1413, 1480)
@@ -1436,6 +1446,13 @@ __device__ __forceinline__ void leg_phase(const DevMap& m, const PlanConsts& pc,
             if (live) {
                 const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
                 if (out.nominal) store_foothold(out.nominal + o, no, leg, cyc);
+                if (out.selected) {
+                    fpe_selected_foothold sf;
+                    sf.row = no.row; sf.col = no.col; sf.z = no.z;
+                    sf.valid = static_cast<uint8_t>(no.valid); sf.source = static_cast<uint8_t>(no.source);
+                    sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
+                    out.selected[o] = sf;
+                }
                 if (out.centroid) {
                     fpe_centroid_foothold cf;
                     cf.x = co.x; cf.y = co.y; cf.z = co.z; cf.row = co.row; cf.col = co.col;
@@ -1529,6 +1546,8 @@ __global__ __launch_bounds__(G == 64 ? 256 : 64, G == 64 ? 4 : (G == 16 ? FPE_MI
         }
     }
     pose_sync<G>();
+    if (out.pose_status && live && leg == 0 && g.sub == 0)
+        out.pose_status[b] = opt_gate_cycle0(m.g, pc, polygon_center_x(sh.cur[0]), y0);
 
     double adjY = 0.0;  // ajustedPose_[1], cpp:759
     const int nPhases = (gait == 1) ? 4 : 1;
@@ -1645,6 +1664,7 @@ __global__ __launch_bounds__(64, 4) void plan_sequential_kernel(DevMap m, PlanCo
         }
     }
     pose_sync<16>();
+    if (out.pose_status && tid == 0) out.pose_status[b] = opt_gate_cycle0(m.g, pc, polygon_center_x(sh.cur[0]), y0);
 
     double adjY = 0.0;  // ajustedPose_[1], cpp:759
     const int nPhases = (gait == 1) ? 4 : 1;
@@ -1828,11 +1848,11 @@ size_t search_lds_bytes(const PlanConsts& pc) {
 
 // The 3x3-only variant of the 8-lane kernel: foot radius in [0.9, 1] x resolution (a disc box then spans at most
 // three cells per axis) with a host-proved candidate foot disc of at most four cells (no LDS window: the staged
-// spiral path is not compiled into it), e.g. the reference's yaml footRadius 0.02 on a 2 cm map.  FPE_NO_MID_VARIANT=1 keeps the
-// generic kernel (tests run both).
+// spiral path is not compiled into it), e.g. the reference's yaml footRadius 0.02 on a 2 cm map.
+// fpe_set_tuning("no_mid_variant", 1) keeps the generic kernel (tests run both).
 static bool mid_variant(const PlanConsts& pc, double res) {
     return pc.midCellInside != 0 && pc.rf <= res && pc.footRobust != 0 && pc.nFoot <= kOnDemandMaxFoot &&
-           std::getenv("FPE_NO_MID_VARIANT") == nullptr;
+           pc.noMidVariant == 0;
 }
 
 hipError_t launch_plan_chained(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const fpe_pose* d_poses,
@@ -1872,6 +1892,19 @@ hipError_t launch_canonicalise(const float* d_src, float* d_dst, int rows, int c
     dim3 grid((cols + 31) / 32, (rows + 31) / 32);
     hipLaunchKernelGGL(canonicalise_layer_kernel, grid, dim3(256), 0, stream, d_src, d_dst, rows, cols, si, sj, srcRowMajor);
     return hipGetLastError();
+}
+
+// ---- bit-window path: placeholders until fpe_bits.hpp lands -----------------------------------------------
+size_t bitmap_words(int rows, int cols, int* strideW, int* nw) {
+    *nw = (cols + 31) / 32;
+    *strideW = *nw + 2 * kBitPadW;
+    return static_cast<size_t>(rows + 2) * (*strideW) * 4;
+}
+hipError_t launch_build_bitmap(const float*, int, int, float, float, uint32_t*, hipStream_t) { return hipErrorNotSupported; }
+bool bits_supported(const PlanConsts&, const MapGeom&) { return false; }
+hipError_t launch_plan_bits(const DevMap&, const BitMap&, const PlanConsts&, const SpiralLut&, const fpe_pose*, int, int,
+                            const fpe_plan_out&, hipStream_t) {
+    return hipErrorNotSupported;
 }
 
 hipError_t set_max_lds(size_t planBytes, size_t searchBytes) {

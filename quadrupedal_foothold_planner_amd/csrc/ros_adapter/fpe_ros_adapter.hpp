@@ -1,7 +1,11 @@
 // fpe_ros_adapter.hpp — header-only glue between the reference's ROS node and libfpe.so.
 //
-// NOT built in this repository (neither this image nor the GPU box has ROS1 / grid_map): compile
-// it inside the reference's catkin package with -DFPE_WITH_ROS and link -lfpe.  It keeps the
+// Not linked in this repository (neither this image nor the GPU box has ROS1 / grid_map): compile
+// it inside the reference's catkin package with -DFPE_WITH_ROS and link -lfpe.  tests/test_cpu_abi_and_host.py
+// parses it (-fsyntax-only) against a minimal mock of the few ROS / grid_map types it touches (tests/probe/ros_mock).
+// Thread safety: the service handler may run concurrently with itself under AsyncSpinner(0)
+// (foothold_planner_node.cpp:12), so every response / report buffer lives on the CALLER's stack (heap for the
+// 33 KB message structs) — the adapter has no mutable members besides the engine handle.  It keeps the
 // service name, message types and subscriber of the reference untouched (cpp:188, cpp:219, cpp:237)
 // and only replaces (a) the body of gridmapCallback's map copy and (b) the per-cycle loop of
 // globalFootholdPlan for the nominal response.  See INTEGRATION.md for the three call sites.
@@ -15,6 +19,7 @@
 
 #include <algorithm>
 #include <array>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -53,21 +58,10 @@ public:
     // the node's ROS parameters with their member types (readParameters, cpp:248-314).
     bool plan(const fpe_params& params, const double initialPose[3], uint8_t gaitCycles,
               foothold_planner_msgs::GlobalFootholds& msg) {
-        if (fpe_plan_service(h_, &params, initialPose, gaitCycles, &resp_) != FPE_OK) return false;  // cpp:566/933: service fails
-        msg.success = resp_.success;
-        msg.gait_cycles = resp_.gait_cycles;
-        msg.gait_cycles_succeed = resp_.gait_cycles_succeed;
-        msg.footholds.clear();  // cpp:591
-        msg.footholds.reserve(resp_.n_footholds);
-        for (int k = 0; k < resp_.n_footholds; ++k) {
-            foothold_planner_msgs::Foothold f;
-            f.point.x = resp_.footholds[k].x;
-            f.point.y = resp_.footholds[k].y;
-            f.point.z = resp_.footholds[k].z;
-            f.foot_id = resp_.footholds[k].foot_id;
-            f.gait_cycle_id = resp_.footholds[k].gait_cycle_id;
-            msg.footholds.push_back(f);
-        }
+        std::unique_ptr<fpe_global_footholds> resp(new fpe_global_footholds);  // per call: handlers may run concurrently
+        // FPE_E_SERVICE_FALSE included: the reference's handler returns false there too (cpp:566 / cpp:931-934)
+        if (fpe_plan_service(h_, &params, initialPose, gaitCycles, resp.get()) != FPE_OK) return false;
+        fill(*resp, msg, true);  // cpp:591 clears the nominal message
         return true;
     }
 
@@ -83,11 +77,20 @@ public:
                        std::vector<double>& feetDistanceCentroid) {
         std::vector<double> rows(static_cast<size_t>(1 + gaitCycles) * 12);
         int32_t nRows = 0;
-        if (fpe_plan_service_report(h_, &params, initialPose, gaitCycles, &resp_, &cen_, rows.data(), &nRows, &repNominal_,
-                                    &repCentroid_) != FPE_OK)
+        // per-call buffers (no shared members): two service calls may be in flight at once
+        std::unique_ptr<fpe_global_footholds> resp(new fpe_global_footholds), cen(new fpe_global_footholds);
+        std::unique_ptr<fpe_track_report> repNominal(new fpe_track_report), repCentroid(new fpe_track_report);
+        const fpe_track_report& repNominal_ = *repNominal;
+        const fpe_track_report& repCentroid_ = *repCentroid;
+        if (fpe_plan_service_report(h_, &params, initialPose, gaitCycles, resp.get(), cen.get(), rows.data(), &nRows,
+                                    repNominal.get(), repCentroid.get()) != FPE_OK)
             return false;
-        fill(resp_, msg, true);
-        fill(cen_, centroidMsg, false);
+        fill(*resp, msg, true);
+        // centroidGlobalFootholdsMsg_ is never cleared between calls (cpp:715): append; its gait_cycles field is
+        // never written by the reference, so the caller's value is kept
+        const uint8_t keepGaitCycles = centroidMsg.gait_cycles;
+        fill(*cen, centroidMsg, false);
+        centroidMsg.gait_cycles = keepGaitCycles;
         defaultFootholds.clear();  // cpp:601
         for (int r = 0; r < nRows; ++r) {
             std::array<double, 12> row;
@@ -132,9 +135,7 @@ private:
             path.poses.push_back(p);
         }
     }
-    fpe_handle h_ = nullptr;
-    fpe_global_footholds resp_, cen_;
-    fpe_track_report repNominal_, repCentroid_;
+    fpe_handle h_ = nullptr;  // the only member: fpe_* entry points are thread-safe per include/fpe.h
 };
 
 }  // namespace fpe_ros

@@ -11,6 +11,7 @@ import torch
 import torch.distributed as dist
 
 from ._capi import FOOTHOLD_DTYPE
+from ._capi import SELECTED_DTYPE as _SELECTED_DTYPE
 
 
 def shard_range(total, rank, world):
@@ -58,25 +59,10 @@ def all_gather_records(local, total_poses, pose_bytes):
 
 
 # The exchange record of a selected foothold (16 B per foothold): what north_star asks every
-# rank to end up with — the chosen grid index and the height — plus the flag bytes.  It is words 0, 1, 6, 7 of the
-# 32-byte fpe_foothold (row, col | z | valid, source, foot_id, gait_cycle_id); x and y stay with the owning rank.
-SELECTED_DTYPE = np.dtype(
-    [("row", "<i4"), ("col", "<i4"), ("z", "<f4"), ("valid", "u1"), ("source", "u1"), ("foot_id", "u1"), ("gait_cycle_id", "u1")]
-)
-_SELECT_WORDS = {}
-
-
-def pack_selected(records_u8, out=None):
-    """fpe_foothold records (uint8 tensor, 32 B each) -> SELECTED_DTYPE records (uint8 tensor, 16 B each), one
-    index_select on the records' stream; `out` (uint8, half the size) is written in place when given."""
-    w = records_u8.view(torch.int32).view(-1, 8)
-    key = str(records_u8.device)
-    if key not in _SELECT_WORDS:
-        _SELECT_WORDS[key] = torch.tensor([0, 1, 6, 7], dtype=torch.int64, device=records_u8.device)
-    if out is None:
-        return torch.index_select(w, 1, _SELECT_WORDS[key]).view(torch.uint8).view(-1)
-    torch.index_select(w, 1, _SELECT_WORDS[key], out=out.view(torch.int32).view(-1, 4))
-    return out
+# rank to end up with — the chosen grid index and the height — plus the flag bytes.  It is `fpe_selected_foothold`
+# of include/fpe.h, written by the plan kernels themselves as the `selected` product of fpe_plan_out (x and y stay
+# with the owning rank): the exchange needs no packing pass.
+SELECTED_DTYPE = _SELECTED_DTYPE
 
 
 class FootholdExchange:
@@ -89,8 +75,8 @@ class FootholdExchange:
 
         ex = FootholdExchange(local_bytes, device)
         for k in range(steps):
-            buf = ex.acquire(k)          # device block the plan of step k writes its footholds into
-            plan(..., buf.data_ptr())
+            buf = ex.acquire(k)          # device block the plan of step k writes its selected records into
+            plan(..., d_selected_ptr=buf.data_ptr())
             ex.gather(k)                 # asynchronous all-gather of that block
         all_footholds = ex.result(steps - 1)   # [world * local_bytes], waits for that step only
         ex.drain()

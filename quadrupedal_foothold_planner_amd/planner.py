@@ -6,13 +6,14 @@
 `plan_device` are the build-defined batch axis.  There is no CPU path: if
 libfpe.so cannot be loaded or no gfx950 GPU is present, construction raises EngineUnavailable.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
 
 from . import _capi
 from ._capi import (CENTROID_DTYPE, FOOTHOLD_DTYPE, GLOBAL_FOOTHOLDS_DTYPE, POSE_DTYPE, PARAMS_DTYPE, QUERY_DTYPE,
-                    TRACK_REPORT_DTYPE, EngineUnavailable, MapDesc, PlanOut, ptr)
+                    SELECTED_DTYPE, TRACK_REPORT_DTYPE, EngineUnavailable, MapDesc, PlanOut, ptr)
 
 
 class FpeError(RuntimeError):
@@ -97,35 +98,48 @@ class FootholdPlanner:
     def set_max_leg_search_radius(self, r):
         self._check(self._lib.fpe_set_max_leg_search_radius(self._h, np.float32(r)))
 
+    def set_tuning(self, **kw):
+        """fpe_set_tuning: plan_group, literal_discs, no_mid_variant, no_bits (build-defined test / tuning knobs)."""
+        for k, v in kw.items():
+            self._check(self._lib.fpe_set_tuning(self._h, k.encode(), int(v)))
+
+    @contextlib.contextmanager
+    def tuning(self, **kw):
+        """Set knobs for the duration of a with-block, then restore the automatic defaults (0)."""
+        self.set_tuning(**kw)
+        try:
+            yield self
+        finally:
+            self.set_tuning(**{k: 0 for k in kw})
+
     # ---- chained plan, host buffers ------------------------------------------------------------------
-    def plan(self, poses, n_cycles, products=("nominal", "centroid", "default", "cycle_ok", "stance")):
+    def plan(self, poses, n_cycles, products=("nominal", "centroid", "default", "cycle_ok", "stance", "selected", "pose_status"),
+             out=None):
+        """fpe_plan with host buffers.  `out`: a dict returned by an earlier call with the same shapes (timing loops
+        reuse the arrays instead of allocating ~100 B per foothold per call)."""
         poses = np.ascontiguousarray(poses, dtype=POSE_DTYPE)
         B = poses.shape[0]
-        out = {}
+        shapes = {
+            "nominal": ((B, n_cycles, 4), FOOTHOLD_DTYPE), "centroid": ((B, n_cycles, 4), CENTROID_DTYPE),
+            "default": ((B, n_cycles, 4, 3), np.float64), "cycle_ok": ((B, n_cycles), np.uint8),
+            "stance": ((B, 4, 3), np.float64), "selected": ((B, n_cycles, 4), SELECTED_DTYPE), "pose_status": ((B,), np.uint8),
+        }
+        fields = {"nominal": "nominal", "centroid": "centroid", "default": "default_next", "cycle_ok": "cycle_ok",
+                  "stance": "stance", "selected": "selected", "pose_status": "pose_status"}
+        if out is None:
+            out = {k: np.zeros(shapes[k][0], dtype=shapes[k][1]) for k in products}
         po = PlanOut()
-        if "nominal" in products:
-            out["nominal"] = np.zeros((B, n_cycles, 4), dtype=FOOTHOLD_DTYPE)
-            po.nominal = ptr(out["nominal"])
-        if "centroid" in products:
-            out["centroid"] = np.zeros((B, n_cycles, 4), dtype=CENTROID_DTYPE)
-            po.centroid = ptr(out["centroid"])
-        if "default" in products:
-            out["default"] = np.zeros((B, n_cycles, 4, 3), dtype=np.float64)
-            po.default_next = ptr(out["default"])
-        if "cycle_ok" in products:
-            out["cycle_ok"] = np.zeros((B, n_cycles), dtype=np.uint8)
-            po.cycle_ok = ptr(out["cycle_ok"])
-        if "stance" in products:
-            out["stance"] = np.zeros((B, 4, 3), dtype=np.float64)
-            po.stance = ptr(out["stance"])
+        for k in products:
+            assert out[k].shape == shapes[k][0] and out[k].dtype == shapes[k][1]
+            setattr(po, fields[k], ptr(out[k]))
         self._check(self._lib.fpe_plan(self._h, ptr(self.params), ptr(poses), B, int(n_cycles), C.byref(po)))
         return out
 
     # ---- chained plan, device-resident (torch tensors / raw pointers) ----------------------------------
     def plan_device(self, d_poses_ptr, B, n_cycles, d_nominal_ptr=0, d_centroid_ptr=0, d_default_ptr=0,
-                    d_cycle_ok_ptr=0, d_stance_ptr=0, stream=0):
+                    d_cycle_ok_ptr=0, d_stance_ptr=0, stream=0, d_selected_ptr=0, d_pose_status_ptr=0):
         po = PlanOut(d_nominal_ptr or None, d_centroid_ptr or None, d_default_ptr or None, d_cycle_ok_ptr or None,
-                     d_stance_ptr or None)
+                     d_stance_ptr or None, d_selected_ptr or None, d_pose_status_ptr or None)
         self._check(self._lib.fpe_plan_device(self._h, ptr(self.params), C.c_void_p(d_poses_ptr), int(B), int(n_cycles),
                                               C.byref(po), C.c_void_p(stream or 0)))
 
@@ -158,21 +172,28 @@ class FootholdPlanner:
                 "cog_speed": r["cog_speed"][: int(r["n_kpi"])].copy()}
 
     def globalFootholdPlan(self, gait_cycles, initial_position, all_tracks=False):
-        """Response content of the service; with all_tracks also the centroid message, the default-track
+        """Response content of the service, or False where the reference's handler returns false
+        (getGaitCycleSearchGridMap fails in the first gait cycle, cpp:920-934); with all_tracks also the centroid message, the default-track
         rows (global_footholds_centroid, globalFootholdsResult_.defaultFootholds), and per track the
         feet-centre path and KPIs (nominal/centroid_feet_center_path, footholdsKPI_)."""
         msg = np.zeros(1, dtype=GLOBAL_FOOTHOLDS_DTYPE)
         pos = np.ascontiguousarray(initial_position, dtype=np.float64).reshape(3)
         if not all_tracks:
-            self._check(self._lib.fpe_plan_service(self._h, ptr(self.params), ptr(pos), int(gait_cycles) & 0xFF, ptr(msg)))
+            rc = self._lib.fpe_plan_service(self._h, ptr(self.params), ptr(pos), int(gait_cycles) & 0xFF, ptr(msg))
+            if rc == _capi.FPE_E_SERVICE_FALSE:
+                return False  # the reference's handler returns false here (cpp:931-934): the ROS call fails
+            self._check(rc)
             return self._msg(msg[0])
         cen = np.zeros(1, dtype=GLOBAL_FOOTHOLDS_DTYPE)
         dflt = np.zeros((1 + int(gait_cycles), 4, 3), dtype=np.float64)
         nrows = C.c_int32(0)
         rep = np.zeros(2, dtype=TRACK_REPORT_DTYPE)
-        self._check(self._lib.fpe_plan_service_report(self._h, ptr(self.params), ptr(pos), int(gait_cycles) & 0xFF, ptr(msg),
-                                                      ptr(cen), ptr(dflt), C.cast(C.byref(nrows), C.c_void_p),
-                                                      ptr(rep[0:1]), ptr(rep[1:2])))
+        rc = self._lib.fpe_plan_service_report(self._h, ptr(self.params), ptr(pos), int(gait_cycles) & 0xFF, ptr(msg),
+                                               ptr(cen), ptr(dflt), C.cast(C.byref(nrows), C.c_void_p),
+                                               ptr(rep[0:1]), ptr(rep[1:2]))
+        if rc == _capi.FPE_E_SERVICE_FALSE:
+            return False
+        self._check(rc)
         out = self._msg(msg[0])
         out["centroid"] = self._msg(cen[0])
         out["default_footholds"] = dflt[: nrows.value].copy()

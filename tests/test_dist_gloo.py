@@ -69,7 +69,7 @@ def _pipelined_worker(rank, world, port, B, n_cycles, steps, tmpdir):
     local_bytes = (hi - lo) * n_cycles * 4 * fdist.SELECTED_DTYPE.itemsize  # the 16 B exchange records
     ex = fdist.FootholdExchange(local_bytes, torch.device("cpu"))
 
-    def selected(nominal):  # what pack_selected must produce, field by field
+    def selected(nominal):  # the `selected` product of a plan (fpe_selected_foothold), field by field
         o = np.zeros(nominal.size, dtype=fdist.SELECTED_DTYPE)
         flat = nominal.reshape(-1)
         for f in ("row", "col", "z", "valid", "source"):
@@ -82,7 +82,7 @@ def _pipelined_worker(rank, world, port, B, n_cycles, steps, tmpdir):
         poses = synth.poses_in_map(B, 3.2, 3.2, n_cycles, 0.18, seed=40 + k, margin=0.65)
         buf = ex.acquire(k)
         out = omap.plan(yaml_params(), to_oracle_poses(poses[lo:hi]), n_cycles)
-        fdist.pack_selected(torch.from_numpy(np.ascontiguousarray(out["nominal"]).view(np.uint8).reshape(-1)), out=buf)
+        buf.copy_(torch.frombuffer(bytearray(selected(out["nominal"])), dtype=torch.uint8))
         ex.gather(k)
         expected.append(selected(omap.plan(yaml_params(), to_oracle_poses(poses), n_cycles)["nominal"]))
         if k >= 1:  # read step k-1 while step k's exchange is in flight

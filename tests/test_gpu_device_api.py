@@ -1,0 +1,245 @@
+"""Parity of the DEVICE-RESIDENT entry points (what bench.py times) and of the open-loop mode against the
+chained plan.  Everything goes through the C ABI; torch is only the owner of device buffers and streams."""
+import numpy as np
+import pytest
+
+from oracle import fpo
+from quadrupedal_foothold_planner_amd import _capi, synth
+from quadrupedal_foothold_planner_amd.planner import FootholdPlanner, FpeError, make_poses
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def planner():
+    p = FootholdPlanner(0)
+    yield p
+    p.close()
+
+
+def _device_plan(planner, torch, dev, stream, trav, elev, res, poses, n_cycles, upload_stream=None):
+    """upload_map_device + plan_device with torch-owned buffers; returns the same dict planner.plan() does."""
+    rows, cols = trav.shape
+    B = poses.shape[0]
+    n_rec = B * n_cycles * 4
+    up = upload_stream or stream
+    with torch.cuda.stream(up):
+        d_trav = torch.from_numpy(trav).to(dev, non_blocking=False)
+        d_elev = torch.from_numpy(elev).to(dev, non_blocking=False)
+        planner.upload_map_device(d_trav.data_ptr(), d_elev.data_ptr(), rows, cols, res, stream=up.cuda_stream)
+    with torch.cuda.stream(stream):
+        d_poses = torch.from_numpy(poses.view(np.uint8).reshape(-1).copy()).to(dev)
+        bufs = {
+            "nominal": torch.zeros(n_rec * _capi.FOOTHOLD_DTYPE.itemsize, dtype=torch.uint8, device=dev),
+            "centroid": torch.zeros(n_rec * _capi.CENTROID_DTYPE.itemsize, dtype=torch.uint8, device=dev),
+            "default": torch.zeros(n_rec * 3, dtype=torch.float64, device=dev),
+            "cycle_ok": torch.zeros(B * n_cycles, dtype=torch.uint8, device=dev),
+            "stance": torch.zeros(B * 12, dtype=torch.float64, device=dev),
+            "selected": torch.zeros(n_rec * _capi.SELECTED_DTYPE.itemsize, dtype=torch.uint8, device=dev),
+            "pose_status": torch.zeros(B, dtype=torch.uint8, device=dev),
+        }
+    stream.synchronize()  # the input copies above ran on `stream`; the plan below is asynchronous on it
+    planner.plan_device(d_poses.data_ptr(), B, n_cycles, bufs["nominal"].data_ptr(), bufs["centroid"].data_ptr(),
+                        bufs["default"].data_ptr(), bufs["cycle_ok"].data_ptr(), bufs["stance"].data_ptr(),
+                        stream=stream.cuda_stream, d_selected_ptr=bufs["selected"].data_ptr(),
+                        d_pose_status_ptr=bufs["pose_status"].data_ptr())
+    stream.synchronize()
+    host = {k: v.cpu().numpy() for k, v in bufs.items()}
+    return {
+        "nominal": host["nominal"].view(_capi.FOOTHOLD_DTYPE).reshape(B, n_cycles, 4),
+        "centroid": host["centroid"].view(_capi.CENTROID_DTYPE).reshape(B, n_cycles, 4),
+        "default": host["default"].reshape(B, n_cycles, 4, 3),
+        "cycle_ok": host["cycle_ok"].reshape(B, n_cycles),
+        "stance": host["stance"].reshape(B, 4, 3),
+        "selected": host["selected"].view(_capi.SELECTED_DTYPE).reshape(B, n_cycles, 4),
+        "pose_status": host["pose_status"],
+    }
+
+
+def _oracle_plan(planner, trav, elev, res, poses, n_cycles):
+    omap = fpo.OracleMap(trav, elev, res)
+    op, opo = util.to_oracle_params(planner.params), util.to_oracle_poses(poses)
+    ora = omap.plan(op, opo, n_cycles, threads=8)
+    ora["pose_status"] = omap.pose_status(op, opo)
+    return ora
+
+
+@pytest.mark.parametrize("case", ["headline_2cm", "rough_1cm_r012", "walk_mixed_1cm"])
+def test_device_entry_points_on_a_side_stream(planner, case):
+    """fpe_upload_map_device + fpe_plan_device (the calls bench.py times) with torch buffers on a NON-default
+    stream, compared record by record with the oracle."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    planner.params = _capi.params_yaml()
+    if case == "headline_2cm":
+        trav, elev = synth.rough_map(1000, 1000, 0.02, seed=1)
+        res, n = 0.02, 8
+        poses = synth.poses_in_map(1024, 20.0, 20.0, n, 0.18, seed=6)
+    elif case == "rough_1cm_r012":
+        planner.params["searchRadius"] = np.float32(0.12)
+        trav, elev = synth.rough_map(700, 700, 0.01, seed=31, bad_frac=0.1)
+        res, n = 0.01, 6
+        poses = synth.poses_in_map(256, 7.0, 7.0, n, 0.18, seed=32, margin=0.7)
+    else:
+        planner.params["searchRadius"] = np.float32(0.15)
+        trav, elev = synth.rough_map(600, 600, 0.01, seed=33, bad_frac=0.08)
+        res, n = 0.01, 5
+        poses = synth.poses_in_map(128, 6.0, 6.0, n, 0.18, seed=34, margin=0.7)
+        poses["gait"][::2] = 1
+    side = torch.cuda.Stream(device=dev)
+    eng = _device_plan(planner, torch, dev, side, trav, elev, res, poses, n)
+    util.assert_plan_equal(eng, _oracle_plan(planner, trav, elev, res, poses, n))
+    planner.params = _capi.params_yaml()
+
+
+def test_plan_on_one_stream_right_after_an_upload_on_another(planner):
+    """The new snapshot is published before its asynchronous device-to-device upload has completed: a plan on a
+    DIFFERENT stream must wait for it (MapSnapshot::ready), and an upload that follows an asynchronous plan must not
+    recycle the layers that plan still reads (MapSnapshot::note_use)."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    planner.params = _capi.params_yaml()
+    s_up, s_plan = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    n = 6
+    for k in range(6):
+        rows = 600 + 40 * (k % 3)
+        trav, elev = synth.rough_map(rows, rows, 0.02, seed=400 + k, bad_frac=0.1)
+        poses = synth.poses_in_map(512, rows * 0.02, rows * 0.02, n, 0.18, seed=500 + k, margin=0.7)
+        eng = _device_plan(planner, torch, dev, s_plan, trav, elev, 0.02, poses, n, upload_stream=s_up)
+        util.assert_plan_equal(eng, _oracle_plan(planner, trav, elev, 0.02, poses, n))
+
+
+def test_search_legs_device_on_a_side_stream(planner):
+    """fpe_search_legs_device (bench.py's open_loop leg) against the oracle's checkFoothold, 2 cm and 1 cm."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(device=dev)
+    for res, rows, R in [(0.02, 500, 0.1), (0.01, 500, 0.15)]:
+        planner.params = _capi.params_yaml()
+        planner.params["searchRadius"] = np.float32(R)
+        trav, elev = synth.rough_map(rows, rows, res, seed=41, bad_frac=0.1)
+        planner.gridmapCallback(trav, elev, res)
+        rng = np.random.default_rng(42)
+        nq = 4096
+        half = 0.5 * rows * res - 0.4
+        q = np.zeros(nq, dtype=_capi.QUERY_DTYPE)
+        q["cx"], q["cy"] = rng.uniform(-half, half, nq), rng.uniform(-half, half, nq)
+        q["search_radius"], q["n_vertices"] = np.float32(R), 4
+        Rd = float(np.float32(R))
+        q["vx"][:, :4] = q["cx"][:, None] + np.array([Rd, Rd, -Rd, -Rd])
+        q["vy"][:, :4] = q["cy"][:, None] + 0.5 * np.array([Rd, -Rd, -Rd, Rd])
+        with torch.cuda.stream(side):
+            d_q = torch.from_numpy(q.view(np.uint8).reshape(-1).copy()).to(dev)
+            d_o = torch.zeros(nq * _capi.FOOTHOLD_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        side.synchronize()
+        planner.search_legs_device(d_q.data_ptr(), nq, d_o.data_ptr(), stream=side.cuda_stream)
+        side.synchronize()
+        eng = d_o.cpu().numpy().view(_capi.FOOTHOLD_DTYPE)
+        ora = fpo.OracleMap(trav, elev, res).search_legs(util.to_oracle_params(planner.params), util.to_oracle_queries(q))
+        util.assert_nominal_equal(eng, ora, "search_legs_device")
+        assert (eng["source"] == 1).sum() > 100
+    planner.params = _capi.params_yaml()
+
+
+@pytest.mark.parametrize("res,rows,R", [(0.02, 500, 0.1), (0.01, 600, 0.12)])
+def test_open_loop_fed_with_chained_centres_equals_chained(planner, res, rows, R):
+    """the open-loop mode must equal the chained mode when fed the chained centres.  Query (b, g, leg)
+    = checkFoothold(centre = the centroid track's next default position, polygon = getSearchPolygon around the
+    nominal track's next default position) — both reconstructed on the host from the chained plan's committed
+    results with the reference's expression order (cpp:2199-2213, 2411-2418, 2496-2517)."""
+    planner.params = _capi.params_yaml()
+    planner.params["searchRadius"] = np.float32(R)
+    trav, elev = synth.rough_map(rows, rows, res, seed=51, bad_frac=0.12)
+    side = rows * res
+    n = 6
+    poses = synth.poses_in_map(200, side, side, n, 0.18, seed=52, margin=0.7)
+    planner.gridmapCallback(trav, elev, res)
+    ch = planner.plan(poses, n)
+    c = fpo.constants(util.to_oracle_params(planner.params))
+    step, step_half = c["step"], c["stepHalf"]
+    Rd = float(np.float32(R))
+    drift = float(planner.params["lateralDrift"][0])
+    B = poses.shape[0]
+    q = np.zeros((B, n, 4), dtype=_capi.QUERY_DTYPE)
+    for b in range(B):
+        y0 = float(poses["position"][b, 1])
+        cur = np.zeros((2, 4, 3))  # [centroid, nominal] current feet: shifted stance (setFirstGait, cpp:2693)
+        for t in range(2):
+            cur[t] = ch["stance"][b]
+            cur[t][:, 0] = ch["stance"][b][:, 0] - step_half
+        adj = 0.0
+        for g in range(n):
+            ctr = [fpo.polygon_center(cur[t])[0] for t in range(2)]
+            ny = y0 + adj
+            for l in range(4):
+                cx = (ctr[0] + step) + c["biasX"][l]      # centroid track (cpp:2199, 2414)
+                px = (ctr[1] + step) + c["biasX"][l]      # nominal track: polygon centre
+                cy = ny + c["biasY"][l]
+                q[b, g, l]["cx"], q[b, g, l]["cy"] = cx, cy
+                q[b, g, l]["vx"][:4] = [px + Rd, px + Rd, px - Rd, px - Rd]
+                q[b, g, l]["vy"][:4] = [cy + 0.5 * Rd, cy - 0.5 * Rd, cy - 0.5 * Rd, cy + 0.5 * Rd]
+            if ch["cycle_ok"][b, g]:
+                for l in range(4):
+                    cen, nom = ch["centroid"][b, g, l], ch["nominal"][b, g, l]
+                    cur[0][l] = (cen["x"], cen["y"], float(cen["z"]))
+                    cur[1][l] = (nom["x"], nom["y"], float(nom["z"]))
+            adj += drift
+    q["search_radius"], q["n_vertices"] = np.float32(R), 4
+    # a degenerate feet polygon (after a committed "no case" centroid result) gives a non-finite centre, which the
+    # host-buffer open-loop entry point rejects as an argument error: such units are left out of the comparison
+    usable = np.isfinite(q["cx"]) & (np.abs(q["cx"]) <= 1e6) & np.isfinite(q["vx"]).all(-1)
+    for f in ("cx", "cy", "vx", "vy"):
+        q[f][~usable] = 0.0
+    ol = planner.checkFoothold(q.reshape(-1)).reshape(B, n, 4)
+    nom = ch["nominal"]
+    assert usable.mean() > 0.9
+    for f in ("valid", "source", "row", "col", "x", "y"):
+        bad = np.nonzero((ol[f] != nom[f]) & usable)
+        assert bad[0].size == 0, f"open-loop {f} differs from the chained plan at {tuple(x[0] for x in bad)}"
+    assert np.array_equal(ol["z"][usable].view(np.uint32), nom["z"][usable].view(np.uint32)), "z must be the same f32 bits"
+    assert (nom["source"] == 1).sum() > 50
+    planner.params = _capi.params_yaml()
+
+
+def test_service_returns_false_where_the_opt_track_gate_fails(planner):
+    """getGaitCycleSearchGridMap (cpp:2307-2349) fails in the first gait cycle when the next feet centre lies off the
+    map: the reference's handler returns false (cpp:931-934).  Batch plans report it per pose instead."""
+    planner.params = _capi.params_yaml()
+    trav, elev = synth.rough_map(300, 300, 0.02, seed=61)  # 6 x 6 m
+    planner.gridmapCallback(trav, elev, 0.02)
+    omap = fpo.OracleMap(trav, elev, 0.02)
+    xs = np.array([-3.4, -3.12, -3.08, -2.0, 0.0, 2.8, 2.9, 2.95, 3.2])
+    ys = np.array([0.0, 0.0, 0.0, 3.2, 0.0, 0.0, 0.0, -2.99, 0.0])
+    poses = make_poses(np.column_stack([xs, ys, np.zeros(xs.size)]))
+    out = planner.plan(poses, 3)
+    want = omap.pose_status(util.to_oracle_params(planner.params), util.to_oracle_poses(poses))
+    assert np.array_equal(out["pose_status"], want)
+    assert want.any() and not want.all()
+    for k in range(xs.size):
+        r = planner.globalFootholdPlan(3, poses["position"][k])
+        assert (r is False) == bool(want[k] & _capi.FPE_POSE_OPT_SUBMAP_FAILED)
+        if r is not False:
+            assert r["gait_cycles"] == 3
+
+
+def test_foot_radius_much_larger_than_search_radius(planner):
+    """The per-leg LDS tile doubles as float scratch of the ordered height sums; a foot disc much larger than the
+    search window must not overrun it (the tile grows with the disc's bounding box)."""
+    planner.params = _capi.params_yaml()
+    planner.params["searchRadius"] = np.float32(0.02)
+    planner.params["footRadius"] = np.float32(0.12)
+    trav, elev = synth.rough_map(300, 300, 0.01, seed=71, bad_frac=0.002, nan_frac=0.001)
+    poses = synth.poses_in_map(64, 3.0, 3.0, 4, 0.18, seed=72, margin=0.6)
+    for group in (0, 8, 65):
+        with planner.tuning(plan_group=group, no_bits=int(group != 0)):
+            try:
+                eng, ora = util.run_both(planner, trav, elev, 0.01, poses, 4, threads=8)
+            except FpeError as e:
+                assert e.code == _capi.FPE_E_UNSUPPORTED
+                continue
+        util.assert_plan_equal(eng, ora)
+    planner.params = _capi.params_yaml()

@@ -59,18 +59,15 @@ def make_case(seed):
     return dict(res=res, pos=pos, params=p, trav=trav, elev=elev, poses=poses, n=N, group=group, literal=literal)
 
 
-def test_random_differential_campaign(monkeypatch):
+def test_random_differential_campaign():
     planner = FootholdPlanner(0)
     n_cases = int(os.environ.get("FPE_FUZZ_CASES", "120"))
     src = np.zeros(4, np.int64)
     codes = np.zeros(7, np.int64)
     for k in range(n_cases):
         c = make_case(20000 + k)
-        monkeypatch.setenv("FPE_PLAN_GROUP", c["group"])
-        if c["literal"]:
-            monkeypatch.setenv("FPE_LITERAL_DISCS", "1")
-        else:
-            monkeypatch.delenv("FPE_LITERAL_DISCS", raising=False)
+        # group "0" = automatic dispatch (the bit-window kernels where they apply); a forced grouping runs the direct kernels
+        planner.set_tuning(plan_group=int(c["group"]), literal_discs=int(c["literal"]), no_bits=int(c["group"] != "0"))
         planner.params = c["params"]
         try:
             eng, ora = util.run_both(planner, c["trav"], c["elev"], c["res"], c["poses"], c["n"], position=c["pos"], threads=8)

@@ -58,24 +58,24 @@ def test_resolutions_and_radii(planner, res, R, rows):
 
 
 @pytest.mark.parametrize("group", ["4", "8", "16", "64", "65"])
-def test_both_lane_groupings_agree_with_the_oracle(planner, group, monkeypatch):
+def test_both_lane_groupings_agree_with_the_oracle(planner, group):
     """The chained kernel has two decompositions (16 lanes per leg = one wavefront per pose, 64 lanes
     per leg = one wavefront per leg); both must reproduce the oracle on 2 cm and 1 cm maps."""
-    monkeypatch.setenv("FPE_PLAN_GROUP", group)
     for res, rows, R in [(0.02, 400, 0.1), (0.01, 500, 0.12)]:
         set_params(planner, searchRadius=np.float32(R))
         trav, elev = synth.rough_map(rows, rows, res, seed=13, bad_frac=0.15)
         side = rows * res
         poses = synth.poses_in_map(160, side, side, 6, 0.18, seed=14, margin=0.7)
         poses["gait"][::3] = 1
-        eng, ora = util.run_both(planner, trav, elev, res, poses, 6, threads=8)
+        with planner.tuning(plan_group=int(group), no_bits=1):  # the direct kernels' lane groupings
+            eng, ora = util.run_both(planner, trav, elev, res, poses, 6, threads=8)
         util.assert_plan_equal(eng, ora)
         assert (eng["nominal"]["source"] == 1).sum() > 50
 
 
 @pytest.mark.parametrize("res,R,rf", [(0.02, 0.1, 0.02), (0.01, 0.1, 0.02), (0.02, 0.1, 0.03)])
-def test_literal_disc_walk_equals_offset_table(planner, res, R, rf, monkeypatch):
-    """FPE_LITERAL_DISCS forces the per-candidate f64 bounding-box walk (the path taken when the host
+def test_literal_disc_walk_equals_offset_table(planner, res, R, rf):
+    """fpe_set_tuning("literal_discs") forces the per-candidate f64 bounding-box walk (the path taken when the host
     cannot prove the foot-disc offset table rounding-robust); both must match the oracle."""
     set_params(planner, searchRadius=np.float32(R), footRadius=np.float32(rf))
     rows = 400
@@ -83,9 +83,8 @@ def test_literal_disc_walk_equals_offset_table(planner, res, R, rf, monkeypatch)
     side = rows * res
     poses = synth.poses_in_map(96, side, side, 5, 0.18, seed=18, margin=0.7)
     for literal in (False, True):
-        if literal:
-            monkeypatch.setenv("FPE_LITERAL_DISCS", "1")
-        eng, ora = util.run_both(planner, trav, elev, res, poses, 5, threads=8)
+        with planner.tuning(literal_discs=int(literal)):
+            eng, ora = util.run_both(planner, trav, elev, res, poses, 5, threads=8)
         util.assert_plan_equal(eng, ora)
     assert (eng["nominal"]["source"] == 1).sum() > 50
 
@@ -297,15 +296,16 @@ def test_service_message(planner):
 
 @pytest.mark.parametrize("group", ["4", "8"])
 @pytest.mark.parametrize("B", [1, 2, 3, 5, 7])
-def test_ragged_batches_pad_the_last_wavefront(planner, group, B, monkeypatch):
+def test_ragged_batches_pad_the_last_wavefront(planner, group, B):
     """B not a multiple of the poses-per-wavefront (2 at 8 lanes per leg, 4 at 4): the padding poses of
     the last wavefront must neither store nor disturb the live ones."""
-    monkeypatch.setenv("FPE_PLAN_GROUP", group)
     set_params(planner)
     trav, elev = synth.rough_map(300, 300, 0.02, seed=23, bad_frac=0.2)
     poses = synth.poses_in_map(B, 6.0, 6.0, 5, 0.18, seed=24 + B, margin=0.7)
-    eng, ora = util.run_both(planner, trav, elev, 0.02, poses, 5)
-    util.assert_plan_equal(eng, ora)
+    for no_bits in (1, 0):  # direct kernel of that grouping, then the bit-window kernel (automatic grouping)
+        with planner.tuning(plan_group=int(group) if no_bits else 0, no_bits=no_bits):
+            eng, ora = util.run_both(planner, trav, elev, 0.02, poses, 5)
+        util.assert_plan_equal(eng, ora)
 
 
 def test_maximum_gait_cycles_255(planner):
@@ -328,13 +328,22 @@ def test_service_all_tracks(planner):
     planner.gridmapCallback(trav, elev, 0.02)
     omap = fpo.OracleMap(trav, elev, 0.02)
     rng = np.random.default_rng(92)
-    for _ in range(8):
+    seen_split = False
+    for _ in range(24):
         pos = [rng.uniform(-3.2, -2.0), rng.uniform(-3, 3), 0.0]
         r = planner.globalFootholdPlan(6, pos, all_tracks=True)
         o = omap.plan(util.to_oracle_params(planner.params), util.to_oracle_poses(make_poses([pos])), 6)
         ok = o["cycle_ok"][0].astype(bool)
         cf = r["centroid"]["footholds"]
-        assert len(cf) == 4 + 4 * int(ok.sum()) and r["centroid"]["success"] == r["success"]
+        assert len(cf) == 4 + 4 * int(ok.sum())
+        # centroidGlobalFootholdsMsg_ keeps its own books (cpp:711, 1445-1446): success = some cycle committed,
+        # gait_cycles_succeed = last committed cycle + 1, gait_cycles never written; the nominal message's success
+        # is the LAST cycle's validity (cpp:1380, 1574)
+        assert r["centroid"]["success"] == bool(ok.any())
+        assert r["centroid"]["gait_cycles_succeed"] == (int(np.nonzero(ok)[0][-1]) + 1 if ok.any() else 0)
+        assert r["centroid"]["gait_cycles"] == 0
+        assert r["success"] == bool(ok[-1]) and r["gait_cycles"] == 6
+        seen_split |= bool(ok.any() and not ok[-1])
         want = o["centroid"][0][ok].reshape(-1)
         assert np.array_equal(cf["x"][4:], want["x"]) and np.array_equal(cf["y"][4:], want["y"])
         assert np.all(np.abs(cf["z"][4:] - want["z"].astype(np.float64)) <= util.Z_TOL)
@@ -343,6 +352,7 @@ def test_service_all_tracks(planner):
         assert np.array_equal(d[0], o["stance"][0])
         assert np.array_equal(d[1:, :, :2], o["default"][0][ok][:, :, :2])
         assert np.all(np.abs(d[1:, :, 2] - o["default"][0][ok][:, :, 2]) <= util.Z_TOL)
+    assert seen_split, "need a plan whose last cycle fails after an earlier one committed (centroid.success != nominal.success)"
 
 
 @pytest.mark.parametrize("rf_first", [0, 1])
@@ -488,19 +498,19 @@ def test_foot_radius_ratios_around_the_middle_cell_shortcut(planner, ratio):
     set_params(planner)
 
 
-def test_generic_and_3x3_only_kernel_variants_agree(planner, monkeypatch):
+def test_generic_and_3x3_only_kernel_variants_agree(planner):
     """foot radius in [0.9, 1] x resolution launches the 3x3-only variant of the 8-lane kernel (no generic disc issue
-    compiled in; clamped boxes at the map border take the direct pass).  FPE_NO_MID_VARIANT=1 forces the generic
-    kernel: both must reproduce the oracle on a map whose border is inside the pose range."""
+    compiled in; clamped boxes at the map border take the direct pass).  fpe_set_tuning("no_mid_variant") forces the generic
+    kernel, "no_bits" the direct kernels: both must reproduce the oracle on a map whose border is inside the pose range."""
     set_params(planner)
     trav, elev = synth.rough_map(220, 220, 0.02, seed=81, bad_frac=0.15)
     rng = np.random.default_rng(82)
     poses = make_poses(np.column_stack([rng.uniform(-2.4, 2.3, 200), rng.uniform(-2.3, 2.3, 200), np.zeros(200)]))
-    for env in (None, "1"):
-        if env:
-            monkeypatch.setenv("FPE_NO_MID_VARIANT", env)
-        eng, ora = util.run_both(planner, trav, elev, 0.02, poses, 6, threads=8)
-        util.assert_plan_equal(eng, ora)
+    for no_mid in (0, 1):
+        for no_bits in (0, 1):
+            with planner.tuning(no_mid_variant=no_mid, no_bits=no_bits):
+                eng, ora = util.run_both(planner, trav, elev, 0.02, poses, 6, threads=8)
+            util.assert_plan_equal(eng, ora)
     assert (eng["nominal"]["valid"] == 0).any() and (eng["centroid"]["code"] == 6).any(), "poses must reach the border"
 
 

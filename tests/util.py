@@ -66,6 +66,13 @@ def assert_plan_equal(eng, ora, swing_only_mask=None):
     assert_centroid_equal(eng["centroid"], ora["centroid"])
     assert np.array_equal(eng["cycle_ok"], ora["cycle_ok"]), "cycle_ok differs"
     assert np.array_equal(eng["stance"], ora["stance"]), "stance differs"
+    if "selected" in eng:  # the 16-byte exchange record is the nominal record minus x / y
+        sel, nom = eng["selected"], eng["nominal"]
+        for f in ("row", "col", "valid", "source", "foot_id", "gait_cycle_id"):
+            assert np.array_equal(sel[f], nom[f]), f"selected.{f} differs from nominal.{f}"
+        assert np.array_equal(sel["z"].view(np.uint32), nom["z"].view(np.uint32)), "selected.z differs from nominal.z"
+    if "pose_status" in eng and "pose_status" in ora:
+        assert np.array_equal(eng["pose_status"], ora["pose_status"]), "pose_status (opt-track gate of cycle 0) differs"
     d_e, d_o = eng["default"], ora["default"]
     assert not _neq(d_e[..., :2], d_o[..., :2]).any(), "default track x/y differ"
     assert np.all(np.abs(d_e[..., 2] - d_o[..., 2]) <= Z_TOL), "default track z differs"
@@ -76,4 +83,5 @@ def run_both(planner, trav, elev, res, poses, n_cycles, position=(0.0, 0.0), thr
     eng = planner.plan(poses, n_cycles)
     omap = fpo.OracleMap(trav, elev, res, position)
     ora = omap.plan(to_oracle_params(planner.params), to_oracle_poses(poses), n_cycles, threads=threads)
+    ora["pose_status"] = omap.pose_status(to_oracle_params(planner.params), to_oracle_poses(poses))
     return eng, ora
