@@ -176,9 +176,10 @@ const char* fpe_version(void);
  * Host pointers, `rows*cols` floats per layer in desc->storage_order.  Uploads both layers to HBM
  * once, canonicalised (row-major, start index 0); the new snapshot becomes current atomically. */
 int fpe_upload_map(fpe_handle h, const fpe_map_desc* desc, const float* traversability, const float* elevation);
-/* Same with DEVICE pointers (e.g. a map RCCL-broadcast from rank 0); async on `stream`.  Callers of
- * the device-resident entry points order uploads and plans on ONE stream (or synchronise between
- * them): layer buffers of retired snapshots are recycled in stream order. */
+/* Same with DEVICE pointers (e.g. a map RCCL-broadcast from rank 0); async on `stream`.  Ordering is the
+ * engine's job, not the caller's: a plan / search on ANY stream waits (GPU-side) for the upload of the snapshot it
+ * uses, and the layer buffers of a snapshot retired while asynchronous launches may still read it are recycled only
+ * behind a device synchronisation performed by the NEXT upload — plans never pay for it. */
 int fpe_upload_map_device(fpe_handle h, const fpe_map_desc* desc, const float* d_traversability,
                           const float* d_elevation, void* stream);
 int fpe_map_info(fpe_handle h, fpe_map_desc* out); /* geometry of the current snapshot */

@@ -1,2 +1,745 @@
-// fpe_bits.hpp — bit-window helpers (placeholder; filled in with the bit-window kernels).
+// fpe_bits.hpp — part two of the kernel translation unit (included at the end of fpe_kernels.hip, inside
+// namespace fpe): the BIT-WINDOW kernels.
+//
+// Per map snapshot and threshold pair the engine keeps four bit planes (BitMap, fpe_device.hpp): D (trav <
+// defaultFootholdThreshold_, raw compare), Df (the same for finite cells only), C (finite && trav <
+// candidateFootholdThreshold_), F (finite).  A leg's search window — every cell its default disc, centroid
+// rectangle (cpp:1615-1750) and spiral candidates' foot discs (cpp:2085-2163) can touch — is then one 32-bit row
+// mask per plane and window row: lane s of the leg's group loads rows s, s + G, ... (two 16-byte loads per row),
+// and everything the reference decides by comparing traversability values becomes bit arithmetic:
+//   * centroid row scan (cpp:1717-1750): popcount of the D row under the rectangle's column mask;
+//   * checkDefaultFoothold (cpp:2039-2082): Df bit of every cell of the disc (membership stays the f64 test);
+//   * checkCirclePolygonFoothold (cpp:2117-2163) for EVERY candidate at once: per window row
+//         P = ~F | (~C & inside)      ("cell does not fail": non-finite, or above threshold and inside the polygon)
+//     eroded with the host-proved foot-disc offset table, E = AND_k shift(P[row + da_k], db_k); a candidate is
+//     valid iff its E bit is set, so a spiral round is an LDS read and a bit test — no map access at all.
+//     The reference rectangle's PNPOLY test is exact in INDEX space: cell centres are monotone in the index, so
+//     {i : xlo <= x_i < xhi} is an index interval whose ends are found by evaluating the reference's own f64
+//     comparison at the two indices next to a predicted boundary.  Other polygons keep the per-cell PNPOLY test,
+//     applied only to candidates that pass the threshold erosion.
+// The f32 elevation layer is read for the mean heights only (cpp:2520-2554, unchanged ordered sums).
+// Exactness rests on three host-side proofs (bits_supported): the foot-disc offset table (derive_foot_offsets), the
+// window half-width (every cell that can be touched lies inside it), and getIndex(submap cell centre) == top-left +
+// (row, col) for the centroid result.  When a proof fails the engine launches the direct kernels instead.
 #pragma once
+
+namespace {
+
+// ---- bit-plane build: one wavefront ballots 64 columns of a row ---------------------------------------------
+__global__ __launch_bounds__(256) void build_bitmap_kernel(const float* __restrict__ trav, int rows, int cols, float thrD,
+                                                           float thrC, uint4* __restrict__ words, int strideW, int nw) {
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 256 + static_cast<int>(threadIdx.x);
+    const bool in = j < cols;
+    float v = 0.0f;
+    if (in) v = trav[static_cast<size_t>(i) * cols + j];
+    const bool fin = in && __builtin_isfinite(v);
+    const bool d = in && v < thrD;  // raw compare: NaN -> false, -inf -> true (cpp:1653, 1736)
+    const bool c = fin && v < thrC;
+    const unsigned long long bD = __ballot(d), bDf = __ballot(d && fin), bC = __ballot(c), bF = __ballot(fin);
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    if (lane < 2) {
+        const int w = (blockIdx.x * 256 + (static_cast<int>(threadIdx.x) & ~63)) / 32 + lane;
+        if (w < nw) {
+            uint4 o;
+            o.x = static_cast<unsigned>(bD >> (32 * lane));
+            o.y = static_cast<unsigned>(bDf >> (32 * lane));
+            o.z = static_cast<unsigned>(bC >> (32 * lane));
+            o.w = static_cast<unsigned>(bF >> (32 * lane));
+            words[static_cast<size_t>(i + 1) * strideW + w + kBitPadW] = o;
+        }
+    }
+}
+
+// ---- window rows ------------------------------------------------------------------------------------------
+template <int NRL>
+struct WinRows {
+    uint32_t D[NRL], Df[NRL], C[NRL], F[NRL];
+};
+// Per-leg LDS: row masks shared between the lanes of the leg's group (a: Df rows, later P rows; b: E rows;
+// f: F rows for non-rectangle polygons).  The same bytes serve as float scratch of a direct disc pass.
+template <int NR>
+struct LegBits {
+    uint32_t a[NR];
+    uint32_t b[NR];
+    uint32_t f[NR];
+};
+
+// Window origin (iw0, jw0) = getIndex(centre) - winH.  Lane `sub` holds window rows sub + G * k.  Rows and word
+// groups outside the map are clamped onto the zero padding of the planes.
+template <int G, int NRL>
+__device__ __forceinline__ void win_issue(const BitMap& bm, const MapGeom& mg, const Grp<G>& g, int iw0, int jw0,
+                                          uint4 (&lo)[NRL], uint4 (&hi)[NRL]) {
+    int w0 = jw0 >> 5;
+    w0 = max(-kBitPadW, min(w0, bm.nw + kBitPadW - 2));
+#pragma unroll
+    for (int k = 0; k < NRL; ++k) {
+        int i = iw0 + g.sub + G * k;
+        i = max(-1, min(i, mg.rows));
+        const uint4* p = bm.words + (static_cast<size_t>(i + 1) * bm.strideW + (w0 + kBitPadW));
+        lo[k] = p[0];
+        hi[k] = p[1];
+    }
+}
+template <int NRL>
+__device__ __forceinline__ void win_finish(int jw0, const uint4 (&lo)[NRL], const uint4 (&hi)[NRL], WinRows<NRL>& w) {
+    const unsigned sh = static_cast<unsigned>(jw0) & 31u;
+#pragma unroll
+    for (int k = 0; k < NRL; ++k) {
+        w.D[k] = __builtin_amdgcn_alignbit(hi[k].x, lo[k].x, sh);
+        w.Df[k] = __builtin_amdgcn_alignbit(hi[k].y, lo[k].y, sh);
+        w.C[k] = __builtin_amdgcn_alignbit(hi[k].z, lo[k].z, sh);
+        w.F[k] = __builtin_amdgcn_alignbit(hi[k].w, lo[k].w, sh);
+    }
+}
+// Bit (window row ri, window column cj) of a row array in LDS; 0 outside the window.
+template <int NR>
+__device__ __forceinline__ unsigned win_bit(const uint32_t* rows, int ri, int cj) {
+    const bool in = static_cast<unsigned>(ri) < static_cast<unsigned>(NR) && static_cast<unsigned>(cj) < 32u;
+    const uint32_t wd = rows[min(max(ri, 0), NR - 1)];
+    return in ? (wd >> (cj & 31)) & 1u : 0u;
+}
+
+// checkFootholdUseCentroidMethod's row scan (cpp:1649-1658 whole-region test, cpp:1717-1750 blocked rows) from the
+// D rows: lane = window row.  `cnt > (rightCol + 1) * 0.5` (cpp:1743) is 2 * cnt > nj in integers.
+template <int G, int NRL>
+__device__ __forceinline__ CentroidScan rows_from_bits(const Submap& s, const WinRows<NRL>& w, const Grp<G>& g, int iw0, int jw0) {
+    static_assert(G * NRL <= 32, "row masks of a leg are collected in one 32-bit word");
+    CentroidScan r0;
+    const int ni = s.ni, nj = s.nj;
+    const unsigned sh = static_cast<unsigned>(s.j0 - jw0) & 31u;
+    const unsigned njMask = nj >= 32 ? ~0u : ((1u << (nj & 31)) - 1u);
+    unsigned blockedMask = 0u;
+    bool anyBelow = false;
+#pragma unroll
+    for (int k = 0; k < NRL; ++k) {
+        const int r = iw0 + g.sub + G * k - s.i0;  // row of the rectangle held by this lane in slot k
+        const bool liveRow = s.ok && r >= 0 && r < ni;
+        const int cnt = __builtin_popcount((w.D[k] >> sh) & njMask);
+        anyBelow |= liveRow && cnt > 0;
+        const bool blocked = liveRow && 2 * cnt > nj;
+        blockedMask |= static_cast<unsigned>(g.ballot(blocked)) << (G * k);  // bit = window row
+    }
+    const int off = s.i0 - iw0;  // the rectangle lies inside the window (bits_window_halfwidth)
+    const unsigned rel = (off >= 0 && off < 32) ? (blockedMask >> off) : 0u;
+    r0.minRow = rel ? __builtin_ctz(rel) : 0;
+    r0.maxRow = rel ? 31 - __builtin_clz(rel) : 0;
+    r0.whole = s.ok && ni * nj > 0 && !g.any(anyBelow);
+    return r0;
+}
+
+// checkDefaultFoothold (cpp:2039-2082) from the Df rows: valid iff >= 1 cell visited and no visited cell has its Df
+// bit set.  The visited cells are the ones disc_issue() enumerated (d.vis / the 3x3 form); boxes it did not
+// pipeline (clamped at the map border, or larger than the pipeline) are walked here, membership test included.
+template <int G, int NR, bool kMid>
+__device__ __forceinline__ bool default_ok_bits(const DevMap& m, const PlanConsts& pc, double cx, double cy, const BBox& bb,
+                                                const DiscLoads& d, const uint32_t* rowsDf, int iw0, int jw0, const Grp<G>& g) {
+    bool any = false, fail = false;
+    if (d.pipelined) {
+        if (G == 8 && d.mid) {  // wave-uniform: cells 0-3 and 5-8 on the lanes, the middle cell always visited
+            const int t = g.sub + (g.sub >= 4 ? 1 : 0);
+            const int a = t >= 6 ? 2 : (t >= 3 ? 1 : 0);
+            const int ri = bb.i0 - iw0, cj = bb.j0 - jw0;
+            fail = (d.vis[0] != 0 && win_bit<NR>(rowsDf, ri + a, cj + (t - 3 * a)) != 0u) || win_bit<NR>(rowsDf, ri + 1, cj + 1) != 0u;
+            return !g.any(fail);
+        }
+        if constexpr (!kMid) {
+            const float njInv = rcp_small(bb.nj);
+#pragma unroll
+            for (int r = 0; r < disc_rounds<G>(); ++r) {
+                int a, bq;
+                divmod_small(min(r * G + g.sub, 4095), max(bb.nj, 1), njInv, a, bq);
+                const bool v = d.vis[r] != 0;
+                any |= v;
+                fail |= v && win_bit<NR>(rowsDf, bb.i0 + a - iw0, bb.j0 + bq - jw0) != 0u;
+            }
+            return g.any(any) && !g.any(fail);
+        }
+    }
+    const int nb = bb.ni * bb.nj;
+    const float njInv = rcp_small(bb.nj);
+    for (int base = 0; base < nb; base += G) {
+        const int t = base + g.sub;
+        if (t < nb) {
+            int a, bq;
+            divmod_small(t, bb.nj, njInv, a, bq);
+            const int i = bb.i0 + a, j = bb.j0 + bq;
+            if (in_range(i, j, m.g.rows, m.g.cols) && cell_in_disc(m.g, i, j, cx, cy, pc.rf2)) {
+                any = true;
+                fail |= win_bit<NR>(rowsDf, i - iw0, j - jw0) != 0u;
+            }
+        }
+    }
+    return g.any(any) && !g.any(fail);
+}
+
+// Centroid case logic (cpp:1684-1952) given the row scan; the result's foot disc is cell-centred, i.e. the
+// host-proved offset table in CircleIterator order, and getIndex(result) is top-left + (newRow, newCol).
+// kOneCell: the 3x3-only variants run with a one-cell foot disc (rf < res): the result's height is that cell's.
+struct CentroidPendingBits {
+    CentroidOut o;
+    int needDisc;  // 0/1
+    float e0;      // kOneCell: elevation of the result's own cell
+    float e[kDiscRounds];
+    int vis[kDiscRounds];
+};
+template <int G, bool kOneCell>
+__device__ __forceinline__ void centroid_begin_bits(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const Submap& s,
+                                                    const CentroidScan& sc, float zCentre, const Grp<G>& g, CentroidPendingBits& cp) {
+    CentroidOut& o = cp.o;
+    cp.needDisc = 0;
+    cp.e0 = 0.0f;
+    o.x = 0.0;
+    o.y = 0.0;
+    o.z = 0.0f;
+    o.row = -1;
+    o.col = -1;
+    o.code = 5;
+    if (!s.ok) {  // cpp:1628-1631
+        o.code = 6;
+        return;
+    }
+    const int bottomRow = s.ni - 1, rightCol = s.nj - 1;
+    const int minRow = sc.minRow, maxRow = sc.maxRow;
+    if (sc.whole) {  // cpp:1684-1689
+        o.x = c.cx;
+        o.y = c.cy;
+        o.z = zCentre;
+        o.row = c.ici;
+        o.col = c.icj;
+        o.code = 0;
+        return;
+    }
+    // floor((a) * 0.5) / ceil((a) * 0.5) of small non-negative integers, as integer arithmetic (exact)
+    int newRow, newCol;
+    if (minRow == 0 && maxRow != bottomRow) {  // case 1, cpp:1777-1786
+        newRow = (maxRow + bottomRow + 1) >> 1;
+        newCol = (rightCol + 1) >> 1;
+        o.code = 1;
+    } else if (minRow != 0 && maxRow != bottomRow) {  // case 2, cpp:1843-1886
+        if ((minRow - 0) >= (bottomRow - maxRow)) {
+            newRow = (minRow + 1) >> 1;
+            o.code = 2;
+        } else {
+            newRow = (maxRow + bottomRow) >> 1;
+            o.code = 3;
+        }
+        newCol = rightCol >> 1;
+    } else if (minRow != 0 && maxRow == bottomRow) {  // case 3, cpp:1944-1952
+        newRow = (minRow + 1) >> 1;
+        newCol = rightCol >> 1;
+        o.code = 4;
+    } else {
+        return;  // first and last row blocked: no branch taken, result stays (0,0,0)
+    }
+    o.x = cell_pos(s.baseX, m.g.res, newRow);  // map.getPosition(newIndex) on the SUBMAP (cpp:1816)
+    o.y = cell_pos(s.baseY, m.g.res, newCol);
+    o.row = s.i0 + newRow;
+    o.col = s.j0 + newCol;
+    if constexpr (kOneCell) {
+        cp.e0 = m.elev[static_cast<size_t>(o.row) * m.g.cols + o.col];  // a cell of the submap: inside the map
+    } else {
+#pragma unroll
+        for (int r = 0; r < kDiscRounds; ++r) {
+            const int k = r * G + g.sub;
+            cp.vis[r] = 0;
+            cp.e[r] = 0.0f;
+            if (k < pc.nFoot) {
+                const int qi = o.row + c.footDa[k], qj = o.col + c.footDb[k];
+                if (in_range(qi, qj, m.g.rows, m.g.cols)) {
+                    cp.vis[r] = 1;
+                    cp.e[r] = m.elev[static_cast<size_t>(qi) * m.g.cols + qj];
+                }
+            }
+        }
+    }
+    cp.needDisc = 1;
+}
+// getFootholdMeanHeight (cpp:2520-2554) of the centroid result from the loads centroid_begin_bits issued.
+template <int G, bool kOneCell>
+__device__ __forceinline__ float centroid_height_bits(const PlanConsts& pc, const Grp<G>& g, const CentroidPendingBits& cp) {
+    if constexpr (kOneCell) {
+        const float v = __builtin_isfinite(cp.e0) ? cp.e0 : 0.0f;  // cpp:2532-2537
+        const bool inc = v < 10;                                   // cpp:2539
+        return finish_mean(inc ? 0.0f + v : 0.0f, v, inc ? 1 : 0, pc.h);
+    } else {
+        // lanes = table entries in CircleIterator (row-major) order: G dependent adds per round on swizzled lane values
+        float sum = 0.0f, last = 0.0f;
+        int cnt = 0;
+        float v[kDiscRounds];
+        bool anyVis = false;
+#pragma unroll
+        for (int r = 0; r < kDiscRounds; ++r) {
+            v[r] = __builtin_isfinite(cp.e[r]) ? cp.e[r] : 0.0f;
+            const bool inc = cp.vis[r] != 0 && v[r] < 10;
+            anyVis |= cp.vis[r] != 0;
+            cnt += __builtin_popcountll(g.ballot(inc));
+            if (r == 0 || __ballot(cp.vis[r] != 0) != 0ull) sum = SeqSum<G>::run(sum, inc ? v[r] : -0.0f);
+        }
+        if (__ballot(cnt == 0 && g.any(anyVis)) != 0ull) {  // every visited value >= 10: the LAST visited value (cpp:2547-2551)
+#pragma unroll
+            for (int r = 0; r < kDiscRounds; ++r) {
+                const unsigned long long mr = g.ballot(cp.vis[r] != 0);
+                const float lv = g.bcast(v[r], mr ? 63 - __builtin_clzll(mr) : 0);
+                if (mr) last = lv;
+            }
+        }
+        return finish_mean(sum, last, cnt, pc.h);
+    }
+}
+
+// The reference rectangle in index space.  Cell centres x_i = base + res * (-i) are non-increasing in i, so
+// {i : lo <= x_i < hi} = [iA, iB] with iA = min{i : x_i < hi}, iB = max{i : x_i >= lo}; each end is found by evaluating
+// the reference's own comparison at the two indices next to the boundary predicted by (base - limit) * (1/res).
+// Lane q of the group evaluates one predicate (q & 4: y axis, q & 2: lower limit, q & 1: second index); the
+// prediction e is read back from the even lanes.
+struct IndexRect {
+    int iA, iB, jA, jB;
+};
+template <int G>
+__device__ __forceinline__ IndexRect rectangle_index_bounds(const MapGeom& mg, double xlo, double xhi, double ylo, double yhi,
+                                                            const Grp<G>& g) {
+    // (the limits arrive by value: a select between FIELDS of the leg context would keep the whole struct in scratch)
+    const int q = g.sub & 7;
+    const bool isY = (q & 4) != 0, isLo = (q & 2) != 0;
+    const double base = isY ? mg.baseY : mg.baseX;
+    const double lim = isY ? (isLo ? ylo : yhi) : (isLo ? xlo : xhi);
+    double qf = floor((base - lim) * mg.rinv);
+    qf = fmin(fmax(qf, -1.0e9), 1.0e9);
+    const int e = static_cast<int>(qf);
+    // upper limit: P(e), P(e + 1) with P(i) = x_i < hi;  lower limit: Q(e + 1), Q(e) with Q(i) = x_i >= lo
+    const int t = isLo ? e + 1 - (q & 1) : e + (q & 1);
+    const double x = cell_pos(base, mg.res, t);
+    const bool pred = isLo ? (x >= lim) : (x < lim);
+    const unsigned b = static_cast<unsigned>(g.ballot(pred && g.sub < 8));
+    const int eXhi = g.bcast(e, 0), eXlo = g.bcast(e, 2), eYhi = g.bcast(e, 4), eYlo = g.bcast(e, 6);
+    IndexRect r;
+    r.iA = (b & 1u) ? eXhi : ((b & 2u) ? eXhi + 1 : eXhi + 2);
+    r.iB = (b & 4u) ? eXlo + 1 : ((b & 8u) ? eXlo : eXlo - 1);
+    r.jA = (b & 16u) ? eYhi : ((b & 32u) ? eYhi + 1 : eYhi + 2);
+    r.jB = (b & 64u) ? eYlo + 1 : ((b & 128u) ? eYlo : eYlo - 1);
+    return r;
+}
+__device__ __forceinline__ unsigned bits_from(int lo) { return lo >= 32 ? 0u : (lo <= 0 ? ~0u : (~0u << lo)); }
+__device__ __forceinline__ unsigned bits_to(int hi) { return hi < 0 ? 0u : (hi >= 31 ? ~0u : ((2u << hi) - 1u)); }
+
+// checkCandidateFoothold (cpp:2085-2114) on the window's bit rows: first valid cell in SpiralIterator order.
+template <int G, int NRL>
+__device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head, const LegCtx& c,
+                            const WinRows<NRL>& w, LegBits<G * NRL>& lb, const Grp<G>& g, int iw0, int jw0, int& wi, int& wj) {
+    constexpr int NR = G * NRL;
+    // (1) per row: P = cells that do NOT fail checkCirclePolygonFoothold's per-cell test (cpp:2132-2138)
+    if (c.rect) {
+        const IndexRect ir = rectangle_index_bounds(m.g, c.xlo, c.xhi, c.ylo, c.yhi, g);
+        const unsigned colMask = bits_from(ir.jA - jw0) & bits_to(ir.jB - jw0);
+#pragma unroll
+        for (int k = 0; k < NRL; ++k) {
+            const int ri = g.sub + G * k;
+            const int i = iw0 + ri;
+            const unsigned inside = (i >= ir.iA && i <= ir.iB) ? colMask : 0u;
+            lb.a[ri] = ~w.F[k] | (~w.C[k] & inside);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NRL; ++k) {
+            const int ri = g.sub + G * k;
+            lb.a[ri] = ~w.C[k];  // threshold only (C implies F); the polygon is tested per candidate below
+            lb.f[ri] = w.F[k];
+        }
+    }
+    pose_sync<G>();
+    // (2) erosion with the foot-disc offset table: E bit (row, col) = AND_k P(row + da_k, col + db_k)
+    const uint32_t* E = lb.a;
+    if (pc.nFoot > 1) {
+#pragma unroll
+        for (int k = 0; k < NRL; ++k) {
+            const int ri = g.sub + G * k;
+            unsigned e = ~0u;
+            for (int f = 0; f < pc.nFoot; ++f) {
+                const int da = c.footDa[f], db = c.footDb[f];
+                const unsigned p = lb.a[min(max(ri + da, 0), NR - 1)];
+                e &= db >= 0 ? (p >> db) : (p << (-db));
+            }
+            lb.b[ri] = e;
+        }
+        pose_sync<G>();
+        E = lb.b;
+    }
+    // (3) candidates in rank order, lane = rank; lowest set ballot bit = argmin of rank
+    const int M = c.nCand;
+    int round = 0;
+    int nDi = 0, nDj = 0, nR = c.nRings;
+    for (int base = 0; base < M; base += G, ++round) {
+        const int k = base + g.sub;
+        bool ok = false;
+        int i = 0, j = 0;
+        int di = 0, dj = 0, r = c.nRings;
+        if (round < kLutHeadRounds) {
+            if (k < M) {
+                const int e = round == 0 ? head.dij[0] : head.dij[1];
+                di = static_cast<int16_t>(e & 0xFFFF);
+                dj = e >> 16;
+                r = round == 0 ? head.ring[0] : head.ring[1];
+            }
+        } else {
+            di = nDi;
+            dj = nDj;
+            r = nR;
+        }
+        if (round + 1 >= kLutHeadRounds) {
+            const int kn = k + G;
+            nR = c.nRings;
+            if (kn < M) {
+                nDi = lut.di[kn];
+                nDj = lut.dj[kn];
+                nR = lut.ring[kn];
+            }
+        }
+        if (k < M) {
+            i = c.ici + di;
+            j = c.icj + dj;
+            ok = in_range(i, j, m.g.rows, m.g.cols);
+            // SpiralIterator::generateRing filters rings nRings-1 and nRings by isInside; the centre cell (ring 0)
+            // is pushed unfiltered by the constructor
+            if (ok && r >= 1 && (r == c.nRings || r + 1 == c.nRings)) ok = cell_in_disc(m.g, i, j, c.cx, c.cy, c.R2);
+            if (ok) ok = win_bit<NR>(E, i - iw0, j - jw0) != 0u;
+            if (ok && !c.rect) {
+                // arbitrary polygon: every FINITE cell of the foot disc must lie inside it (cpp:2138)
+                for (int f = 0; f < pc.nFoot; ++f) {
+                    const int qi = i + c.footDa[f], qj = j + c.footDb[f];
+                    if (win_bit<NR>(lb.f, qi - iw0, qj - jw0) != 0u &&
+                        !polygon_inside_fast(c.vx, c.vy, c.nv, cell_pos(m.g.baseX, m.g.res, qi), cell_pos(m.g.baseY, m.g.res, qj))) {
+                        ok = false;
+                        break;
+                    }
+                }
+            }
+        }
+        const unsigned long long mask = g.ballot(ok);
+        if (mask) {
+            const int l = __builtin_ctzll(mask);
+            wi = g.bcast(i, l);
+            wj = g.bcast(j, l);
+            return true;
+        }
+    }
+    return false;
+}
+
+// One swing leg of one phase on the bit window: the three tracks' next positions, the centroid method
+// (cpp:1605-1997) and checkFoothold (cpp:2001-2036) around the centroid track's position, the mean heights.
+template <int G, int NRL, bool kMid>
+__device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut,
+                                               const LutHead& head, PoseShared& sh, LegBits<G * NRL>& lb, const Grp<G>& g, int leg,
+                                               const LegStatic& ls, double y0, double adjY, double advance, int cyc, int nCycles,
+                                               int b, bool live, const fpe_plan_out& out, LegCommit* lc) {
+    constexpr int NR = G * NRL;
+    const float Rf = ls.Rf;
+    const int polyKind = ls.polyKind;
+    const LegConst& lk = ls.lk;
+    const double biasX = ls.biasX, biasY = ls.biasY;
+    // next default positions of this leg on the three tracks (cpp:2199-2213, 2270-2284)
+    const double Ny = y0 + adjY;                         // cpp:2201
+    const double nx0 = (sh.ctr[0] + advance) + biasX;  // cpp:2199, 2414
+    const double nx1 = (sh.ctr[1] + advance) + biasX;
+    const double nx2 = (sh.ctr[2] + advance) + biasX;
+    const double ny = Ny + biasY;                        // identical on the three tracks
+    if (polyKind != 0 && g.sub == 0) {  // hexagon vertices from the NOMINAL track's position (build-defined, App. E)
+        const double r = static_cast<double>(Rf);
+        double* vx = sh.polyX[leg];
+        double* vy = sh.polyY[leg];
+        const double hx = 0.5 * r;
+        const double hy = (0.5 * r) * 0.8660254037844386;
+        vx[0] = nx2 + r;   vy[0] = ny;
+        vx[1] = nx2 + hx;  vy[1] = ny - hy;
+        vx[2] = nx2 - hx;  vy[2] = ny - hy;
+        vx[3] = nx2 - r;   vy[3] = ny;
+        vx[4] = nx2 - hx;  vy[4] = ny + hy;
+        vx[5] = nx2 + hx;  vy[5] = ny + hy;
+    }
+    LegCtx c;
+    c.cyc = cyc;
+    c.cx = nx1;  // centre from the CENTROID track (cpp:861-862)
+    c.cy = ny;
+    c.nv = (polyKind == 0) ? 4 : 6;
+    {
+        const double r = static_cast<double>(Rf);  // getSearchPolygon's rectangle around the NOMINAL track (cpp:2496-2517)
+        c.rect = polyKind == 0;
+        c.xhi = nx2 + r;
+        c.xlo = nx2 - r;
+        c.yhi = ny + 0.5 * r;
+        c.ylo = ny - 0.5 * r;
+    }
+    c.vx = sh.polyX[leg];
+    c.vy = sh.polyY[leg];
+    c.footDa = sh.footDa;
+    c.footDb = sh.footDb;
+    c.footOff = sh.footOff;
+    c.R2 = lk.R2;
+    c.nRings = lk.nRings;
+    c.nCand = lk.nCand;
+    c.ti0 = c.tj0 = 0;
+
+    NominalOut no;
+    CentroidOut co;
+    float zDefault = static_cast<float>(static_cast<double>(0.0f) + pc.h);  // value when no cell is visited
+    float* scratch = reinterpret_cast<float*>(&lb);
+    const bool wantDefault = out.default_next != nullptr;
+    if (!ls.radiusOk || !centre_usable(c.cx, c.cy)) {
+        nominal_invalid(no, c.cx, c.cy, ls.radiusOk ? 2 : 3);
+        co.x = co.y = 0.0; co.z = 0.0f; co.row = co.col = -1; co.code = 6;
+        if (wantDefault && centre_usable(nx0, ny)) {  // cpp:2289-2301 (leg search skipped: radius / centre unusable)
+            const BBox dbox = circle_bbox_fast(m.g, nx0, ny, pc.rf);
+            bool unused;
+            zDefault = disc_pass_direct<G, false>(m, pc, nx0, ny, dbox, g, unused, scratch);
+        }
+    } else {
+        // corner lanes: box 0 = centre foot disc, box 1 = centroid rectangle, box 2 = default-track disc,
+        // box 3 = getIndex(centre)
+        const Box b0{c.cx, c.cy, pc.rf, pc.rf}, b1{c.cx, c.cy, 0.5 * lk.lx, 0.5 * lk.ly};
+        const Box b2{nx0, ny, pc.rf, pc.rf};
+        Corners<G, 16> cs;
+        cs.eval(m.g, g, b0, b1, b2, b0, 0x8u);
+        const BBox bb = cs.template bbox<0>(g);
+        const BBox rbox = cs.template bbox<1>(g);
+        const BBox dbox = cs.template bbox<2>(g);
+        c.ici = cs.template get<12>(g);
+        c.icj = cs.template get<13>(g);
+        const Submap sm = submap_from_corners(m.g, rbox, cs.box_within(1), c.cx, c.cy);
+        const int iw0 = c.ici - pc.winH, jw0 = c.icj - pc.winH;
+        // one memory round trip: the window's bit rows and the elevation of the two discs around known centres
+        uint4 lo[NRL], hi[NRL];
+        win_issue<G, NRL>(bm, m.g, g, iw0, jw0, lo, hi);
+        DiscLoads dc, dd;
+        disc_issue<G, false, kMid>(m, pc, c.cx, c.cy, bb, g, dc);
+        const bool dfltUsable = wantDefault && centre_usable(nx0, ny);
+        if (dfltUsable) disc_issue<G, false, kMid>(m, pc, nx0, ny, dbox, g, dd);
+        WinRows<NRL> w;
+        win_finish<NRL>(jw0, lo, hi, w);
+#pragma unroll
+        for (int k = 0; k < NRL; ++k) lb.a[g.sub + G * k] = w.Df[k];
+        const CentroidScan sc = rows_from_bits<G, NRL>(sm, w, g, iw0, jw0);
+        pose_sync<G>();
+        const bool defaultOk = default_ok_bits<G, NR, kMid>(m, pc, c.cx, c.cy, bb, dc, lb.a, iw0, jw0, g);  // cpp:2012
+        pose_sync<G>();  // lb doubles as scratch below
+        bool unused;
+        const float zCentre = disc_consume<G, false, kMid>(m, pc, c.cx, c.cy, bb, g, dc, unused, scratch);  // cpp:2029
+        constexpr bool kOneCell = kMid;  // the 3x3-only variants are launched for one-cell foot discs (mid_variant_bits)
+        CentroidPendingBits cp;
+        centroid_begin_bits<G, kOneCell>(m, pc, c, sm, sc, zCentre, g, cp);                                 // cpp:818-821
+        if (dfltUsable) zDefault = disc_consume<G, false, kMid>(m, pc, nx0, ny, dbox, g, dd, unused, scratch);  // cpp:2289-2301
+        if (defaultOk) {
+            no.valid = 1;
+            no.source = 0;
+            no.row = c.ici;
+            no.col = c.icj;
+            no.x = c.cx;  // cpp:2016-2017
+            no.y = c.cy;
+            no.z = zCentre;
+        } else {
+            nominal_invalid(no, c.cx, c.cy, 2);
+            int wi = 0, wj = 0;
+            pose_sync<G>();
+            if (spiral_bits<G, NRL>(m, pc, lut, head, c, w, lb, g, iw0, jw0, wi, wj)) {  // cpp:2022
+                no.valid = 1;
+                no.source = 1;
+                no.row = wi;
+                no.col = wj;
+                no.x = cell_pos(m.g.baseX, m.g.res, wi);  // cpp:2105-2107
+                no.y = cell_pos(m.g.baseY, m.g.res, wj);
+                no.z = zCentre;  // z at the DEFAULT centre even for a candidate (cpp:2029)
+            }
+            pose_sync<G>();
+        }
+        if (cp.needDisc != 0) cp.o.z = centroid_height_bits<G, kOneCell>(pc, g, cp);
+        co = cp.o;
+    }
+    lc->valid = no.valid;
+    lc->v[0][0] = nx0;   lc->v[0][1] = ny;    lc->v[0][2] = static_cast<double>(zDefault);
+    lc->v[1][0] = co.x;  lc->v[1][1] = co.y;  lc->v[1][2] = static_cast<double>(co.z);
+    lc->v[2][0] = no.x;  lc->v[2][1] = no.y;  lc->v[2][2] = static_cast<double>(no.z);
+    if (g.sub == 0 && live) {
+        const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
+        if (out.nominal) store_foothold(out.nominal + o, no, leg, cyc);
+        if (out.selected) {
+            fpe_selected_foothold sf;
+            sf.row = no.row; sf.col = no.col; sf.z = no.z;
+            sf.valid = static_cast<uint8_t>(no.valid); sf.source = static_cast<uint8_t>(no.source);
+            sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
+            out.selected[o] = sf;
+        }
+        if (out.centroid) {
+            fpe_centroid_foothold cf;
+            cf.x = co.x; cf.y = co.y; cf.z = co.z; cf.row = co.row; cf.col = co.col;
+            cf.code = static_cast<uint8_t>(co.code); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
+            out.centroid[o] = cf;
+        }
+        if (out.default_next) {
+            out.default_next[o * 3 + 0] = nx0;
+            out.default_next[o * 3 + 1] = ny;
+            out.default_next[o * 3 + 2] = static_cast<double>(zDefault);
+        }
+    }
+}
+
+}  // namespace
+
+// ---- chained plan on the bit window: 8 lanes per leg, two poses per wavefront ------------------------------------
+template <int NRL, bool kMid>
+__global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm, PlanConsts pc, SpiralLut lut,
+                                                          const fpe_pose* __restrict__ poses, int B, int nCycles, fpe_plan_out out) {
+    constexpr int G = 8;
+    constexpr int NR = G * NRL;
+    // the map geometry doubles are operands of vector f64 arithmetic only: parked in VGPRs (see plan_chained_kernel)
+    DevMap m = mArg;
+    m.g.res = in_vgpr(m.g.res);
+    m.g.rinv = in_vgpr(m.g.rinv);
+    m.g.lenX = in_vgpr(m.g.lenX);
+    m.g.lenY = in_vgpr(m.g.lenY);
+    m.g.posX = in_vgpr(m.g.posX);
+    m.g.posY = in_vgpr(m.g.posY);
+    m.g.orgX = in_vgpr(m.g.orgX);
+    m.g.orgY = in_vgpr(m.g.orgY);
+    m.g.baseX = in_vgpr(m.g.baseX);
+    m.g.baseY = in_vgpr(m.g.baseY);
+    constexpr int kPoseThreads = 4 * G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = static_cast<int>(threadIdx.x);
+    const int slot = tid / kPoseThreads;
+    const int leg = (tid / G) & 3;
+    const Grp<G> g(tid);
+    constexpr size_t poseBytes = sizeof(PoseShared) + 4 * sizeof(LegBits<NR>);
+    unsigned char* base = smem + static_cast<size_t>(slot) * poseBytes;
+    PoseShared& sh = *reinterpret_cast<PoseShared*>(base);
+    LegBits<NR>& lb = *reinterpret_cast<LegBits<NR>*>(base + sizeof(PoseShared) + static_cast<size_t>(leg) * sizeof(LegBits<NR>));
+
+    int b = blockIdx.x * 2 + slot;
+    const bool live = b < B;  // the padding pose of the last block runs the chain on pose B-1, stores nothing
+    if (!live) b = B - 1;
+    const fpe_pose* pp = poses + b;
+    const double x0 = pp->position[0], y0 = pp->position[1], z0 = pp->position[2];
+    const int gait = pp->gait;
+    const LegStatic ls = make_leg_static(pc, pp, leg, m.g.res, lut);
+    const LutHead head = load_lut_head(lut, g);
+    for (int k = tid % kPoseThreads; k < pc.nFoot; k += kPoseThreads) {
+        sh.footDa[k] = pc.footDa[k];
+        sh.footDb[k] = pc.footDb[k];
+        sh.footOff[k] = 0;
+    }
+    // initial stance (cpp:350-378) and first-gait shift (setFirstGait, cpp:2679-2699)
+    if (g.sub == 0) {
+        double sx = (leg == 0 || leg == 3) ? pc.LbHalf : -pc.LbHalf;
+        double sy = (leg <= 1) ? pc.WbHalfNeg : pc.WbHalfPos;
+        double sz = 0;
+        sx += x0;
+        sy += y0;
+        sz += z0;
+        if (out.stance && live) {
+            double* st = out.stance + (static_cast<size_t>(b) * 4 + leg) * 3;
+            st[0] = sx;
+            st[1] = sy;
+            st[2] = sz;
+        }
+        for (int t = 0; t < 3; ++t) {
+            sh.cur[t][leg][0] = sx - pc.stepHalf;
+            sh.cur[t][leg][1] = sy;
+            sh.cur[t][leg][2] = sz;
+        }
+    }
+    pose_sync<G>();
+    if (out.pose_status && live && leg == 0 && g.sub == 0)
+        out.pose_status[b] = opt_gate_cycle0(m.g, pc, polygon_center_x(sh.cur[0]), y0);
+
+    double adjY = 0.0;  // ajustedPose_[1], cpp:759
+    const int nPhases = (gait == 1) ? 4 : 1;
+    const double advance = (gait == 1) ? pc.stepQuarter : pc.step;
+    // swing order LF,RH,RF,LH (RF_FIRST=false) or RF,LH,LF,RH (build-defined walk)
+    const int walkOrder = pc.RF_FIRST ? ((0) | (2 << 2) | (3 << 4) | (1 << 6)) : ((3) | (1 << 2) | (0 << 4) | (2 << 6));
+    constexpr int kPoseLanes = 4 * G;
+    const unsigned long long poseMask = ((1ull << kPoseLanes) - 1ull) << (slot * kPoseLanes);
+
+    for (int cyc = 0; cyc < nCycles; ++cyc) {
+        bool cycleOk = true;
+        for (int ph = 0; ph < nPhases; ++ph) {
+            const unsigned mask = (gait == 1) ? (1u << ((walkOrder >> (2 * ph)) & 3)) : 0xFu;
+            const bool active = (mask >> leg) & 1u;
+            // feet-polygon centres: group t computes track t (getPolygonCenter, cpp:2191, 2265)
+            if (leg < 3 && g.sub == 0) sh.ctr[leg] = polygon_center_x(sh.cur[leg]);
+            pose_sync<G>();
+            // footholdValidation_ (cpp:1323) is a ballot over the pose's lanes; the committed positions go from
+            // registers straight to PoseShared::cur (cpp:1332-1576)
+            LegCommit lc;
+            lc.valid = 1;  // non-swing legs do not vote
+            if (active) leg_phase_bits<G, NRL, kMid>(m, bm, pc, lut, head, sh, lb, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out, &lc);
+            const bool phaseOk = (__ballot(lc.valid == 0) & poseMask) == 0ull;
+            if (phaseOk && active && g.sub == 0) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) sh.cur[t][leg][k] = lc.v[t][k];
+            }
+            pose_sync<G>();
+            cycleOk = cycleOk && phaseOk;
+        }
+        if (leg == 0 && g.sub == 0 && live && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = cycleOk ? 1 : 0;
+        adjY += pc.drift;  // cpp:1578
+    }
+}
+
+// ---- host side of the bit-window path --------------------------------------------------------------------------
+size_t bitmap_words(int rows, int cols, int* strideW, int* nw) {
+    *nw = (cols + 31) / 32;
+    *strideW = *nw + 2 * kBitPadW;
+    return static_cast<size_t>(rows + 2) * (*strideW) * 4;  // 4-byte units (4 planes per word group)
+}
+
+hipError_t launch_build_bitmap(const float* d_trav, int rows, int cols, float thrDefault, float thrCandidate, uint32_t* d_words,
+                               hipStream_t stream) {
+    int strideW, nw;
+    const size_t units = bitmap_words(rows, cols, &strideW, &nw);
+    hipError_t e = hipMemsetAsync(d_words, 0, units * 4, stream);  // padding rows / word groups; recycled buffers are dirty
+    if (e != hipSuccess) return e;
+    dim3 grid((cols + 255) / 256, rows);
+    hipLaunchKernelGGL(build_bitmap_kernel, grid, dim3(256), 0, stream, d_trav, rows, cols, thrDefault, thrCandidate,
+                       reinterpret_cast<uint4*>(d_words), strideW, nw);
+    return hipGetLastError();
+}
+
+// Rows per lane of the 8-lane bit-window kernel for a window half-width, or 0 when no instantiation fits.
+static int bits_rows_per_lane(int winH) {
+    const int rows = 2 * winH + 1;
+    if (rows > 32) return 0;  // one 32-bit row mask per plane
+    if (rows <= 16) return 2;
+    if (rows <= 24) return 3;
+    return 4;
+}
+
+bool bits_supported(const PlanConsts& pc, const MapGeom& g) {
+    if (pc.noBits != 0 || pc.winH <= 0) return false;
+    if (pc.groupOverride != 0 && pc.groupOverride != 8) return false;
+    const int nrl = bits_rows_per_lane(pc.winH);
+    if (nrl == 0) return false;
+    // the per-leg LDS (3 row arrays of 8 * nrl words) doubles as float scratch of a direct disc pass over a
+    // CircleIterator bounding box of up to (2 ceil(rf / res) + 2)^2 cells
+    const double side = 2.0 * ceil(pc.rf / g.res) + 2.0;
+    return side * side <= 3.0 * 8.0 * nrl;
+}
+
+hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut, const fpe_pose* d_poses,
+                            int B, int nCycles, const fpe_plan_out& d_out, hipStream_t stream) {
+    const int nrl = bits_rows_per_lane(pc.winH);
+    const bool mid = mid_variant(pc, m.g.res) && pc.nFoot == 1;  // rf < res: the candidate disc is the candidate's own cell
+    const dim3 grid((B + 1) / 2), block(64);
+#define FPE_LAUNCH_BITS(NRL, MID)                                                                                          \
+    hipLaunchKernelGGL((plan_bits_kernel<NRL, MID>), grid, block, 2 * (sizeof(PoseShared) + 4 * sizeof(LegBits<8 * NRL>)), \
+                       stream, m, bm, pc, lut, d_poses, B, nCycles, d_out)
+    if (nrl == 2 && mid) FPE_LAUNCH_BITS(2, true);
+    else if (nrl == 2) FPE_LAUNCH_BITS(2, false);
+    else if (nrl == 3 && mid) FPE_LAUNCH_BITS(3, true);
+    else if (nrl == 3) FPE_LAUNCH_BITS(3, false);
+    else if (nrl == 4 && mid) FPE_LAUNCH_BITS(4, true);
+    else if (nrl == 4) FPE_LAUNCH_BITS(4, false);
+    else return hipErrorInvalidValue;
+#undef FPE_LAUNCH_BITS
+    return hipGetLastError();
+}

@@ -52,6 +52,9 @@ struct PlanConsts {
     int32_t groupOverride; // 0 = automatic lanes-per-leg; 4 / 8 / 16 / 64 / 65 force it (fpe_set_tuning "plan_group")
     int32_t noMidVariant;  // fpe_set_tuning "no_mid_variant": never launch the 3x3-only kernel variants
     int32_t noBits;        // fpe_set_tuning "no_bits": never launch the bit-window kernels
+    // Half-width (cells) of the bit window around getIndex(search centre), or 0 when the host could not prove the
+    // bit-window kernels exact for these parameters on this map (fpe_host.cpp::bits_window_halfwidth)
+    int32_t winH;
     // getGaitCycleSearchGridMap's submap (cpp:2339-2345): isos_.length x isos_.width (cpp:384-394)
     double isosLen, isosWid;
     // Cell offsets of a CELL-CENTRED foot disc (checkCirclePolygonFoothold's CircleIterator around

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -57,35 +58,44 @@ int fail_hip(hipError_t e, const char* what) {
 
 // Layer buffers of retired snapshots are recycled instead of freed: a traversability map arrives
 // at 10-20 Hz and hipMalloc/hipFree (the latter a device-wide sync) would dominate the upload.
-// A buffer reaches the pool only from ~MapSnapshot, i.e. after the upload that filled it and every
-// recorded asynchronous reader have completed (events), so a taker may write it on any stream.
+// Lifetime without per-launch GPU work: a snapshot retired while device-API (asynchronous) launches may still
+// read it hands its buffers over marked "dirty"; whoever takes a dirty buffer — an upload or a bit-plane build,
+// 10-20 Hz paths — synchronises the device once before writing it.  Plans never pay for this: an event recorded
+// after every launch would put a 3-4 us bubble between back-to-back plan kernels (measured).
 struct BufferPool {
+    struct Entry {
+        size_t n;      // 4-byte units
+        float* p;
+        bool dirty;    // retired while asynchronous (device-API) work may still have been reading it
+    };
     std::mutex mu;
-    std::vector<std::pair<size_t, float*>> free;  // (4-byte units, pointer)
-    float* take(size_t n) {
+    std::vector<Entry> free;
+    float* take(size_t n, bool* dirty) {
         std::lock_guard<std::mutex> lk(mu);
         for (size_t k = 0; k < free.size(); ++k)
-            if (free[k].first == n) {
-                float* p = free[k].second;
+            if (free[k].n == n) {
+                float* p = free[k].p;
+                *dirty = free[k].dirty;
                 free.erase(free.begin() + static_cast<long>(k));
                 return p;
             }
+        *dirty = false;
         return nullptr;
     }
-    void give(size_t n, float* p) {
+    void give(size_t n, float* p, bool dirty = false) {
         float* drop = nullptr;
         {
             std::lock_guard<std::mutex> lk(mu);
             if (free.size() >= 10) {  // two snapshots' worth (layers + bit planes) plus the upload staging layer
-                drop = free.front().second;
+                drop = free.front().p;
                 free.erase(free.begin());
             }
-            free.emplace_back(n, p);
+            free.push_back(Entry{n, p, dirty});
         }
-        if (drop) (void)hipFree(drop);
+        if (drop) (void)hipFree(drop);  // hipFree synchronises the device: safe for a dirty buffer too
     }
     ~BufferPool() {
-        for (auto& e : free) (void)hipFree(e.second);
+        for (auto& e : free) (void)hipFree(e.p);
     }
 };
 
@@ -161,6 +171,7 @@ struct MaskSet {
     size_t n = 0;  // in 4-byte units (BufferPool size key)
     int strideW = 0, nw = 0;
     hipEvent_t ready = nullptr;
+    bool readyDone = false;  // guarded by MapSnapshot::mu
 };
 
 struct MapSnapshot {
@@ -169,42 +180,28 @@ struct MapSnapshot {
     float* d_trav = nullptr;
     float* d_elev = nullptr;
     std::shared_ptr<BufferPool> pool;
-    // `ready` is recorded on the uploading stream after the copy / canonicalise work; every consumer stream waits
-    // on it before its first kernel (a no-op once the upload has completed).  `uses` are events recorded by
-    // asynchronous consumers (fpe_plan_device / fpe_search_legs_device) after their launch: the layer buffers are
-    // recycled only behind them.
+    // `ready` is recorded on the uploading stream after the copy / canonicalise work; a consumer stream waits on
+    // it before its first kernel until the event has been seen complete once (then no GPU-side wait is queued
+    // any more).  `asyncUsed`: some device-API launch read this snapshot without the host waiting for it.
     hipEvent_t ready = nullptr;
+    std::atomic<bool> readyDone{false};
+    std::atomic<bool> asyncUsed{false};
     std::mutex mu;
-    std::vector<std::pair<hipStream_t, hipEvent_t>> uses;
     std::vector<MaskSet> masks;
 
-    hipError_t wait_ready(hipStream_t s) const { return ready ? hipStreamWaitEvent(s, ready, 0) : hipSuccess; }
-    // "last use on stream s": one event per consumer stream, re-recorded by every launch on that stream
-    hipError_t note_use(hipStream_t s) {
-        std::lock_guard<std::mutex> lk(mu);
-        for (auto& u : uses)
-            if (u.first == s) return hipEventRecord(u.second, s);
-        hipEvent_t ev;
-        hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-        if (e != hipSuccess) return e;
-        e = hipEventRecord(ev, s);
-        if (e != hipSuccess) {
-            (void)hipEventDestroy(ev);
-            return e;
+    hipError_t wait_ready(hipStream_t s) {
+        if (!ready || readyDone.load(std::memory_order_acquire)) return hipSuccess;
+        if (hipEventQuery(ready) == hipSuccess) {
+            readyDone.store(true, std::memory_order_release);
+            return hipSuccess;
         }
-        uses.emplace_back(s, ev);
-        return hipSuccess;
+        return hipStreamWaitEvent(s, ready, 0);
     }
+    void note_async_use() { asyncUsed.store(true, std::memory_order_release); }
     ~MapSnapshot() {
-        // A buffer goes back to the pool only after the upload and every recorded asynchronous use have
-        // completed.  A snapshot is retired once per map message (10-20 Hz), never in the per-plan path, and the
-        // events have usually completed long before.
-        for (auto& u : uses) {
-            (void)hipEventSynchronize(u.second);
-            (void)hipEventDestroy(u.second);
-        }
+        const bool dirty = asyncUsed.load(std::memory_order_acquire);
         if (ready) {
-            (void)hipEventSynchronize(ready);
+            (void)hipEventSynchronize(ready);  // the upload itself (normally long complete)
             (void)hipEventDestroy(ready);
         }
         for (MaskSet& ms : masks) {
@@ -212,10 +209,10 @@ struct MapSnapshot {
                 (void)hipEventSynchronize(ms.ready);
                 (void)hipEventDestroy(ms.ready);
             }
-            if (ms.d_words) pool ? pool->give(ms.n, reinterpret_cast<float*>(ms.d_words)) : (void)hipFree(ms.d_words);
+            if (ms.d_words) pool ? pool->give(ms.n, reinterpret_cast<float*>(ms.d_words), dirty) : (void)hipFree(ms.d_words);
         }
-        if (d_trav) pool ? pool->give(n, d_trav) : (void)hipFree(d_trav);
-        if (d_elev) pool ? pool->give(n, d_elev) : (void)hipFree(d_elev);
+        if (d_trav) pool ? pool->give(n, d_trav, dirty) : (void)hipFree(d_trav);
+        if (d_elev) pool ? pool->give(n, d_elev, dirty) : (void)hipFree(d_elev);
     }
 };
 
@@ -247,8 +244,9 @@ namespace {
 // Device allocation in 4-byte units with the tail padding every pooled buffer carries (the row scan reads whole
 // 16-byte groups past the end of a layer, fpe_kernels.hip::rows_issue), so any pooled buffer can serve any role.
 hipError_t alloc_units(BufferPool& pool, size_t n, float** out) {
-    *out = pool.take(n);
-    if (*out) return hipSuccess;
+    bool dirty = false;
+    *out = pool.take(n, &dirty);
+    if (*out) return dirty ? hipDeviceSynchronize() : hipSuccess;  // see BufferPool: asynchronous readers may be in flight
     return hipMalloc(reinterpret_cast<void**>(out), n * sizeof(float) + kLayerPadBytes);
 }
 
@@ -259,7 +257,6 @@ struct CallPlan {
     size_t planLds = 0, searchLds = 0;
     bool useBits = false;
     fpe::BitMap bits{nullptr, 0, 0};
-    hipEvent_t bitsReady = nullptr;
 };
 
 int prepare_call(fpe_engine* h, const fpe_params* params, float maxRadius, CallPlan& cp, hipStream_t stream, bool wantBits) {
@@ -310,15 +307,17 @@ int prepare_call(fpe_engine* h, const fpe_params* params, float maxRadius, CallP
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ms.ready, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventRecord(ms.ready, stream);
             if (e != hipSuccess) {
-                snap.pool->give(ms.n, buf);
+                snap.pool->give(ms.n, buf, true);
                 return fail_hip(e, "bit-plane build");
             }
             snap.masks.push_back(ms);
             found = &snap.masks.back();
         }
         cp.bits = fpe::BitMap{reinterpret_cast<const uint4*>(found->d_words), found->strideW, found->nw};
-        cp.bitsReady = found->ready;
-        FPE_HIP(hipStreamWaitEvent(stream, cp.bitsReady, 0));
+        if (!found->readyDone) {
+            if (hipEventQuery(found->ready) == hipSuccess) found->readyDone = true;
+            else FPE_HIP(hipStreamWaitEvent(stream, found->ready, 0));
+        }
     }
     return FPE_OK;
 }
@@ -532,8 +531,7 @@ int fpe_plan_device(fpe_handle h, const fpe_params* params, const fpe_pose* d_po
     if (rc != FPE_OK) return rc;
     rc = launch_plan(h, cp, d_poses, B, n_cycles, *d_out, st);
     if (rc != FPE_OK) return rc;
-    // the launch is asynchronous: the snapshot's buffers must not be recycled before it has completed
-    FPE_HIP(cp.snap->note_use(st));
+    cp.snap->note_async_use();  // asynchronous launch: the snapshot's buffers are recycled only behind a device sync
     return FPE_OK;
 }
 
@@ -629,7 +627,7 @@ int fpe_search_legs_device(fpe_handle h, const fpe_params* params, const fpe_leg
     int rc = prepare_call(h, params, 0.0f, cp, st, false);
     if (rc != FPE_OK) return rc;
     FPE_HIP(fpe::launch_search_legs(dev_map(*cp.snap), cp.pc, h->lut(), d_queries, n, d_out, st));
-    FPE_HIP(cp.snap->note_use(st));
+    cp.snap->note_async_use();
     return FPE_OK;
 }
 

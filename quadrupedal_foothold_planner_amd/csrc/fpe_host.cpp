@@ -72,6 +72,44 @@ int tile_halfwidth(float maxSearchRadius, float footRadius, double resolution) {
     return nRings + nFootBox + 1;
 }
 
+// The bit-window kernels (fpe_bits.hpp) look every traversability decision up in a window of row masks around
+// getIndex(centre).  They are exact when
+//  (1) the foot-disc offset table is proved (derive_foot_offsets) and has at most 32 entries;
+//  (2) every cell a search can touch lies within `H` cells of the centre index.  For a bounded position p and the
+//      centre c the index difference is floor-like in (p - c) / res; with rounding errors of at most `slack` cells
+//      (positions are rewritten by boundPositionToRange and divided by res in f64) the reach of an extent d is
+//      floor(d / res + frac) <= ceil(d / res) cells, one more when d / res is within `slack` of an integer.
+//      Extents: the centroid rectangle reaches R rows (lx / 2 = R) and R / 2 columns (cpp:1616-1617); a spiral
+//      candidate of an unfiltered ring lies within nRings - 2 cells, one of the two filtered rings within
+//      R + res / 2 of the centre (SpiralIterator::isInside), and its foot disc footReach further; a cell of the
+//      centre's own disc within rf + res / 2;
+//  (3) getIndex(cell centre of the centroid submap) is the top-left index plus (row, col): the submap's cell centres
+//      differ from the map's by a few ulps of the coordinate magnitude, which must be far below half a cell;
+//  (4) index predictions (base - limit) / res fit an int with room to spare.
+// Search centres outside the map need no extra room: their clamped boxes hold no disc member and getSubmap fails.
+int bits_window_halfwidth(const PlanConsts& c, const MapGeom& g) {
+    if (!c.footRobust || c.nFoot < 1 || c.nFoot > 32) return 0;
+    const double res = g.res;
+    const double R = static_cast<double>(c.maxSearchRadius), rf = c.rf;
+    const double mag = std::fabs(g.posX) + g.lenX + std::fabs(g.posY) + g.lenY + R + rf + 1.0;
+    const double slack = 64.0 * DBL_EPSILON * mag / res + 1e-12;  // rounding error of an index quotient, in cells
+    if (!(slack < 1e-3)) return 0;                                 // (3): also keeps cell centres far from cell edges
+    if (!((mag + 2.0e6) / res < 5.0e8)) return 0;                  // (4)
+    if (!(R / res < 1.0e4) || !(rf / res < 1.0e3)) return 0;
+    auto reach = [&](double d) {  // cells an extent d can reach from the centre's cell
+        const double q = d / res;
+        int n = static_cast<int>(std::ceil(q));
+        if (std::fabs(q - std::round(q)) <= slack) n = static_cast<int>(std::round(q)) + 1;
+        return n;
+    };
+    const int nRings = spiral_rings(c.maxSearchRadius, res);
+    const int rectReach = reach(R);
+    const int filtered = reach(R + 0.5 * res);                      // |offset| * res <= R + res / 2 (+ rounding)
+    const int candReach = std::min(nRings, std::max(nRings - 2, filtered)) + c.footReach;
+    const int discReach = reach(rf + 0.5 * res);
+    return std::max(std::max(rectReach, candReach), std::max(discReach, 1));
+}
+
 int validate_params(const fpe_params& p) {
     const float fs[] = {p.footRadius, p.defaultFootholdThreshold, p.candidateFootholdThreshold, p.searchRadius,
                         p.stepLength, p.length, p.width, p.l1, p.skew};
@@ -205,6 +243,7 @@ void derive_constants(const fpe_params& p, const MapGeom& geom, float maxSearchR
         c.footRobust = 0;
         c.footReach = static_cast<int>(std::ceil(c.rf / resolution)) + 1;
     }  // test knob: force the literal bounding-box walk
+    c.winH = bits_window_halfwidth(c, geom);
 }
 
 // globalFootholdPlan message bookkeeping: cpp:681-699 (stance entries), cpp:1378-1396 (valid

@@ -32,6 +32,10 @@ void derive_foot_offsets(float footRadius, const MapGeom& g, PlanConsts& out);
 // the centroid rectangle for search radii up to maxSearchRadius.
 int tile_halfwidth(float maxSearchRadius, float footRadius, double resolution);
 
+// Half-width of the window that provably contains every cell a leg search can touch (bit-window kernels), or 0
+// when one of the proofs those kernels rest on does not hold for these parameters on this map.
+int bits_window_halfwidth(const PlanConsts& c, const MapGeom& g);
+
 // number of rings ceil(double(R)/res) as SpiralIterator computes it
 int spiral_rings(float searchRadius, double resolution);
 

@@ -1894,18 +1894,8 @@ hipError_t launch_canonicalise(const float* d_src, float* d_dst, int rows, int c
     return hipGetLastError();
 }
 
-// ---- bit-window path: placeholders until fpe_bits.hpp lands -----------------------------------------------
-size_t bitmap_words(int rows, int cols, int* strideW, int* nw) {
-    *nw = (cols + 31) / 32;
-    *strideW = *nw + 2 * kBitPadW;
-    return static_cast<size_t>(rows + 2) * (*strideW) * 4;
-}
-hipError_t launch_build_bitmap(const float*, int, int, float, float, uint32_t*, hipStream_t) { return hipErrorNotSupported; }
-bool bits_supported(const PlanConsts&, const MapGeom&) { return false; }
-hipError_t launch_plan_bits(const DevMap&, const BitMap&, const PlanConsts&, const SpiralLut&, const fpe_pose*, int, int,
-                            const fpe_plan_out&, hipStream_t) {
-    return hipErrorNotSupported;
-}
+// ---- part two of this translation unit: the bit-window kernels ---------------------------------------------
+#include "fpe_bits.hpp"
 
 hipError_t set_max_lds(size_t planBytes, size_t searchBytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_chained_kernel<16>),
