@@ -507,6 +507,7 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
         c.icj = cs.template get<13>(g);
         const Submap sm = submap_from_corners(m.g, rbox, cs.box_within(1), c.cx, c.cy);
         const int iw0 = c.ici - pc.winH, jw0 = c.icj - pc.winH;
+        stamp(pc, cyc, 2);
         // one memory round trip: the window's bit rows and the elevation of the two discs around known centres
         uint4 lo[NRL], hi[NRL];
         win_issue<G, NRL>(bm, m.g, g, iw0, jw0, lo, hi);
@@ -514,20 +515,25 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
         disc_issue<G, false, kMid>(m, pc, c.cx, c.cy, bb, g, dc);
         const bool dfltUsable = wantDefault && centre_usable(nx0, ny);
         if (dfltUsable) disc_issue<G, false, kMid>(m, pc, nx0, ny, dbox, g, dd);
+        stamp(pc, cyc, 3);
         WinRows<NRL> w;
         win_finish<NRL>(jw0, lo, hi, w);
 #pragma unroll
         for (int k = 0; k < NRL; ++k) lb.a[g.sub + G * k] = w.Df[k];
         const CentroidScan sc = rows_from_bits<G, NRL>(sm, w, g, iw0, jw0);
         pose_sync<G>();
+        stamp(pc, cyc, 4);
         const bool defaultOk = default_ok_bits<G, NR, kMid>(m, pc, c.cx, c.cy, bb, dc, lb.a, iw0, jw0, g);  // cpp:2012
         pose_sync<G>();  // lb doubles as scratch below
         bool unused;
         const float zCentre = disc_consume<G, false, kMid>(m, pc, c.cx, c.cy, bb, g, dc, unused, scratch);  // cpp:2029
+        stamp(pc, cyc, 5);
         constexpr bool kOneCell = kMid;  // the 3x3-only variants are launched for one-cell foot discs (mid_variant_bits)
         CentroidPendingBits cp;
         centroid_begin_bits<G, kOneCell>(m, pc, c, sm, sc, zCentre, g, cp);                                 // cpp:818-821
+        stamp(pc, cyc, 6);
         if (dfltUsable) zDefault = disc_consume<G, false, kMid>(m, pc, nx0, ny, dbox, g, dd, unused, scratch);  // cpp:2289-2301
+        stamp(pc, cyc, 7);
         if (defaultOk) {
             no.valid = 1;
             no.source = 0;
@@ -551,6 +557,7 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
             }
             pose_sync<G>();
         }
+        stamp(pc, cyc, 8);
         if (cp.needDisc != 0) cp.o.z = centroid_height_bits<G, kOneCell>(pc, g, cp);
         co = cp.o;
     }
@@ -664,13 +671,16 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
             const unsigned mask = (gait == 1) ? (1u << ((walkOrder >> (2 * ph)) & 3)) : 0xFu;
             const bool active = (mask >> leg) & 1u;
             // feet-polygon centres: group t computes track t (getPolygonCenter, cpp:2191, 2265)
+            stamp(pc, cyc, 0);
             if (leg < 3 && g.sub == 0) sh.ctr[leg] = polygon_center_x(sh.cur[leg]);
             pose_sync<G>();
+            stamp(pc, cyc, 1);
             // footholdValidation_ (cpp:1323) is a ballot over the pose's lanes; the committed positions go from
             // registers straight to PoseShared::cur (cpp:1332-1576)
             LegCommit lc;
             lc.valid = 1;  // non-swing legs do not vote
             if (active) leg_phase_bits<G, NRL, kMid>(m, bm, pc, lut, head, sh, lb, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out, &lc);
+            stamp(pc, cyc, 9);
             const bool phaseOk = (__ballot(lc.valid == 0) & poseMask) == 0ull;
             if (phaseOk && active && g.sub == 0) {
 #pragma unroll
@@ -680,6 +690,7 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
             }
             pose_sync<G>();
             cycleOk = cycleOk && phaseOk;
+            stamp(pc, cyc, 10);
         }
         if (leg == 0 && g.sub == 0 && live && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = cycleOk ? 1 : 0;
         adjY += pc.drift;  // cpp:1578
