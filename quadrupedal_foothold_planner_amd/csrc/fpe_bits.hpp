@@ -52,78 +52,98 @@ __global__ __launch_bounds__(256) void build_bitmap_kernel(const float* __restri
 }
 
 // ---- window rows ------------------------------------------------------------------------------------------
-template <int NRL>
+// A window row is KW 32-bit words per plane (KW = 1: windows of up to 32 columns, the 8-lane kernels; 2 / 3: the
+// one-wavefront-per-pose kernels of 1 cm / 0.5 cm maps).
+template <int NRL, int KW>
 struct WinRows {
-    uint32_t D[NRL], Df[NRL], C[NRL], F[NRL];
+    uint32_t D[NRL][KW], Df[NRL][KW], C[NRL][KW], F[NRL][KW];
 };
 // Per-leg LDS: row masks shared between the lanes of the leg's group (a: Df rows, later P rows; b: E rows;
-// f: F rows for non-rectangle polygons).  The same bytes serve as float scratch of a direct disc pass.
-template <int NR>
+// f: F rows for non-rectangle polygons), and for non-rectangle polygons the two boundary crossings per window
+// column.  The row arrays double as float scratch of a direct disc pass / ordered height sum.
+template <int NR, int KW>
 struct LegBits {
-    uint32_t a[NR];
-    uint32_t b[NR];
-    uint32_t f[NR];
+    uint32_t a[NR * KW];
+    uint32_t b[NR * KW];
+    uint32_t f[NR * KW];
+    double colX[KW > 1 ? 2 * 32 * KW : 2];
 };
+
+__device__ __forceinline__ unsigned bits_from(int lo) { return lo >= 32 ? 0u : (lo <= 0 ? ~0u : (~0u << lo)); }
+__device__ __forceinline__ unsigned bits_to(int hi) { return hi < 0 ? 0u : (hi >= 31 ? ~0u : ((2u << hi) - 1u)); }
+// word `wi` of the mask with bits [lo, hi] set (bit positions over the whole multi-word row)
+__device__ __forceinline__ unsigned range_word(int lo, int hi, int wi) { return bits_from(lo - 32 * wi) & bits_to(hi - 32 * wi); }
 
 // Window origin (iw0, jw0) = getIndex(centre) - winH.  Lane `sub` holds window rows sub + G * k.  Rows and word
 // groups outside the map are clamped onto the zero padding of the planes.
-template <int G, int NRL>
+template <int G, int NRL, int KW>
 __device__ __forceinline__ void win_issue(const BitMap& bm, const MapGeom& mg, const Grp<G>& g, int iw0, int jw0,
-                                          uint4 (&lo)[NRL], uint4 (&hi)[NRL]) {
+                                          uint4 (&grp)[NRL][KW + 1]) {
+    static_assert(KW + 1 <= kBitPadW, "the planes' zero padding must cover a whole window row");
     int w0 = jw0 >> 5;
-    w0 = max(-kBitPadW, min(w0, bm.nw + kBitPadW - 2));
+    w0 = max(-kBitPadW, min(w0, bm.nw + kBitPadW - (KW + 1)));
 #pragma unroll
     for (int k = 0; k < NRL; ++k) {
         int i = iw0 + g.sub + G * k;
         i = max(-1, min(i, mg.rows));
         const uint4* p = bm.words + (static_cast<size_t>(i + 1) * bm.strideW + (w0 + kBitPadW));
-        lo[k] = p[0];
-        hi[k] = p[1];
+#pragma unroll
+        for (int q = 0; q <= KW; ++q) grp[k][q] = p[q];
     }
 }
-template <int NRL>
-__device__ __forceinline__ void win_finish(int jw0, const uint4 (&lo)[NRL], const uint4 (&hi)[NRL], WinRows<NRL>& w) {
+template <int NRL, int KW>
+__device__ __forceinline__ void win_finish(int jw0, const uint4 (&grp)[NRL][KW + 1], WinRows<NRL, KW>& w) {
     const unsigned sh = static_cast<unsigned>(jw0) & 31u;
 #pragma unroll
-    for (int k = 0; k < NRL; ++k) {
-        w.D[k] = __builtin_amdgcn_alignbit(hi[k].x, lo[k].x, sh);
-        w.Df[k] = __builtin_amdgcn_alignbit(hi[k].y, lo[k].y, sh);
-        w.C[k] = __builtin_amdgcn_alignbit(hi[k].z, lo[k].z, sh);
-        w.F[k] = __builtin_amdgcn_alignbit(hi[k].w, lo[k].w, sh);
-    }
+    for (int k = 0; k < NRL; ++k)
+#pragma unroll
+        for (int q = 0; q < KW; ++q) {
+            w.D[k][q] = __builtin_amdgcn_alignbit(grp[k][q + 1].x, grp[k][q].x, sh);
+            w.Df[k][q] = __builtin_amdgcn_alignbit(grp[k][q + 1].y, grp[k][q].y, sh);
+            w.C[k][q] = __builtin_amdgcn_alignbit(grp[k][q + 1].z, grp[k][q].z, sh);
+            w.F[k][q] = __builtin_amdgcn_alignbit(grp[k][q + 1].w, grp[k][q].w, sh);
+        }
 }
 // Bit (window row ri, window column cj) of a row array in LDS; 0 outside the window.
-template <int NR>
+template <int NR, int KW>
 __device__ __forceinline__ unsigned win_bit(const uint32_t* rows, int ri, int cj) {
-    const bool in = static_cast<unsigned>(ri) < static_cast<unsigned>(NR) && static_cast<unsigned>(cj) < 32u;
-    const uint32_t wd = rows[min(max(ri, 0), NR - 1)];
-    return in ? (wd >> (cj & 31)) & 1u : 0u;
+    const bool in = static_cast<unsigned>(ri) < static_cast<unsigned>(NR) && static_cast<unsigned>(cj) < 32u * KW;
+    const int r = min(max(ri, 0), NR - 1), c = min(max(cj, 0), 32 * KW - 1);
+    const uint32_t wd = rows[r * KW + (c >> 5)];
+    return in ? (wd >> (c & 31)) & 1u : 0u;
 }
 
 // checkFootholdUseCentroidMethod's row scan (cpp:1649-1658 whole-region test, cpp:1717-1750 blocked rows) from the
 // D rows: lane = window row.  `cnt > (rightCol + 1) * 0.5` (cpp:1743) is 2 * cnt > nj in integers.
-template <int G, int NRL>
-__device__ __forceinline__ CentroidScan rows_from_bits(const Submap& s, const WinRows<NRL>& w, const Grp<G>& g, int iw0, int jw0) {
-    static_assert(G * NRL <= 32, "row masks of a leg are collected in one 32-bit word");
+template <int G, int NRL, int KW>
+__device__ __forceinline__ CentroidScan rows_from_bits(const Submap& s, const WinRows<NRL, KW>& w, const Grp<G>& g, int iw0, int jw0) {
+    static_assert(G * NRL <= 128, "blocked-row masks are kept in two 64-bit words");
     CentroidScan r0;
     const int ni = s.ni, nj = s.nj;
-    const unsigned sh = static_cast<unsigned>(s.j0 - jw0) & 31u;
-    const unsigned njMask = nj >= 32 ? ~0u : ((1u << (nj & 31)) - 1u);
-    unsigned blockedMask = 0u;
+    const int c0 = s.j0 - jw0, c1 = c0 + nj - 1;  // window columns of the rectangle
+    unsigned long long blk[2] = {0ull, 0ull};      // bit = window row
     bool anyBelow = false;
 #pragma unroll
     for (int k = 0; k < NRL; ++k) {
-        const int r = iw0 + g.sub + G * k - s.i0;  // row of the rectangle held by this lane in slot k
+        const int ri = g.sub + G * k;
+        const int r = iw0 + ri - s.i0;  // row of the rectangle held by this lane in slot k
         const bool liveRow = s.ok && r >= 0 && r < ni;
-        const int cnt = __builtin_popcount((w.D[k] >> sh) & njMask);
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < KW; ++q) cnt += __builtin_popcount(w.D[k][q] & range_word(c0, c1, q));
         anyBelow |= liveRow && cnt > 0;
         const bool blocked = liveRow && 2 * cnt > nj;
-        blockedMask |= static_cast<unsigned>(g.ballot(blocked)) << (G * k);  // bit = window row
+        const unsigned long long mk = g.ballot(blocked);
+        constexpr int kPerWord = 64 / G;  // ballots of G lanes packed into a 64-bit word
+        if constexpr (G == 64) blk[k & 1] |= mk;
+        else blk[(k / kPerWord) & 1] |= mk << (G * (k % kPerWord));
     }
-    const int off = s.i0 - iw0;  // the rectangle lies inside the window (bits_window_halfwidth)
-    const unsigned rel = (off >= 0 && off < 32) ? (blockedMask >> off) : 0u;
-    r0.minRow = rel ? __builtin_ctz(rel) : 0;
-    r0.maxRow = rel ? 31 - __builtin_clz(rel) : 0;
+    const int off = s.i0 - iw0;  // the rectangle lies inside the window (bits_window_halfwidth); ni <= 64
+    unsigned long long rel = 0ull;
+    if (off >= 0 && off < 64) rel = (blk[0] >> off) | (off ? (blk[1] << (64 - off)) : 0ull);
+    else if (off >= 64 && off < 128) rel = blk[1] >> (off - 64);
+    r0.minRow = rel ? __builtin_ctzll(rel) : 0;
+    r0.maxRow = rel ? 63 - __builtin_clzll(rel) : 0;
     r0.whole = s.ok && ni * nj > 0 && !g.any(anyBelow);
     return r0;
 }
@@ -131,7 +151,7 @@ __device__ __forceinline__ CentroidScan rows_from_bits(const Submap& s, const Wi
 // checkDefaultFoothold (cpp:2039-2082) from the Df rows: valid iff >= 1 cell visited and no visited cell has its Df
 // bit set.  The visited cells are the ones disc_issue() enumerated (d.vis / the 3x3 form); boxes it did not
 // pipeline (clamped at the map border, or larger than the pipeline) are walked here, membership test included.
-template <int G, int NR, bool kMid>
+template <int G, int NR, int KW, bool kMid>
 __device__ __forceinline__ bool default_ok_bits(const DevMap& m, const PlanConsts& pc, double cx, double cy, const BBox& bb,
                                                 const DiscLoads& d, const uint32_t* rowsDf, int iw0, int jw0, const Grp<G>& g) {
     bool any = false, fail = false;
@@ -140,7 +160,8 @@ __device__ __forceinline__ bool default_ok_bits(const DevMap& m, const PlanConst
             const int t = g.sub + (g.sub >= 4 ? 1 : 0);
             const int a = t >= 6 ? 2 : (t >= 3 ? 1 : 0);
             const int ri = bb.i0 - iw0, cj = bb.j0 - jw0;
-            fail = (d.vis[0] != 0 && win_bit<NR>(rowsDf, ri + a, cj + (t - 3 * a)) != 0u) || win_bit<NR>(rowsDf, ri + 1, cj + 1) != 0u;
+            fail = (d.vis[0] != 0 && win_bit<NR, KW>(rowsDf, ri + a, cj + (t - 3 * a)) != 0u) ||
+                   win_bit<NR, KW>(rowsDf, ri + 1, cj + 1) != 0u;
             return !g.any(fail);
         }
         if constexpr (!kMid) {
@@ -151,7 +172,7 @@ __device__ __forceinline__ bool default_ok_bits(const DevMap& m, const PlanConst
                 divmod_small(min(r * G + g.sub, 4095), max(bb.nj, 1), njInv, a, bq);
                 const bool v = d.vis[r] != 0;
                 any |= v;
-                fail |= v && win_bit<NR>(rowsDf, bb.i0 + a - iw0, bb.j0 + bq - jw0) != 0u;
+                fail |= v && win_bit<NR, KW>(rowsDf, bb.i0 + a - iw0, bb.j0 + bq - jw0) != 0u;
             }
             return g.any(any) && !g.any(fail);
         }
@@ -166,7 +187,7 @@ __device__ __forceinline__ bool default_ok_bits(const DevMap& m, const PlanConst
             const int i = bb.i0 + a, j = bb.j0 + bq;
             if (in_range(i, j, m.g.rows, m.g.cols) && cell_in_disc(m.g, i, j, cx, cy, pc.rf2)) {
                 any = true;
-                fail |= win_bit<NR>(rowsDf, i - iw0, j - jw0) != 0u;
+                fail |= win_bit<NR, KW>(rowsDf, i - iw0, j - jw0) != 0u;
             }
         }
     }
@@ -195,6 +216,11 @@ __device__ __forceinline__ void centroid_begin_bits(const DevMap& m, const PlanC
     o.row = -1;
     o.col = -1;
     o.code = 5;
+#pragma unroll
+    for (int r = 0; r < kDiscRounds; ++r) {
+        cp.vis[r] = 0;
+        cp.e[r] = 0.0f;
+    }
     if (!s.ok) {  // cpp:1628-1631
         o.code = 6;
         return;
@@ -239,11 +265,10 @@ __device__ __forceinline__ void centroid_begin_bits(const DevMap& m, const PlanC
     if constexpr (kOneCell) {
         cp.e0 = m.elev[static_cast<size_t>(o.row) * m.g.cols + o.col];  // a cell of the submap: inside the map
     } else {
+        constexpr int kRounds = G >= 64 ? 1 : kDiscRounds;  // nFoot <= 64 fits one 64-lane round (bits_supported)
 #pragma unroll
-        for (int r = 0; r < kDiscRounds; ++r) {
+        for (int r = 0; r < kRounds; ++r) {
             const int k = r * G + g.sub;
-            cp.vis[r] = 0;
-            cp.e[r] = 0.0f;
             if (k < pc.nFoot) {
                 const int qi = o.row + c.footDa[k], qj = o.col + c.footDb[k];
                 if (in_range(qi, qj, m.g.rows, m.g.cols)) {
@@ -257,13 +282,22 @@ __device__ __forceinline__ void centroid_begin_bits(const DevMap& m, const PlanC
 }
 // getFootholdMeanHeight (cpp:2520-2554) of the centroid result from the loads centroid_begin_bits issued.
 template <int G, bool kOneCell>
-__device__ __forceinline__ float centroid_height_bits(const PlanConsts& pc, const Grp<G>& g, const CentroidPendingBits& cp) {
+__device__ __forceinline__ float centroid_height_bits(const PlanConsts& pc, const Grp<G>& g, const CentroidPendingBits& cp, float* scratch) {
     if constexpr (kOneCell) {
         const float v = __builtin_isfinite(cp.e0) ? cp.e0 : 0.0f;  // cpp:2532-2537
         const bool inc = v < 10;                                   // cpp:2539
         return finish_mean(inc ? 0.0f + v : 0.0f, v, inc ? 1 : 0, pc.h);
+    } else if constexpr (G >= 64) {
+        // one round of table entries in CircleIterator (row-major) order: compacted into LDS, summed sequentially
+        float sum = 0.0f, last = 0.0f;
+        int cnt = 0;
+        OrderedSum os{scratch, 0};
+        const float v = __builtin_isfinite(cp.e[0]) ? cp.e[0] : 0.0f;
+        ordered_push(g, os, cp.vis[0] != 0, v);
+        ordered_finish(os, sum, last, cnt);
+        return finish_mean(sum, last, cnt, pc.h);
     } else {
-        // lanes = table entries in CircleIterator (row-major) order: G dependent adds per round on swizzled lane values
+        // lanes = table entries in CircleIterator order: G dependent adds per round on swizzled lane values
         float sum = 0.0f, last = 0.0f;
         int cnt = 0;
         float v[kDiscRounds];
@@ -320,32 +354,67 @@ __device__ __forceinline__ IndexRect rectangle_index_bounds(const MapGeom& mg, d
     r.jB = (b & 64u) ? eYlo + 1 : ((b & 128u) ? eYlo : eYlo - 1);
     return r;
 }
-__device__ __forceinline__ unsigned bits_from(int lo) { return lo >= 32 ? 0u : (lo <= 0 ? ~0u : (~0u << lo)); }
-__device__ __forceinline__ unsigned bits_to(int hi) { return hi < 0 ? 0u : (hi >= 31 ? ~0u : ((2u << hi) - 1u)); }
+
+// PNPOLY's boundary crossings per window column (see column_crossings above), for arbitrary polygons on the
+// multi-word windows: colX[2 c], colX[2 c + 1] = the two crossing abscissae of window column c (-inf: none).
+// Returns false when a column has more than two crossings (the per-cell PNPOLY loop is then used).
+template <int G, int KW>
+__device__ __forceinline__ bool window_column_crossings(const MapGeom& mg, const LegCtx& c, const Grp<G>& g, int jw0, double* colX) {
+    const double ninf = -__builtin_huge_val();
+    bool over = false;
+    for (int b = g.sub; b < 32 * KW; b += G) {
+        const double py = cell_pos(mg.baseY, mg.res, jw0 + b);
+        double X0 = ninf, X1 = ninf;
+        int n = 0;
+        for (int i = 0, j = c.nv - 1; i < c.nv; j = i++) {
+            if ((c.vy[i] > py) != (c.vy[j] > py)) {
+                const double ex = c.vx[j] - c.vx[i];
+                const double t = py - c.vy[i];
+                double xi = c.vx[i];
+                if (!(ex == 0.0 && fabs(t) <= DBL_MAX)) xi = ex * t / (c.vy[j] - c.vy[i]) + c.vx[i];  // polygon_inside_fast
+                if (n == 0) X0 = xi;
+                else if (n == 1) X1 = xi;
+                ++n;
+            }
+        }
+        over |= n > 2;
+        colX[2 * b] = X0;
+        colX[2 * b + 1] = X1;
+    }
+    return !g.any(over);
+}
 
 // checkCandidateFoothold (cpp:2085-2114) on the window's bit rows: first valid cell in SpiralIterator order.
-template <int G, int NRL>
+template <int G, int NRL, int KW>
 __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head, const LegCtx& c,
-                            const WinRows<NRL>& w, LegBits<G * NRL>& lb, const Grp<G>& g, int iw0, int jw0, int& wi, int& wj) {
+                            const WinRows<NRL, KW>& w, LegBits<G * NRL, KW>& lb, const Grp<G>& g, int iw0, int jw0, int& wi, int& wj) {
     constexpr int NR = G * NRL;
+    bool useColX = false;
     // (1) per row: P = cells that do NOT fail checkCirclePolygonFoothold's per-cell test (cpp:2132-2138)
     if (c.rect) {
         const IndexRect ir = rectangle_index_bounds(m.g, c.xlo, c.xhi, c.ylo, c.yhi, g);
-        const unsigned colMask = bits_from(ir.jA - jw0) & bits_to(ir.jB - jw0);
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
             const int ri = g.sub + G * k;
             const int i = iw0 + ri;
-            const unsigned inside = (i >= ir.iA && i <= ir.iB) ? colMask : 0u;
-            lb.a[ri] = ~w.F[k] | (~w.C[k] & inside);
+            const bool rowIn = i >= ir.iA && i <= ir.iB;
+#pragma unroll
+            for (int q = 0; q < KW; ++q) {
+                const unsigned inside = rowIn ? range_word(ir.jA - jw0, ir.jB - jw0, q) : 0u;
+                lb.a[ri * KW + q] = ~w.F[k][q] | (~w.C[k][q] & inside);
+            }
         }
     } else {
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
             const int ri = g.sub + G * k;
-            lb.a[ri] = ~w.C[k];  // threshold only (C implies F); the polygon is tested per candidate below
-            lb.f[ri] = w.F[k];
+#pragma unroll
+            for (int q = 0; q < KW; ++q) {
+                lb.a[ri * KW + q] = ~w.C[k][q];  // threshold only (C implies F); the polygon is tested per candidate below
+                lb.f[ri * KW + q] = w.F[k][q];
+            }
         }
+        if constexpr (KW > 1) useColX = window_column_crossings<G, KW>(m.g, c, g, jw0, lb.colX);
     }
     pose_sync<G>();
     // (2) erosion with the foot-disc offset table: E bit (row, col) = AND_k P(row + da_k, col + db_k)
@@ -354,13 +423,24 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
             const int ri = g.sub + G * k;
-            unsigned e = ~0u;
+            unsigned e[KW];
+#pragma unroll
+            for (int q = 0; q < KW; ++q) e[q] = ~0u;
             for (int f = 0; f < pc.nFoot; ++f) {
                 const int da = c.footDa[f], db = c.footDb[f];
-                const unsigned p = lb.a[min(max(ri + da, 0), NR - 1)];
-                e &= db >= 0 ? (p >> db) : (p << (-db));
+                const uint32_t* p = lb.a + min(max(ri + da, 0), NR - 1) * KW;
+                // shift the row by db columns (|db| <= footReach < 32): bit j of the result = bit j + db of the row
+#pragma unroll
+                for (int q = 0; q < KW; ++q) {
+                    const unsigned cur = p[q];
+                    const unsigned up = q + 1 < KW ? p[q + 1] : 0u, dn = q > 0 ? p[q - 1] : 0u;
+                    const unsigned sh = db >= 0 ? __builtin_amdgcn_alignbit(up, cur, static_cast<unsigned>(db))
+                                                : __builtin_amdgcn_alignbit(cur, dn, static_cast<unsigned>(32 + db));
+                    e[q] &= sh;
+                }
             }
-            lb.b[ri] = e;
+#pragma unroll
+            for (int q = 0; q < KW; ++q) lb.b[ri * KW + q] = e[q];
         }
         pose_sync<G>();
         E = lb.b;
@@ -402,13 +482,21 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             // SpiralIterator::generateRing filters rings nRings-1 and nRings by isInside; the centre cell (ring 0)
             // is pushed unfiltered by the constructor
             if (ok && r >= 1 && (r == c.nRings || r + 1 == c.nRings)) ok = cell_in_disc(m.g, i, j, c.cx, c.cy, c.R2);
-            if (ok) ok = win_bit<NR>(E, i - iw0, j - jw0) != 0u;
+            if (ok) ok = win_bit<NR, KW>(E, i - iw0, j - jw0) != 0u;
             if (ok && !c.rect) {
                 // arbitrary polygon: every FINITE cell of the foot disc must lie inside it (cpp:2138)
                 for (int f = 0; f < pc.nFoot; ++f) {
                     const int qi = i + c.footDa[f], qj = j + c.footDb[f];
-                    if (win_bit<NR>(lb.f, qi - iw0, qj - jw0) != 0u &&
-                        !polygon_inside_fast(c.vx, c.vy, c.nv, cell_pos(m.g.baseX, m.g.res, qi), cell_pos(m.g.baseY, m.g.res, qj))) {
+                    if (win_bit<NR, KW>(lb.f, qi - iw0, qj - jw0) == 0u) continue;
+                    const double px = cell_pos(m.g.baseX, m.g.res, qi);
+                    bool inside;
+                    if (KW > 1 && useColX) {
+                        const int cc = min(max(qj - jw0, 0), 32 * KW - 1);
+                        inside = (px < lb.colX[2 * cc]) != (px < lb.colX[2 * cc + 1]);
+                    } else {
+                        inside = polygon_inside_fast(c.vx, c.vy, c.nv, px, cell_pos(m.g.baseY, m.g.res, qj));
+                    }
+                    if (!inside) {
                         ok = false;
                         break;
                     }
@@ -428,9 +516,11 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
 
 // One swing leg of one phase on the bit window: the three tracks' next positions, the centroid method
 // (cpp:1605-1997) and checkFoothold (cpp:2001-2036) around the centroid track's position, the mean heights.
-template <int G, int NRL, bool kMid>
+// kDirect: the results stay in registers (LegCommit) for a commit decided by wave ballot (8-lane kernels); otherwise
+// they are staged in PoseShared::nxt / valid (one-wavefront-per-pose kernels, legs in sequence).
+template <int G, int NRL, int KW, bool kMid, bool kDirect>
 __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut,
-                                               const LutHead& head, PoseShared& sh, LegBits<G * NRL>& lb, const Grp<G>& g, int leg,
+                                               const LutHead& head, PoseShared& sh, LegBits<G * NRL, KW>& lb, const Grp<G>& g, int leg,
                                                const LegStatic& ls, double y0, double adjY, double advance, int cyc, int nCycles,
                                                int b, bool live, const fpe_plan_out& out, LegCommit* lc) {
     constexpr int NR = G * NRL;
@@ -457,6 +547,7 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
         vx[4] = nx2 - hx;  vy[4] = ny + hy;
         vx[5] = nx2 + hx;  vy[5] = ny + hy;
     }
+    if (G == 64 && polyKind != 0) pose_sync<G>();  // the vertices are read by the other lanes of the wavefront
     LegCtx c;
     c.cyc = cyc;
     c.cx = nx1;  // centre from the CENTROID track (cpp:861-862)
@@ -479,6 +570,7 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
     c.nRings = lk.nRings;
     c.nCand = lk.nCand;
     c.ti0 = c.tj0 = 0;
+    c.ici = c.icj = 0;
 
     NominalOut no;
     CentroidOut co;
@@ -509,26 +601,28 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
         const int iw0 = c.ici - pc.winH, jw0 = c.icj - pc.winH;
         stamp(pc, cyc, 2);
         // one memory round trip: the window's bit rows and the elevation of the two discs around known centres
-        uint4 lo[NRL], hi[NRL];
-        win_issue<G, NRL>(bm, m.g, g, iw0, jw0, lo, hi);
+        uint4 grp[NRL][KW + 1];
+        win_issue<G, NRL, KW>(bm, m.g, g, iw0, jw0, grp);
         DiscLoads dc, dd;
         disc_issue<G, false, kMid>(m, pc, c.cx, c.cy, bb, g, dc);
         const bool dfltUsable = wantDefault && centre_usable(nx0, ny);
         if (dfltUsable) disc_issue<G, false, kMid>(m, pc, nx0, ny, dbox, g, dd);
         stamp(pc, cyc, 3);
-        WinRows<NRL> w;
-        win_finish<NRL>(jw0, lo, hi, w);
+        WinRows<NRL, KW> w;
+        win_finish<NRL, KW>(jw0, grp, w);
 #pragma unroll
-        for (int k = 0; k < NRL; ++k) lb.a[g.sub + G * k] = w.Df[k];
-        const CentroidScan sc = rows_from_bits<G, NRL>(sm, w, g, iw0, jw0);
+        for (int k = 0; k < NRL; ++k)
+#pragma unroll
+            for (int q = 0; q < KW; ++q) lb.a[(g.sub + G * k) * KW + q] = w.Df[k][q];
+        const CentroidScan sc = rows_from_bits<G, NRL, KW>(sm, w, g, iw0, jw0);
         pose_sync<G>();
         stamp(pc, cyc, 4);
-        const bool defaultOk = default_ok_bits<G, NR, kMid>(m, pc, c.cx, c.cy, bb, dc, lb.a, iw0, jw0, g);  // cpp:2012
+        const bool defaultOk = default_ok_bits<G, NR, KW, kMid>(m, pc, c.cx, c.cy, bb, dc, lb.a, iw0, jw0, g);  // cpp:2012
         pose_sync<G>();  // lb doubles as scratch below
         bool unused;
         const float zCentre = disc_consume<G, false, kMid>(m, pc, c.cx, c.cy, bb, g, dc, unused, scratch);  // cpp:2029
         stamp(pc, cyc, 5);
-        constexpr bool kOneCell = kMid;  // the 3x3-only variants are launched for one-cell foot discs (mid_variant_bits)
+        constexpr bool kOneCell = kMid;  // the 3x3-only variants are launched for one-cell foot discs
         CentroidPendingBits cp;
         centroid_begin_bits<G, kOneCell>(m, pc, c, sm, sc, zCentre, g, cp);                                 // cpp:818-821
         stamp(pc, cyc, 6);
@@ -546,7 +640,7 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
             nominal_invalid(no, c.cx, c.cy, 2);
             int wi = 0, wj = 0;
             pose_sync<G>();
-            if (spiral_bits<G, NRL>(m, pc, lut, head, c, w, lb, g, iw0, jw0, wi, wj)) {  // cpp:2022
+            if (spiral_bits<G, NRL, KW>(m, pc, lut, head, c, w, lb, g, iw0, jw0, wi, wj)) {  // cpp:2022
                 no.valid = 1;
                 no.source = 1;
                 no.row = wi;
@@ -558,33 +652,43 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
             pose_sync<G>();
         }
         stamp(pc, cyc, 8);
-        if (cp.needDisc != 0) cp.o.z = centroid_height_bits<G, kOneCell>(pc, g, cp);
+        if (cp.needDisc != 0) cp.o.z = centroid_height_bits<G, kOneCell>(pc, g, cp, scratch);
         co = cp.o;
     }
-    lc->valid = no.valid;
-    lc->v[0][0] = nx0;   lc->v[0][1] = ny;    lc->v[0][2] = static_cast<double>(zDefault);
-    lc->v[1][0] = co.x;  lc->v[1][1] = co.y;  lc->v[1][2] = static_cast<double>(co.z);
-    lc->v[2][0] = no.x;  lc->v[2][1] = no.y;  lc->v[2][2] = static_cast<double>(no.z);
-    if (g.sub == 0 && live) {
-        const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
-        if (out.nominal) store_foothold(out.nominal + o, no, leg, cyc);
-        if (out.selected) {
-            fpe_selected_foothold sf;
-            sf.row = no.row; sf.col = no.col; sf.z = no.z;
-            sf.valid = static_cast<uint8_t>(no.valid); sf.source = static_cast<uint8_t>(no.source);
-            sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
-            out.selected[o] = sf;
+    if constexpr (kDirect) {
+        lc->valid = no.valid;
+        lc->v[0][0] = nx0;   lc->v[0][1] = ny;    lc->v[0][2] = static_cast<double>(zDefault);
+        lc->v[1][0] = co.x;  lc->v[1][1] = co.y;  lc->v[1][2] = static_cast<double>(co.z);
+        lc->v[2][0] = no.x;  lc->v[2][1] = no.y;  lc->v[2][2] = static_cast<double>(no.z);
+    }
+    if (g.sub == 0) {
+        if constexpr (!kDirect) {
+            sh.valid[leg] = no.valid;
+            sh.nxt[0][leg][0] = nx0;   sh.nxt[0][leg][1] = ny;    sh.nxt[0][leg][2] = static_cast<double>(zDefault);
+            sh.nxt[1][leg][0] = co.x;  sh.nxt[1][leg][1] = co.y;  sh.nxt[1][leg][2] = static_cast<double>(co.z);
+            sh.nxt[2][leg][0] = no.x;  sh.nxt[2][leg][1] = no.y;  sh.nxt[2][leg][2] = static_cast<double>(no.z);
         }
-        if (out.centroid) {
-            fpe_centroid_foothold cf;
-            cf.x = co.x; cf.y = co.y; cf.z = co.z; cf.row = co.row; cf.col = co.col;
-            cf.code = static_cast<uint8_t>(co.code); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
-            out.centroid[o] = cf;
-        }
-        if (out.default_next) {
-            out.default_next[o * 3 + 0] = nx0;
-            out.default_next[o * 3 + 1] = ny;
-            out.default_next[o * 3 + 2] = static_cast<double>(zDefault);
+        if (live) {
+            const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
+            if (out.nominal) store_foothold(out.nominal + o, no, leg, cyc);
+            if (out.selected) {
+                fpe_selected_foothold sf;
+                sf.row = no.row; sf.col = no.col; sf.z = no.z;
+                sf.valid = static_cast<uint8_t>(no.valid); sf.source = static_cast<uint8_t>(no.source);
+                sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
+                out.selected[o] = sf;
+            }
+            if (out.centroid) {
+                fpe_centroid_foothold cf;
+                cf.x = co.x; cf.y = co.y; cf.z = co.z; cf.row = co.row; cf.col = co.col;
+                cf.code = static_cast<uint8_t>(co.code); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
+                out.centroid[o] = cf;
+            }
+            if (out.default_next) {
+                out.default_next[o * 3 + 0] = nx0;
+                out.default_next[o * 3 + 1] = ny;
+                out.default_next[o * 3 + 2] = static_cast<double>(zDefault);
+            }
         }
     }
 }
@@ -615,10 +719,11 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
     const int slot = tid / kPoseThreads;
     const int leg = (tid / G) & 3;
     const Grp<G> g(tid);
-    constexpr size_t poseBytes = sizeof(PoseShared) + 4 * sizeof(LegBits<NR>);
+    typedef LegBits<NR, 1> Lb;
+    constexpr size_t poseBytes = sizeof(PoseShared) + 4 * sizeof(Lb);
     unsigned char* base = smem + static_cast<size_t>(slot) * poseBytes;
     PoseShared& sh = *reinterpret_cast<PoseShared*>(base);
-    LegBits<NR>& lb = *reinterpret_cast<LegBits<NR>*>(base + sizeof(PoseShared) + static_cast<size_t>(leg) * sizeof(LegBits<NR>));
+    Lb& lb = *reinterpret_cast<Lb*>(base + sizeof(PoseShared) + static_cast<size_t>(leg) * sizeof(Lb));
 
     int b = blockIdx.x * 2 + slot;
     const bool live = b < B;  // the padding pose of the last block runs the chain on pose B-1, stores nothing
@@ -670,8 +775,8 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
         for (int ph = 0; ph < nPhases; ++ph) {
             const unsigned mask = (gait == 1) ? (1u << ((walkOrder >> (2 * ph)) & 3)) : 0xFu;
             const bool active = (mask >> leg) & 1u;
-            // feet-polygon centres: group t computes track t (getPolygonCenter, cpp:2191, 2265)
             stamp(pc, cyc, 0);
+            // feet-polygon centres: group t computes track t (getPolygonCenter, cpp:2191, 2265)
             if (leg < 3 && g.sub == 0) sh.ctr[leg] = polygon_center_x(sh.cur[leg]);
             pose_sync<G>();
             stamp(pc, cyc, 1);
@@ -679,7 +784,8 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
             // registers straight to PoseShared::cur (cpp:1332-1576)
             LegCommit lc;
             lc.valid = 1;  // non-swing legs do not vote
-            if (active) leg_phase_bits<G, NRL, kMid>(m, bm, pc, lut, head, sh, lb, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out, &lc);
+            if (active)
+                leg_phase_bits<G, NRL, 1, kMid, true>(m, bm, pc, lut, head, sh, lb, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out, &lc);
             stamp(pc, cyc, 9);
             const bool phaseOk = (__ballot(lc.valid == 0) & poseMask) == 0ull;
             if (phaseOk && active && g.sub == 0) {
@@ -693,6 +799,92 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
             stamp(pc, cyc, 10);
         }
         if (leg == 0 && g.sub == 0 && live && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = cycleOk ? 1 : 0;
+        adjY += pc.drift;  // cpp:1578
+    }
+}
+
+// ---- chained plan on the bit window, sequential-legs form (large windows): one wavefront per pose, lane = window
+// row, KW words per row; the swing legs of a phase are searched one after the other (see plan_sequential_kernel) ----
+template <int NRL, int KW>
+__global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap bm, PlanConsts pc, SpiralLut lut,
+                                                              const fpe_pose* __restrict__ poses, int B, int nCycles, fpe_plan_out out) {
+    constexpr int G = 64;
+    constexpr int NR = G * NRL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = static_cast<int>(threadIdx.x);
+    const Grp<G> g(tid);
+    typedef LegBits<NR, KW> Lb;
+    PoseShared& sh = *reinterpret_cast<PoseShared*>(smem);
+    Lb& lb = *reinterpret_cast<Lb*>(smem + sizeof(PoseShared));
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const bool live = true;
+
+    const fpe_pose* pp = poses + b;
+    const double x0 = pp->position[0], y0 = pp->position[1], z0 = pp->position[2];
+    const int gait = pp->gait;
+    const LutHead head = load_lut_head(lut, g);
+    for (int k = tid; k < pc.nFoot; k += G) {
+        sh.footDa[k] = pc.footDa[k];
+        sh.footDb[k] = pc.footDb[k];
+        sh.footOff[k] = 0;
+    }
+    // initial stance (cpp:350-378) and first-gait shift (setFirstGait, cpp:2679-2699): lane = leg
+    if (tid < 4) {
+        const int leg = tid;
+        double sx = (leg == 0 || leg == 3) ? pc.LbHalf : -pc.LbHalf;
+        double sy = (leg <= 1) ? pc.WbHalfNeg : pc.WbHalfPos;
+        double sz = 0;
+        sx += x0;
+        sy += y0;
+        sz += z0;
+        if (out.stance) {
+            double* st = out.stance + (static_cast<size_t>(b) * 4 + leg) * 3;
+            st[0] = sx;
+            st[1] = sy;
+            st[2] = sz;
+        }
+        for (int t = 0; t < 3; ++t) {
+            sh.cur[t][leg][0] = sx - pc.stepHalf;
+            sh.cur[t][leg][1] = sy;
+            sh.cur[t][leg][2] = sz;
+        }
+    }
+    pose_sync<16>();
+    if (out.pose_status && tid == 0) out.pose_status[b] = opt_gate_cycle0(m.g, pc, polygon_center_x(sh.cur[0]), y0);
+
+    double adjY = 0.0;  // ajustedPose_[1], cpp:759
+    const int nPhases = (gait == 1) ? 4 : 1;
+    const double advance = (gait == 1) ? pc.stepQuarter : pc.step;
+    const int walkOrder = pc.RF_FIRST ? ((0) | (2 << 2) | (3 << 4) | (1 << 6)) : ((3) | (1 << 2) | (0 << 4) | (2 << 6));
+
+    for (int cyc = 0; cyc < nCycles; ++cyc) {
+        bool cycleOk = true;
+        for (int ph = 0; ph < nPhases; ++ph) {
+            const unsigned mask = (gait == 1) ? (1u << ((walkOrder >> (2 * ph)) & 3)) : 0xFu;
+            // feet-polygon centres: lane t computes track t (getPolygonCenter, cpp:2191, 2265)
+            if (tid < 3) sh.ctr[tid] = polygon_center_x(sh.cur[tid]);
+            if (tid < 4) sh.valid[tid] = 1;  // non-swing legs do not vote
+            pose_sync<16>();
+            for (int leg = 0; leg < 4; ++leg) {
+                if (!((mask >> leg) & 1u)) continue;
+                const LegStatic ls = make_leg_static(pc, pp, leg, m.g.res, lut);
+                leg_phase_bits<G, NRL, KW, false, false>(m, bm, pc, lut, head, sh, lb, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out, nullptr);
+            }
+            pose_sync<16>();
+            // footholdValidation_ = AND of the swing legs' flags (cpp:1323); commit or skip (cpp:1332-1576)
+            const bool phaseOk = (sh.valid[0] & sh.valid[1] & sh.valid[2] & sh.valid[3]) != 0;
+            if (phaseOk && tid < 36) {
+                const int leg = tid / 9, e = tid - leg * 9;
+                if ((mask >> leg) & 1u) {
+                    const int t = e / 3, k = e - t * 3;
+                    sh.cur[t][leg][k] = sh.nxt[t][leg][k];
+                }
+            }
+            pose_sync<16>();
+            cycleOk = cycleOk && phaseOk;
+        }
+        if (tid == 0 && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = cycleOk ? 1 : 0;
         adjY += pc.drift;  // cpp:1578
     }
 }
@@ -716,41 +908,60 @@ hipError_t launch_build_bitmap(const float* d_trav, int rows, int cols, float th
     return hipGetLastError();
 }
 
-// Rows per lane of the 8-lane bit-window kernel for a window half-width, or 0 when no instantiation fits.
-static int bits_rows_per_lane(int winH) {
-    const int rows = 2 * winH + 1;
-    if (rows > 32) return 0;  // one 32-bit row mask per plane
-    if (rows <= 16) return 2;
-    if (rows <= 24) return 3;
-    return 4;
+// Kernel shape for a window half-width: 8 lanes per leg with 2-4 rows per lane (windows of up to 32 rows / columns);
+// one wavefront per pose with 64-bit rows (up to 64 rows) or 96-bit rows (up to 96 columns, 2 rows per lane).
+struct BitsShape {
+    int lanes;  // 8 or 64; 0 = no instantiation fits
+    int nrl, kw;
+};
+static BitsShape bits_shape(int winH) {
+    const int side = 2 * winH + 1;
+    if (winH <= 0) return {0, 0, 0};
+    if (side <= 16) return {8, 2, 1};
+    if (side <= 24) return {8, 3, 1};
+    if (side <= 32) return {8, 4, 1};
+    if (side <= 64) return {64, 1, 2};
+    if (side <= 96) return {64, 2, 3};
+    return {0, 0, 0};
 }
 
 bool bits_supported(const PlanConsts& pc, const MapGeom& g) {
     if (pc.noBits != 0 || pc.winH <= 0) return false;
-    if (pc.groupOverride != 0 && pc.groupOverride != 8) return false;
-    const int nrl = bits_rows_per_lane(pc.winH);
-    if (nrl == 0) return false;
-    // the per-leg LDS (3 row arrays of 8 * nrl words) doubles as float scratch of a direct disc pass over a
-    // CircleIterator bounding box of up to (2 ceil(rf / res) + 2)^2 cells
+    const BitsShape sp = bits_shape(pc.winH);
+    if (sp.lanes == 0) return false;
+    if (pc.groupOverride != 0 && pc.groupOverride != (sp.lanes == 8 ? 8 : 65)) return false;
+    if (pc.nFoot > (sp.lanes == 8 ? kDiscRounds * 8 : 64)) return false;  // the offset table is walked one entry per lane
+    // the per-leg LDS (3 row arrays) doubles as float scratch of a direct disc pass over a CircleIterator
+    // bounding box of up to (2 ceil(rf / res) + 2)^2 cells
     const double side = 2.0 * ceil(pc.rf / g.res) + 2.0;
-    return side * side <= 3.0 * 8.0 * nrl;
+    return side * side <= 3.0 * sp.lanes * sp.nrl * sp.kw;
 }
 
 hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut, const fpe_pose* d_poses,
                             int B, int nCycles, const fpe_plan_out& d_out, hipStream_t stream) {
-    const int nrl = bits_rows_per_lane(pc.winH);
+    const BitsShape sp = bits_shape(pc.winH);
     const bool mid = mid_variant(pc, m.g.res) && pc.nFoot == 1;  // rf < res: the candidate disc is the candidate's own cell
-    const dim3 grid((B + 1) / 2), block(64);
-#define FPE_LAUNCH_BITS(NRL, MID)                                                                                          \
-    hipLaunchKernelGGL((plan_bits_kernel<NRL, MID>), grid, block, 2 * (sizeof(PoseShared) + 4 * sizeof(LegBits<8 * NRL>)), \
+    const dim3 block(64);
+#define FPE_LAUNCH_BITS(NRL, MID)                                                                                            \
+    hipLaunchKernelGGL((plan_bits_kernel<NRL, MID>), dim3((B + 1) / 2), block,                                              \
+                       2 * (sizeof(PoseShared) + 4 * sizeof(LegBits<8 * NRL, 1>)), stream, m, bm, pc, lut, d_poses, B, nCycles, d_out)
+#define FPE_LAUNCH_BITS_SEQ(NRL, KW)                                                                                         \
+    hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW>), dim3(B), block, sizeof(PoseShared) + sizeof(LegBits<64 * NRL, KW>), \
                        stream, m, bm, pc, lut, d_poses, B, nCycles, d_out)
-    if (nrl == 2 && mid) FPE_LAUNCH_BITS(2, true);
-    else if (nrl == 2) FPE_LAUNCH_BITS(2, false);
-    else if (nrl == 3 && mid) FPE_LAUNCH_BITS(3, true);
-    else if (nrl == 3) FPE_LAUNCH_BITS(3, false);
-    else if (nrl == 4 && mid) FPE_LAUNCH_BITS(4, true);
-    else if (nrl == 4) FPE_LAUNCH_BITS(4, false);
-    else return hipErrorInvalidValue;
+    if (sp.lanes == 8) {
+        if (sp.nrl == 2 && mid) FPE_LAUNCH_BITS(2, true);
+        else if (sp.nrl == 2) FPE_LAUNCH_BITS(2, false);
+        else if (sp.nrl == 3 && mid) FPE_LAUNCH_BITS(3, true);
+        else if (sp.nrl == 3) FPE_LAUNCH_BITS(3, false);
+        else if (sp.nrl == 4 && mid) FPE_LAUNCH_BITS(4, true);
+        else FPE_LAUNCH_BITS(4, false);
+    } else if (sp.lanes == 64) {
+        if (sp.kw == 2) FPE_LAUNCH_BITS_SEQ(1, 2);
+        else FPE_LAUNCH_BITS_SEQ(2, 3);
+    } else {
+        return hipErrorInvalidValue;
+    }
 #undef FPE_LAUNCH_BITS
+#undef FPE_LAUNCH_BITS_SEQ
     return hipGetLastError();
 }

@@ -74,7 +74,8 @@ int tile_halfwidth(float maxSearchRadius, float footRadius, double resolution) {
 
 // The bit-window kernels (fpe_bits.hpp) look every traversability decision up in a window of row masks around
 // getIndex(centre).  They are exact when
-//  (1) the foot-disc offset table is proved (derive_foot_offsets) and has at most 32 entries;
+//  (1) the foot-disc offset table is proved (derive_foot_offsets) and has at most 64 entries (one per lane of the
+//      widest kernel; the 8-lane kernels take up to 32: fpe_bits.hpp::bits_supported);
 //  (2) every cell a search can touch lies within `H` cells of the centre index.  For a bounded position p and the
 //      centre c the index difference is floor-like in (p - c) / res; with rounding errors of at most `slack` cells
 //      (positions are rewritten by boundPositionToRange and divided by res in f64) the reach of an extent d is
@@ -88,7 +89,7 @@ int tile_halfwidth(float maxSearchRadius, float footRadius, double resolution) {
 //  (4) index predictions (base - limit) / res fit an int with room to spare.
 // Search centres outside the map need no extra room: their clamped boxes hold no disc member and getSubmap fails.
 int bits_window_halfwidth(const PlanConsts& c, const MapGeom& g) {
-    if (!c.footRobust || c.nFoot < 1 || c.nFoot > 32) return 0;
+    if (!c.footRobust || c.nFoot < 1 || c.nFoot > 64) return 0;
     const double res = g.res;
     const double R = static_cast<double>(c.maxSearchRadius), rf = c.rf;
     const double mag = std::fabs(g.posX) + g.lenX + std::fabs(g.posY) + g.lenY + R + rf + 1.0;
