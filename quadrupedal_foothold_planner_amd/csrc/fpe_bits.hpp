@@ -66,8 +66,21 @@ struct LegBits {
     uint32_t a[NR * KW];
     uint32_t b[NR * KW];
     uint32_t f[NR * KW];
-    double colX[KW > 1 ? 2 * 32 * KW : 2];
+    uint32_t h[kMaxHW][NR * KW];             // horizontally eroded P rows, one array per distinct row half-width of the disc
+    int colRows[KW > 1 ? 2 * 32 * KW : 2];  // arbitrary polygons: the row interval [lo, hi) inside the polygon, per window column
 };
+
+// Multi-word row shifts by 0 <= s < 32 columns: shr: bit j of the result = bit j + s of the row; shl: bit j - s.
+template <int KW>
+__device__ __forceinline__ void row_shr(const unsigned (&x)[KW], unsigned s, unsigned (&o)[KW]) {
+#pragma unroll
+    for (int q = 0; q < KW; ++q) o[q] = __builtin_amdgcn_alignbit(q + 1 < KW ? x[q + 1] : 0u, x[q], s);
+}
+template <int KW>
+__device__ __forceinline__ void row_shl(const unsigned (&x)[KW], unsigned s, unsigned (&o)[KW]) {
+#pragma unroll
+    for (int q = 0; q < KW; ++q) o[q] = s ? __builtin_amdgcn_alignbit(x[q], q > 0 ? x[q - 1] : 0u, 32u - s) : x[q];
+}
 
 __device__ __forceinline__ unsigned bits_from(int lo) { return lo >= 32 ? 0u : (lo <= 0 ? ~0u : (~0u << lo)); }
 __device__ __forceinline__ unsigned bits_to(int hi) { return hi < 0 ? 0u : (hi >= 31 ? ~0u : ((2u << hi) - 1u)); }
@@ -355,16 +368,20 @@ __device__ __forceinline__ IndexRect rectangle_index_bounds(const MapGeom& mg, d
     return r;
 }
 
-// PNPOLY's boundary crossings per window column (see column_crossings above), for arbitrary polygons on the
-// multi-word windows: colX[2 c], colX[2 c + 1] = the two crossing abscissae of window column c (-inf: none).
-// Returns false when a column has more than two crossings (the per-cell PNPOLY loop is then used).
+// Arbitrary polygons on the multi-word windows.  PNPOLY (Polygon::isInside, cpp:2138) counts, for a cell centre
+// (px, py), the edges straddling py whose intersection abscissa lies beyond px; py and therefore the abscissae depend
+// on the window COLUMN only (see column_crossings above).  With at most two crossings X0, X1 per column a cell is
+// inside iff (px < X0) != (px < X1), and since cell centres px_i are non-increasing in the row index i each
+// comparison is a row threshold t(X) = min{i : px_i < X} (found exactly, as in rectangle_index_bounds): column c is
+// inside for the rows [min(t0, t1), max(t0, t1)).  Lane = column; writes (lo, hi) per column.  Returns false when
+// some column has more than two crossings (non-convex polygon): the per-cell PNPOLY loop is then used.
 template <int G, int KW>
-__device__ __forceinline__ bool window_column_crossings(const MapGeom& mg, const LegCtx& c, const Grp<G>& g, int jw0, double* colX) {
+__device__ __forceinline__ bool window_column_rows(const MapGeom& mg, const LegCtx& c, const Grp<G>& g, int jw0, int* colRows) {
     const double ninf = -__builtin_huge_val();
     bool over = false;
     for (int b = g.sub; b < 32 * KW; b += G) {
         const double py = cell_pos(mg.baseY, mg.res, jw0 + b);
-        double X0 = ninf, X1 = ninf;
+        double X[2] = {ninf, ninf};
         int n = 0;
         for (int i = 0, j = c.nv - 1; i < c.nv; j = i++) {
             if ((c.vy[i] > py) != (c.vy[j] > py)) {
@@ -372,14 +389,23 @@ __device__ __forceinline__ bool window_column_crossings(const MapGeom& mg, const
                 const double t = py - c.vy[i];
                 double xi = c.vx[i];
                 if (!(ex == 0.0 && fabs(t) <= DBL_MAX)) xi = ex * t / (c.vy[j] - c.vy[i]) + c.vx[i];  // polygon_inside_fast
-                if (n == 0) X0 = xi;
-                else if (n == 1) X1 = xi;
+                if (n == 0) X[0] = xi;
+                else if (n == 1) X[1] = xi;
                 ++n;
             }
         }
         over |= n > 2;
-        colX[2 * b] = X0;
-        colX[2 * b + 1] = X1;
+        int t[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            double qf = floor((mg.baseX - X[u]) * mg.rinv);
+            qf = fmin(fmax(qf, -1.0e9), 1.0e9);
+            const int e = static_cast<int>(qf);
+            const bool p0 = cell_pos(mg.baseX, mg.res, e) < X[u], p1 = cell_pos(mg.baseX, mg.res, e + 1) < X[u];
+            t[u] = p0 ? e : (p1 ? e + 1 : e + 2);
+        }
+        colRows[2 * b] = min(t[0], t[1]);
+        colRows[2 * b + 1] = max(t[0], t[1]);
     }
     return !g.any(over);
 }
@@ -389,7 +415,7 @@ template <int G, int NRL, int KW>
 __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head, const LegCtx& c,
                             const WinRows<NRL, KW>& w, LegBits<G * NRL, KW>& lb, const Grp<G>& g, int iw0, int jw0, int& wi, int& wj) {
     constexpr int NR = G * NRL;
-    bool useColX = false;
+    bool polyFolded = true;  // the polygon test is part of P (rectangle: always; other polygons: see below)
     // (1) per row: P = cells that do NOT fail checkCirclePolygonFoothold's per-cell test (cpp:2132-2138)
     if (c.rect) {
         const IndexRect ir = rectangle_index_bounds(m.g, c.xlo, c.xhi, c.ylo, c.yhi, g);
@@ -405,21 +431,121 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             }
         }
     } else {
+        bool folded = false;
+        if constexpr (KW > 1) {
+            static_assert(G == 64, "the column -> row transposition runs on whole wavefronts");
+            // the polygon's row interval per window column (lane = column), then transposed into per-row column
+            // masks by ballots over the columns, one window row at a time
+            folded = window_column_rows<G, KW>(m.g, c, g, jw0, lb.colRows);
+            if (folded) {
+                pose_sync<G>();
+                int lo[(32 * KW + G - 1) / G], hi[(32 * KW + G - 1) / G];
 #pragma unroll
-        for (int k = 0; k < NRL; ++k) {
-            const int ri = g.sub + G * k;
+                for (int u = 0; u < (32 * KW + G - 1) / G; ++u) {
+                    const int col = g.sub + G * u;
+                    const bool live = col < 32 * KW;
+                    lo[u] = live ? lb.colRows[2 * min(col, 32 * KW - 1)] : 0;
+                    hi[u] = live ? lb.colRows[2 * min(col, 32 * KW - 1) + 1] : 0;
+                }
+                unsigned inside[NRL][KW];
 #pragma unroll
-            for (int q = 0; q < KW; ++q) {
-                lb.a[ri * KW + q] = ~w.C[k][q];  // threshold only (C implies F); the polygon is tested per candidate below
-                lb.f[ri * KW + q] = w.F[k][q];
+                for (int k = 0; k < NRL; ++k)
+#pragma unroll
+                    for (int q = 0; q < KW; ++q) inside[k][q] = 0u;
+                const int rowsUsed = min(2 * pc.winH + 1, NR);
+#pragma unroll
+                for (int k = 0; k < NRL; ++k) {
+                    const int rEnd = min(rowsUsed - G * k, G);
+                    for (int r = 0; r < rEnd; ++r) {
+                        const int i = iw0 + r + G * k;
+                        unsigned wd[KW];
+#pragma unroll
+                        for (int u = 0; u < (32 * KW + G - 1) / G; ++u) {
+                            const unsigned long long mk = __ballot(i >= lo[u] && i < hi[u]);
+                            if (2 * u < KW) wd[2 * u] = static_cast<unsigned>(mk);
+                            if (2 * u + 1 < KW) wd[2 * u + 1] = static_cast<unsigned>(mk >> 32);
+                        }
+                        if (g.sub == r) {
+#pragma unroll
+                            for (int q = 0; q < KW; ++q) inside[k][q] = wd[q];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NRL; ++k) {
+                    const int ri = g.sub + G * k;
+#pragma unroll
+                    for (int q = 0; q < KW; ++q) lb.a[ri * KW + q] = ~w.F[k][q] | (~w.C[k][q] & inside[k][q]);
+                }
             }
         }
-        if constexpr (KW > 1) useColX = window_column_crossings<G, KW>(m.g, c, g, jw0, lb.colX);
+        polyFolded = folded;
+        if (!folded) {
+#pragma unroll
+            for (int k = 0; k < NRL; ++k) {
+                const int ri = g.sub + G * k;
+#pragma unroll
+                for (int q = 0; q < KW; ++q) {
+                    lb.a[ri * KW + q] = ~w.C[k][q];  // threshold only (C implies F); the polygon is tested per candidate below
+                    lb.f[ri * KW + q] = w.F[k][q];
+                }
+            }
+        }
     }
     pose_sync<G>();
     // (2) erosion with the foot-disc offset table: E bit (row, col) = AND_k P(row + da_k, col + db_k)
     const uint32_t* E = lb.a;
-    if (pc.nFoot > 1) {
+    if (pc.nFoot > 1 && pc.nHW > 0) {
+        // row-interval form: the disc's row +-a holds the columns [-w(a), w(a)], so
+        //   E(row) = AND_a H_w(a)(P(row + a)) & H_w(a)(P(row - a)),   H_w(x) bit j = AND_{|t| <= w} x bit j + t,
+        // and H_w is built by doubling (x & x>>1, & >>2, ...) — a handful of shifts per distinct width instead of one
+        // shift per offset (45 offsets on a 0.5 cm map)
+        for (int hw = 0; hw < pc.nHW; ++hw) {
+            const int wdt = pc.hwList[hw];
+            const int L = 2 * wdt + 1;
+#pragma unroll
+            for (int k = 0; k < NRL; ++k) {
+                const int ri = g.sub + G * k;
+                unsigned A[KW], T[KW];
+#pragma unroll
+                for (int q = 0; q < KW; ++q) A[q] = lb.a[ri * KW + q];
+                int span = 1;
+                while (2 * span <= L) {  // A covers columns [j, j + span)
+                    row_shr<KW>(A, static_cast<unsigned>(span), T);
+#pragma unroll
+                    for (int q = 0; q < KW; ++q) A[q] &= T[q];
+                    span *= 2;
+                }
+                if (span < L) {
+                    row_shr<KW>(A, static_cast<unsigned>(L - span), T);
+#pragma unroll
+                    for (int q = 0; q < KW; ++q) A[q] &= T[q];
+                }
+                row_shl<KW>(A, static_cast<unsigned>(wdt), T);  // centre the interval: [j - w, j + w]
+#pragma unroll
+                for (int q = 0; q < KW; ++q) lb.h[hw][ri * KW + q] = T[q];
+            }
+        }
+        pose_sync<G>();
+#pragma unroll
+        for (int k = 0; k < NRL; ++k) {
+            const int ri = g.sub + G * k;
+            unsigned e[KW];
+#pragma unroll
+            for (int q = 0; q < KW; ++q) e[q] = ~0u;
+            for (int a = 0; a <= pc.footReach; ++a) {
+                const uint32_t* hrow = lb.h[pc.hwIdx[a]];
+                const uint32_t* up = hrow + min(max(ri - a, 0), NR - 1) * KW;
+                const uint32_t* dn = hrow + min(max(ri + a, 0), NR - 1) * KW;
+#pragma unroll
+                for (int q = 0; q < KW; ++q) e[q] &= up[q] & dn[q];
+            }
+#pragma unroll
+            for (int q = 0; q < KW; ++q) lb.b[ri * KW + q] = e[q];
+        }
+        pose_sync<G>();
+        E = lb.b;
+    } else if (pc.nFoot > 1) {
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
             const int ri = g.sub + G * k;
@@ -483,20 +609,12 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             // is pushed unfiltered by the constructor
             if (ok && r >= 1 && (r == c.nRings || r + 1 == c.nRings)) ok = cell_in_disc(m.g, i, j, c.cx, c.cy, c.R2);
             if (ok) ok = win_bit<NR, KW>(E, i - iw0, j - jw0) != 0u;
-            if (ok && !c.rect) {
-                // arbitrary polygon: every FINITE cell of the foot disc must lie inside it (cpp:2138)
+            if (ok && !polyFolded) {
+                // arbitrary polygon not folded into P: every FINITE cell of the foot disc must lie inside it (cpp:2138)
                 for (int f = 0; f < pc.nFoot; ++f) {
                     const int qi = i + c.footDa[f], qj = j + c.footDb[f];
                     if (win_bit<NR, KW>(lb.f, qi - iw0, qj - jw0) == 0u) continue;
-                    const double px = cell_pos(m.g.baseX, m.g.res, qi);
-                    bool inside;
-                    if (KW > 1 && useColX) {
-                        const int cc = min(max(qj - jw0, 0), 32 * KW - 1);
-                        inside = (px < lb.colX[2 * cc]) != (px < lb.colX[2 * cc + 1]);
-                    } else {
-                        inside = polygon_inside_fast(c.vx, c.vy, c.nv, px, cell_pos(m.g.baseY, m.g.res, qj));
-                    }
-                    if (!inside) {
+                    if (!polygon_inside_fast(c.vx, c.vy, c.nv, cell_pos(m.g.baseX, m.g.res, qi), cell_pos(m.g.baseY, m.g.res, qj))) {
                         ok = false;
                         break;
                     }
@@ -862,6 +980,7 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
         bool cycleOk = true;
         for (int ph = 0; ph < nPhases; ++ph) {
             const unsigned mask = (gait == 1) ? (1u << ((walkOrder >> (2 * ph)) & 3)) : 0xFu;
+            stamp(pc, cyc, 0);
             // feet-polygon centres: lane t computes track t (getPolygonCenter, cpp:2191, 2265)
             if (tid < 3) sh.ctr[tid] = polygon_center_x(sh.cur[tid]);
             if (tid < 4) sh.valid[tid] = 1;  // non-swing legs do not vote
@@ -869,7 +988,9 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
             for (int leg = 0; leg < 4; ++leg) {
                 if (!((mask >> leg) & 1u)) continue;
                 const LegStatic ls = make_leg_static(pc, pp, leg, m.g.res, lut);
+                stamp(pc, cyc, 1);
                 leg_phase_bits<G, NRL, KW, false, false>(m, bm, pc, lut, head, sh, lb, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out, nullptr);
+                stamp(pc, cyc, 9);
             }
             pose_sync<16>();
             // footholdValidation_ = AND of the swing legs' flags (cpp:1323); commit or skip (cpp:1332-1576)
@@ -883,6 +1004,7 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
             }
             pose_sync<16>();
             cycleOk = cycleOk && phaseOk;
+            stamp(pc, cyc, 10);
         }
         if (tid == 0 && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = cycleOk ? 1 : 0;
         adjY += pc.drift;  // cpp:1578

@@ -71,7 +71,14 @@ struct PlanConsts {
     int32_t midCellInside;
     int8_t footDa[kMaxFootOffsets];
     int8_t footDb[kMaxFootOffsets];
+    // The same disc as row intervals (bit-window erosion): the offsets with row offset +-a are the columns
+    // [-hwList[hwIdx[a]], +hwList[hwIdx[a]]], a = 0..footReach; nHW distinct half-widths (0: the table is not of that
+    // form, or has more than kMaxHW distinct widths — the kernels then walk the offsets one by one).
+    int32_t nHW;
+    int8_t hwList[4];
+    int8_t hwIdx[16];
 };
+constexpr int kMaxHW = 4;
 
 // Bit planes of one map snapshot for one (defaultFootholdThreshold, candidateFootholdThreshold) pair
 // (fpe_bits.hpp).  One uint4 per 32 columns of a row: x = D  (trav < thrDefault, raw compare: NaN 0, -inf 1),

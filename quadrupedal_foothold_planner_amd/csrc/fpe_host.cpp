@@ -169,6 +169,38 @@ void derive_foot_offsets(float footRadius, const MapGeom& g, PlanConsts& c) {
     int mx = 0;
     for (int k = 0; k < c.nFoot; ++k) mx = std::max(mx, std::max(std::abs(static_cast<int>(c.footDa[k])), std::abs(static_cast<int>(c.footDb[k]))));
     c.footReach = mx;
+    // Row-interval form of the table: a disc's row +-a holds the columns [-w(a), w(a)].  Verified entry by entry, so
+    // the kernels may erode with one interval per row instead of one shift per offset.
+    c.nHW = 0;
+    if (mx <= 15) {
+        int w[16];
+        for (int a = 0; a < 16; ++a) w[a] = -1;
+        for (int k = 0; k < c.nFoot; ++k) w[std::abs(static_cast<int>(c.footDa[k]))] = std::max(w[std::abs(static_cast<int>(c.footDa[k]))], std::abs(static_cast<int>(c.footDb[k])));
+        int expect = 0;
+        bool ok = true;
+        for (int a = 0; a <= mx; ++a) {
+            if (w[a] < 0) ok = false;
+            else expect += (a == 0 ? 1 : 2) * (2 * w[a] + 1);
+        }
+        if (ok && expect == c.nFoot) {  // |set| matches and every entry lies inside its row interval: the forms are equal
+            int n = 0;
+            for (int a = 0; a <= mx && ok; ++a) {
+                int idx = -1;
+                for (int q = 0; q < n; ++q)
+                    if (c.hwList[q] == w[a]) idx = q;
+                if (idx < 0) {
+                    if (n >= kMaxHW) {
+                        ok = false;
+                        break;
+                    }
+                    c.hwList[n] = static_cast<int8_t>(w[a]);
+                    idx = n++;
+                }
+                c.hwIdx[a] = static_cast<int8_t>(idx);
+            }
+            if (ok) c.nHW = n;
+        }
+    }
 }
 
 void derive_constants(const fpe_params& p, const MapGeom& geom, float maxSearchRadius, const Tuning& tuning, PlanConsts& c) {
