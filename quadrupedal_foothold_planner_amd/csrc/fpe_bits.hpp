@@ -51,6 +51,9 @@ __global__ __launch_bounds__(256) void build_bitmap_kernel(const float* __restri
     }
 }
 
+// 64-lane kernels: upper bound of a CircleIterator bounding box (cells) whose elevations are compacted into LDS
+constexpr int kBitsMaxBoxCells = 128;
+
 // ---- window rows ------------------------------------------------------------------------------------------
 // A window row is KW 32-bit words per plane (KW = 1: windows of up to 32 columns, the 8-lane kernels; 2 / 3: the
 // one-wavefront-per-pose kernels of 1 cm / 0.5 cm maps).
@@ -58,17 +61,41 @@ template <int NRL, int KW>
 struct WinRows {
     uint32_t D[NRL][KW], Df[NRL][KW], C[NRL][KW], F[NRL][KW];
 };
-// Per-leg LDS: row masks shared between the lanes of the leg's group (a: Df rows, later P rows; b: E rows;
-// f: F rows for non-rectangle polygons), and for non-rectangle polygons the two boundary crossings per window
-// column.  The row arrays double as float scratch of a direct disc pass / ordered height sum.
-template <int NR, int KW>
+// Per-leg LDS: row masks shared between the lanes of the leg's group — a: Df rows, later P rows, then E rows (row-
+// interval erosion); f: F rows for polygons that are not folded into P; h[k]: horizontally eroded P rows, one array
+// per distinct row half-width of the disc (h[0] doubles as the E rows of the offset-by-offset erosion); colRows: the
+// polygon's row interval per window column (64-lane kernels); hs: the visited elevations of the three discs (64-lane
+// kernels).  Arrays hold `rows` window rows of KW words (the 64-lane kernels allocate 2 winH + 1 rows, not 64 * NRL:
+// LDS, not registers, bounds their occupancy).  The row arrays double as float scratch of a direct disc pass.
 struct LegBits {
-    uint32_t a[NR * KW];
-    uint32_t b[NR * KW];
-    uint32_t f[NR * KW];
-    uint32_t h[kMaxHW][NR * KW];             // horizontally eroded P rows, one array per distinct row half-width of the disc
-    int colRows[KW > 1 ? 2 * 32 * KW : 2];  // arbitrary polygons: the row interval [lo, hi) inside the polygon, per window column
+    uint32_t* a;
+    uint32_t* f;
+    uint32_t* h0;  // array k of the eroded rows at h0 + k * hStride (a pointer array indexed at run time would live in scratch)
+    int hStride;
+    int* colRows;
+    float* hs;
+    int rows;
 };
+// words (4 bytes) of one leg's LDS: (2 + max(nHW, 1)) row arrays, then colRows and hs for the 64-lane kernels
+__host__ __device__ __forceinline__ int legbits_words(int rows, int kw, int nHW, bool wide) {
+    const int arrays = 2 + (nHW > 0 ? nHW : 1);
+    return ((arrays * rows * kw + 3) & ~3) + (wide ? 2 * 32 * kw + 3 * kBitsMaxBoxCells : 0);
+}
+__device__ __forceinline__ LegBits make_legbits(unsigned char* base, int rows, int kw, int nHW, bool wide) {
+    LegBits lb;
+    uint32_t* p = reinterpret_cast<uint32_t*>(base);
+    const int n = rows * kw;
+    lb.rows = rows;
+    lb.a = p;
+    lb.f = p + n;
+    lb.h0 = p + 2 * n;
+    lb.hStride = n;
+    const int arrays = 2 + (nHW > 0 ? nHW : 1);
+    uint32_t* tail = p + ((arrays * n + 3) & ~3);
+    lb.colRows = reinterpret_cast<int*>(tail);
+    lb.hs = reinterpret_cast<float*>(tail + (wide ? 2 * 32 * kw : 0));
+    return lb;
+}
 
 // Multi-word row shifts by 0 <= s < 32 columns: shr: bit j of the result = bit j + s of the row; shl: bit j - s.
 template <int KW>
@@ -118,10 +145,10 @@ __device__ __forceinline__ void win_finish(int jw0, const uint4 (&grp)[NRL][KW +
         }
 }
 // Bit (window row ri, window column cj) of a row array in LDS; 0 outside the window.
-template <int NR, int KW>
-__device__ __forceinline__ unsigned win_bit(const uint32_t* rows, int ri, int cj) {
-    const bool in = static_cast<unsigned>(ri) < static_cast<unsigned>(NR) && static_cast<unsigned>(cj) < 32u * KW;
-    const int r = min(max(ri, 0), NR - 1), c = min(max(cj, 0), 32 * KW - 1);
+template <int KW>
+__device__ __forceinline__ unsigned win_bit(const uint32_t* rows, int nRows, int ri, int cj) {
+    const bool in = static_cast<unsigned>(ri) < static_cast<unsigned>(nRows) && static_cast<unsigned>(cj) < 32u * KW;
+    const int r = min(max(ri, 0), nRows - 1), c = min(max(cj, 0), 32 * KW - 1);
     const uint32_t wd = rows[r * KW + (c >> 5)];
     return in ? (wd >> (c & 31)) & 1u : 0u;
 }
@@ -164,17 +191,17 @@ __device__ __forceinline__ CentroidScan rows_from_bits(const Submap& s, const Wi
 // checkDefaultFoothold (cpp:2039-2082) from the Df rows: valid iff >= 1 cell visited and no visited cell has its Df
 // bit set.  The visited cells are the ones disc_issue() enumerated (d.vis / the 3x3 form); boxes it did not
 // pipeline (clamped at the map border, or larger than the pipeline) are walked here, membership test included.
-template <int G, int NR, int KW, bool kMid>
+template <int G, int KW, bool kMid>
 __device__ __forceinline__ bool default_ok_bits(const DevMap& m, const PlanConsts& pc, double cx, double cy, const BBox& bb,
-                                                const DiscLoads& d, const uint32_t* rowsDf, int iw0, int jw0, const Grp<G>& g) {
+                                                const DiscLoads& d, const uint32_t* rowsDf, int nRows, int iw0, int jw0, const Grp<G>& g) {
     bool any = false, fail = false;
     if (d.pipelined) {
         if (G == 8 && d.mid) {  // wave-uniform: cells 0-3 and 5-8 on the lanes, the middle cell always visited
             const int t = g.sub + (g.sub >= 4 ? 1 : 0);
             const int a = t >= 6 ? 2 : (t >= 3 ? 1 : 0);
             const int ri = bb.i0 - iw0, cj = bb.j0 - jw0;
-            fail = (d.vis[0] != 0 && win_bit<NR, KW>(rowsDf, ri + a, cj + (t - 3 * a)) != 0u) ||
-                   win_bit<NR, KW>(rowsDf, ri + 1, cj + 1) != 0u;
+            fail = (d.vis[0] != 0 && win_bit<KW>(rowsDf, nRows, ri + a, cj + (t - 3 * a)) != 0u) ||
+                   win_bit<KW>(rowsDf, nRows, ri + 1, cj + 1) != 0u;
             return !g.any(fail);
         }
         if constexpr (!kMid) {
@@ -185,7 +212,7 @@ __device__ __forceinline__ bool default_ok_bits(const DevMap& m, const PlanConst
                 divmod_small(min(r * G + g.sub, 4095), max(bb.nj, 1), njInv, a, bq);
                 const bool v = d.vis[r] != 0;
                 any |= v;
-                fail |= v && win_bit<NR, KW>(rowsDf, bb.i0 + a - iw0, bb.j0 + bq - jw0) != 0u;
+                fail |= v && win_bit<KW>(rowsDf, nRows, bb.i0 + a - iw0, bb.j0 + bq - jw0) != 0u;
             }
             return g.any(any) && !g.any(fail);
         }
@@ -200,7 +227,7 @@ __device__ __forceinline__ bool default_ok_bits(const DevMap& m, const PlanConst
             const int i = bb.i0 + a, j = bb.j0 + bq;
             if (in_range(i, j, m.g.rows, m.g.cols) && cell_in_disc(m.g, i, j, cx, cy, pc.rf2)) {
                 any = true;
-                fail |= win_bit<NR, KW>(rowsDf, i - iw0, j - jw0) != 0u;
+                fail |= win_bit<KW>(rowsDf, nRows, i - iw0, j - jw0) != 0u;
             }
         }
     }
@@ -335,6 +362,40 @@ __device__ __forceinline__ float centroid_height_bits(const PlanConsts& pc, cons
     }
 }
 
+// 64-lane kernels: the three mean heights of a leg (centre disc, default-track disc, centroid result; cpp:2520-2554)
+// in ONE pass.  Each disc's visited elevations were compacted into its own LDS array in CircleIterator order
+// (ordered_push); here lanes 0-15 walk the first array, 16-31 the second, 32-63 the third — the same instruction
+// stream performs the three strictly sequential f32 sums side by side, and the f32 division runs once.
+template <int G>
+__device__ __forceinline__ void heights3_finish(const Grp<G>& g, const float* hs, int nA, int nB, int nC, double h, float& zA,
+                                                float& zB, float& zC) {
+    const int d = min(g.sub >> 4, 2);
+    const int n = d == 0 ? nA : (d == 1 ? nB : nC);
+    const float* p = hs + d * kBitsMaxBoxCells;
+    float sum = 0.0f, last = 0.0f;
+    int cnt = 0;
+    const int nMax = max(nA, max(nB, nC));
+    for (int t = 0; t < nMax; t += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(p + t);
+        if (t + 0 < n) ordered_step(q.x, sum, last, cnt);
+        if (t + 1 < n) ordered_step(q.y, sum, last, cnt);
+        if (t + 2 < n) ordered_step(q.z, sum, last, cnt);
+        if (t + 3 < n) ordered_step(q.w, sum, last, cnt);
+    }
+    const float z = finish_mean(sum, last, cnt, h);
+    zA = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), 0));
+    zB = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), 16));
+    zC = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), 32));
+}
+template <int G>
+__device__ __forceinline__ void push_disc(const Grp<G>& g, OrderedSum& os, const DiscLoads& d) {
+#pragma unroll
+    for (int r = 0; r < disc_rounds<G>(); ++r) {
+        const float v = __builtin_isfinite(d.e[r]) ? d.e[r] : 0.0f;  // cpp:2532-2537
+        ordered_push(g, os, d.vis[r] != 0, v);
+    }
+}
+
 // The reference rectangle in index space.  Cell centres x_i = base + res * (-i) are non-increasing in i, so
 // {i : lo <= x_i < hi} = [iA, iB] with iA = min{i : x_i < hi}, iB = max{i : x_i >= lo}; each end is found by evaluating
 // the reference's own comparison at the two indices next to the boundary predicted by (base - limit) * (1/res).
@@ -413,8 +474,8 @@ __device__ __forceinline__ bool window_column_rows(const MapGeom& mg, const LegC
 // checkCandidateFoothold (cpp:2085-2114) on the window's bit rows: first valid cell in SpiralIterator order.
 template <int G, int NRL, int KW>
 __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head, const LegCtx& c,
-                            const WinRows<NRL, KW>& w, LegBits<G * NRL, KW>& lb, const Grp<G>& g, int iw0, int jw0, int& wi, int& wj) {
-    constexpr int NR = G * NRL;
+                            const WinRows<NRL, KW>& w, const LegBits& lb, const Grp<G>& g, int iw0, int jw0, int& wi, int& wj) {
+    const int NR = lb.rows;  // allocated window rows (lanes beyond them hold nothing a search can touch)
     bool polyFolded = true;  // the polygon test is part of P (rectangle: always; other polygons: see below)
     // (1) per row: P = cells that do NOT fail checkCirclePolygonFoothold's per-cell test (cpp:2132-2138)
     if (c.rect) {
@@ -427,7 +488,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
 #pragma unroll
             for (int q = 0; q < KW; ++q) {
                 const unsigned inside = rowIn ? range_word(ir.jA - jw0, ir.jB - jw0, q) : 0u;
-                lb.a[ri * KW + q] = ~w.F[k][q] | (~w.C[k][q] & inside);
+                if (ri < NR) lb.a[ri * KW + q] = ~w.F[k][q] | (~w.C[k][q] & inside);
             }
         }
     } else {
@@ -452,11 +513,13 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                 for (int k = 0; k < NRL; ++k)
 #pragma unroll
                     for (int q = 0; q < KW; ++q) inside[k][q] = 0u;
-                const int rowsUsed = min(2 * pc.winH + 1, NR);
+                // rows a candidate's foot disc can touch: within nRings + footReach rows of the centre row (winH)
+                const int reachRows = min(c.nRings + pc.footReach, pc.winH);
+                const int rowLo = pc.winH - reachRows, rowHi = min(pc.winH + reachRows + 1, NR);  // NR: allocated rows
 #pragma unroll
                 for (int k = 0; k < NRL; ++k) {
-                    const int rEnd = min(rowsUsed - G * k, G);
-                    for (int r = 0; r < rEnd; ++r) {
+                    const int rBeg = max(rowLo - G * k, 0), rEnd = min(rowHi - G * k, G);
+                    for (int r = rBeg; r < rEnd; ++r) {
                         const int i = iw0 + r + G * k;
                         unsigned wd[KW];
 #pragma unroll
@@ -475,7 +538,8 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                 for (int k = 0; k < NRL; ++k) {
                     const int ri = g.sub + G * k;
 #pragma unroll
-                    for (int q = 0; q < KW; ++q) lb.a[ri * KW + q] = ~w.F[k][q] | (~w.C[k][q] & inside[k][q]);
+                    for (int q = 0; q < KW; ++q)
+                        if (ri < NR) lb.a[ri * KW + q] = ~w.F[k][q] | (~w.C[k][q] & inside[k][q]);
                 }
             }
         }
@@ -486,6 +550,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                 const int ri = g.sub + G * k;
 #pragma unroll
                 for (int q = 0; q < KW; ++q) {
+                    if (ri >= NR) continue;
                     lb.a[ri * KW + q] = ~w.C[k][q];  // threshold only (C implies F); the polygon is tested per candidate below
                     lb.f[ri * KW + q] = w.F[k][q];
                 }
@@ -508,7 +573,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                 const int ri = g.sub + G * k;
                 unsigned A[KW], T[KW];
 #pragma unroll
-                for (int q = 0; q < KW; ++q) A[q] = lb.a[ri * KW + q];
+                for (int q = 0; q < KW; ++q) A[q] = lb.a[min(ri, NR - 1) * KW + q];
                 int span = 1;
                 while (2 * span <= L) {  // A covers columns [j, j + span)
                     row_shr<KW>(A, static_cast<unsigned>(span), T);
@@ -523,7 +588,8 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                 }
                 row_shl<KW>(A, static_cast<unsigned>(wdt), T);  // centre the interval: [j - w, j + w]
 #pragma unroll
-                for (int q = 0; q < KW; ++q) lb.h[hw][ri * KW + q] = T[q];
+                for (int q = 0; q < KW; ++q)
+                    if (ri < NR) lb.h0[hw * lb.hStride + ri * KW + q] = T[q];
             }
         }
         pose_sync<G>();
@@ -534,17 +600,17 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
 #pragma unroll
             for (int q = 0; q < KW; ++q) e[q] = ~0u;
             for (int a = 0; a <= pc.footReach; ++a) {
-                const uint32_t* hrow = lb.h[pc.hwIdx[a]];
+                const uint32_t* hrow = lb.h0 + pc.hwIdx[a] * lb.hStride;
                 const uint32_t* up = hrow + min(max(ri - a, 0), NR - 1) * KW;
                 const uint32_t* dn = hrow + min(max(ri + a, 0), NR - 1) * KW;
 #pragma unroll
                 for (int q = 0; q < KW; ++q) e[q] &= up[q] & dn[q];
             }
 #pragma unroll
-            for (int q = 0; q < KW; ++q) lb.b[ri * KW + q] = e[q];
+            for (int q = 0; q < KW; ++q)
+                if (ri < NR) lb.a[ri * KW + q] = e[q];  // the P rows are dead: E takes their place
         }
         pose_sync<G>();
-        E = lb.b;
     } else if (pc.nFoot > 1) {
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
@@ -566,10 +632,11 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                 }
             }
 #pragma unroll
-            for (int q = 0; q < KW; ++q) lb.b[ri * KW + q] = e[q];
+            for (int q = 0; q < KW; ++q)
+                if (ri < NR) lb.h0[ri * KW + q] = e[q];
         }
         pose_sync<G>();
-        E = lb.b;
+        E = lb.h0;
     }
     // (3) candidates in rank order, lane = rank; lowest set ballot bit = argmin of rank
     const int M = c.nCand;
@@ -608,12 +675,12 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             // SpiralIterator::generateRing filters rings nRings-1 and nRings by isInside; the centre cell (ring 0)
             // is pushed unfiltered by the constructor
             if (ok && r >= 1 && (r == c.nRings || r + 1 == c.nRings)) ok = cell_in_disc(m.g, i, j, c.cx, c.cy, c.R2);
-            if (ok) ok = win_bit<NR, KW>(E, i - iw0, j - jw0) != 0u;
+            if (ok) ok = win_bit<KW>(E, NR, i - iw0, j - jw0) != 0u;
             if (ok && !polyFolded) {
                 // arbitrary polygon not folded into P: every FINITE cell of the foot disc must lie inside it (cpp:2138)
                 for (int f = 0; f < pc.nFoot; ++f) {
                     const int qi = i + c.footDa[f], qj = j + c.footDb[f];
-                    if (win_bit<NR, KW>(lb.f, qi - iw0, qj - jw0) == 0u) continue;
+                    if (win_bit<KW>(lb.f, NR, qi - iw0, qj - jw0) == 0u) continue;
                     if (!polygon_inside_fast(c.vx, c.vy, c.nv, cell_pos(m.g.baseX, m.g.res, qi), cell_pos(m.g.baseY, m.g.res, qj))) {
                         ok = false;
                         break;
@@ -638,10 +705,9 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
 // they are staged in PoseShared::nxt / valid (one-wavefront-per-pose kernels, legs in sequence).
 template <int G, int NRL, int KW, bool kMid, bool kDirect>
 __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut,
-                                               const LutHead& head, PoseShared& sh, LegBits<G * NRL, KW>& lb, const Grp<G>& g, int leg,
+                                               const LutHead& head, PoseShared& sh, const LegBits& lb, const Grp<G>& g, int leg,
                                                const LegStatic& ls, double y0, double adjY, double advance, int cyc, int nCycles,
                                                int b, bool live, const fpe_plan_out& out, LegCommit* lc) {
-    constexpr int NR = G * NRL;
     const float Rf = ls.Rf;
     const int polyKind = ls.polyKind;
     const LegConst& lk = ls.lk;
@@ -693,7 +759,7 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
     NominalOut no;
     CentroidOut co;
     float zDefault = static_cast<float>(static_cast<double>(0.0f) + pc.h);  // value when no cell is visited
-    float* scratch = reinterpret_cast<float*>(&lb);
+    float* scratch = reinterpret_cast<float*>(lb.a);
     const bool wantDefault = out.default_next != nullptr;
     if (!ls.radiusOk || !centre_usable(c.cx, c.cy)) {
         nominal_invalid(no, c.cx, c.cy, ls.radiusOk ? 2 : 3);
@@ -731,20 +797,35 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
 #pragma unroll
         for (int k = 0; k < NRL; ++k)
 #pragma unroll
-            for (int q = 0; q < KW; ++q) lb.a[(g.sub + G * k) * KW + q] = w.Df[k][q];
+            for (int q = 0; q < KW; ++q)
+                if (g.sub + G * k < lb.rows) lb.a[(g.sub + G * k) * KW + q] = w.Df[k][q];
         const CentroidScan sc = rows_from_bits<G, NRL, KW>(sm, w, g, iw0, jw0);
         pose_sync<G>();
         stamp(pc, cyc, 4);
-        const bool defaultOk = default_ok_bits<G, NR, KW, kMid>(m, pc, c.cx, c.cy, bb, dc, lb.a, iw0, jw0, g);  // cpp:2012
+        const bool defaultOk = default_ok_bits<G, KW, kMid>(m, pc, c.cx, c.cy, bb, dc, lb.a, lb.rows, iw0, jw0, g);  // cpp:2012
         pose_sync<G>();  // lb doubles as scratch below
         bool unused;
-        const float zCentre = disc_consume<G, false, kMid>(m, pc, c.cx, c.cy, bb, g, dc, unused, scratch);  // cpp:2029
+        float zCentre = 0.0f;
+        OrderedSum osA{nullptr, 0}, osB{nullptr, 0}, osC{nullptr, 0};
+        if constexpr (G == 64) {
+            // the three ordered height sums run side by side at the end of the leg (heights3_finish): here the visited
+            // elevations of the two discs around known centres are only compacted into LDS
+            osA.scratch = lb.hs;
+            osB.scratch = lb.hs + kBitsMaxBoxCells;
+            osC.scratch = lb.hs + 2 * kBitsMaxBoxCells;
+            push_disc(g, osA, dc);
+            if (dfltUsable) push_disc(g, osB, dd);
+        } else {
+            zCentre = disc_consume<G, false, kMid>(m, pc, c.cx, c.cy, bb, g, dc, unused, scratch);  // cpp:2029
+        }
         stamp(pc, cyc, 5);
         constexpr bool kOneCell = kMid;  // the 3x3-only variants are launched for one-cell foot discs
         CentroidPendingBits cp;
         centroid_begin_bits<G, kOneCell>(m, pc, c, sm, sc, zCentre, g, cp);                                 // cpp:818-821
         stamp(pc, cyc, 6);
-        if (dfltUsable) zDefault = disc_consume<G, false, kMid>(m, pc, nx0, ny, dbox, g, dd, unused, scratch);  // cpp:2289-2301
+        if constexpr (G != 64) {
+            if (dfltUsable) zDefault = disc_consume<G, false, kMid>(m, pc, nx0, ny, dbox, g, dd, unused, scratch);  // cpp:2289-2301
+        }
         stamp(pc, cyc, 7);
         if (defaultOk) {
             no.valid = 1;
@@ -753,7 +834,6 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
             no.col = c.icj;
             no.x = c.cx;  // cpp:2016-2017
             no.y = c.cy;
-            no.z = zCentre;
         } else {
             nominal_invalid(no, c.cx, c.cy, 2);
             int wi = 0, wj = 0;
@@ -765,12 +845,25 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
                 no.col = wj;
                 no.x = cell_pos(m.g.baseX, m.g.res, wi);  // cpp:2105-2107
                 no.y = cell_pos(m.g.baseY, m.g.res, wj);
-                no.z = zCentre;  // z at the DEFAULT centre even for a candidate (cpp:2029)
             }
             pose_sync<G>();
         }
         stamp(pc, cyc, 8);
-        if (cp.needDisc != 0) cp.o.z = centroid_height_bits<G, kOneCell>(pc, g, cp, scratch);
+        if constexpr (G == 64) {
+            if (cp.needDisc != 0) {
+                const float v = __builtin_isfinite(cp.e[0]) ? cp.e[0] : 0.0f;
+                ordered_push(g, osC, cp.vis[0] != 0, v);
+            }
+            pose_sync<G>();
+            float zB, zC;
+            heights3_finish(g, lb.hs, osA.n, osB.n, osC.n, pc.h, zCentre, zB, zC);
+            if (dfltUsable) zDefault = zB;
+            if (cp.needDisc != 0) cp.o.z = zC;
+            else if (cp.o.code == 0) cp.o.z = zCentre;  // whole region valid: the height at the centre (cpp:1687)
+        } else {
+            if (cp.needDisc != 0) cp.o.z = centroid_height_bits<G, kOneCell>(pc, g, cp, scratch);
+        }
+        if (no.valid) no.z = zCentre;  // z at the DEFAULT centre, for a spiral candidate too (cpp:2029)
         co = cp.o;
     }
     if constexpr (kDirect) {
@@ -837,11 +930,11 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
     const int slot = tid / kPoseThreads;
     const int leg = (tid / G) & 3;
     const Grp<G> g(tid);
-    typedef LegBits<NR, 1> Lb;
-    constexpr size_t poseBytes = sizeof(PoseShared) + 4 * sizeof(Lb);
+    const size_t legBytes = 4 * static_cast<size_t>(legbits_words(NR, 1, pc.nHW, false));
+    const size_t poseBytes = sizeof(PoseShared) + 4 * legBytes;
     unsigned char* base = smem + static_cast<size_t>(slot) * poseBytes;
     PoseShared& sh = *reinterpret_cast<PoseShared*>(base);
-    Lb& lb = *reinterpret_cast<Lb*>(base + sizeof(PoseShared) + static_cast<size_t>(leg) * sizeof(Lb));
+    const LegBits lb = make_legbits(base + sizeof(PoseShared) + static_cast<size_t>(leg) * legBytes, NR, 1, pc.nHW, false);
 
     int b = blockIdx.x * 2 + slot;
     const bool live = b < B;  // the padding pose of the last block runs the chain on pose B-1, stores nothing
@@ -931,9 +1024,9 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = static_cast<int>(threadIdx.x);
     const Grp<G> g(tid);
-    typedef LegBits<NR, KW> Lb;
     PoseShared& sh = *reinterpret_cast<PoseShared*>(smem);
-    Lb& lb = *reinterpret_cast<Lb*>(smem + sizeof(PoseShared));
+    // rows actually allocated: the window's 2 winH + 1 (not 64 * NRL) — LDS bounds the occupancy of these kernels
+    const LegBits lb = make_legbits(smem + sizeof(PoseShared), min(2 * pc.winH + 1, NR), KW, pc.nHW, true);
     const int b = blockIdx.x;
     if (b >= B) return;
     const bool live = true;
@@ -1056,7 +1149,8 @@ bool bits_supported(const PlanConsts& pc, const MapGeom& g) {
     // the per-leg LDS (3 row arrays) doubles as float scratch of a direct disc pass over a CircleIterator
     // bounding box of up to (2 ceil(rf / res) + 2)^2 cells
     const double side = 2.0 * ceil(pc.rf / g.res) + 2.0;
-    return side * side <= 3.0 * sp.lanes * sp.nrl * sp.kw;
+    if (sp.lanes == 64) return side * side <= kBitsMaxBoxCells;  // 64-lane kernels: pipelined in two rounds, compacted into LegBits::hs
+    return side * side <= legbits_words(8 * sp.nrl, 1, pc.nHW, false);
 }
 
 hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut, const fpe_pose* d_poses,
@@ -1066,9 +1160,10 @@ hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts&
     const dim3 block(64);
 #define FPE_LAUNCH_BITS(NRL, MID)                                                                                            \
     hipLaunchKernelGGL((plan_bits_kernel<NRL, MID>), dim3((B + 1) / 2), block,                                              \
-                       2 * (sizeof(PoseShared) + 4 * sizeof(LegBits<8 * NRL, 1>)), stream, m, bm, pc, lut, d_poses, B, nCycles, d_out)
+                       2 * (sizeof(PoseShared) + 16 * legbits_words(8 * NRL, 1, pc.nHW, false)), stream, m, bm, pc, lut, d_poses, B, nCycles, d_out)
 #define FPE_LAUNCH_BITS_SEQ(NRL, KW)                                                                                         \
-    hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW>), dim3(B), block, sizeof(PoseShared) + sizeof(LegBits<64 * NRL, KW>), \
+    hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW>), dim3(B), block,                                                      \
+                       sizeof(PoseShared) + 4 * legbits_words(2 * pc.winH + 1 < 64 * NRL ? 2 * pc.winH + 1 : 64 * NRL, KW, pc.nHW, true),           \
                        stream, m, bm, pc, lut, d_poses, B, nCycles, d_out)
     if (sp.lanes == 8) {
         if (sp.nrl == 2 && mid) FPE_LAUNCH_BITS(2, true);
