@@ -97,6 +97,20 @@ __device__ __forceinline__ LegBits make_legbits(unsigned char* base, int rows, i
     return lb;
 }
 
+// The y side of a leg's geometry for one gait cycle (8-lane kernels; see fill_yentry below).
+struct YEntry {
+    int jc;        // getIndex(centre), column
+    int j0d, njd;  // foot-disc box columns (centre disc and default-track disc: same y, same radius)
+    int j0r, njr;  // centroid rectangle columns (getSubmap, cpp:1615-1627)
+    int jA, jB;    // reference rectangle polygon: the columns j with ylo <= y_j < yhi (rectangle_index_bounds)
+    int flags;     // bit 0: y part of getSubmap's success; bit 1: |y| usable (centre_usable)
+    double ny;
+    double sbaseY;   // submap position.y + (0.5 * sublength.y - 0.5 * res)
+    double yA, yB;   // cell_pos(sbaseY, res, (rightCol + 1) >> 1), cell_pos(sbaseY, res, rightCol >> 1)  (cpp:1816)
+    double dy2[3];   // (cell_pos(baseY, res, j0d + k) - ny)^2, k = 0..2 (3x3 disc form)
+};
+static_assert(sizeof(YEntry) == 88, "YEntry layout");
+
 // Multi-word row shifts by 0 <= s < 32 columns: shr: bit j of the result = bit j + s of the row; shl: bit j - s.
 template <int KW>
 __device__ __forceinline__ void row_shr(const unsigned (&x)[KW], unsigned s, unsigned (&o)[KW]) {
@@ -244,9 +258,12 @@ struct CentroidPendingBits {
     float e[kDiscRounds];
     int vis[kDiscRounds];
 };
-template <int G, bool kOneCell>
-__device__ __forceinline__ void centroid_begin_bits(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const Submap& s,
-                                                    const CentroidScan& sc, float zCentre, const Grp<G>& g, CentroidPendingBits& cp) {
+// yA / yB (optional): the two possible result ordinates cell_pos(s.baseY, res, (rightCol + 1) >> 1) and
+// cell_pos(s.baseY, res, rightCol >> 1), precomputed with the y side of the leg's geometry (YEntry).
+template <int G, bool kOneCell, bool kHaveY = false>
+__device__ __forceinline__ void centroid_begin_bits_impl(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const Submap& s,
+                                                         const CentroidScan& sc, float zCentre, const Grp<G>& g, CentroidPendingBits& cp,
+                                                         double yA, double yB) {
     CentroidOut& o = cp.o;
     cp.needDisc = 0;
     cp.e0 = 0.0f;
@@ -299,7 +316,8 @@ __device__ __forceinline__ void centroid_begin_bits(const DevMap& m, const PlanC
         return;  // first and last row blocked: no branch taken, result stays (0,0,0)
     }
     o.x = cell_pos(s.baseX, m.g.res, newRow);  // map.getPosition(newIndex) on the SUBMAP (cpp:1816)
-    o.y = cell_pos(s.baseY, m.g.res, newCol);
+    if constexpr (kHaveY) o.y = (o.code == 1) ? yA : yB;
+    else o.y = cell_pos(s.baseY, m.g.res, newCol);
     o.row = s.i0 + newRow;
     o.col = s.j0 + newCol;
     if constexpr (kOneCell) {
@@ -319,6 +337,17 @@ __device__ __forceinline__ void centroid_begin_bits(const DevMap& m, const PlanC
         }
     }
     cp.needDisc = 1;
+}
+template <int G, bool kOneCell>
+__device__ __forceinline__ void centroid_begin_bits(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const Submap& s,
+                                                    const CentroidScan& sc, float zCentre, const Grp<G>& g, CentroidPendingBits& cp) {
+    centroid_begin_bits_impl<G, kOneCell, false>(m, pc, c, s, sc, zCentre, g, cp, 0.0, 0.0);
+}
+template <int G, bool kOneCell>
+__device__ __forceinline__ void centroid_begin_bits(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const Submap& s,
+                                                    const CentroidScan& sc, float zCentre, const Grp<G>& g, CentroidPendingBits& cp,
+                                                    double yA, double yB) {
+    centroid_begin_bits_impl<G, kOneCell, true>(m, pc, c, s, sc, zCentre, g, cp, yA, yB);
 }
 // getFootholdMeanHeight (cpp:2520-2554) of the centroid result from the loads centroid_begin_bits issued.
 template <int G, bool kOneCell>
@@ -474,12 +503,17 @@ __device__ __forceinline__ bool window_column_rows(const MapGeom& mg, const LegC
 // checkCandidateFoothold (cpp:2085-2114) on the window's bit rows: first valid cell in SpiralIterator order.
 template <int G, int NRL, int KW>
 __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head, const LegCtx& c,
-                            const WinRows<NRL, KW>& w, const LegBits& lb, const Grp<G>& g, int iw0, int jw0, int& wi, int& wj) {
+                            const WinRows<NRL, KW>& w, const LegBits& lb, const Grp<G>& g, int iw0, int jw0, int& wi, int& wj,
+                            const YEntry* ye = nullptr) {
     const int NR = lb.rows;  // allocated window rows (lanes beyond them hold nothing a search can touch)
     bool polyFolded = true;  // the polygon test is part of P (rectangle: always; other polygons: see below)
     // (1) per row: P = cells that do NOT fail checkCirclePolygonFoothold's per-cell test (cpp:2132-2138)
     if (c.rect) {
-        const IndexRect ir = rectangle_index_bounds(m.g, c.xlo, c.xhi, c.ylo, c.yhi, g);
+        IndexRect ir = rectangle_index_bounds(m.g, c.xlo, c.xhi, c.ylo, c.yhi, g);
+        if (ye) {  // the column interval is chain-independent: taken from the hoisted y side (same evaluation)
+            ir.jA = ye->jA;
+            ir.jB = ye->jB;
+        }
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
             const int ri = g.sub + G * k;
@@ -904,6 +938,273 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
     }
 }
 
+// ---- 8-lane kernels: the y side of a leg's geometry, hoisted out of the chain ---------------------------------------
+// A leg's search centre and boxes have y = (initialPose_[1] + ajustedPose_[1]) + defaultBias.y (cpp:2201, 2411-2418):
+// it depends on the gait cycle only, never on earlier results.  Everything derived from it — the column indices of
+// the foot-disc box, of the centroid rectangle and of getIndex(centre), the y part of getSubmap's geometry, the
+// rectangle polygon's column interval, the squared y distances of the 3x3 disc's columns — is computed for eight
+// cycles at a time, one (leg, cycle) entry per lane, with the exact functions; the chain then evaluates x only.
+
+__device__ __forceinline__ void fill_yentry(const MapGeom& mg, const PlanConsts& pc, const LegStatic& ls, double ny, YEntry& e) {
+    const double ly = ls.lk.ly;  // centroid rectangle width (cpp:1617)
+    const double r = static_cast<double>(ls.Rf);
+    int flags = fabs(ny) <= 1e6 ? 2 : 0;
+    e.ny = ny;
+    // foot-disc box (CircleIterator::findSubmapParameters, y axis)
+    const double tly = bound_axis(ny + pc.rf, mg.orgY, mg.posY, mg.lenY);
+    const double bry = bound_axis(ny - pc.rf, mg.orgY, mg.posY, mg.lenY);
+    e.j0d = index_of_fast(tly, mg.orgY, mg.posY, mg.res, mg.rinv);
+    e.njd = index_of_fast(bry, mg.orgY, mg.posY, mg.res, mg.rinv) - e.j0d + 1;
+    e.jc = index_of_fast(ny, mg.orgY, mg.posY, mg.res, mg.rinv);
+    // centroid rectangle (getSubmapInformation, y axis): corners centre +- 0.5 * ly
+    const double tlr = bound_axis(ny + 0.5 * ly, mg.orgY, mg.posY, mg.lenY);
+    const double brr = bound_axis(ny - 0.5 * ly, mg.orgY, mg.posY, mg.lenY);
+    const int j0r = index_of_fast(tlr, mg.orgY, mg.posY, mg.res, mg.rinv);
+    const int j1r = index_of_fast(brr, mg.orgY, mg.posY, mg.res, mg.rinv);
+    e.j0r = j0r;
+    e.njr = j1r - j0r + 1;
+    bool okY = within_axis(tlr, mg.orgY, mg.posY, mg.lenY) && within_axis(brr, mg.orgY, mg.posY, mg.lenY) && j0r >= 0 && j0r < mg.cols;
+    const double cornerY = cell_pos(mg.baseY, mg.res, j0r) - (-(0.5 * mg.res));
+    const double subLenY = static_cast<double>(e.njr) * mg.res;
+    const double subOrgY = 0.5 * subLenY;
+    const double subPosY = cornerY - subOrgY;
+    okY = okY && within_axis(ny, subOrgY, subPosY, subLenY);
+    e.sbaseY = subPosY + (subOrgY - 0.5 * mg.res);
+    const int rightCol = e.njr - 1;
+    e.yA = cell_pos(e.sbaseY, mg.res, (rightCol + 1) >> 1);
+    e.yB = cell_pos(e.sbaseY, mg.res, rightCol >> 1);
+    if (okY) flags |= 1;
+    e.flags = flags;
+    // reference rectangle polygon (getSearchPolygon, cpp:2496-2517): y limits centre -+ 0.5 * r
+    {
+        const double yhi = ny + 0.5 * r, ylo = ny - 0.5 * r;
+        double qh = floor((mg.baseY - yhi) * mg.rinv), ql = floor((mg.baseY - ylo) * mg.rinv);
+        qh = fmin(fmax(qh, -1.0e9), 1.0e9);
+        ql = fmin(fmax(ql, -1.0e9), 1.0e9);
+        const int eh = static_cast<int>(qh), el = static_cast<int>(ql);
+        const bool p0 = cell_pos(mg.baseY, mg.res, eh) < yhi, p1 = cell_pos(mg.baseY, mg.res, eh + 1) < yhi;
+        const bool q1 = cell_pos(mg.baseY, mg.res, el + 1) >= ylo, q0 = cell_pos(mg.baseY, mg.res, el) >= ylo;
+        e.jA = p0 ? eh : (p1 ? eh + 1 : eh + 2);
+        e.jB = q1 ? el + 1 : (q0 ? el : el - 1);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double dy = cell_pos(mg.baseY, mg.res, e.j0d + k) - ny;
+        e.dy2[k] = dy * dy;
+    }
+}
+
+// One swing leg of one phase, 8 lanes per leg, y side from the YEntry.  The x side is ONE lane-transposed pass: lane
+// q evaluates the index of one box corner — 0/1 foot disc (cx +- rf), 2/3 centroid rectangle (cx +- lx / 2),
+// 4 getIndex(cx), 5/6 default-track disc (nx0 +- rf) — by prediction (PlanConsts::cornerEps); when any lane of the
+// wavefront is within rounding distance of a cell boundary, or outside the map, the wavefront evaluates the
+// reference's own expressions (corner_quantity) instead.
+template <int NRL, bool kMid>
+__device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut,
+                                                const LutHead& head, PoseShared& sh, const LegBits& lb, const Grp<8>& g, int leg,
+                                                const LegStatic& ls, const YEntry& ye, double advance, int cyc, int nCycles,
+                                                int b, bool live, const fpe_plan_out& out, LegCommit* lc) {
+    constexpr int G = 8, KW = 1;
+    const float Rf = ls.Rf;
+    const int polyKind = ls.polyKind;
+    const LegConst& lk = ls.lk;
+    const double biasX = ls.biasX;
+    // next default positions of this leg on the three tracks (cpp:2199-2213, 2270-2284)
+    const double nx0 = (sh.ctr[0] + advance) + biasX;  // cpp:2199, 2414
+    const double nx1 = (sh.ctr[1] + advance) + biasX;
+    const double nx2 = (sh.ctr[2] + advance) + biasX;
+    const double ny = ye.ny;  // (initialPose_[1] + ajustedPose_[1]) + bias.y, identical on the three tracks (cpp:2201)
+    if (polyKind != 0 && g.sub == 0) {  // hexagon vertices from the NOMINAL track's position (build-defined, App. E)
+        const double r = static_cast<double>(Rf);
+        double* vx = sh.polyX[leg];
+        double* vy = sh.polyY[leg];
+        const double hx = 0.5 * r;
+        const double hy = (0.5 * r) * 0.8660254037844386;
+        vx[0] = nx2 + r;   vy[0] = ny;
+        vx[1] = nx2 + hx;  vy[1] = ny - hy;
+        vx[2] = nx2 - hx;  vy[2] = ny - hy;
+        vx[3] = nx2 - r;   vy[3] = ny;
+        vx[4] = nx2 - hx;  vy[4] = ny + hy;
+        vx[5] = nx2 + hx;  vy[5] = ny + hy;
+    }
+    LegCtx c;
+    c.cyc = cyc;
+    c.cx = nx1;  // centre from the CENTROID track (cpp:861-862)
+    c.cy = ny;
+    c.nv = (polyKind == 0) ? 4 : 6;
+    {
+        const double r = static_cast<double>(Rf);  // getSearchPolygon's rectangle around the NOMINAL track (cpp:2496-2517)
+        c.rect = polyKind == 0;
+        c.xhi = nx2 + r;
+        c.xlo = nx2 - r;
+        c.yhi = ny + 0.5 * r;
+        c.ylo = ny - 0.5 * r;
+    }
+    c.vx = sh.polyX[leg];
+    c.vy = sh.polyY[leg];
+    c.footDa = sh.footDa;
+    c.footDb = sh.footDb;
+    c.footOff = sh.footOff;
+    c.R2 = lk.R2;
+    c.nRings = lk.nRings;
+    c.nCand = lk.nCand;
+    c.ti0 = c.tj0 = 0;
+    c.ici = c.icj = 0;
+
+    NominalOut no;
+    CentroidOut co;
+    float zDefault = static_cast<float>(static_cast<double>(0.0f) + pc.h);  // value when no cell is visited
+    float* scratch = reinterpret_cast<float*>(lb.a);
+    const bool wantDefault = out.default_next != nullptr;
+    const bool usable = (ye.flags & 2) != 0 && fabs(c.cx) <= 1e6;  // centre_usable(c.cx, c.cy)
+    if (!ls.radiusOk || !usable) {
+        nominal_invalid(no, c.cx, c.cy, ls.radiusOk ? 2 : 3);
+        co.x = co.y = 0.0; co.z = 0.0f; co.row = co.col = -1; co.code = 6;
+        if (wantDefault && centre_usable(nx0, ny)) {  // cpp:2289-2301 (leg search skipped: radius / centre unusable)
+            const BBox dbox = circle_bbox_fast(m.g, nx0, ny, pc.rf);
+            bool unused;
+            zDefault = disc_pass_direct<G, false>(m, pc, nx0, ny, dbox, g, unused, scratch);
+        }
+    } else {
+        // ---- x side: one corner quantity per lane ----
+        const int q = g.sub;
+        const double cq = (q == 5 || q == 6) ? nx0 : c.cx;
+        const bool rawq = q == 4 || q == 7;
+        const double hq = (q == 2 || q == 3) ? 0.5 * lk.lx : (rawq ? 0.0 : pc.rf);
+        const bool minus = q == 1 || q == 3 || q == 6;
+        const double xq = rawq ? cq : (minus ? cq - hq : cq + hq);
+        int idxq;
+        bool withinq = true;
+        {
+            const double n = (xq - m.g.orgX) - m.g.posX;
+            const double qf = n * m.g.rinv;
+            const double k = trunc(qf);
+            const double fr = fabs(qf - k);
+            bool safe = fr > pc.cornerEps && fr < 1.0 - pc.cornerEps;
+            // strictly inside the map: boundPositionToRange only rewrites the position (no clamp), within stays true
+            if (!rawq) safe = safe && qf < -pc.cornerEps && qf > pc.cornerEps - static_cast<double>(m.g.rows);
+            idxq = -static_cast<int>(k);
+            if (__ballot(!safe) != 0ull) {  // wave-uniform, rare: the reference's own expressions
+                const Box bq{cq, 0.0, hq, 0.0};
+                const CornerVal cv = corner_quantity(m.g, minus ? 2 : 0, bq, rawq);
+                idxq = cv.idx;
+                withinq = cv.within;
+            }
+        }
+        constexpr int kKeep = (~(G - 1)) & 0x1F;
+        BBox bb, rbox, dbox;
+        bb.i0 = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (0 << 5));
+        bb.ni = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (1 << 5)) - bb.i0 + 1;
+        rbox.i0 = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (2 << 5));
+        rbox.ni = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (3 << 5)) - rbox.i0 + 1;
+        c.ici = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (4 << 5));
+        dbox.i0 = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (5 << 5));
+        dbox.ni = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (6 << 5)) - dbox.i0 + 1;
+        bb.j0 = dbox.j0 = ye.j0d;
+        bb.nj = dbox.nj = ye.njd;
+        rbox.j0 = ye.j0r;
+        rbox.nj = ye.njr;
+        c.icj = ye.jc;
+        const unsigned wbits = static_cast<unsigned>(g.ballot(withinq));
+        // getSubmapInformation's tail (submap_from_corners), x part here, y part from the entry
+        Submap sm;
+        sm.i0 = rbox.i0;
+        sm.j0 = rbox.j0;
+        sm.ni = rbox.ni;
+        sm.nj = rbox.nj;
+        {
+            const bool okX = (wbits & 0xCu) == 0xCu && sm.i0 >= 0 && sm.i0 < m.g.rows;
+            const double cornerX = cell_pos(m.g.baseX, m.g.res, sm.i0) - (-(0.5 * m.g.res));
+            const double subLenX = static_cast<double>(sm.ni) * m.g.res;
+            const double subOrgX = 0.5 * subLenX;
+            const double subPosX = cornerX - subOrgX;
+            sm.ok = okX && (ye.flags & 1) != 0 && within_axis(c.cx, subOrgX, subPosX, subLenX);
+            sm.baseX = sm.ok ? subPosX + (subOrgX - 0.5 * m.g.res) : 0.0;
+            sm.baseY = sm.ok ? ye.sbaseY : 0.0;
+        }
+        const int iw0 = c.ici - pc.winH, jw0 = c.icj - pc.winH;
+        stamp(pc, cyc, 2);
+        // one memory round trip: the window's bit rows and the elevation of the two discs around known centres
+        uint4 grp[NRL][KW + 1];
+        win_issue<G, NRL, KW>(bm, m.g, g, iw0, jw0, grp);
+        DiscLoads dc, dd;
+        disc_issue<G, false, kMid>(m, pc, c.cx, c.cy, bb, g, dc, ye.dy2);
+        const bool dfltUsable = wantDefault && fabs(nx0) <= 1e6;
+        if (dfltUsable) disc_issue<G, false, kMid>(m, pc, nx0, ny, dbox, g, dd, ye.dy2);
+        stamp(pc, cyc, 3);
+        WinRows<NRL, KW> w;
+        win_finish<NRL, KW>(jw0, grp, w);
+#pragma unroll
+        for (int k = 0; k < NRL; ++k) lb.a[g.sub + G * k] = w.Df[k][0];
+        const CentroidScan sc = rows_from_bits<G, NRL, KW>(sm, w, g, iw0, jw0);
+        pose_sync<G>();
+        stamp(pc, cyc, 4);
+        const bool defaultOk = default_ok_bits<G, KW, kMid>(m, pc, c.cx, c.cy, bb, dc, lb.a, lb.rows, iw0, jw0, g);  // cpp:2012
+        pose_sync<G>();  // lb doubles as scratch below
+        bool unused;
+        const float zCentre = disc_consume<G, false, kMid>(m, pc, c.cx, c.cy, bb, g, dc, unused, scratch);  // cpp:2029
+        stamp(pc, cyc, 5);
+        constexpr bool kOneCell = kMid;  // the 3x3-only variants are launched for one-cell foot discs
+        CentroidPendingBits cp;
+        centroid_begin_bits<G, kOneCell>(m, pc, c, sm, sc, zCentre, g, cp, ye.yA, ye.yB);                  // cpp:818-821
+        stamp(pc, cyc, 6);
+        if (dfltUsable) zDefault = disc_consume<G, false, kMid>(m, pc, nx0, ny, dbox, g, dd, unused, scratch);  // cpp:2289-2301
+        stamp(pc, cyc, 7);
+        if (defaultOk) {
+            no.valid = 1;
+            no.source = 0;
+            no.row = c.ici;
+            no.col = c.icj;
+            no.x = c.cx;  // cpp:2016-2017
+            no.y = c.cy;
+            no.z = zCentre;
+        } else {
+            nominal_invalid(no, c.cx, c.cy, 2);
+            int wi = 0, wj = 0;
+            pose_sync<G>();
+            if (spiral_bits<G, NRL, KW>(m, pc, lut, head, c, w, lb, g, iw0, jw0, wi, wj, &ye)) {  // cpp:2022
+                no.valid = 1;
+                no.source = 1;
+                no.row = wi;
+                no.col = wj;
+                no.x = cell_pos(m.g.baseX, m.g.res, wi);  // cpp:2105-2107
+                no.y = cell_pos(m.g.baseY, m.g.res, wj);
+                no.z = zCentre;  // z at the DEFAULT centre even for a candidate (cpp:2029)
+            }
+            pose_sync<G>();
+        }
+        stamp(pc, cyc, 8);
+        if (cp.needDisc != 0) cp.o.z = centroid_height_bits<G, kOneCell>(pc, g, cp, scratch);
+        co = cp.o;
+    }
+    lc->valid = no.valid;
+    lc->v[0][0] = nx0;   lc->v[0][1] = ny;    lc->v[0][2] = static_cast<double>(zDefault);
+    lc->v[1][0] = co.x;  lc->v[1][1] = co.y;  lc->v[1][2] = static_cast<double>(co.z);
+    lc->v[2][0] = no.x;  lc->v[2][1] = no.y;  lc->v[2][2] = static_cast<double>(no.z);
+    if (g.sub == 0 && live) {
+        const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
+        if (out.nominal) store_foothold(out.nominal + o, no, leg, cyc);
+        if (out.selected) {
+            fpe_selected_foothold sf;
+            sf.row = no.row; sf.col = no.col; sf.z = no.z;
+            sf.valid = static_cast<uint8_t>(no.valid); sf.source = static_cast<uint8_t>(no.source);
+            sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
+            out.selected[o] = sf;
+        }
+        if (out.centroid) {
+            fpe_centroid_foothold cf;
+            cf.x = co.x; cf.y = co.y; cf.z = co.z; cf.row = co.row; cf.col = co.col;
+            cf.code = static_cast<uint8_t>(co.code); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
+            out.centroid[o] = cf;
+        }
+        if (out.default_next) {
+            out.default_next[o * 3 + 0] = nx0;
+            out.default_next[o * 3 + 1] = ny;
+            out.default_next[o * 3 + 2] = static_cast<double>(zDefault);
+        }
+    }
+}
+
 }  // namespace
 
 // ---- chained plan on the bit window: 8 lanes per leg, two poses per wavefront ------------------------------------
@@ -931,10 +1232,11 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
     const int leg = (tid / G) & 3;
     const Grp<G> g(tid);
     const size_t legBytes = 4 * static_cast<size_t>(legbits_words(NR, 1, pc.nHW, false));
-    const size_t poseBytes = sizeof(PoseShared) + 4 * legBytes;
+    const size_t poseBytes = sizeof(PoseShared) + 4 * legBytes + sizeof(YEntry) * 4 * 8;
     unsigned char* base = smem + static_cast<size_t>(slot) * poseBytes;
     PoseShared& sh = *reinterpret_cast<PoseShared*>(base);
     const LegBits lb = make_legbits(base + sizeof(PoseShared) + static_cast<size_t>(leg) * legBytes, NR, 1, pc.nHW, false);
+    YEntry* ytab = reinterpret_cast<YEntry*>(base + sizeof(PoseShared) + 4 * legBytes) + leg * 8;  // [cycle & 7] of this leg
 
     int b = blockIdx.x * 2 + slot;
     const bool live = b < B;  // the padding pose of the last block runs the chain on pose B-1, stores nothing
@@ -982,6 +1284,19 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
     const unsigned long long poseMask = ((1ull << kPoseLanes) - 1ull) << (slot * kPoseLanes);
 
     for (int cyc = 0; cyc < nCycles; ++cyc) {
+        if ((cyc & 7) == 0) {
+            // y side of the next eight cycles: lane (leg, s) fills the entry of cycle cyc + s.  ajustedPose_[1] is the
+            // reference's running sum (cpp:1578): cycle cyc + s has seen s more additions of the drift
+            double a = adjY, mine = adjY;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                a += pc.drift;
+                if (g.sub == k) mine = a;
+            }
+            fill_yentry(m.g, pc, ls, (y0 + mine) + ls.biasY, ytab[g.sub]);  // cpp:2201, 2414
+            pose_sync<G>();
+        }
+        const YEntry& ye = ytab[cyc & 7];
         bool cycleOk = true;
         for (int ph = 0; ph < nPhases; ++ph) {
             const unsigned mask = (gait == 1) ? (1u << ((walkOrder >> (2 * ph)) & 3)) : 0xFu;
@@ -995,8 +1310,7 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
             // registers straight to PoseShared::cur (cpp:1332-1576)
             LegCommit lc;
             lc.valid = 1;  // non-swing legs do not vote
-            if (active)
-                leg_phase_bits<G, NRL, 1, kMid, true>(m, bm, pc, lut, head, sh, lb, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out, &lc);
+            if (active) leg_phase_bits8<NRL, kMid>(m, bm, pc, lut, head, sh, lb, g, leg, ls, ye, advance, cyc, nCycles, b, live, out, &lc);
             stamp(pc, cyc, 9);
             const bool phaseOk = (__ballot(lc.valid == 0) & poseMask) == 0ull;
             if (phaseOk && active && g.sub == 0) {
@@ -1160,7 +1474,8 @@ hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts&
     const dim3 block(64);
 #define FPE_LAUNCH_BITS(NRL, MID)                                                                                            \
     hipLaunchKernelGGL((plan_bits_kernel<NRL, MID>), dim3((B + 1) / 2), block,                                              \
-                       2 * (sizeof(PoseShared) + 16 * legbits_words(8 * NRL, 1, pc.nHW, false)), stream, m, bm, pc, lut, d_poses, B, nCycles, d_out)
+                       2 * (sizeof(PoseShared) + 16 * legbits_words(8 * NRL, 1, pc.nHW, false) + sizeof(YEntry) * 32), stream, m, bm, pc, lut, \
+                       d_poses, B, nCycles, d_out)
 #define FPE_LAUNCH_BITS_SEQ(NRL, KW)                                                                                         \
     hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW>), dim3(B), block,                                                      \
                        sizeof(PoseShared) + 4 * legbits_words(2 * pc.winH + 1 < 64 * NRL ? 2 * pc.winH + 1 : 64 * NRL, KW, pc.nHW, true),           \

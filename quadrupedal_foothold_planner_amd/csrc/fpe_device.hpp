@@ -55,6 +55,10 @@ struct PlanConsts {
     // Half-width (cells) of the bit window around getIndex(search centre), or 0 when the host could not prove the
     // bit-window kernels exact for these parameters on this map (fpe_host.cpp::bits_window_halfwidth)
     int32_t winH;
+    // A box corner strictly inside the map whose predicted cell coordinate ((x - org) - pos) * (1 / res) is farther
+    // than cornerEps from an integer has the index -trunc(prediction): the reference's boundPositionToRange rewrite
+    // and index division change the quotient by far less (fpe_host.cpp::bits_window_halfwidth, `slack`).
+    double cornerEps;
     // getGaitCycleSearchGridMap's submap (cpp:2339-2345): isos_.length x isos_.width (cpp:384-394)
     double isosLen, isosWid;
     // Cell offsets of a CELL-CENTRED foot disc (checkCirclePolygonFoothold's CircleIterator around

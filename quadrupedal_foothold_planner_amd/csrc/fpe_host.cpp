@@ -277,6 +277,12 @@ void derive_constants(const fpe_params& p, const MapGeom& geom, float maxSearchR
         c.footReach = static_cast<int>(std::ceil(c.rf / resolution)) + 1;
     }  // test knob: force the literal bounding-box walk
     c.winH = bits_window_halfwidth(c, geom);
+    {
+        // bound of the rounding error of an index quotient, in cells (the same bound as `slack` above, doubled)
+        const double mag = std::fabs(geom.posX) + geom.lenX + std::fabs(geom.posY) + geom.lenY +
+                           static_cast<double>(maxSearchRadius) + c.rf + 1.0;
+        c.cornerEps = 128.0 * DBL_EPSILON * mag / resolution + 1e-12;
+    }
 }
 
 // globalFootholdPlan message bookkeeping: cpp:681-699 (stance entries), cpp:1378-1396 (valid

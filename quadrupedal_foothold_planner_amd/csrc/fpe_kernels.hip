@@ -739,9 +739,11 @@ struct DiscLoads {
 // pass at consume time).  Besides the instructions, this removes the generic path's load destinations from the
 // hot region: with both forms present the compiler's s_waitcnt insertion has to assume those loads pending at the
 // join and stalls the 3x3 form on the row loads issued just before it (measured: 56.2 -> 53.7 us per launch).
+// dy2tab (optional, 3x3 form only): (cell_pos(baseY, res, bb.j0 + k) - cy)^2 for k = 0..2, precomputed by the caller —
+// the y side of a leg's geometry does not depend on the chain (fpe_bits.hpp, YEntry).
 template <int G, bool kCheck, bool kMid = false>
 __device__ __forceinline__ void disc_issue(const DevMap& m, const PlanConsts& pc, double cx, double cy, const BBox& bb,
-                                           const Grp<G>& g, DiscLoads& d) {
+                                           const Grp<G>& g, DiscLoads& d, const double* dy2tab = nullptr) {
     const int nb = bb.ni * bb.nj;
     d.mid = false;
     d.eMid = d.tMid = 0.0f;
@@ -765,7 +767,12 @@ __device__ __forceinline__ void disc_issue(const DevMap& m, const PlanConsts& pc
                 d.vis[r] = false;
                 d.e[r] = d.t[r] = 0.0f;
             }
-            d.vis[0] = cell_in_disc(m.g, i, j, cx, cy, pc.rf2) ? 1 : 0;  // the unclamped box lies inside the map
+            if (dy2tab) {
+                const double dx = cell_pos(m.g.baseX, m.g.res, i) - cx;  // cell_in_disc with the column's dy * dy looked up
+                d.vis[0] = ((dx * dx + dy2tab[t - 3 * a]) <= pc.rf2) ? 1 : 0;
+            } else {
+                d.vis[0] = cell_in_disc(m.g, i, j, cx, cy, pc.rf2) ? 1 : 0;  // the unclamped box lies inside the map
+            }
             const size_t offM = static_cast<size_t>(bb.i0 + 1) * m.g.cols + (bb.j0 + 1);
             d.eMid = m.elev[offM];
             if (kCheck) d.tMid = m.trav[offM];
