@@ -945,6 +945,112 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
 // rectangle polygon's column interval, the squared y distances of the 3x3 disc's columns — is computed for eight
 // cycles at a time, one (leg, cycle) entry per lane, with the exact functions; the chain then evaluates x only.
 
+// ---- 3x3-only 8-lane kernels: results and heights leave the chain ----------------------------------------------------
+// Nothing a later gait cycle reads depends on a mean height (getPolygonCenter uses x and y only, cpp:2421-2463), and
+// the output records are write-only.  The chain therefore only DEPOSITS, per (leg, cycle), the elevations its disc
+// loads returned and the few words that identify the results; every eighth cycle the 32 lanes of a pose each take one
+// (leg, cycle) unit, run its three ordered height sums (cpp:2520-2554) serially and write its four output records —
+// one instruction stream for 32 units instead of one per leg and cycle.
+struct Unit {
+    float eA[9];  // centre disc (checkFoothold's centre, cpp:2029): elevations in CircleIterator order, [4] = middle cell
+    float eB[9];  // default-track disc (cpp:2289-2301)
+    float eC;     // centroid result's own cell (one-cell foot disc)
+    uint32_t visA, visB;  // bit k: cell k visited; bit 31: the height was computed in the chain (direct pass) and is in e[0]
+    int nomRow, nomCol;
+    uint32_t nomFlags;    // valid | source << 8
+    int cenRow, cenCol;
+    uint32_t cenCode;     // code | needDisc << 8
+    double cx;    // search centre x (nominal x of a default hit / invalid leg; centroid x of code 0)
+    double cenX;  // centroid result x (codes 1-4)
+    double defX;  // default track x
+    uint32_t pad;
+    uint32_t written;
+};
+static_assert(sizeof(Unit) == 144 && sizeof(Unit) % 16 == 0, "Unit layout");
+
+// 3x3 form: lane s holds cell s + (s >= 4) of the box, every lane the middle cell (disc_issue); else the direct pass.
+template <bool kWant>
+__device__ __forceinline__ void unit_put_disc(const DevMap& m, const PlanConsts& pc, double cx, double cy, const BBox& bb,
+                                              const Grp<8>& g, const DiscLoads& d, float* e, uint32_t& vis, float* scratch) {
+    if (!kWant) return;
+    if (d.pipelined) {  // wave-uniform: the 3x3 form
+        e[g.sub + (g.sub >= 4 ? 1 : 0)] = d.e[0];
+        if (g.sub == 0) e[4] = d.eMid;
+        const unsigned mk = static_cast<unsigned>(g.ballot(d.vis[0] != 0));
+        vis = (mk & 0xFu) | 0x10u | ((mk & 0xF0u) << 1);
+    } else {
+        bool unused;
+        const float z = disc_pass_direct<8, false>(m, pc, cx, cy, bb, g, unused, scratch);
+        if (g.sub == 0) e[0] = z;
+        vis = 0x80000000u;
+    }
+}
+// getFootholdMeanHeight (cpp:2520-2554) over up to nine deposited cells, in order
+__device__ __forceinline__ float unit_mean9(const float* e, uint32_t vis, double h) {
+    if (vis & 0x80000000u) return e[0];
+    float sum = 0.0f, last = 0.0f;
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if ((vis >> k) & 1u) {
+            const float v = __builtin_isfinite(e[k]) ? e[k] : 0.0f;  // cpp:2532-2537
+            ordered_step(v, sum, last, cnt);
+        }
+    }
+    return finish_mean(sum, last, cnt, h);
+}
+// One (leg, cycle) unit per lane: heights and the four output records of that unit.
+__device__ __forceinline__ void flush_unit(const MapGeom& mg, const PlanConsts& pc, const Unit& u, const YEntry& ye, int b, int cyc,
+                                           int leg, int nCycles, const fpe_plan_out& out) {
+    const float zA = unit_mean9(u.eA, u.visA, pc.h);
+    const float zB = unit_mean9(u.eB, u.visB, pc.h);
+    const int code = static_cast<int>(u.cenCode & 0xFFu);
+    float zC = 0.0f;
+    if (u.cenCode & 0x100u) {
+        const float v = __builtin_isfinite(u.eC) ? u.eC : 0.0f;
+        const bool inc = v < 10;
+        zC = finish_mean(inc ? 0.0f + v : 0.0f, v, inc ? 1 : 0, pc.h);
+    } else if (code == 0) {
+        zC = zA;  // whole region valid: the height at the centre (cpp:1687)
+    }
+    const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
+    const int valid = static_cast<int>(u.nomFlags & 0xFFu), source = static_cast<int>((u.nomFlags >> 8) & 0xFFu);
+    const float zN = valid ? zA : 0.0f;  // z at the DEFAULT centre, for a spiral candidate too (cpp:2029)
+    if (out.nominal) {
+        fpe_foothold f;
+        f.row = u.nomRow;
+        f.col = u.nomCol;
+        f.x = source == 1 ? cell_pos(mg.baseX, mg.res, u.nomRow) : u.cx;  // cpp:2105-2107 / cpp:2016-2017
+        f.y = source == 1 ? cell_pos(mg.baseY, mg.res, u.nomCol) : ye.ny;
+        f.z = zN;
+        f.valid = static_cast<uint8_t>(valid);
+        f.source = static_cast<uint8_t>(source);
+        f.foot_id = static_cast<uint8_t>(leg);
+        f.gait_cycle_id = static_cast<uint8_t>(cyc);
+        out.nominal[o] = f;
+    }
+    if (out.selected) {
+        fpe_selected_foothold sf;
+        sf.row = u.nomRow; sf.col = u.nomCol; sf.z = zN;
+        sf.valid = static_cast<uint8_t>(valid); sf.source = static_cast<uint8_t>(source);
+        sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
+        out.selected[o] = sf;
+    }
+    if (out.centroid) {
+        fpe_centroid_foothold cf;
+        cf.x = code == 0 ? u.cx : (code <= 4 ? u.cenX : 0.0);
+        cf.y = code == 0 ? ye.ny : (code == 1 ? ye.yA : (code <= 4 ? ye.yB : 0.0));
+        cf.z = zC; cf.row = u.cenRow; cf.col = u.cenCol;
+        cf.code = static_cast<uint8_t>(code); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
+        out.centroid[o] = cf;
+    }
+    if (out.default_next) {
+        out.default_next[o * 3 + 0] = u.defX;
+        out.default_next[o * 3 + 1] = ye.ny;
+        out.default_next[o * 3 + 2] = static_cast<double>(zB);
+    }
+}
+
 __device__ __forceinline__ void fill_yentry(const MapGeom& mg, const PlanConsts& pc, const LegStatic& ls, double ny, YEntry& e) {
     const double ly = ls.lk.ly;  // centroid rectangle width (cpp:1617)
     const double r = static_cast<double>(ls.Rf);
@@ -1003,8 +1109,9 @@ template <int NRL, bool kMid>
 __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut,
                                                 const LutHead& head, PoseShared& sh, const LegBits& lb, const Grp<8>& g, int leg,
                                                 const LegStatic& ls, const YEntry& ye, double advance, int cyc, int nCycles,
-                                                int b, bool live, const fpe_plan_out& out, LegCommit* lc) {
+                                                int b, bool live, const fpe_plan_out& out, LegCommit* lc, Unit* unit) {
     constexpr int G = 8, KW = 1;
+    constexpr bool kDefer = kMid;  // heights and records deposited in `unit`, finished by flush_unit every eighth cycle
     const float Rf = ls.Rf;
     const int polyKind = ls.polyKind;
     const LegConst& lk = ls.lk;
@@ -1064,6 +1171,15 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
             const BBox dbox = circle_bbox_fast(m.g, nx0, ny, pc.rf);
             bool unused;
             zDefault = disc_pass_direct<G, false>(m, pc, nx0, ny, dbox, g, unused, scratch);
+        }
+        if constexpr (kDefer) {
+            if (g.sub == 0) {
+                unit->visA = 0x80000000u;  // the nominal leg is invalid: its height is never used
+                unit->eA[0] = 0.0f;
+                unit->visB = 0x80000000u;
+                unit->eB[0] = zDefault;
+                unit->eC = 0.0f;
+            }
         }
     } else {
         // ---- x side: one corner quantity per lane ----
@@ -1142,13 +1258,26 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
         const bool defaultOk = default_ok_bits<G, KW, kMid>(m, pc, c.cx, c.cy, bb, dc, lb.a, lb.rows, iw0, jw0, g);  // cpp:2012
         pose_sync<G>();  // lb doubles as scratch below
         bool unused;
-        const float zCentre = disc_consume<G, false, kMid>(m, pc, c.cx, c.cy, bb, g, dc, unused, scratch);  // cpp:2029
+        float zCentre = 0.0f;
+        if constexpr (kDefer) {
+            uint32_t visA = 0u, visB = 0u;
+            unit_put_disc<true>(m, pc, c.cx, c.cy, bb, g, dc, unit->eA, visA, scratch);
+            if (dfltUsable) unit_put_disc<true>(m, pc, nx0, ny, dbox, g, dd, unit->eB, visB, scratch);
+            if (g.sub == 0) {
+                unit->visA = visA;
+                unit->visB = visB;
+            }
+        } else {
+            zCentre = disc_consume<G, false, kMid>(m, pc, c.cx, c.cy, bb, g, dc, unused, scratch);  // cpp:2029
+        }
         stamp(pc, cyc, 5);
         constexpr bool kOneCell = kMid;  // the 3x3-only variants are launched for one-cell foot discs
         CentroidPendingBits cp;
         centroid_begin_bits<G, kOneCell>(m, pc, c, sm, sc, zCentre, g, cp, ye.yA, ye.yB);                  // cpp:818-821
         stamp(pc, cyc, 6);
-        if (dfltUsable) zDefault = disc_consume<G, false, kMid>(m, pc, nx0, ny, dbox, g, dd, unused, scratch);  // cpp:2289-2301
+        if constexpr (!kDefer) {
+            if (dfltUsable) zDefault = disc_consume<G, false, kMid>(m, pc, nx0, ny, dbox, g, dd, unused, scratch);  // cpp:2289-2301
+        }
         stamp(pc, cyc, 7);
         if (defaultOk) {
             no.valid = 1;
@@ -1174,13 +1303,37 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
             pose_sync<G>();
         }
         stamp(pc, cyc, 8);
-        if (cp.needDisc != 0) cp.o.z = centroid_height_bits<G, kOneCell>(pc, g, cp, scratch);
+        if constexpr (kDefer) {
+            if (g.sub == 0) unit->eC = cp.e0;
+            cp.o.z = 0.0f;
+            if (g.sub == 0) unit->cenCode = static_cast<uint32_t>(cp.o.code) | (cp.needDisc != 0 ? 0x100u : 0u);
+        } else {
+            if (cp.needDisc != 0) cp.o.z = centroid_height_bits<G, kOneCell>(pc, g, cp, scratch);
+        }
         co = cp.o;
     }
     lc->valid = no.valid;
     lc->v[0][0] = nx0;   lc->v[0][1] = ny;    lc->v[0][2] = static_cast<double>(zDefault);
     lc->v[1][0] = co.x;  lc->v[1][1] = co.y;  lc->v[1][2] = static_cast<double>(co.z);
     lc->v[2][0] = no.x;  lc->v[2][1] = no.y;  lc->v[2][2] = static_cast<double>(no.z);
+    if constexpr (kDefer) {
+        if (g.sub == 0) {  // what flush_unit needs to rebuild this leg's four records
+            unit->nomRow = no.row;
+            unit->nomCol = no.col;
+            unit->nomFlags = static_cast<uint32_t>(no.valid) | (static_cast<uint32_t>(no.source) << 8);
+            unit->cenRow = co.row;
+            unit->cenCol = co.col;
+            if (!(!ls.radiusOk || !usable)) {
+                // (cenCode was written above)
+            } else {
+                unit->cenCode = static_cast<uint32_t>(co.code);
+            }
+            unit->cx = c.cx;
+            unit->cenX = co.x;
+            unit->defX = nx0;
+        }
+        return;
+    }
     if (g.sub == 0 && live) {
         const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
         if (out.nominal) store_foothold(out.nominal + o, no, leg, cyc);
@@ -1232,11 +1385,12 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
     const int leg = (tid / G) & 3;
     const Grp<G> g(tid);
     const size_t legBytes = 4 * static_cast<size_t>(legbits_words(NR, 1, pc.nHW, false));
-    const size_t poseBytes = sizeof(PoseShared) + 4 * legBytes + sizeof(YEntry) * 4 * 8;
+    const size_t poseBytes = sizeof(PoseShared) + 4 * legBytes + sizeof(YEntry) * 4 * 8 + (kMid ? sizeof(Unit) * 4 * 8 : 0);
     unsigned char* base = smem + static_cast<size_t>(slot) * poseBytes;
     PoseShared& sh = *reinterpret_cast<PoseShared*>(base);
     const LegBits lb = make_legbits(base + sizeof(PoseShared) + static_cast<size_t>(leg) * legBytes, NR, 1, pc.nHW, false);
     YEntry* ytab = reinterpret_cast<YEntry*>(base + sizeof(PoseShared) + 4 * legBytes) + leg * 8;  // [cycle & 7] of this leg
+    Unit* units = reinterpret_cast<Unit*>(base + sizeof(PoseShared) + 4 * legBytes + sizeof(YEntry) * 4 * 8) + leg * 8;
 
     int b = blockIdx.x * 2 + slot;
     const bool live = b < B;  // the padding pose of the last block runs the chain on pose B-1, stores nothing
@@ -1310,7 +1464,9 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
             // registers straight to PoseShared::cur (cpp:1332-1576)
             LegCommit lc;
             lc.valid = 1;  // non-swing legs do not vote
-            if (active) leg_phase_bits8<NRL, kMid>(m, bm, pc, lut, head, sh, lb, g, leg, ls, ye, advance, cyc, nCycles, b, live, out, &lc);
+            if (active)
+                leg_phase_bits8<NRL, kMid>(m, bm, pc, lut, head, sh, lb, g, leg, ls, ye, advance, cyc, nCycles, b, live, out, &lc,
+                                           kMid ? units + (cyc & 7) : nullptr);
             stamp(pc, cyc, 9);
             const bool phaseOk = (__ballot(lc.valid == 0) & poseMask) == 0ull;
             if (phaseOk && active && g.sub == 0) {
@@ -1325,6 +1481,14 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
         }
         if (leg == 0 && g.sub == 0 && live && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = cycleOk ? 1 : 0;
         adjY += pc.drift;  // cpp:1578
+        if constexpr (kMid) {
+            if ((cyc & 7) == 7 || cyc == nCycles - 1) {
+                // heights and output records of the last (up to) eight cycles: lane (leg, s) takes the unit of cycle base + s
+                const int c0 = cyc & ~7;
+                if (live && c0 + g.sub <= cyc) flush_unit(m.g, pc, units[g.sub], ytab[g.sub], b, c0 + g.sub, leg, nCycles, out);
+                pose_sync<G>();  // the units and the y entries are rewritten next
+            }
+        }
     }
 }
 
@@ -1474,7 +1638,8 @@ hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts&
     const dim3 block(64);
 #define FPE_LAUNCH_BITS(NRL, MID)                                                                                            \
     hipLaunchKernelGGL((plan_bits_kernel<NRL, MID>), dim3((B + 1) / 2), block,                                              \
-                       2 * (sizeof(PoseShared) + 16 * legbits_words(8 * NRL, 1, pc.nHW, false) + sizeof(YEntry) * 32), stream, m, bm, pc, lut, \
+                       2 * (sizeof(PoseShared) + 16 * legbits_words(8 * NRL, 1, pc.nHW, false) + sizeof(YEntry) * 32 +                \
+                            (MID ? sizeof(Unit) * 32 : 0)), stream, m, bm, pc, lut,                                                 \
                        d_poses, B, nCycles, d_out)
 #define FPE_LAUNCH_BITS_SEQ(NRL, KW)                                                                                         \
     hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW>), dim3(B), block,                                                      \
