@@ -248,6 +248,27 @@ int fpe_plan_service_report(fpe_handle h, const fpe_params* params, const double
                             double* default_footholds, int32_t* n_default_rows, fpe_track_report* nominal_report,
                             fpe_track_report* centroid_report);
 
+/* ---- several GPUs in ONE process (fpe_multi.cpp) ----------------------------------------------
+ * north_star: "a batch of candidate body trajectories is the parallel axis and shards across the 8 GPUs of one
+ * node".  A C++ host that owns every GPU of the node (the ROS node) creates one group: an engine per device, the
+ * map replicated by fpe_multi_upload_map, and fpe_multi_plan splitting the pose batch into contiguous blocks (the
+ * first B % n devices take one pose more), one host thread per device, results written into the caller's arrays
+ * at their global positions.  Same semantics, argument meaning and status codes as the single-device calls they
+ * fan out to (fpe_upload_map, fpe_plan: the seam at cpp:863-909 for every pose of the batch).  The
+ * one-process-per-GPU deployment (torch.distributed + RCCL all-gather of fpe_plan_out.selected) uses the
+ * single-device entry points instead (bench.py, quadrupedal_foothold_planner_amd/dist.py). */
+typedef struct fpe_multi* fpe_multi_handle;
+int fpe_multi_create(const int32_t* device_ids, int32_t n_devices, fpe_multi_handle* out);
+int fpe_multi_destroy(fpe_multi_handle h);
+int fpe_multi_device_count(fpe_multi_handle h);
+fpe_handle fpe_multi_engine(fpe_multi_handle h, int32_t k); /* engine of device k (for the single-device calls) */
+const char* fpe_multi_last_error(fpe_multi_handle h);
+int fpe_multi_upload_map(fpe_multi_handle h, const fpe_map_desc* desc, const float* traversability,
+                         const float* elevation);
+int fpe_multi_set_tuning(fpe_multi_handle h, const char* key, int32_t value);
+int fpe_multi_plan(fpe_multi_handle h, const fpe_params* params, const fpe_pose* poses, int32_t B, int32_t n_cycles,
+                   const fpe_plan_out* out);
+
 /* ---- host-side helpers (no GPU needed) -------------------------------------------------------- */
 /* SpiralIterator visiting order as index offsets (di,dj) for rings 0..n_rings (generateRing walk,
  * consumed from the back).  Writes min(count, max_cells) entries of (di, dj, ring); returns count. */

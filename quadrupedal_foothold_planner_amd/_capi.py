@@ -120,6 +120,14 @@ EXPORTED_SYMBOLS = [
     "fpe_plan_service",
     "fpe_plan_service_ex",
     "fpe_plan_service_report",
+    "fpe_multi_create",
+    "fpe_multi_destroy",
+    "fpe_multi_device_count",
+    "fpe_multi_engine",
+    "fpe_multi_last_error",
+    "fpe_multi_upload_map",
+    "fpe_multi_set_tuning",
+    "fpe_multi_plan",
     "fpe_spiral_offsets",
     "fpe_tile_halfwidth",
     "fpe_algorithmic_bytes_per_foothold",
@@ -166,6 +174,16 @@ def lib():
     L.fpe_plan_service.argtypes = [vp, vp, vp, C.c_uint8, vp]
     L.fpe_plan_service_ex.argtypes = [vp, vp, vp, C.c_uint8, vp, vp, vp, vp]
     L.fpe_plan_service_report.argtypes = [vp, vp, vp, C.c_uint8, vp, vp, vp, vp, vp, vp]
+    L.fpe_multi_create.argtypes = [vp, i32, C.POINTER(vp)]
+    L.fpe_multi_destroy.argtypes = [vp]
+    L.fpe_multi_device_count.argtypes = [vp]
+    L.fpe_multi_engine.restype = vp
+    L.fpe_multi_engine.argtypes = [vp, i32]
+    L.fpe_multi_last_error.restype = C.c_char_p
+    L.fpe_multi_last_error.argtypes = [vp]
+    L.fpe_multi_upload_map.argtypes = [vp, C.POINTER(MapDesc), vp, vp]
+    L.fpe_multi_set_tuning.argtypes = [vp, C.c_char_p, i32]
+    L.fpe_multi_plan.argtypes = [vp, vp, vp, i32, i32, C.POINTER(PlanOut)]
     L.fpe_spiral_offsets.argtypes = [i32, vp, i32]
     L.fpe_tile_halfwidth.argtypes = [f32, f32, f64]
     L.fpe_algorithmic_bytes_per_foothold.restype = f64

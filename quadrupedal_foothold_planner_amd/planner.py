@@ -200,3 +200,65 @@ class FootholdPlanner:
         out["report"] = self._report(rep[0])
         out["centroid"]["report"] = self._report(rep[1])
         return out
+
+
+class MultiFootholdPlanner:
+    """Several GPUs in ONE process behind the C ABI (fpe_multi_*): the map is replicated on every device and a pose
+    batch is split into contiguous blocks, one host thread per device (include/fpe.h, "several GPUs")."""
+
+    def __init__(self, device_ids, params=None):
+        self._lib = _capi.lib()
+        ids = np.ascontiguousarray(device_ids, dtype=np.int32)
+        self._h = C.c_void_p()
+        rc = self._lib.fpe_multi_create(ptr(ids), ids.size, C.byref(self._h))
+        if rc != _capi.FPE_OK:
+            msg = self._lib.fpe_multi_last_error(None).decode()
+            self._h = None
+            if rc == _capi.FPE_E_NO_DEVICE:
+                raise EngineUnavailable(f"fpe_multi_create failed: {msg} (the engine has no CPU fallback)")
+            raise FpeError(rc, msg)
+        self.params = _capi.params_yaml() if params is None else np.array(params, dtype=PARAMS_DTYPE).reshape(1)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fpe_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != _capi.FPE_OK:
+            raise FpeError(rc, self._lib.fpe_multi_last_error(self._h).decode())
+
+    @property
+    def device_count(self):
+        return int(self._lib.fpe_multi_device_count(self._h))
+
+    def set_tuning(self, **kw):
+        for k, v in kw.items():
+            self._check(self._lib.fpe_multi_set_tuning(self._h, k.encode(), int(v)))
+
+    def gridmapCallback(self, traversability, elevation, resolution, position=(0.0, 0.0)):
+        trav = np.ascontiguousarray(traversability, dtype=np.float32)
+        elev = np.ascontiguousarray(elevation, dtype=np.float32)
+        rows, cols = trav.shape
+        d = MapDesc(rows, cols, float(resolution), (C.c_double * 2)(*map(float, position)), (C.c_int32 * 2)(0, 0), 1)
+        self._check(self._lib.fpe_multi_upload_map(self._h, C.byref(d), ptr(trav), ptr(elev)))
+
+    def plan(self, poses, n_cycles):
+        poses = np.ascontiguousarray(poses, dtype=POSE_DTYPE)
+        B = poses.shape[0]
+        out = {
+            "nominal": np.zeros((B, n_cycles, 4), dtype=FOOTHOLD_DTYPE), "centroid": np.zeros((B, n_cycles, 4), dtype=CENTROID_DTYPE),
+            "default": np.zeros((B, n_cycles, 4, 3), dtype=np.float64), "cycle_ok": np.zeros((B, n_cycles), dtype=np.uint8),
+            "stance": np.zeros((B, 4, 3), dtype=np.float64), "selected": np.zeros((B, n_cycles, 4), dtype=SELECTED_DTYPE),
+            "pose_status": np.zeros(B, dtype=np.uint8),
+        }
+        po = PlanOut(ptr(out["nominal"]), ptr(out["centroid"]), ptr(out["default"]), ptr(out["cycle_ok"]), ptr(out["stance"]),
+                     ptr(out["selected"]), ptr(out["pose_status"]))
+        self._check(self._lib.fpe_multi_plan(self._h, ptr(self.params), ptr(poses), B, int(n_cycles), C.byref(po)))
+        return out

@@ -243,3 +243,25 @@ def test_foot_radius_much_larger_than_search_radius(planner):
                 continue
         util.assert_plan_equal(eng, ora)
     planner.params = _capi.params_yaml()
+
+
+@pytest.mark.parametrize("n_engines,B", [(1, 37), (2, 37), (3, 5), (4, 3)])
+def test_multi_device_group_shards_a_batch_through_the_c_abi(n_engines, B):
+    """fpe_multi_*: a C++ host shards a pose batch over a device list without Python or torch.distributed.  A 1-GPU
+    box lists cuda:0 several times (independent engines, one host thread each): uneven shards, more engines than poses
+    and the global result order are checked against the oracle."""
+    from quadrupedal_foothold_planner_amd.planner import MultiFootholdPlanner
+
+    mp = MultiFootholdPlanner([0] * n_engines)
+    assert mp.device_count == n_engines
+    trav, elev = synth.rough_map(300, 300, 0.02, seed=91, bad_frac=0.15)
+    poses = synth.poses_in_map(B, 6.0, 6.0, 5, 0.18, seed=92, margin=0.7)
+    poses["gait"][::4] = 1
+    mp.gridmapCallback(trav, elev, 0.02)
+    eng = mp.plan(poses, 5)
+    omap = fpo.OracleMap(trav, elev, 0.02)
+    op, opo = util.to_oracle_params(mp.params), util.to_oracle_poses(poses)
+    ora = omap.plan(op, opo, 5, threads=4)
+    ora["pose_status"] = omap.pose_status(op, opo)
+    util.assert_plan_equal(eng, ora)
+    mp.close()

@@ -115,3 +115,21 @@ def test_submap_geometry_matches_oracle_getSubmap(probe, res, x, y, R):
         assert out.tolist() == o.tolist()
         # submap getPosition(0,0) = subPos + (subLen/2 - res/2)
         assert base[0] == pl[0] + (0.5 * pl[2] - 0.5 * res) and base[1] == pl[1] + (0.5 * pl[3] - 0.5 * res)
+
+
+def test_engine_geometry_reproduces_the_hand_traced_submaps(probe):
+    """The hand-derived getSubmap answers of tests/test_oracle_kat.py (border clamp, and the 12-row rectangle of
+    double(0.2f) / 0.02 = 10.00000015 cells) on the ENGINE's closed-form geometry."""
+    out = np.zeros(4, np.int32)
+    base = np.zeros(2, np.float64)
+    ok = probe.probe_submap(10, 10, 1.0, 0.0, 0.0, 4.0, 0.0, 4.0, 2.0, out.ctypes.data_as(C.c_void_p), base.ctypes.data_as(C.c_void_p))
+    assert ok == 1 and out.tolist() == [0, 4, 4, 3]
+    # submap cell (0, 0) = map cell (0, 4): centre (4.5, 0.5)
+    assert base.tolist() == [4.5, 0.5]
+    assert probe.probe_submap(10, 10, 1.0, 0.0, 0.0, 5.5, 0.0, 4.0, 2.0, out.ctypes.data_as(C.c_void_p), base.ctypes.data_as(C.c_void_p)) == 0
+    lx, ly = float(np.float32(0.1) * np.float32(2)), float(np.float32(0.1))
+    cx = 2.0 - 0.5 * lx - 0.02 * 49.99999995
+    assert probe.probe_submap(200, 200, 0.02, 0.0, 0.0, cx, 0.0, lx, ly, out.ctypes.data_as(C.c_void_p), base.ctypes.data_as(C.c_void_p)) == 1
+    assert out[0] == 49 and out[2] == 12
+    assert probe.probe_submap(200, 200, 0.02, 0.0, 0.0, cx + 1e-8, 0.0, lx, ly, out.ctypes.data_as(C.c_void_p), base.ctypes.data_as(C.c_void_p)) == 1
+    assert out[0] == 49 and out[2] == 11

@@ -266,3 +266,100 @@ def test_as_written_emulation_changes_cost_not_results():
     assert nom.tobytes() == ref.tobytes()
     assert copies >= 2 * 4 * 4 * 4  # at least 4 copies per checkFoothold call (cpp:863-869, 2012, 2029)
     assert m.plan(p, poses, 4)["nominal"].tobytes() == ref.tobytes()  # emulation switched off again
+
+
+# ---- hand-traced known answers (round 2) ------------------------------------------------------------------------
+# Every expected value below was derived BY HAND from the assumed grid_map semantics — not
+# produced by the oracle or by the engine.  They pin pieces both implementations share only through that spec.
+
+# SpiralIterator::generateRing walk of ring 2, traced step by step from (2, 0) with n = (-sgn(py), sgn(px)) and the
+# (int)norm == d rule (App. A.5): (2,0) (2,1) (2,2) (1,2) (0,2) (-1,2) (-2,2) (-2,1) (-2,0) (-2,-1) (-2,-2) (-1,-2) (0,-2)
+# (1,-2) (2,-2) (2,-1); consumed from the back, so VISITED in the reverse order:
+RING2_VISIT = [(2, -1), (2, -2), (1, -2), (0, -2), (-1, -2), (-2, -2), (-2, -1), (-2, 0), (-2, 1), (-2, 2), (-1, 2), (0, 2),
+               (1, 2), (2, 2), (2, 1), (2, 0)]
+# Ring 3 (the walk cuts the corners: (int)|(3,3)| = 4, and (2,2) belongs to ring 2): (3,0) (3,1) (3,2) (2,3) (1,3) (0,3)
+# (-1,3) (-2,3) (-3,2) (-3,1) (-3,0) (-3,-1) (-3,-2) (-2,-3) (-1,-3) (0,-3) (1,-3) (2,-3) (3,-2) (3,-1); reversed:
+RING3_VISIT = [(3, -1), (3, -2), (2, -3), (1, -3), (0, -3), (-1, -3), (-2, -3), (-3, -2), (-3, -1), (-3, 0), (-3, 1), (-3, 2),
+               (-2, 3), (-1, 3), (0, 3), (1, 3), (2, 3), (3, 2), (3, 1), (3, 0)]
+RING1_VISIT = [(1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1), (0, 1), (1, 1), (1, 0)]
+
+
+def test_kat_spiral_rings_2_and_3_hand_traced():
+    """Rings 0-3 of a spiral with nRings = 5 are unfiltered (only rings nRings-1 and nRings are tested against the
+    radius): the first 1 + 8 + 16 + 20 visited cells must be the hand-traced offsets, in order."""
+    res = 0.02
+    trav = np.ones((41, 41), np.float32)
+    omap = fpo.OracleMap(trav, np.zeros_like(trav), res)
+    ok, cx, cy = omap.get_position(20, 20)
+    assert ok
+    cells = omap.spiral_cells(cx, cy, 5 * res)  # nRings = ceil(5.0) = 5
+    want = [(0, 0)] + RING1_VISIT + RING2_VISIT + RING3_VISIT
+    got = [(int(i) - 20, int(j) - 20) for i, j in cells[: len(want)]]
+    assert got == want
+    # the engine's host-built rank table is the same order, unfiltered
+    from quadrupedal_foothold_planner_amd import _capi
+    tab = _capi.spiral_offsets(3)
+    assert [(int(a), int(b)) for a, b, _ in tab] == want
+    assert [int(r) for _, _, r in tab] == [0] + [1] * 8 + [2] * 16 + [3] * 20
+
+
+def test_kat_circle_iterator_clamped_at_the_map_border():
+    """10 x 10 map, res 1, centred at the origin: cell (i, j) has centre (4.5 - i, 4.5 - j).  Hand-computed discs:
+    (4.9, 4.9) r 1.2 -> only cell (0,0) (d^2 = 0.32; its neighbours are at d^2 = 2.12 > 1.44);
+    (4.9, 0.2) r 1.2 -> (0,4) (d^2 = 0.25) and (0,5) (d^2 = 0.65), row-major;  (6.0, 0.2) r 1.2 -> nothing (row 0 is 1.5 away)."""
+    trav = np.ones((10, 10), np.float32)
+    elev = np.arange(100, dtype=np.float32).reshape(10, 10) * 0.01
+    omap = fpo.OracleMap(trav, elev, 1.0)
+    assert [tuple(c) for c in omap.circle_cells(4.9, 4.9, 1.2)] == [(0, 0)]
+    assert [tuple(c) for c in omap.circle_cells(4.9, 0.2, 1.2)] == [(0, 4), (0, 5)]
+    assert len(omap.circle_cells(6.0, 0.2, 1.2)) == 0
+    # mean heights: (0.04 + 0.05) / 2 + h in f32, and h alone for the empty disc (cpp:2547-2553)
+    z = omap.mean_height(4.9, 0.2, 1.2, 0.01)
+    want = np.float32(np.float64((np.float32(0.0) + elev[0, 4] + elev[0, 5]) / np.float32(2)) + 0.01)  # f32 sum, f32 division, + h in f64
+    assert z == want
+    assert omap.mean_height(6.0, 0.2, 1.2, 0.01) == np.float32(0.0 + 0.01)
+
+
+def test_kat_submap_clamped_at_the_map_border():
+    """getSubmap((4, 0), 4 x 2) on the same 10 x 10 map: the top-left corner (6, 1) is clamped to just inside x = 5, the
+    bottom-right (2, -1) sits exactly on a cell boundary (y = -1 belongs to column 6).  By hand: rows 0..3, columns 4..6,
+    top-left corner of cell (0,4) = (5, 1), submap length (4, 3), submap position (5 - 2, 1 - 1.5) = (3, -0.5)."""
+    trav = np.ones((10, 10), np.float32)
+    omap = fpo.OracleMap(trav, np.zeros_like(trav), 1.0)
+    ok, out, pl = omap.submap_info(4.0, 0.0, 4.0, 2.0)
+    assert ok
+    assert out.tolist() == [0, 4, 4, 3]
+    assert pl.tolist() == [3.0, -0.5, 4.0, 3.0]
+    # a centre outside the map: the clamped submap does not contain it -> getSubmap fails (cpp:1628-1631 path)
+    ok, _, _ = omap.submap_info(5.5, 0.0, 4.0, 2.0)
+    assert not ok
+
+
+def test_kat_centroid_rectangle_has_12_rows_when_the_far_edge_crosses_a_cell_boundary():
+    """double(float(0.1) * 2) / 0.02 = 10.00000015 cells, so the centroid rectangle spans 11 rows unless its top edge
+    lies within 1.5e-7 cells BELOW a cell boundary.  200 x 200 map at 2 cm around the origin: row
+    coordinate u(x) = (2 - x) / 0.02.  With u(top) = 49.99999995 the bottom edge is at 60.0000001: rows 49..60 = 12;
+    moving the centre 1e-8 m (5e-7 cells) up gives u(top) = 49.99999945, bottom 59.9999996: rows 49..59 = 11."""
+    res = 0.02
+    trav = np.ones((200, 200), np.float32)
+    omap = fpo.OracleMap(trav, np.zeros_like(trav), res)
+    lx = float(np.float32(0.1) * np.float32(2))   # cpp:1616: searchRadius_ * 2 in f32
+    ly = float(np.float32(0.1))
+    cx = 2.0 - 0.5 * lx - res * 49.99999995
+    ok, out, _ = omap.submap_info(cx, 0.0, lx, ly)
+    assert ok and out[0] == 49 and out[2] == 12
+    ok, out, _ = omap.submap_info(cx + 1e-8, 0.0, lx, ly)
+    assert ok and out[0] == 49 and out[2] == 11
+
+
+def test_kat_spiral_skips_empty_rings_when_the_centre_is_outside_the_map():
+    """3 x 3 map, res 1, centre (4.0, 0.0): getIndex gives (-2, 1) — two rows above the map.  Ring 0 and ring 1 hold no
+    cell of the map (EMPTY rings before a non-empty one: upstream's `if` instead of `while` would dereference an empty
+    vector there; both restatements define: skip).  Ring 2 (unfiltered, nRings = 4) reaches row 0: offsets (2,-1), (2,1),
+    (2,0) in visiting order -> cells (0,0), (0,2), (0,1).  Ring 3 is filtered by |cell - centre| <= 4: only (3,0) -> cell
+    (1,1), at distance exactly 4.  Ring 4: nothing within the radius."""
+    trav = np.ones((3, 3), np.float32)
+    omap = fpo.OracleMap(trav, np.zeros_like(trav), 1.0)
+    ok, i, j = omap.get_index(4.0, 0.0)
+    assert (not ok) and (i, j) == (-2, 1)
+    assert [tuple(c) for c in omap.spiral_cells(4.0, 0.0, 4.0)] == [(0, 0), (0, 2), (0, 1), (1, 1)]
