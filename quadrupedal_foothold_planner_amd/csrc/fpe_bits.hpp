@@ -111,6 +111,15 @@ struct YEntry {
 };
 static_assert(sizeof(YEntry) == 88, "YEntry layout");
 
+// ds_swizzle of a double (bit mode), two dwords
+template <int kPattern>
+__device__ __forceinline__ double swizzle_f64(double v) {
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_ds_swizzle(static_cast<int>(bits), kPattern);
+    const int hi = __builtin_amdgcn_ds_swizzle(static_cast<int>(bits >> 32), kPattern);
+    return __builtin_bit_cast(double, (static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+
 // Multi-word row shifts by 0 <= s < 32 columns: shr: bit j of the result = bit j + s of the row; shl: bit j - s.
 template <int KW>
 __device__ __forceinline__ void row_shr(const unsigned (&x)[KW], unsigned s, unsigned (&o)[KW]) {
@@ -1108,8 +1117,9 @@ __device__ __forceinline__ void fill_yentry(const MapGeom& mg, const PlanConsts&
 template <int NRL, bool kMid>
 __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut,
                                                 const LutHead& head, PoseShared& sh, const LegBits& lb, const Grp<8>& g, int leg,
-                                                const LegStatic& ls, const YEntry& ye, double advance, int cyc, int nCycles,
-                                                int b, bool live, const fpe_plan_out& out, LegCommit* lc, Unit* unit) {
+                                                const LegStatic& ls, const YEntry& ye, double ctr0, double ctr1, double ctr2,
+                                                double advance, int cyc, int nCycles, int b, bool live, const fpe_plan_out& out,
+                                                LegCommit* lc, Unit* unit) {
     constexpr int G = 8, KW = 1;
     constexpr bool kDefer = kMid;  // heights and records deposited in `unit`, finished by flush_unit every eighth cycle
     const float Rf = ls.Rf;
@@ -1117,9 +1127,9 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
     const LegConst& lk = ls.lk;
     const double biasX = ls.biasX;
     // next default positions of this leg on the three tracks (cpp:2199-2213, 2270-2284)
-    const double nx0 = (sh.ctr[0] + advance) + biasX;  // cpp:2199, 2414
-    const double nx1 = (sh.ctr[1] + advance) + biasX;
-    const double nx2 = (sh.ctr[2] + advance) + biasX;
+    const double nx0 = (ctr0 + advance) + biasX;  // cpp:2199, 2414
+    const double nx1 = (ctr1 + advance) + biasX;
+    const double nx2 = (ctr2 + advance) + biasX;
     const double ny = ye.ny;  // (initialPose_[1] + ajustedPose_[1]) + bias.y, identical on the three tracks (cpp:2201)
     if (polyKind != 0 && g.sub == 0) {  // hexagon vertices from the NOMINAL track's position (build-defined, App. E)
         const double r = static_cast<double>(Rf);
@@ -1358,6 +1368,213 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
     }
 }
 
+// The common case of the 3x3-only kernels as straight-line code: every swing leg of the wavefront has a usable centre,
+// its two foot-disc boxes are unclamped 3x3 boxes (the middle cell is inside the disc whatever the centre,
+// PlanConsts::midCellInside) and the default track is wanted and usable.  No LDS hand-offs besides the spiral's pass
+// rows: the default check is evaluated by the lanes that OWN the three window rows of the box against the ballot of
+// the membership tests; loads are unconditional; the centroid case logic is a chain of selects.  Any other situation
+// (map border, unusable centre, missing products) sends the whole wavefront through leg_phase_bits8 for this phase.
+template <int NRL>
+__device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut,
+                                           const LutHead& head, PoseShared& sh, const LegBits& lb, const Grp<8>& g, int leg,
+                                           const LegStatic& ls, const YEntry& ye, double ctr0, double ctr1, double ctr2, double advance,
+                                           int cyc, int nCycles, int b, bool live, const fpe_plan_out& out, LegCommit* lc, Unit* unit) {
+    constexpr int G = 8, KW = 1;
+    const LegConst& lk = ls.lk;
+    const double nx0 = (ctr0 + advance) + ls.biasX;  // cpp:2199, 2414
+    const double nx1 = (ctr1 + advance) + ls.biasX;
+    const double nx2 = (ctr2 + advance) + ls.biasX;
+    const double ny = ye.ny;
+    const double cx = nx1;  // centre from the CENTROID track (cpp:861-862)
+    const bool wantDefault = out.default_next != nullptr;
+    bool rare = !ls.radiusOk || (ye.flags & 2) == 0 || !(fabs(cx) <= 1e6) || !wantDefault || !(fabs(nx0) <= 1e6);
+    // ---- x side: one corner quantity per lane (see leg_phase_bits8) ----
+    const int q = g.sub;
+    const double cq = (q == 5 || q == 6) ? nx0 : cx;
+    const bool rawq = q == 4 || q == 7;
+    const double hq = (q == 2 || q == 3) ? 0.5 * lk.lx : (rawq ? 0.0 : pc.rf);
+    const bool minus = q == 1 || q == 3 || q == 6;
+    const double xq = rawq ? cq : (minus ? cq - hq : cq + hq);
+    const double qf = ((xq - m.g.orgX) - m.g.posX) * m.g.rinv;
+    const double kq = trunc(qf);
+    const double fr = fabs(qf - kq);
+    bool safe = fr > pc.cornerEps && fr < 1.0 - pc.cornerEps;
+    if (!rawq) safe = safe && qf < -pc.cornerEps && qf > pc.cornerEps - static_cast<double>(m.g.rows);
+    const int idxq = -static_cast<int>(kq);
+    constexpr int kKeep = (~(G - 1)) & 0x1F;
+    const int i0d = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (0 << 5));
+    const int i1d = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (1 << 5));
+    const int i0r = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (2 << 5));
+    const int i1r = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (3 << 5));
+    const int ici = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (4 << 5));
+    const int i0f = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (5 << 5));
+    const int i1f = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (6 << 5));
+    const int j0d = ye.j0d, icj = ye.jc;
+    // both foot-disc boxes: 3x3 and clear of the map's outermost rows / columns (not clamped, inside the map)
+    const bool boxes = (i1d - i0d) == 2 && (i1f - i0f) == 2 && ye.njd == 3 && i0d >= 1 && i0f >= 1 && j0d >= 1 &&
+                       i0d + 4 <= m.g.rows && i0f + 4 <= m.g.rows && j0d + 4 <= m.g.cols;
+    rare = rare || !safe || !boxes;
+    if (__ballot(rare) != 0ull) {  // wave-uniform
+        leg_phase_bits8<NRL, true>(m, bm, pc, lut, head, sh, lb, g, leg, ls, ye, ctr0, ctr1, ctr2, advance, cyc, nCycles, b, live, out, lc, unit);
+        return;
+    }
+    // getSubmapInformation's tail, x part (corners strictly inside the map: within); y part from the entry
+    Submap sm;
+    sm.i0 = i0r;
+    sm.j0 = ye.j0r;
+    sm.ni = i1r - i0r + 1;
+    sm.nj = ye.njr;
+    {
+        const double cornerX = cell_pos(m.g.baseX, m.g.res, sm.i0) - (-(0.5 * m.g.res));
+        const double subLenX = static_cast<double>(sm.ni) * m.g.res;
+        const double subOrgX = 0.5 * subLenX;
+        const double subPosX = cornerX - subOrgX;
+        sm.ok = (ye.flags & 1) != 0 && within_axis(cx, subOrgX, subPosX, subLenX);
+        sm.baseX = subPosX + (subOrgX - 0.5 * m.g.res);
+        sm.baseY = ye.sbaseY;
+    }
+    const int iw0 = ici - pc.winH, jw0 = icj - pc.winH;
+    stamp(pc, cyc, 2);
+    // ---- one memory round trip: window rows, and the elevation of both discs (lane = cell t of the 3x3 boxes) ----
+    uint4 grp[NRL][KW + 1];
+    win_issue<G, NRL, KW>(bm, m.g, g, iw0, jw0, grp);
+    const int t = g.sub + (g.sub >= 4 ? 1 : 0);
+    const int a = t >= 6 ? 2 : (t >= 3 ? 1 : 0);
+    const int bq = t - 3 * a;
+    const double dy2 = ye.dy2[bq];
+    const double dxA = cell_pos(m.g.baseX, m.g.res, i0d + a) - cx;
+    const double dxB = cell_pos(m.g.baseX, m.g.res, i0f + a) - nx0;
+    const bool visA = (dxA * dxA + dy2) <= pc.rf2;  // CircleIterator::isInside (cell_in_disc)
+    const bool visB = (dxB * dxB + dy2) <= pc.rf2;
+    const float eA = m.elev[static_cast<size_t>(i0d + a) * m.g.cols + (j0d + bq)];
+    const float eB = m.elev[static_cast<size_t>(i0f + a) * m.g.cols + (j0d + bq)];
+    const float eMidA = m.elev[static_cast<size_t>(i0d + 1) * m.g.cols + (j0d + 1)];
+    const float eMidB = m.elev[static_cast<size_t>(i0f + 1) * m.g.cols + (j0d + 1)];
+    stamp(pc, cyc, 3);
+    WinRows<NRL, KW> w;
+    win_finish<NRL, KW>(jw0, grp, w);
+    const CentroidScan sc = rows_from_bits<G, NRL, KW>(sm, w, g, iw0, jw0);
+    stamp(pc, cyc, 4);
+    // ---- checkDefaultFoothold: the lanes owning the box's three window rows test their Df bits under the members ----
+    const unsigned mA = static_cast<unsigned>(g.ballot(visA)), mB = static_cast<unsigned>(g.ballot(visB));
+    bool fail = false;
+    {
+        const unsigned m0 = mA & 7u, m1 = ((mA >> 3) & 1u) | 2u | (((mA >> 4) & 1u) << 2), m2 = (mA >> 5) & 7u;
+        const unsigned sh3 = static_cast<unsigned>(j0d - jw0) & 31u;
+#pragma unroll
+        for (int k = 0; k < NRL; ++k) {
+            const int ar = g.sub + G * k - (i0d - iw0);  // row of the box held in slot k
+            const unsigned sel = ar == 0 ? m0 : (ar == 1 ? m1 : (ar == 2 ? m2 : 0u));
+            fail |= (((w.Df[k][0] >> sh3) & 7u) & sel) != 0u;
+        }
+    }
+    const bool defaultOk = !g.any(fail);  // the middle cell is always visited (cpp:2069-2081: at least one cell)
+    // ---- deposits for flush_unit: elevations in CircleIterator order ----
+    unit->eA[t] = eA;
+    unit->eA[4] = eMidA;  // every lane stores the same value
+    unit->eB[t] = eB;
+    unit->eB[4] = eMidB;
+    stamp(pc, cyc, 5);
+    // ---- centroid method (cpp:1684-1952) as selects ----
+    const int bottomRow = sm.ni - 1, rightCol = sm.nj - 1;
+    const int minRow = sc.minRow, maxRow = sc.maxRow;
+    const bool case1 = minRow == 0 && maxRow != bottomRow;
+    const bool case2 = minRow != 0 && maxRow != bottomRow;
+    const bool case3 = minRow != 0 && maxRow == bottomRow;
+    const bool upper = minRow >= (bottomRow - maxRow);
+    const int code = !sm.ok ? 6 : (sc.whole ? 0 : (case1 ? 1 : (case2 ? (upper ? 2 : 3) : (case3 ? 4 : 5))));
+    const int newRow = case1 ? ((maxRow + bottomRow + 1) >> 1) : ((case2 && !upper) ? ((maxRow + bottomRow) >> 1) : ((minRow + 1) >> 1));
+    const int newCol = case1 ? ((rightCol + 1) >> 1) : (rightCol >> 1);
+    const bool hasCell = code >= 1 && code <= 4;
+    CentroidOut co;
+    co.code = code;
+    co.z = 0.0f;
+    co.x = code == 0 ? cx : (hasCell ? cell_pos(sm.baseX, m.g.res, newRow) : 0.0);  // cpp:1687 / cpp:1816
+    co.y = code == 0 ? ny : (code == 1 ? ye.yA : (hasCell ? ye.yB : 0.0));
+    co.row = code == 0 ? ici : (hasCell ? sm.i0 + newRow : -1);
+    co.col = code == 0 ? icj : (hasCell ? sm.j0 + newCol : -1);
+    // the result's own cell (one-cell foot disc); any in-map cell when there is none (the value is ignored)
+    const float eC = m.elev[static_cast<size_t>(hasCell ? co.row : i0d + 1) * m.g.cols + (hasCell ? co.col : j0d + 1)];
+    stamp(pc, cyc, 7);
+    // ---- nominal result: the default foothold, else the spiral search (cpp:2012-2029) ----
+    NominalOut no;
+    no.valid = 1;
+    no.source = 0;
+    no.row = ici;
+    no.col = icj;
+    no.x = cx;  // cpp:2016-2017
+    no.y = ny;
+    no.z = 0.0f;
+    if (!defaultOk) {
+        LegCtx c;
+        c.cyc = cyc;
+        c.cx = cx;
+        c.cy = ny;
+        c.nv = ls.polyKind == 0 ? 4 : 6;
+        const double r = static_cast<double>(ls.Rf);
+        c.rect = ls.polyKind == 0;
+        c.xhi = nx2 + r;
+        c.xlo = nx2 - r;
+        c.yhi = ny + 0.5 * r;
+        c.ylo = ny - 0.5 * r;
+        c.vx = sh.polyX[leg];
+        c.vy = sh.polyY[leg];
+        c.footDa = sh.footDa;
+        c.footDb = sh.footDb;
+        c.footOff = sh.footOff;
+        c.R2 = lk.R2;
+        c.nRings = lk.nRings;
+        c.nCand = lk.nCand;
+        c.ti0 = c.tj0 = 0;
+        c.ici = ici;
+        c.icj = icj;
+        if (!c.rect) {  // hexagon vertices from the NOMINAL track's position (build-defined, App. E)
+            if (g.sub == 0) {
+                double* vx = sh.polyX[leg];
+                double* vy = sh.polyY[leg];
+                const double hx = 0.5 * r, hy = (0.5 * r) * 0.8660254037844386;
+                vx[0] = nx2 + r;   vy[0] = ny;
+                vx[1] = nx2 + hx;  vy[1] = ny - hy;
+                vx[2] = nx2 - hx;  vy[2] = ny - hy;
+                vx[3] = nx2 - r;   vy[3] = ny;
+                vx[4] = nx2 - hx;  vy[4] = ny + hy;
+                vx[5] = nx2 + hx;  vy[5] = ny + hy;
+            }
+            pose_sync<G>();
+        }
+        nominal_invalid(no, cx, ny, 2);
+        int wi = 0, wj = 0;
+        if (spiral_bits<G, NRL, KW>(m, pc, lut, head, c, w, lb, g, iw0, jw0, wi, wj, &ye)) {  // cpp:2022
+            no.valid = 1;
+            no.source = 1;
+            no.row = wi;
+            no.col = wj;
+            no.x = cell_pos(m.g.baseX, m.g.res, wi);  // cpp:2105-2107
+            no.y = cell_pos(m.g.baseY, m.g.res, wj);
+        }
+        pose_sync<G>();
+    }
+    stamp(pc, cyc, 8);
+    if (g.sub == 0) {  // what flush_unit needs to rebuild this leg's four records
+        unit->eC = eC;
+        unit->visA = (mA & 0xFu) | 0x10u | ((mA & 0xF0u) << 1);
+        unit->visB = (mB & 0xFu) | 0x10u | ((mB & 0xF0u) << 1);
+        unit->nomRow = no.row;
+        unit->nomCol = no.col;
+        unit->nomFlags = static_cast<uint32_t>(no.valid) | (static_cast<uint32_t>(no.source) << 8);
+        unit->cenRow = co.row;
+        unit->cenCol = co.col;
+        unit->cenCode = static_cast<uint32_t>(code) | (hasCell ? 0x100u : 0u);
+        unit->cx = cx;
+        unit->cenX = co.x;
+        unit->defX = nx0;
+    }
+    lc->valid = no.valid;
+    lc->v[0][0] = nx0;   lc->v[0][1] = ny;    lc->v[0][2] = 0.0;
+    lc->v[1][0] = co.x;  lc->v[1][1] = co.y;  lc->v[1][2] = 0.0;
+    lc->v[2][0] = no.x;  lc->v[2][1] = no.y;  lc->v[2][2] = 0.0;
+}
+
 }  // namespace
 
 // ---- chained plan on the bit window: 8 lanes per leg, two poses per wavefront ------------------------------------
@@ -1456,24 +1673,33 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
             const unsigned mask = (gait == 1) ? (1u << ((walkOrder >> (2 * ph)) & 3)) : 0xFu;
             const bool active = (mask >> leg) & 1u;
             stamp(pc, cyc, 0);
-            // feet-polygon centres: group t computes track t (getPolygonCenter, cpp:2191, 2265)
-            if (leg < 3 && g.sub == 0) sh.ctr[leg] = polygon_center_x(sh.cur[leg]);
-            pose_sync<G>();
+            // feet-polygon centres (getPolygonCenter, cpp:2191, 2265): lane t of every leg group computes track t from the
+            // committed feet in LDS; the three values reach the group's lanes by swizzle (no LDS hand-off, no barrier)
+            const double myCtr = polygon_center_x(sh.cur[g.sub < 2 ? g.sub : 2]);
+            constexpr int kKeep = (~(G - 1)) & 0x1F;
+            const double ctr0 = swizzle_f64<kKeep | (0 << 5)>(myCtr), ctr1 = swizzle_f64<kKeep | (1 << 5)>(myCtr),
+                         ctr2 = swizzle_f64<kKeep | (2 << 5)>(myCtr);
             stamp(pc, cyc, 1);
             // footholdValidation_ (cpp:1323) is a ballot over the pose's lanes; the committed positions go from
             // registers straight to PoseShared::cur (cpp:1332-1576)
             LegCommit lc;
             lc.valid = 1;  // non-swing legs do not vote
-            if (active)
-                leg_phase_bits8<NRL, kMid>(m, bm, pc, lut, head, sh, lb, g, leg, ls, ye, advance, cyc, nCycles, b, live, out, &lc,
-                                           kMid ? units + (cyc & 7) : nullptr);
+            if (active) {
+                if constexpr (kMid)
+                    leg_fast8m<NRL>(m, bm, pc, lut, head, sh, lb, g, leg, ls, ye, ctr0, ctr1, ctr2, advance, cyc, nCycles, b, live, out, &lc,
+                                    units + (cyc & 7));
+                else
+                    leg_phase_bits8<NRL, false>(m, bm, pc, lut, head, sh, lb, g, leg, ls, ye, ctr0, ctr1, ctr2, advance, cyc, nCycles, b, live,
+                                                out, &lc, nullptr);
+            }
             stamp(pc, cyc, 9);
             const bool phaseOk = (__ballot(lc.valid == 0) & poseMask) == 0ull;
             if (phaseOk && active && g.sub == 0) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) sh.cur[t][leg][k] = lc.v[t][k];
+                for (int t = 0; t < 3; ++t) {  // x and y only: no later cycle reads a committed z (getPolygonCenter, cpp:2421-2463)
+                    sh.cur[t][leg][0] = lc.v[t][0];
+                    sh.cur[t][leg][1] = lc.v[t][1];
+                }
             }
             pose_sync<G>();
             cycleOk = cycleOk && phaseOk;
