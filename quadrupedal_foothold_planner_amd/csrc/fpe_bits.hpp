@@ -1000,11 +1000,13 @@ __device__ __forceinline__ float unit_mean9(const float* e, uint32_t vis, double
     float sum = 0.0f, last = 0.0f;
     int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        if ((vis >> k) & 1u) {
-            const float v = __builtin_isfinite(e[k]) ? e[k] : 0.0f;  // cpp:2532-2537
-            ordered_step(v, sum, last, cnt);
-        }
+    for (int k = 0; k < 9; ++k) {  // branch-free: an unvisited cell adds -0.0f (s + (-0.0f) == s for every s) and leaves `last`
+        const bool visited = ((vis >> k) & 1u) != 0u;
+        const float v = __builtin_isfinite(e[k]) ? e[k] : 0.0f;  // cpp:2532-2537
+        const bool inc = visited && v < 10;                      // cpp:2539
+        last = visited ? v : last;
+        cnt += inc ? 1 : 0;
+        sum = sum + (inc ? v : -0.0f);
     }
     return finish_mean(sum, last, cnt, h);
 }
@@ -1065,17 +1067,35 @@ __device__ __forceinline__ void fill_yentry(const MapGeom& mg, const PlanConsts&
     const double r = static_cast<double>(ls.Rf);
     int flags = fabs(ny) <= 1e6 ? 2 : 0;
     e.ny = ny;
-    // foot-disc box (CircleIterator::findSubmapParameters, y axis)
+    // foot-disc box (CircleIterator::findSubmapParameters, y axis), getIndex(centre), centroid rectangle
+    // (getSubmapInformation, y axis: corners centre +- 0.5 * ly).  The five indices are predicted without the f64
+    // division (index_of_fast's test); when any lane of the wavefront is too close to a cell boundary the wavefront
+    // takes the true divisions (a real branch: the if-converted form would pay five divisions per entry)
     const double tly = bound_axis(ny + pc.rf, mg.orgY, mg.posY, mg.lenY);
     const double bry = bound_axis(ny - pc.rf, mg.orgY, mg.posY, mg.lenY);
-    e.j0d = index_of_fast(tly, mg.orgY, mg.posY, mg.res, mg.rinv);
-    e.njd = index_of_fast(bry, mg.orgY, mg.posY, mg.res, mg.rinv) - e.j0d + 1;
-    e.jc = index_of_fast(ny, mg.orgY, mg.posY, mg.res, mg.rinv);
-    // centroid rectangle (getSubmapInformation, y axis): corners centre +- 0.5 * ly
     const double tlr = bound_axis(ny + 0.5 * ly, mg.orgY, mg.posY, mg.lenY);
     const double brr = bound_axis(ny - 0.5 * ly, mg.orgY, mg.posY, mg.lenY);
-    const int j0r = index_of_fast(tlr, mg.orgY, mg.posY, mg.res, mg.rinv);
-    const int j1r = index_of_fast(brr, mg.orgY, mg.posY, mg.res, mg.rinv);
+    const double xs[5] = {tly, bry, ny, tlr, brr};
+    int idx[5];
+    bool tie = false;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const double qf = ((xs[k] - mg.orgY) - mg.posY) * mg.rinv;
+        const double kk = trunc(qf);
+        const double fr = fabs(qf - kk);
+        const double eps = fabs(qf) * 4.5e-16 + 1e-290;
+        tie |= !(fr > eps && fr < 1.0 - eps);
+        idx[k] = -static_cast<int>(kk);
+    }
+    if (__ballot(tie) != 0ull) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) idx[k] = index_of(xs[k], mg.orgY, mg.posY, mg.res);
+    }
+    e.j0d = idx[0];
+    e.njd = idx[1] - idx[0] + 1;
+    e.jc = idx[2];
+    const int j0r = idx[3];
+    const int j1r = idx[4];
     e.j0r = j0r;
     e.njr = j1r - j0r + 1;
     bool okY = within_axis(tlr, mg.orgY, mg.posY, mg.lenY) && within_axis(brr, mg.orgY, mg.posY, mg.lenY) && j0r >= 0 && j0r < mg.cols;
@@ -1583,6 +1603,7 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
                                                           const fpe_pose* __restrict__ poses, int B, int nCycles, fpe_plan_out out) {
     constexpr int G = 8;
     constexpr int NR = G * NRL;
+    stamp(pc, 1, 11);
     // the map geometry doubles are operands of vector f64 arithmetic only: parked in VGPRs (see plan_chained_kernel)
     DevMap m = mArg;
     m.g.res = in_vgpr(m.g.res);
@@ -1615,8 +1636,27 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
     const fpe_pose* pp = poses + b;
     const double x0 = pp->position[0], y0 = pp->position[1], z0 = pp->position[2];
     const int gait = pp->gait;
-    const LegStatic ls = make_leg_static(pc, pp, leg, m.g.res, lut);
     const LutHead head = load_lut_head(lut, g);
+    LegStatic ls;
+    {
+        const float rOverride = pp->leg_search_radius[leg];
+        if (__ballot(rOverride > 0.0f) != 0ull) {  // some leg of the wavefront overrides the search radius (build-defined)
+            ls = make_leg_static(pc, pp, leg, m.g.res, lut);
+        } else {  // the reference's single searchRadius_: constants precomputed on the host
+            ls.Rf = pc.searchRadius;
+            ls.polyKind = pp->leg_polygon_kind[leg];
+            ls.radiusOk = true;
+            const double R = static_cast<double>(pc.searchRadius);
+            ls.lk.Rf = pc.searchRadius;
+            ls.lk.R2 = R * R;
+            ls.lk.nRings = pc.defNRings;
+            ls.lk.nCand = pc.defNCand;
+            ls.lk.lx = static_cast<double>(pc.searchRadius * 2);
+            ls.lk.ly = static_cast<double>(pc.searchRadius);
+            ls.biasX = pc.biasX[leg];
+            ls.biasY = pc.biasY[leg];
+        }
+    }
     for (int k = tid % kPoseThreads; k < pc.nFoot; k += kPoseThreads) {
         sh.footDa[k] = pc.footDa[k];
         sh.footDb[k] = pc.footDb[k];
@@ -1643,8 +1683,18 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
         }
     }
     pose_sync<G>();
-    if (out.pose_status && live && leg == 0 && g.sub == 0)
-        out.pose_status[b] = opt_gate_cycle0(m.g, pc, polygon_center_x(sh.cur[0]), y0);
+    stamp(pc, 1, 12);
+    if (out.pose_status) {
+        // getGaitCycleSearchGridMap's getSubmap in the first cycle (opt_gate_cycle0), its four corners on four lanes
+        const double gx = polygon_center_x(sh.cur[0]) + pc.step, gy = y0 + 0.0;  // cpp:2327-2329
+        const Box gb{gx, gy, 0.5 * pc.isosLen, 0.5 * pc.isosWid};
+        Corners<G, 8> gc;
+        gc.eval(m.g, g, gb, gb, gb, gb, 0x0u);
+        const Submap gs = submap_from_corners(m.g, gc.template bbox<0>(g), gc.box_within(0), gx, gy);
+        if (live && leg == 0 && g.sub == 0)
+            out.pose_status[b] = (centre_usable(gx, gy) && gs.ok) ? 0 : static_cast<uint8_t>(FPE_POSE_OPT_SUBMAP_FAILED);
+    }
+    stamp(pc, 1, 13);
 
     double adjY = 0.0;  // ajustedPose_[1], cpp:759
     const int nPhases = (gait == 1) ? 4 : 1;
@@ -1666,6 +1716,7 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
             }
             fill_yentry(m.g, pc, ls, (y0 + mine) + ls.biasY, ytab[g.sub]);  // cpp:2201, 2414
             pose_sync<G>();
+            stamp(pc, 1, 14);
         }
         const YEntry& ye = ytab[cyc & 7];
         bool cycleOk = true;
@@ -1711,8 +1762,10 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
             if ((cyc & 7) == 7 || cyc == nCycles - 1) {
                 // heights and output records of the last (up to) eight cycles: lane (leg, s) takes the unit of cycle base + s
                 const int c0 = cyc & ~7;
+                stamp(pc, 2, 11);
                 if (live && c0 + g.sub <= cyc) flush_unit(m.g, pc, units[g.sub], ytab[g.sub], b, c0 + g.sub, leg, nCycles, out);
                 pose_sync<G>();  // the units and the y entries are rewritten next
+                stamp(pc, 2, 12);
             }
         }
     }

@@ -81,6 +81,10 @@ struct PlanConsts {
     int32_t nHW;
     int8_t hwList[4];
     int8_t hwIdx[16];
+    // SpiralIterator constants of the DEFAULT search radius (fpe_params.searchRadius; a pose may override it per leg):
+    // nRings = ceil(R / res), spiral rank-table entries of rings 0..nRings — spares every wavefront a division and a
+    // dependent table load in its prologue
+    int32_t defNRings, defNCand;
 };
 constexpr int kMaxHW = 4;
 

@@ -233,6 +233,7 @@ struct fpe_engine {
     uint8_t* d_ring = nullptr;
     int32_t* d_ringStart = nullptr;
     int maxRing = 0;
+    std::vector<int32_t> ringStart;   // host copy of the rank table's ring offsets
     float maxLegSearchRadius = 0.0f;  // fpe_set_max_leg_search_radius
     fpe::Tuning tuning;               // fpe_set_tuning; seeded from the environment once, in fpe_create
 
@@ -276,6 +277,8 @@ int prepare_call(fpe_engine* h, const fpe_params* params, float maxRadius, CallP
     fpe::derive_constants(*params, snap.g, maxRadius, tuning, pc);
     if (fpe::spiral_rings(maxRadius, snap.g.res) > h->maxRing)
         return fail(FPE_E_UNSUPPORTED, "search radius needs more spiral rings than the rank table holds");
+    pc.defNRings = fpe::spiral_rings(params->searchRadius, snap.g.res);
+    pc.defNCand = h->ringStart[static_cast<size_t>(std::min(pc.defNRings, h->maxRing)) + 1];
     cp.planLds = fpe::plan_lds_bytes(pc);
     cp.searchLds = fpe::search_lds_bytes(pc);
     if (cp.planLds > kMaxLdsBytes || cp.searchLds > kMaxLdsBytes)
@@ -426,6 +429,7 @@ int fpe_create(int device_id, fpe_handle* out) {
     fpe::SpiralTable t;
     fpe::build_spiral_table(fpe::kMaxRings, t);
     h->maxRing = t.maxRing;
+    h->ringStart = t.ringStart;
     const size_t n = t.di.size();
     auto cleanup = [&]() { fpe_destroy(h); };
 #define FPE_HIP_C(call)                       \
