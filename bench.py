@@ -376,7 +376,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / peak,
             "traffic": traffic,
-            "kernel": "plan_bits_kernel" if not args.no_bits else "plan_chained_kernel",
+            "kernel": planner.describe_plan(),
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_foothold": alg_bytes,
             "note": "latency/ALU bound; map is L2/Infinity-Cache resident (DESIGN.md)",

@@ -184,6 +184,10 @@ int fpe_upload_map_device(fpe_handle h, const fpe_map_desc* desc, const float* d
                           const float* d_elevation, void* stream);
 int fpe_map_info(fpe_handle h, fpe_map_desc* out); /* geometry of the current snapshot */
 
+/* Name and shape of the kernel a chained plan with these parameters launches on the current map (evidence for
+ * benchmarks and profiles; e.g. "plan_bits_kernel<2, true> (8 lanes per leg, 13 x 13 bit window, 3x3-only fast path)"). */
+int fpe_describe_plan(fpe_handle h, const fpe_params* params, char* buf, int32_t n);
+
 /* Build-defined: upper bound of fpe_pose.leg_search_radius the device-resident entry points size
  * their LDS tile for (the host-buffer entry points scan the poses themselves).  Default 0 =
  * fpe_params.searchRadius only; legs asking for more come back invalid with source = 3. */

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round-2 evidence at HEAD: per configuration kernel stats + counters (bit-window kernels), the direct kernels' stats for
+# comparison, the full bench line of the headline (cpu_baseline, ingest, open loop, D2H-inclusive rate), the open-loop
+# kernel's counter bytes, and the -m gpu suite with durations.
+set -u
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -q --durations=15 > gpurun_out/r2p_pytest.log 2>&1; echo "pytest rc=$?"
+bash profiles/collect.sh r2p_headline headline full > /dev/null 2>&1
+for c in cfg2 cfg3 cfg4 cfg5; do bash profiles/collect.sh r2p_$c $c lite > /dev/null 2>&1; done
+for c in headline cfg3 cfg4 cfg5; do bash profiles/collect.sh r2p_${c}_direct $c stats --no-bits > /dev/null 2>&1; done
+python3 bench.py > gpurun_out/r2p_bench_full.json 2> gpurun_out/r2p_bench_full.err; echo "full bench rc=$?"
+FPE_BENCH_SHARE_GPU=1 python3 bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/r2p_bench_2rank.json 2> gpurun_out/r2p_bench_2rank.err; echo "2-rank rc=$?"
+# open-loop kernel: counter bytes of search_legs_kernel (the full bench runs it when extras are on)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/r2p_ol_fetch -o ol -- python3 bench.py --steps 5 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/r2p_ol_write -o ol -- python3 bench.py --steps 5 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2p_ol_stats -o ol -- python3 bench.py --steps 5 --no-cpu-baseline > /dev/null 2>&1
+ls gpurun_out | grep r2p_ | wc -l

@@ -1910,6 +1910,24 @@ bool bits_supported(const PlanConsts& pc, const MapGeom& g) {
     return side * side <= legbits_words(8 * sp.nrl, 1, pc.nHW, false);
 }
 
+// Which kernel a chained plan with these constants launches (evidence for bench.py / profiles).
+void describe_plan_kernel(const PlanConsts& pc, const MapGeom& g, char* buf, size_t n) {
+    if (bits_supported(pc, g)) {
+        const BitsShape sp = bits_shape(pc.winH);
+        const bool mid = mid_variant(pc, g.res) && pc.nFoot == 1;
+        if (sp.lanes == 8)
+            snprintf(buf, n, "plan_bits_kernel<%d, %s> (8 lanes per leg, %d x %d bit window%s)", sp.nrl, mid ? "true" : "false",
+                     2 * pc.winH + 1, 2 * pc.winH + 1, mid ? ", 3x3-only fast path" : "");
+        else
+            snprintf(buf, n, "plan_bits_seq_kernel<%d, %d> (one wavefront per pose, %d x %d bit window, %d-bit rows)", sp.nrl, sp.kw,
+                     2 * pc.winH + 1, 2 * pc.winH + 1, 32 * sp.kw);
+        return;
+    }
+    const int G = plan_group_size(pc);
+    if (G == 65) snprintf(buf, n, "plan_sequential_kernel (direct, one wavefront per pose)");
+    else snprintf(buf, n, "plan_chained_kernel<%d, %s> (direct)", G, (G == 8 && mid_variant(pc, g.res)) ? "true" : "false");
+}
+
 hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut, const fpe_pose* d_poses,
                             int B, int nCycles, const fpe_plan_out& d_out, hipStream_t stream) {
     const BitsShape sp = bits_shape(pc.winH);

@@ -34,6 +34,7 @@ size_t bitmap_words(int rows, int cols, int* strideW, int* nw);
 hipError_t launch_build_bitmap(const float* d_trav, int rows, int cols, float thrDefault, float thrCandidate,
                                uint32_t* d_words, hipStream_t stream);
 bool bits_supported(const PlanConsts& pc, const MapGeom& g);
+void describe_plan_kernel(const PlanConsts& pc, const MapGeom& g, char* buf, size_t n);
 hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut,
                             const fpe_pose* d_poses, int B, int nCycles, const fpe_plan_out& d_out, hipStream_t stream);
 }  // namespace fpe
@@ -478,6 +479,24 @@ int fpe_set_tuning(fpe_handle h, const char* key, int32_t value) {
     else if (k == "no_mid_variant") h->tuning.noMidVariant = value ? 1 : 0;
     else if (k == "no_bits") h->tuning.noBits = value ? 1 : 0;
     else return fail(FPE_E_INVALID_ARG, "unknown tuning key: " + k);
+    return FPE_OK;
+}
+
+int fpe_describe_plan(fpe_handle h, const fpe_params* params, char* buf, int32_t n) {
+    if (!h || !params || !buf || n <= 0) return fail(FPE_E_INVALID_ARG, "null argument");
+    std::shared_ptr<MapSnapshot> snap;
+    fpe::Tuning tuning;
+    float maxRadius;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        snap = h->map;
+        tuning = h->tuning;
+        maxRadius = std::max(params->searchRadius, h->maxLegSearchRadius);
+    }
+    if (!snap) return fail(FPE_E_NO_MAP, "no map uploaded");
+    fpe::PlanConsts pc;
+    fpe::derive_constants(*params, snap->g, maxRadius, tuning, pc);
+    fpe::describe_plan_kernel(pc, snap->g, buf, static_cast<size_t>(n));
     return FPE_OK;
 }
 

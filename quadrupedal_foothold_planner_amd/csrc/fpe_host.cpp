@@ -81,9 +81,10 @@ int tile_halfwidth(float maxSearchRadius, float footRadius, double resolution) {
 //      (positions are rewritten by boundPositionToRange and divided by res in f64) the reach of an extent d is
 //      floor(d / res + frac) <= ceil(d / res) cells, one more when d / res is within `slack` of an integer.
 //      Extents: the centroid rectangle reaches R rows (lx / 2 = R) and R / 2 columns (cpp:1616-1617); a spiral
-//      candidate of an unfiltered ring lies within nRings - 2 cells, one of the two filtered rings within
-//      R + res / 2 of the centre (SpiralIterator::isInside), and its foot disc footReach further; a cell of the
-//      centre's own disc within rf + res / 2;
+//      candidate of an unfiltered ring lies within nRings - 2 cells, one of the two filtered rings has its cell
+//      centre within R of the continuous centre (SpiralIterator::isInside), i.e. at most floor(R / res + 1/2) cells
+//      from the centre cell, and its foot disc footReach further; a member of the centre's own disc at most
+//      floor(rf / res + 1/2) cells;
 //  (3) getIndex(cell centre of the centroid submap) is the top-left index plus (row, col): the submap's cell centres
 //      differ from the map's by a few ulps of the coordinate magnitude, which must be far below half a cell;
 //  (4) index predictions (base - limit) / res fit an int with room to spare.
@@ -97,17 +98,21 @@ int bits_window_halfwidth(const PlanConsts& c, const MapGeom& g) {
     if (!(slack < 1e-3)) return 0;                                 // (3): also keeps cell centres far from cell edges
     if (!((mag + 2.0e6) / res < 5.0e8)) return 0;                  // (4)
     if (!(R / res < 1.0e4) || !(rf / res < 1.0e3)) return 0;
-    auto reach = [&](double d) {  // cells an extent d can reach from the centre's cell
+    auto reach = [&](double d) {  // rows between getIndex(centre) and getIndex(centre +- d): ceil(d / res), one more on a tie
         const double q = d / res;
         int n = static_cast<int>(std::ceil(q));
         if (std::fabs(q - std::round(q)) <= slack) n = static_cast<int>(std::round(q)) + 1;
         return n;
     };
+    auto within = [&](double d) {  // largest index offset of a cell CENTRE within d of a point of the centre cell
+        return static_cast<int>(std::floor((d + 0.5 * res) / res + slack));
+    };
     const int nRings = spiral_rings(c.maxSearchRadius, res);
     const int rectReach = reach(R);
-    const int filtered = reach(R + 0.5 * res);                      // |offset| * res <= R + res / 2 (+ rounding)
-    const int candReach = std::min(nRings, std::max(nRings - 2, filtered)) + c.footReach;
-    const int discReach = reach(rf + 0.5 * res);
+    // a candidate of the two filtered rings has its cell centre within R of the continuous centre, which lies within
+    // half a cell of the centre cell's centre; unfiltered rings end at nRings - 2
+    const int candReach = std::min(nRings, std::max(nRings - 2, within(R))) + c.footReach;
+    const int discReach = within(rf);  // members of the continuous-centre disc
     return std::max(std::max(rectReach, candReach), std::max(discReach, 1));
 }
 

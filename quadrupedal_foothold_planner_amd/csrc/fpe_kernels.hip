@@ -19,6 +19,8 @@
 // -ffp-contract=off.  Reference citations: "cpp:" = foothold_planner/src/FootholdPlanner.cpp.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+
 #include "fpe_device.hpp"
 
 namespace fpe {

@@ -98,6 +98,12 @@ class FootholdPlanner:
     def set_max_leg_search_radius(self, r):
         self._check(self._lib.fpe_set_max_leg_search_radius(self._h, np.float32(r)))
 
+    def describe_plan(self):
+        """Name and shape of the kernel a chained plan launches with the current parameters and map."""
+        buf = C.create_string_buffer(256)
+        self._check(self._lib.fpe_describe_plan(self._h, ptr(self.params), buf, 256))
+        return buf.value.decode()
+
     def set_tuning(self, **kw):
         """fpe_set_tuning: plan_group, literal_discs, no_mid_variant, no_bits (build-defined test / tuning knobs)."""
         for k, v in kw.items():
