@@ -1394,8 +1394,13 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
 // rows: the default check is evaluated by the lanes that OWN the three window rows of the box against the ballot of
 // the membership tests; loads are unconditional; the centroid case logic is a chain of selects.  Any other situation
 // (map border, unusable centre, missing products) sends the whole wavefront through leg_phase_bits8 for this phase.
+// Constants of the fast path held in VECTOR registers for the whole kernel: as kernel arguments they live in scalar
+// memory, and with more uniform state than SGPRs the compiler re-fetches them (s_load + wait) inside the cycle loop.
+struct HotConsts {
+    double rf, rf2, cornerEps, rowsD;
+};
 template <int NRL>
-__device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut,
+__device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const HotConsts& hc, const SpiralLut& lut,
                                            const LutHead& head, PoseShared& sh, const LegBits& lb, const Grp<8>& g, int leg,
                                            const LegStatic& ls, const YEntry& ye, double ctr0, double ctr1, double ctr2, double advance,
                                            int cyc, int nCycles, int b, bool live, const fpe_plan_out& out, LegCommit* lc, Unit* unit) {
@@ -1412,14 +1417,14 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     const int q = g.sub;
     const double cq = (q == 5 || q == 6) ? nx0 : cx;
     const bool rawq = q == 4 || q == 7;
-    const double hq = (q == 2 || q == 3) ? 0.5 * lk.lx : (rawq ? 0.0 : pc.rf);
+    const double hq = (q == 2 || q == 3) ? 0.5 * lk.lx : (rawq ? 0.0 : hc.rf);
     const bool minus = q == 1 || q == 3 || q == 6;
     const double xq = rawq ? cq : (minus ? cq - hq : cq + hq);
     const double qf = ((xq - m.g.orgX) - m.g.posX) * m.g.rinv;
     const double kq = trunc(qf);
     const double fr = fabs(qf - kq);
-    bool safe = fr > pc.cornerEps && fr < 1.0 - pc.cornerEps;
-    if (!rawq) safe = safe && qf < -pc.cornerEps && qf > pc.cornerEps - static_cast<double>(m.g.rows);
+    bool safe = fr > hc.cornerEps && fr < 1.0 - hc.cornerEps;
+    if (!rawq) safe = safe && qf < -hc.cornerEps && qf > hc.cornerEps - hc.rowsD;
     const int idxq = -static_cast<int>(kq);
     constexpr int kKeep = (~(G - 1)) & 0x1F;
     const int i0d = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (0 << 5));
@@ -1464,8 +1469,8 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     const double dy2 = ye.dy2[bq];
     const double dxA = cell_pos(m.g.baseX, m.g.res, i0d + a) - cx;
     const double dxB = cell_pos(m.g.baseX, m.g.res, i0f + a) - nx0;
-    const bool visA = (dxA * dxA + dy2) <= pc.rf2;  // CircleIterator::isInside (cell_in_disc)
-    const bool visB = (dxB * dxB + dy2) <= pc.rf2;
+    const bool visA = (dxA * dxA + dy2) <= hc.rf2;  // CircleIterator::isInside (cell_in_disc)
+    const bool visB = (dxB * dxB + dy2) <= hc.rf2;
     const float eA = m.elev[static_cast<size_t>(i0d + a) * m.g.cols + (j0d + bq)];
     const float eB = m.elev[static_cast<size_t>(i0f + a) * m.g.cols + (j0d + bq)];
     const float eMidA = m.elev[static_cast<size_t>(i0d + 1) * m.g.cols + (j0d + 1)];
@@ -1616,6 +1621,11 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
     m.g.orgY = in_vgpr(m.g.orgY);
     m.g.baseX = in_vgpr(m.g.baseX);
     m.g.baseY = in_vgpr(m.g.baseY);
+    HotConsts hc;
+    hc.rf = in_vgpr(pc.rf);
+    hc.rf2 = in_vgpr(pc.rf2);
+    hc.cornerEps = in_vgpr(pc.cornerEps);
+    hc.rowsD = in_vgpr(static_cast<double>(mArg.g.rows));
     constexpr int kPoseThreads = 4 * G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = static_cast<int>(threadIdx.x);
@@ -1737,7 +1747,7 @@ __global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm
             lc.valid = 1;  // non-swing legs do not vote
             if (active) {
                 if constexpr (kMid)
-                    leg_fast8m<NRL>(m, bm, pc, lut, head, sh, lb, g, leg, ls, ye, ctr0, ctr1, ctr2, advance, cyc, nCycles, b, live, out, &lc,
+                    leg_fast8m<NRL>(m, bm, pc, hc, lut, head, sh, lb, g, leg, ls, ye, ctr0, ctr1, ctr2, advance, cyc, nCycles, b, live, out, &lc,
                                     units + (cyc & 7));
                 else
                     leg_phase_bits8<NRL, false>(m, bm, pc, lut, head, sh, lb, g, leg, ls, ye, ctr0, ctr1, ctr2, advance, cyc, nCycles, b, live,
