@@ -201,12 +201,18 @@ __device__ __forceinline__ CentroidScan rows_from_bits(const Submap& s, const Wi
         if constexpr (G == 64) blk[k & 1] |= mk;
         else blk[(k / kPerWord) & 1] |= mk << (G * (k % kPerWord));
     }
-    const int off = s.i0 - iw0;  // the rectangle lies inside the window (bits_window_halfwidth); ni <= 64
-    unsigned long long rel = 0ull;
-    if (off >= 0 && off < 64) rel = (blk[0] >> off) | (off ? (blk[1] << (64 - off)) : 0ull);
-    else if (off >= 64 && off < 128) rel = blk[1] >> (off - 64);
-    r0.minRow = rel ? __builtin_ctzll(rel) : 0;
-    r0.maxRow = rel ? 63 - __builtin_clzll(rel) : 0;
+    // rows relative to the rectangle's first row: a 128-bit shift (the rectangle lies inside the window, and a window
+    // of more than 64 rows can hold a rectangle of more than 64)
+    const int off = s.i0 - iw0;
+    unsigned long long relLo = 0ull, relHi = 0ull;
+    if (off >= 0 && off < 64) {
+        relLo = (blk[0] >> off) | (off ? (blk[1] << (64 - off)) : 0ull);
+        relHi = blk[1] >> off;
+    } else if (off >= 64 && off < 128) {
+        relLo = blk[1] >> (off - 64);
+    }
+    r0.minRow = relLo ? __builtin_ctzll(relLo) : (relHi ? 64 + __builtin_ctzll(relHi) : 0);
+    r0.maxRow = relHi ? 127 - __builtin_clzll(relHi) : (relLo ? 63 - __builtin_clzll(relLo) : 0);
     r0.whole = s.ok && ni * nj > 0 && !g.any(anyBelow);
     return r0;
 }

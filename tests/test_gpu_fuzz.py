@@ -56,7 +56,12 @@ def make_case(seed):
             poses["leg_search_radius"] = rng.uniform(0.04, float(p["searchRadius"][0]), (B, 4)).astype(np.float32)
     group = str(rng.choice(["0", "4", "8", "16", "64", "65"]))
     literal = rng.random() < 0.15
-    return dict(res=res, pos=pos, params=p, trav=trav, elev=elev, poses=poses, n=N, group=group, literal=literal)
+    # half of the cases run the automatic dispatch (bit-window kernels where their proofs hold), the others force a
+    # lane grouping of the direct kernels
+    bits = rng.random() < 0.5
+    if bits:
+        group = "0"
+    return dict(res=res, pos=pos, params=p, trav=trav, elev=elev, poses=poses, n=N, group=group, literal=literal, bits=bits)
 
 
 def test_random_differential_campaign():
@@ -64,16 +69,19 @@ def test_random_differential_campaign():
     n_cases = int(os.environ.get("FPE_FUZZ_CASES", "120"))
     src = np.zeros(4, np.int64)
     codes = np.zeros(7, np.int64)
+    kernels = {}
     for k in range(n_cases):
         c = make_case(20000 + k)
         # group "0" = automatic dispatch (the bit-window kernels where they apply); a forced grouping runs the direct kernels
-        planner.set_tuning(plan_group=int(c["group"]), literal_discs=int(c["literal"]), no_bits=int(c["group"] != "0"))
+        planner.set_tuning(plan_group=int(c["group"]), literal_discs=int(c["literal"]), no_bits=int(not c["bits"]))
         planner.params = c["params"]
         try:
             eng, ora = util.run_both(planner, c["trav"], c["elev"], c["res"], c["poses"], c["n"], position=c["pos"], threads=8)
         except FpeError as e:
             assert e.code == _capi.FPE_E_UNSUPPORTED, e
             continue
+        name = planner.describe_plan().split("(")[0].strip()
+        kernels[name] = kernels.get(name, 0) + 1
         try:
             util.assert_plan_equal(eng, ora)
         except AssertionError as e:
@@ -81,4 +89,7 @@ def test_random_differential_campaign():
         src += np.bincount(eng["nominal"]["source"].ravel(), minlength=4)[:4]
         codes += np.bincount(eng["centroid"]["code"].ravel(), minlength=7)[:7]
     planner.close()
+    print("kernels exercised:", kernels)
     assert (src[:3] > 0).all() and (codes > 0).all(), (src, codes)
+    if n_cases >= 100:
+        assert any(k.startswith("plan_bits_kernel") for k in kernels) and any(k.startswith("plan_bits_seq_kernel") for k in kernels), kernels

@@ -47,7 +47,8 @@ def test_cfg2_rough_terrain_batch(planner):
     assert (eng["centroid"]["code"] > 0).sum() > 100, "terrain should exercise the centroid row scan"
 
 
-@pytest.mark.parametrize("res,R,rows", [(0.01, 0.1, 600), (0.01, 0.15, 600), (0.005, 0.1, 800), (0.03, 0.1, 300), (0.02, 0.06, 400)])
+@pytest.mark.parametrize("res,R,rows", [(0.01, 0.1, 600), (0.01, 0.15, 600), (0.005, 0.1, 800), (0.03, 0.1, 300), (0.02, 0.06, 400),
+                                        (0.005, 0.1587, 700)])  # the last: a centroid rectangle of 65 rows (> one 64-bit row mask)
 def test_resolutions_and_radii(planner, res, R, rows):
     set_params(planner, searchRadius=np.float32(R))
     trav, elev = synth.rough_map(rows, rows, res, seed=11)
