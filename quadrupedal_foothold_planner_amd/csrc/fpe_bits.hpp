@@ -1609,8 +1609,11 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
 }  // namespace
 
 // ---- chained plan on the bit window: 8 lanes per leg, two poses per wavefront ------------------------------------
+#ifndef FPE_BITS_GENERIC_WAVES
+#define FPE_BITS_GENERIC_WAVES 3  // measured on cfg-4: 2 -> 1.36 ms, 3 -> 1.25 ms (27 spilled VGPRs), 4 -> 1.46 ms (69 spilled)
+#endif
 template <int NRL, bool kMid>
-__global__ __launch_bounds__(64, 2) void plan_bits_kernel(DevMap mArg, BitMap bm, PlanConsts pc, SpiralLut lut,
+__global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bits_kernel(DevMap mArg, BitMap bm, PlanConsts pc, SpiralLut lut,
                                                           const fpe_pose* __restrict__ poses, int B, int nCycles, fpe_plan_out out) {
     constexpr int G = 8;
     constexpr int NR = G * NRL;
