@@ -1801,8 +1801,12 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
     const int tid = static_cast<int>(threadIdx.x);
     const Grp<G> g(tid);
     PoseShared& sh = *reinterpret_cast<PoseShared*>(smem);
+    // per-leg constants of the pose, computed once (lane = leg) instead of once per leg and phase: a division and a
+    // dependent rank-table load each
+    LegStatic* lsTab = reinterpret_cast<LegStatic*>(smem + sizeof(PoseShared));
+    constexpr size_t kLsBytes = (4 * sizeof(LegStatic) + 15) & ~static_cast<size_t>(15);
     // rows actually allocated: the window's 2 winH + 1 (not 64 * NRL) — LDS bounds the occupancy of these kernels
-    const LegBits lb = make_legbits(smem + sizeof(PoseShared), min(2 * pc.winH + 1, NR), KW, pc.nHW, true);
+    const LegBits lb = make_legbits(smem + sizeof(PoseShared) + kLsBytes, min(2 * pc.winH + 1, NR), KW, pc.nHW, true);
     const int b = blockIdx.x;
     if (b >= B) return;
     const bool live = true;
@@ -1819,6 +1823,7 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
     // initial stance (cpp:350-378) and first-gait shift (setFirstGait, cpp:2679-2699): lane = leg
     if (tid < 4) {
         const int leg = tid;
+        lsTab[leg] = make_leg_static(pc, pp, leg, m.g.res, lut);
         double sx = (leg == 0 || leg == 3) ? pc.LbHalf : -pc.LbHalf;
         double sy = (leg <= 1) ? pc.WbHalfNeg : pc.WbHalfPos;
         double sz = 0;
@@ -1856,7 +1861,7 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
             pose_sync<16>();
             for (int leg = 0; leg < 4; ++leg) {
                 if (!((mask >> leg) & 1u)) continue;
-                const LegStatic ls = make_leg_static(pc, pp, leg, m.g.res, lut);
+                const LegStatic ls = lsTab[leg];
                 stamp(pc, cyc, 1);
                 leg_phase_bits<G, NRL, KW, false, false>(m, bm, pc, lut, head, sh, lb, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out, nullptr);
                 stamp(pc, cyc, 9);
@@ -1959,7 +1964,8 @@ hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts&
                        d_poses, B, nCycles, d_out)
 #define FPE_LAUNCH_BITS_SEQ(NRL, KW)                                                                                         \
     hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW>), dim3(B), block,                                                      \
-                       sizeof(PoseShared) + 4 * legbits_words(2 * pc.winH + 1 < 64 * NRL ? 2 * pc.winH + 1 : 64 * NRL, KW, pc.nHW, true),           \
+                       sizeof(PoseShared) + ((4 * sizeof(LegStatic) + 15) & ~static_cast<size_t>(15)) +                                  \
+                           4 * legbits_words(2 * pc.winH + 1 < 64 * NRL ? 2 * pc.winH + 1 : 64 * NRL, KW, pc.nHW, true),        \
                        stream, m, bm, pc, lut, d_poses, B, nCycles, d_out)
     if (sp.lanes == 8) {
         if (sp.nrl == 2 && mid) FPE_LAUNCH_BITS(2, true);
