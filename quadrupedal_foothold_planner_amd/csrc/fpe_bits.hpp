@@ -1408,10 +1408,17 @@ struct HotConsts {
 template <int NRL>
 __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const HotConsts& hc, const SpiralLut& lut,
                                            const LutHead& head, PoseShared& sh, const LegBits& lb, const Grp<8>& g, int leg,
-                                           const LegStatic& ls, const YEntry& ye, double ctr0, double ctr1, double ctr2, double advance,
+                                           const LegStatic& ls, const YEntry& yeIn, double ctr0, double ctr1, double ctr2, double advance,
                                            int cyc, int nCycles, int b, bool live, const fpe_plan_out& out, LegCommit* lc, Unit* unit) {
     constexpr int G = 8, KW = 1;
     const LegConst& lk = ls.lk;
+    // the entry's scalar fields in ONE batch of LDS reads (scattered reads would each wait for their own round trip);
+    // dy2 stays in LDS (lane-dependent index)
+    const YEntry& yeLds = yeIn;
+    YEntry ye;
+    ye.jc = yeLds.jc; ye.j0d = yeLds.j0d; ye.njd = yeLds.njd; ye.j0r = yeLds.j0r;
+    ye.njr = yeLds.njr; ye.jA = yeLds.jA; ye.jB = yeLds.jB; ye.flags = yeLds.flags;
+    ye.ny = yeLds.ny; ye.sbaseY = yeLds.sbaseY; ye.yA = yeLds.yA; ye.yB = yeLds.yB;
     const double nx0 = (ctr0 + advance) + ls.biasX;  // cpp:2199, 2414
     const double nx1 = (ctr1 + advance) + ls.biasX;
     const double nx2 = (ctr2 + advance) + ls.biasX;
@@ -1446,7 +1453,7 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
                        i0d + 4 <= m.g.rows && i0f + 4 <= m.g.rows && j0d + 4 <= m.g.cols;
     rare = rare || !safe || !boxes;
     if (__ballot(rare) != 0ull) {  // wave-uniform
-        leg_phase_bits8<NRL, true>(m, bm, pc, lut, head, sh, lb, g, leg, ls, ye, ctr0, ctr1, ctr2, advance, cyc, nCycles, b, live, out, lc, unit);
+        leg_phase_bits8<NRL, true>(m, bm, pc, lut, head, sh, lb, g, leg, ls, yeIn, ctr0, ctr1, ctr2, advance, cyc, nCycles, b, live, out, lc, unit);
         return;
     }
     // getSubmapInformation's tail, x part (corners strictly inside the map: within); y part from the entry
@@ -1472,7 +1479,7 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     const int t = g.sub + (g.sub >= 4 ? 1 : 0);
     const int a = t >= 6 ? 2 : (t >= 3 ? 1 : 0);
     const int bq = t - 3 * a;
-    const double dy2 = ye.dy2[bq];
+    const double dy2 = yeLds.dy2[bq];
     const double dxA = cell_pos(m.g.baseX, m.g.res, i0d + a) - cx;
     const double dxB = cell_pos(m.g.baseX, m.g.res, i0f + a) - nx0;
     const bool visA = (dxA * dxA + dy2) <= hc.rf2;  // CircleIterator::isInside (cell_in_disc)
@@ -1575,7 +1582,7 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
         }
         nominal_invalid(no, cx, ny, 2);
         int wi = 0, wj = 0;
-        if (spiral_bits<G, NRL, KW>(m, pc, lut, head, c, w, lb, g, iw0, jw0, wi, wj, &ye)) {  // cpp:2022
+        if (spiral_bits<G, NRL, KW>(m, pc, lut, head, c, w, lb, g, iw0, jw0, wi, wj, &yeIn)) {  // cpp:2022
             no.valid = 1;
             no.source = 1;
             no.row = wi;
