@@ -1,3 +1,5 @@
+"""Per-stage clock stamps of the 8-lane bit-window kernel (s_memtime, -DFPE_TRACE builds only): where a gait cycle's time goes.
+usage on the GPU box: FPE_LIB=<trace build of libfpe.so> python3 profiles/trace_stages.py headline 4096"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, '.')
 buf = torch.zeros(256*8*16, dtype=torch.int64, device='cuda')
@@ -21,7 +23,8 @@ for it in range(3):
     pl.plan_device(d_poses.data_ptr(), B, n, d_nom.data_ptr(), d_cen.data_ptr(), d_def.data_ptr(), d_ok.data_ptr(), d_st.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, d_selected_ptr=d_sel.data_ptr(), d_pose_status_ptr=d_ps.data_ptr())
     torch.cuda.synchronize()
 t = buf.cpu().numpy().reshape(256, 8, 16).astype(np.float64)
-names = {0:"cycle start",1:"poly centre+sync",2:"corners+submap",3:"loads issued",4:"rows arrived+scan",5:"default chk+zCentre",6:"centroid begin",7:"zDefault",8:"spiral",9:"centroid z+stores",10:"commit"}
+# stamp points of the 3x3 fast path (leg_fast8m); build the library with -DFPE_TRACE and pass it as FPE_LIB
+names = {0:"cycle start",1:"feet-polygon centres",2:"x pass + submap",3:"loads issued",4:"rows arrived + row scan",5:"default check + deposits",7:"centroid selects",8:"spiral (if any leg needs it)",9:"unit fields",10:"commit"}
 pts = sorted(names)
 prev = 0
 for p in pts[1:]:
@@ -35,4 +38,3 @@ print("kernel span per block", np.mean(t[:,n-1 if n<8 else 7,10]-t[:,0,0]))
 
 print("prologue: entry -> statics/LUT/stance", np.mean(t[:,1,12]-t[:,1,11]), " gate", np.mean(t[:,1,13]-t[:,1,12]), " ytab fill", np.mean(t[:,1,14]-t[:,1,13]), " first cycle start after entry", np.mean(t[:,0,0]-t[:,1,11]))
 print("flush", np.mean(t[:,2,12]-t[:,2,11]), " last commit -> flush start", np.mean(t[:,2,11]-t[:,7,10]))
-e = t[:,1,11]; print("entry skew across first 256 blocks: min/max", e.min(), e.max(), e.max()-e.min(), " end of flush max - entry min", t[:,2,12].max()-e.min())
