@@ -201,9 +201,17 @@ __device__ __forceinline__ CentroidScan rows_from_bits(const Submap& s, const Wi
         if constexpr (G == 64) blk[k & 1] |= mk;
         else blk[(k / kPerWord) & 1] |= mk << (G * (k % kPerWord));
     }
+    const int off = s.i0 - iw0;
+    if constexpr (G * NRL <= 64) {  // the whole window in one word
+        const unsigned long long rel = blk[0] >> (off & 63);
+        const unsigned long long relIn = (static_cast<unsigned>(off) < 64u) ? rel : 0ull;
+        r0.minRow = relIn ? __builtin_ctzll(relIn) : 0;
+        r0.maxRow = relIn ? 63 - __builtin_clzll(relIn) : 0;
+        r0.whole = s.ok && ni * nj > 0 && !g.any(anyBelow);
+        return r0;
+    }
     // rows relative to the rectangle's first row: a 128-bit shift (the rectangle lies inside the window, and a window
     // of more than 64 rows can hold a rectangle of more than 64)
-    const int off = s.i0 - iw0;
     unsigned long long relLo = 0ull, relHi = 0ull;
     if (off >= 0 && off < 64) {
         relLo = (blk[0] >> off) | (off ? (blk[1] << (64 - off)) : 0ull);
@@ -974,7 +982,7 @@ struct Unit {
     int nomRow, nomCol;
     uint32_t nomFlags;    // valid | source << 8
     int cenRow, cenCol;
-    uint32_t cenCode;     // code | needDisc << 8
+    uint32_t cenCode;     // code | 0x100: the result has a one-cell disc whose elevation is in eC | 0x200: ... to be read by flush_unit
     double cx;    // search centre x (nominal x of a default hit / invalid leg; centroid x of code 0)
     double cenX;  // centroid result x (codes 1-4)
     double defX;  // default track x
@@ -1017,14 +1025,20 @@ __device__ __forceinline__ float unit_mean9(const float* e, uint32_t vis, double
     return finish_mean(sum, last, cnt, h);
 }
 // One (leg, cycle) unit per lane: heights and the four output records of that unit.
-__device__ __forceinline__ void flush_unit(const MapGeom& mg, const PlanConsts& pc, const Unit& u, const YEntry& ye, int b, int cyc,
-                                           int leg, int nCycles, const fpe_plan_out& out) {
+__device__ __forceinline__ void flush_unit(const DevMap& m, const PlanConsts& pc, const Unit& u, const YEntry& ye, int b, int cyc,
+                                           int leg, int nCycles, uint32_t okBits, const fpe_plan_out& out) {
+    const MapGeom& mg = m.g;
+    // the centroid result's own cell, when the chain left its elevation to be read here (issued first: the three
+    // height sums below cover the round trip)
+    float eC = u.eC;
+    if (u.cenCode & 0x200u) eC = m.elev[static_cast<size_t>(u.cenRow) * mg.cols + u.cenCol];
+    if (leg == 0 && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = static_cast<uint8_t>((okBits >> (cyc & 7)) & 1u);
     const float zA = unit_mean9(u.eA, u.visA, pc.h);
     const float zB = unit_mean9(u.eB, u.visB, pc.h);
     const int code = static_cast<int>(u.cenCode & 0xFFu);
     float zC = 0.0f;
-    if (u.cenCode & 0x100u) {
-        const float v = __builtin_isfinite(u.eC) ? u.eC : 0.0f;
+    if (u.cenCode & 0x300u) {
+        const float v = __builtin_isfinite(eC) ? eC : 0.0f;
         const bool inc = v < 10;
         zC = finish_mean(inc ? 0.0f + v : 0.0f, v, inc ? 1 : 0, pc.h);
     } else if (code == 0) {
@@ -1403,13 +1417,35 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
 // Constants of the fast path held in VECTOR registers for the whole kernel: as kernel arguments they live in scalar
 // memory, and with more uniform state than SGPRs the compiler re-fetches them (s_load + wait) inside the cycle loop.
 struct HotConsts {
-    double rf, rf2, cornerEps, rowsD;
+    double rf, rf2, cornerEps, oneMinusEps, drift;
 };
+// Lane roles of the x pass.  Lane q of a leg group evaluates the index of ONE box corner — 0/1 centre disc (cx -+ rf),
+// 2/3 centroid rectangle (cx -+ lx / 2), 4 getIndex(cx), 5/6 default-track disc (nx0 -+ rf); lane 7 evaluates nothing
+// — and, before that, the feet-polygon centre of the track its corner belongs to (centroid track on lanes 0-4, default
+// track on 5-6, nominal track on 7), so that indices and positions reach the other lanes in ONE exchange.  The
+// per-lane constants live in vector registers, computed once: written as selects on q inside the cycle loop they are
+// rebuilt every cycle, and a chain of `q == k` tests is compiled into a switch, i.e. into exec-mask branches.
+struct LaneRole {
+    double hqS;       // signed half extent of the lane's corner: xq = (track position) + hqS
+    double qLo, qHi;  // the predicted quotient of a box corner must lie strictly inside the map (raw lanes: unbounded)
+};
+__device__ __forceinline__ int lane_track(int q) { return (q == 5 || q == 6) ? 0 : (q == 7 ? 2 : 1); }
+__device__ __forceinline__ LaneRole make_lane_role(int q, double rf, double lx, double cornerEps, double rowsD) {
+    LaneRole r;
+    const double inf = __builtin_huge_val();
+    const bool raw = q == 4 || q == 7;
+    const double h = (q == 2 || q == 3) ? 0.5 * lx : (raw ? 0.0 : rf);
+    const bool minus = q == 1 || q == 3 || q == 6;
+    r.hqS = in_vgpr(minus ? -h : h);
+    r.qLo = in_vgpr(raw ? -inf : cornerEps - rowsD);
+    r.qHi = in_vgpr(raw ? inf : -cornerEps);
+    return r;
+}
 template <int NRL>
-__device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const HotConsts& hc, const SpiralLut& lut,
-                                           const LutHead& head, PoseShared& sh, const LegBits& lb, const Grp<8>& g, int leg,
-                                           const LegStatic& ls, const YEntry& yeIn, double ctr0, double ctr1, double ctr2, double advance,
-                                           int cyc, int nCycles, int b, bool live, const fpe_plan_out& out, LegCommit* lc, Unit* unit) {
+__device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const HotConsts& hc, const LaneRole& role,
+                                           const SpiralLut& lut, const LutHead& head, PoseShared& sh, const LegBits& lb, const Grp<8>& g,
+                                           int leg, const LegStatic& ls, const YEntry& yeIn, double myCtr, double advance, int cyc,
+                                           int nCycles, int b, bool live, const fpe_plan_out& out, LegCommit* lc, Unit* unit) {
     constexpr int G = 8, KW = 1;
     const LegConst& lk = ls.lk;
     // the entry's scalar fields in ONE batch of LDS reads (scattered reads would each wait for their own round trip);
@@ -1419,25 +1455,15 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     ye.jc = yeLds.jc; ye.j0d = yeLds.j0d; ye.njd = yeLds.njd; ye.j0r = yeLds.j0r;
     ye.njr = yeLds.njr; ye.jA = yeLds.jA; ye.jB = yeLds.jB; ye.flags = yeLds.flags;
     ye.ny = yeLds.ny; ye.sbaseY = yeLds.sbaseY; ye.yA = yeLds.yA; ye.yB = yeLds.yB;
-    const double nx0 = (ctr0 + advance) + ls.biasX;  // cpp:2199, 2414
-    const double nx1 = (ctr1 + advance) + ls.biasX;
-    const double nx2 = (ctr2 + advance) + ls.biasX;
+    // ---- x side: this lane's track position and corner (cpp:2199, 2414; see leg_phase_bits8) ----
+    const double nxq = (myCtr + advance) + ls.biasX;
     const double ny = ye.ny;
-    const double cx = nx1;  // centre from the CENTROID track (cpp:861-862)
     const bool wantDefault = out.default_next != nullptr;
-    bool rare = !ls.radiusOk || (ye.flags & 2) == 0 || !(fabs(cx) <= 1e6) || !wantDefault || !(fabs(nx0) <= 1e6);
-    // ---- x side: one corner quantity per lane (see leg_phase_bits8) ----
-    const int q = g.sub;
-    const double cq = (q == 5 || q == 6) ? nx0 : cx;
-    const bool rawq = q == 4 || q == 7;
-    const double hq = (q == 2 || q == 3) ? 0.5 * lk.lx : (rawq ? 0.0 : hc.rf);
-    const bool minus = q == 1 || q == 3 || q == 6;
-    const double xq = rawq ? cq : (minus ? cq - hq : cq + hq);
+    const double xq = nxq + role.hqS;  // a - h == a + (-h)
     const double qf = ((xq - m.g.orgX) - m.g.posX) * m.g.rinv;
     const double kq = trunc(qf);
     const double fr = fabs(qf - kq);
-    bool safe = fr > hc.cornerEps && fr < 1.0 - hc.cornerEps;
-    if (!rawq) safe = safe && qf < -hc.cornerEps && qf > hc.cornerEps - hc.rowsD;
+    const bool safe = (fr > hc.cornerEps && fr < hc.oneMinusEps && qf < role.qHi && qf > role.qLo) || g.sub == 7;
     const int idxq = -static_cast<int>(kq);
     constexpr int kKeep = (~(G - 1)) & 0x1F;
     const int i0d = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (0 << 5));
@@ -1447,12 +1473,17 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     const int ici = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (4 << 5));
     const int i0f = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (5 << 5));
     const int i1f = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (6 << 5));
+    const double cx = swizzle_f64<kKeep | (0 << 5)>(nxq);   // centre from the CENTROID track (cpp:861-862)
+    const double nx0 = swizzle_f64<kKeep | (5 << 5)>(nxq);  // default track
+    const double nx2 = swizzle_f64<kKeep | (7 << 5)>(nxq);  // nominal track (search polygon)
     const int j0d = ye.j0d, icj = ye.jc;
     // both foot-disc boxes: 3x3 and clear of the map's outermost rows / columns (not clamped, inside the map)
     const bool boxes = (i1d - i0d) == 2 && (i1f - i0f) == 2 && ye.njd == 3 && i0d >= 1 && i0f >= 1 && j0d >= 1 &&
                        i0d + 4 <= m.g.rows && i0f + 4 <= m.g.rows && j0d + 4 <= m.g.cols;
-    rare = rare || !safe || !boxes;
+    const bool rare = !ls.radiusOk || (ye.flags & 2) == 0 || !(fabs(nxq) <= 1e6) || !wantDefault || !safe || !boxes;
     if (__ballot(rare) != 0ull) {  // wave-uniform
+        const double ctr0 = swizzle_f64<kKeep | (5 << 5)>(myCtr), ctr1 = swizzle_f64<kKeep | (0 << 5)>(myCtr),
+                     ctr2 = swizzle_f64<kKeep | (7 << 5)>(myCtr);
         leg_phase_bits8<NRL, true>(m, bm, pc, lut, head, sh, lb, g, leg, ls, yeIn, ctr0, ctr1, ctr2, advance, cyc, nCycles, b, live, out, lc, unit);
         return;
     }
@@ -1495,14 +1526,16 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     stamp(pc, cyc, 4);
     // ---- checkDefaultFoothold: the lanes owning the box's three window rows test their Df bits under the members ----
     const unsigned mA = static_cast<unsigned>(g.ballot(visA)), mB = static_cast<unsigned>(g.ballot(visB));
+    // the nine membership bits in CircleIterator order (the middle cell is always a member)
+    const unsigned visA9 = (mA & 0xFu) | 0x10u | ((mA & 0xF0u) << 1), visB9 = (mB & 0xFu) | 0x10u | ((mB & 0xF0u) << 1);
     bool fail = false;
     {
-        const unsigned m0 = mA & 7u, m1 = ((mA >> 3) & 1u) | 2u | (((mA >> 4) & 1u) << 2), m2 = (mA >> 5) & 7u;
         const unsigned sh3 = static_cast<unsigned>(j0d - jw0) & 31u;
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
             const int ar = g.sub + G * k - (i0d - iw0);  // row of the box held in slot k
-            const unsigned sel = ar == 0 ? m0 : (ar == 1 ? m1 : (ar == 2 ? m2 : 0u));
+            const unsigned bitsRow = (visA9 >> (3u * (static_cast<unsigned>(ar) & 3u))) & 7u;
+            const unsigned sel = static_cast<unsigned>(ar) < 3u ? bitsRow : 0u;
             fail |= (((w.Df[k][0] >> sh3) & 7u) & sel) != 0u;
         }
     }
@@ -1516,23 +1549,33 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     // ---- centroid method (cpp:1684-1952) as selects ----
     const int bottomRow = sm.ni - 1, rightCol = sm.nj - 1;
     const int minRow = sc.minRow, maxRow = sc.maxRow;
-    const bool case1 = minRow == 0 && maxRow != bottomRow;
-    const bool case2 = minRow != 0 && maxRow != bottomRow;
-    const bool case3 = minRow != 0 && maxRow == bottomRow;
+    // (every select below has two ready operands: nested conditionals are compiled into branches)
+    const bool top = minRow == 0, bottom = maxRow == bottomRow;
+    const bool case1 = top && !bottom;
+    const bool case2 = !top && !bottom;
     const bool upper = minRow >= (bottomRow - maxRow);
-    const int code = !sm.ok ? 6 : (sc.whole ? 0 : (case1 ? 1 : (case2 ? (upper ? 2 : 3) : (case3 ? 4 : 5))));
-    const int newRow = case1 ? ((maxRow + bottomRow + 1) >> 1) : ((case2 && !upper) ? ((maxRow + bottomRow) >> 1) : ((minRow + 1) >> 1));
-    const int newCol = case1 ? ((rightCol + 1) >> 1) : (rightCol >> 1);
-    const bool hasCell = code >= 1 && code <= 4;
+    const int code23 = upper ? 2 : 3, code51 = bottom ? 5 : 1;
+    int code = bottom ? 4 : code23;  // case3 (4) / case2 (2, 3): the first row is not blocked
+    code = top ? code51 : code;      // case1 (1) / no case (5)
+    code = sc.whole ? 0 : code;
+    code = sm.ok ? code : 6;
+    const bool useMaxRow = case1 || (case2 && !upper);
+    const int rowA = (maxRow + bottomRow + (case1 ? 1 : 0)) >> 1, rowB = (minRow + 1) >> 1;
+    const int newRow = useMaxRow ? rowA : rowB;
+    const int newCol = (rightCol + (case1 ? 1 : 0)) >> 1;
+    const bool whole = code == 0;
+    const bool hasCell = static_cast<unsigned>(code - 1) < 4u;
     CentroidOut co;
     co.code = code;
     co.z = 0.0f;
-    co.x = code == 0 ? cx : (hasCell ? cell_pos(sm.baseX, m.g.res, newRow) : 0.0);  // cpp:1687 / cpp:1816
-    co.y = code == 0 ? ny : (code == 1 ? ye.yA : (hasCell ? ye.yB : 0.0));
-    co.row = code == 0 ? ici : (hasCell ? sm.i0 + newRow : -1);
-    co.col = code == 0 ? icj : (hasCell ? sm.j0 + newCol : -1);
-    // the result's own cell (one-cell foot disc); any in-map cell when there is none (the value is ignored)
-    const float eC = m.elev[static_cast<size_t>(hasCell ? co.row : i0d + 1) * m.g.cols + (hasCell ? co.col : j0d + 1)];
+    const double cellX = cell_pos(sm.baseX, m.g.res, newRow);  // cpp:1816
+    const double yAB = code == 1 ? ye.yA : ye.yB;
+    const double xCell = hasCell ? cellX : 0.0, yCell = hasCell ? yAB : 0.0;
+    const int rowCell = hasCell ? sm.i0 + newRow : -1, colCell = hasCell ? sm.j0 + newCol : -1;
+    co.x = whole ? cx : xCell;  // cpp:1687
+    co.y = whole ? ny : yCell;
+    co.row = whole ? ici : rowCell;
+    co.col = whole ? icj : colCell;
     stamp(pc, cyc, 7);
     // ---- nominal result: the default foothold, else the spiral search (cpp:2012-2029) ----
     NominalOut no;
@@ -1594,15 +1637,14 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     }
     stamp(pc, cyc, 8);
     if (g.sub == 0) {  // what flush_unit needs to rebuild this leg's four records
-        unit->eC = eC;
-        unit->visA = (mA & 0xFu) | 0x10u | ((mA & 0xF0u) << 1);
-        unit->visB = (mB & 0xFu) | 0x10u | ((mB & 0xF0u) << 1);
+        unit->visA = visA9;
+        unit->visB = visB9;
         unit->nomRow = no.row;
         unit->nomCol = no.col;
         unit->nomFlags = static_cast<uint32_t>(no.valid) | (static_cast<uint32_t>(no.source) << 8);
         unit->cenRow = co.row;
         unit->cenCol = co.col;
-        unit->cenCode = static_cast<uint32_t>(code) | (hasCell ? 0x100u : 0u);
+        unit->cenCode = static_cast<uint32_t>(code) | (hasCell ? 0x200u : 0u);  // flush_unit reads the result's own cell
         unit->cx = cx;
         unit->cenX = co.x;
         unit->defX = nx0;
@@ -1641,7 +1683,8 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
     hc.rf = in_vgpr(pc.rf);
     hc.rf2 = in_vgpr(pc.rf2);
     hc.cornerEps = in_vgpr(pc.cornerEps);
-    hc.rowsD = in_vgpr(static_cast<double>(mArg.g.rows));
+    hc.oneMinusEps = in_vgpr(1.0 - pc.cornerEps);
+    hc.drift = in_vgpr(pc.drift);
     constexpr int kPoseThreads = 4 * G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = static_cast<int>(threadIdx.x);
@@ -1729,6 +1772,11 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
     const int walkOrder = pc.RF_FIRST ? ((0) | (2 << 2) | (3 << 4) | (1 << 6)) : ((3) | (1 << 2) | (0 << 4) | (2 << 6));
     constexpr int kPoseLanes = 4 * G;
     const unsigned long long poseMask = ((1ull << kPoseLanes) - 1ull) << (slot * kPoseLanes);
+    // the track whose feet-polygon centre this lane evaluates: 3x3-only kernels: the track of the lane's corner
+    // (LaneRole); generic kernels: lane t evaluates track t
+    const int myTrack = kMid ? lane_track(g.sub) : (g.sub < 2 ? g.sub : 2);
+    const LaneRole role = make_lane_role(g.sub, pc.rf, ls.lk.lx, pc.cornerEps, static_cast<double>(mArg.g.rows));
+    uint32_t okBits = 0u;  // cycleOk of the cycles since the last flush (3x3-only kernels: stored by flush_unit)
 
     for (int cyc = 0; cyc < nCycles; ++cyc) {
         if ((cyc & 7) == 0) {
@@ -1737,7 +1785,7 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
             double a = adjY, mine = adjY;
 #pragma unroll
             for (int k = 1; k < 8; ++k) {
-                a += pc.drift;
+                a += hc.drift;
                 if (g.sub == k) mine = a;
             }
             fill_yentry(m.g, pc, ls, (y0 + mine) + ls.biasY, ytab[g.sub]);  // cpp:2201, 2414
@@ -1750,24 +1798,25 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
             const unsigned mask = (gait == 1) ? (1u << ((walkOrder >> (2 * ph)) & 3)) : 0xFu;
             const bool active = (mask >> leg) & 1u;
             stamp(pc, cyc, 0);
-            // feet-polygon centres (getPolygonCenter, cpp:2191, 2265): lane t of every leg group computes track t from the
-            // committed feet in LDS; the three values reach the group's lanes by swizzle (no LDS hand-off, no barrier)
-            const double myCtr = polygon_center_x(sh.cur[g.sub < 2 ? g.sub : 2]);
-            constexpr int kKeep = (~(G - 1)) & 0x1F;
-            const double ctr0 = swizzle_f64<kKeep | (0 << 5)>(myCtr), ctr1 = swizzle_f64<kKeep | (1 << 5)>(myCtr),
-                         ctr2 = swizzle_f64<kKeep | (2 << 5)>(myCtr);
+            // feet-polygon centres (getPolygonCenter, cpp:2191, 2265): every lane computes ONE track's centre from the
+            // committed feet in LDS; the values reach the group's other lanes by swizzle (no LDS hand-off, no barrier)
+            const double myCtr = polygon_center_x(sh.cur[myTrack]);
             stamp(pc, cyc, 1);
             // footholdValidation_ (cpp:1323) is a ballot over the pose's lanes; the committed positions go from
             // registers straight to PoseShared::cur (cpp:1332-1576)
             LegCommit lc;
             lc.valid = 1;  // non-swing legs do not vote
             if (active) {
-                if constexpr (kMid)
-                    leg_fast8m<NRL>(m, bm, pc, hc, lut, head, sh, lb, g, leg, ls, ye, ctr0, ctr1, ctr2, advance, cyc, nCycles, b, live, out, &lc,
+                if constexpr (kMid) {
+                    leg_fast8m<NRL>(m, bm, pc, hc, role, lut, head, sh, lb, g, leg, ls, ye, myCtr, advance, cyc, nCycles, b, live, out, &lc,
                                     units + (cyc & 7));
-                else
+                } else {
+                    constexpr int kKeep = (~(G - 1)) & 0x1F;
+                    const double ctr0 = swizzle_f64<kKeep | (0 << 5)>(myCtr), ctr1 = swizzle_f64<kKeep | (1 << 5)>(myCtr),
+                                 ctr2 = swizzle_f64<kKeep | (2 << 5)>(myCtr);
                     leg_phase_bits8<NRL, false>(m, bm, pc, lut, head, sh, lb, g, leg, ls, ye, ctr0, ctr1, ctr2, advance, cyc, nCycles, b, live,
                                                 out, &lc, nullptr);
+                }
             }
             stamp(pc, cyc, 9);
             const bool phaseOk = (__ballot(lc.valid == 0) & poseMask) == 0ull;
@@ -1782,17 +1831,21 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
             cycleOk = cycleOk && phaseOk;
             stamp(pc, cyc, 10);
         }
-        if (leg == 0 && g.sub == 0 && live && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = cycleOk ? 1 : 0;
-        adjY += pc.drift;  // cpp:1578
+        adjY += hc.drift;  // cpp:1578
         if constexpr (kMid) {
+            okBits |= (cycleOk ? 1u : 0u) << (cyc & 7);
             if ((cyc & 7) == 7 || cyc == nCycles - 1) {
-                // heights and output records of the last (up to) eight cycles: lane (leg, s) takes the unit of cycle base + s
+                // heights, output records and cycle validity of the last (up to) eight cycles: lane (leg, s) takes the
+                // unit of cycle base + s
                 const int c0 = cyc & ~7;
                 stamp(pc, 2, 11);
-                if (live && c0 + g.sub <= cyc) flush_unit(m.g, pc, units[g.sub], ytab[g.sub], b, c0 + g.sub, leg, nCycles, out);
+                if (live && c0 + g.sub <= cyc) flush_unit(m, pc, units[g.sub], ytab[g.sub], b, c0 + g.sub, leg, nCycles, okBits, out);
+                okBits = 0u;
                 pose_sync<G>();  // the units and the y entries are rewritten next
                 stamp(pc, 2, 12);
             }
+        } else {
+            if (leg == 0 && g.sub == 0 && live && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = cycleOk ? 1 : 0;
         }
     }
 }

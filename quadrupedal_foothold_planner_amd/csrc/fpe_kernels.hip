@@ -1264,6 +1264,21 @@ __device__ __forceinline__ void store_foothold(fpe_foothold* dst, const NominalO
 // getPolygonCenter (cpp:2421-2463): feet[leg][xyz] in LDS.  Only the centre's x is computed: the next
 // centre takes y from initialPose_/ajustedPose_ (cpp:2201, 2272) and getDefaultFootholdNext zeroes z
 // (cpp:2411-2418), so the y and z of the centre never reach a result (two f64 divisions saved per track).
+// x / 3.0, correctly rounded, in three operations instead of the division sequence (the feet-polygon centre sits at
+// the head of every gait cycle's dependent chain).  With c = RN(1/3), q = RN(x * c) is within 1.5 ulp of x / 3, so
+// r = x - 3 q is exact in an FMA (a small multiple of ulp(q)), and q + r * c = x/3 + (x/3 - q) * eps with |eps| <= 2^-53:
+// the perturbation is < 2^-52 ulp while x / 3 is never closer than ulp / 6 to a rounding boundary (3 * midpoint is an
+// odd multiple of half an ulp of the quotient's grid, x an even one), so the final FMA rounds to RN(x / 3).  Zero, NaN
+// and values near the ends of the exponent range take the division itself (wave-uniform branch).
+__device__ __forceinline__ double div3(double x) {
+    const double ax = fabs(x);
+    if (__ballot(!(ax > 1e-280 && ax < 1e300)) != 0ull) return x / 3.0;
+    const double c = 0x1.5555555555555p-2;
+    const double q = x * c;
+    const double r = __builtin_fma(-3.0, q, x);
+    return __builtin_fma(r, c, q);
+}
+
 __device__ __forceinline__ double polygon_center_x(const double (*feet)[3]) {
     const double x1 = feet[0][0], y1 = feet[0][1];
     double x2 = feet[1][0], y2 = feet[1][1];
@@ -1277,7 +1292,7 @@ __device__ __forceinline__ double polygon_center_x(const double (*feet)[3]) {
         x2 = x3;
         y2 = y3;
     }
-    return sum_x / sum_s / 3.0;
+    return div3(sum_x / sum_s);
 }
 
 // getGaitCycleSearchGridMap (cpp:2307-2349) in the FIRST gait cycle: the opt track's current feet are the shifted
