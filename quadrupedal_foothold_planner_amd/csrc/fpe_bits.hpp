@@ -108,8 +108,11 @@ struct YEntry {
     double sbaseY;   // submap position.y + (0.5 * sublength.y - 0.5 * res)
     double yA, yB;   // cell_pos(sbaseY, res, (rightCol + 1) >> 1), cell_pos(sbaseY, res, rightCol >> 1)  (cpp:1816)
     double dy2[3];   // (cell_pos(baseY, res, j0d + k) - ny)^2, k = 0..2 (3x3 disc form)
+    // window columns (window origin jc - winH, one word) of the centroid rectangle [j0r, j0r + njr) and of the
+    // reference rectangle polygon [jA, jB]
+    uint32_t rmask, pmask;
 };
-static_assert(sizeof(YEntry) == 88, "YEntry layout");
+static_assert(sizeof(YEntry) == 96, "YEntry layout");
 
 // ds_swizzle of a double (bit mode), two dwords
 template <int kPattern>
@@ -137,6 +140,15 @@ __device__ __forceinline__ unsigned bits_to(int hi) { return hi < 0 ? 0u : (hi >
 // word `wi` of the mask with bits [lo, hi] set (bit positions over the whole multi-word row)
 __device__ __forceinline__ unsigned range_word(int lo, int hi, int wi) { return bits_from(lo - 32 * wi) & bits_to(hi - 32 * wi); }
 
+// Layer cell / plane word group at a 32-bit offset from the (uniform) base pointer: one 32-bit multiply-add instead
+// of 64-bit address arithmetic per load.  bits_supported() bounds layers and planes below 2 GiB and 2^24 rows / columns.
+__device__ __forceinline__ float load_cell(const float* base, unsigned cell) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + static_cast<size_t>(cell << 2));
+}
+__device__ __forceinline__ uint4 load_group(const uint4* base, unsigned group) {
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + static_cast<size_t>(group << 4));
+}
+
 // Window origin (iw0, jw0) = getIndex(centre) - winH.  Lane `sub` holds window rows sub + G * k.  Rows and word
 // groups outside the map are clamped onto the zero padding of the planes.
 template <int G, int NRL, int KW>
@@ -149,9 +161,9 @@ __device__ __forceinline__ void win_issue(const BitMap& bm, const MapGeom& mg, c
     for (int k = 0; k < NRL; ++k) {
         int i = iw0 + g.sub + G * k;
         i = max(-1, min(i, mg.rows));
-        const uint4* p = bm.words + (static_cast<size_t>(i + 1) * bm.strideW + (w0 + kBitPadW));
+        const unsigned first = __umul24(static_cast<unsigned>(i + 1), static_cast<unsigned>(bm.strideW)) + static_cast<unsigned>(w0 + kBitPadW);
 #pragma unroll
-        for (int q = 0; q <= KW; ++q) grp[k][q] = p[q];
+        for (int q = 0; q <= KW; ++q) grp[k][q] = load_group(bm.words, first + static_cast<unsigned>(q));
     }
 }
 template <int NRL, int KW>
@@ -179,7 +191,8 @@ __device__ __forceinline__ unsigned win_bit(const uint32_t* rows, int nRows, int
 // checkFootholdUseCentroidMethod's row scan (cpp:1649-1658 whole-region test, cpp:1717-1750 blocked rows) from the
 // D rows: lane = window row.  `cnt > (rightCol + 1) * 0.5` (cpp:1743) is 2 * cnt > nj in integers.
 template <int G, int NRL, int KW>
-__device__ __forceinline__ CentroidScan rows_from_bits(const Submap& s, const WinRows<NRL, KW>& w, const Grp<G>& g, int iw0, int jw0) {
+__device__ __forceinline__ CentroidScan rows_from_bits(const Submap& s, const WinRows<NRL, KW>& w, const Grp<G>& g, int iw0, int jw0,
+                                                       const uint32_t* colMask = nullptr) {  // KW == 1: YEntry::rmask
     static_assert(G * NRL <= 128, "blocked-row masks are kept in two 64-bit words");
     CentroidScan r0;
     const int ni = s.ni, nj = s.nj;
@@ -193,7 +206,7 @@ __device__ __forceinline__ CentroidScan rows_from_bits(const Submap& s, const Wi
         const bool liveRow = s.ok && r >= 0 && r < ni;
         int cnt = 0;
 #pragma unroll
-        for (int q = 0; q < KW; ++q) cnt += __builtin_popcount(w.D[k][q] & range_word(c0, c1, q));
+        for (int q = 0; q < KW; ++q) cnt += __builtin_popcount(w.D[k][q] & (colMask ? *colMask : range_word(c0, c1, q)));
         anyBelow |= liveRow && cnt > 0;
         const bool blocked = liveRow && 2 * cnt > nj;
         const unsigned long long mk = g.ballot(blocked);
@@ -544,7 +557,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             const bool rowIn = i >= ir.iA && i <= ir.iB;
 #pragma unroll
             for (int q = 0; q < KW; ++q) {
-                const unsigned inside = rowIn ? range_word(ir.jA - jw0, ir.jB - jw0, q) : 0u;
+                const unsigned inside = rowIn ? ((ye && KW == 1) ? ye->pmask : range_word(ir.jA - jw0, ir.jB - jw0, q)) : 0u;
                 if (ri < NR) lb.a[ri * KW + q] = ~w.F[k][q] | (~w.C[k][q] & inside);
             }
         }
@@ -1147,6 +1160,9 @@ __device__ __forceinline__ void fill_yentry(const MapGeom& mg, const PlanConsts&
         const double dy = cell_pos(mg.baseY, mg.res, e.j0d + k) - ny;
         e.dy2[k] = dy * dy;
     }
+    const int jw0 = e.jc - pc.winH;
+    e.rmask = range_word(e.j0r - jw0, e.j0r - jw0 + e.njr - 1, 0);
+    e.pmask = range_word(e.jA - jw0, e.jB - jw0, 0);
 }
 
 // One swing leg of one phase, 8 lanes per leg, y side from the YEntry.  The x side is ONE lane-transposed pass: lane
@@ -1455,6 +1471,7 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     ye.jc = yeLds.jc; ye.j0d = yeLds.j0d; ye.njd = yeLds.njd; ye.j0r = yeLds.j0r;
     ye.njr = yeLds.njr; ye.jA = yeLds.jA; ye.jB = yeLds.jB; ye.flags = yeLds.flags;
     ye.ny = yeLds.ny; ye.sbaseY = yeLds.sbaseY; ye.yA = yeLds.yA; ye.yB = yeLds.yB;
+    ye.rmask = yeLds.rmask; ye.pmask = yeLds.pmask;
     // ---- x side: this lane's track position and corner (cpp:2199, 2414; see leg_phase_bits8) ----
     const double nxq = (myCtr + advance) + ls.biasX;
     const double ny = ye.ny;
@@ -1478,9 +1495,10 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     const double nx2 = swizzle_f64<kKeep | (7 << 5)>(nxq);  // nominal track (search polygon)
     const int j0d = ye.j0d, icj = ye.jc;
     // both foot-disc boxes: 3x3 and clear of the map's outermost rows / columns (not clamped, inside the map)
-    const bool boxes = (i1d - i0d) == 2 && (i1f - i0f) == 2 && ye.njd == 3 && i0d >= 1 && i0f >= 1 && j0d >= 1 &&
-                       i0d + 4 <= m.g.rows && i0f + 4 <= m.g.rows && j0d + 4 <= m.g.cols;
-    const bool rare = !ls.radiusOk || (ye.flags & 2) == 0 || !(fabs(nxq) <= 1e6) || !wantDefault || !safe || !boxes;
+    // (bitwise: a short-circuit chain is compiled into exec-mask branches)
+    const int lowest = min(min(i0d, i0f), j0d), lastRow = max(i0d, i0f) + 4;
+    const bool boxes = ((i1d - i0d) == 2) & ((i1f - i0f) == 2) & (ye.njd == 3) & (lowest >= 1) & (lastRow <= m.g.rows) & (j0d + 4 <= m.g.cols);
+    const bool rare = !ls.radiusOk | ((ye.flags & 2) == 0) | !(fabs(nxq) <= 1e6) | !wantDefault | !safe | !boxes;
     if (__ballot(rare) != 0ull) {  // wave-uniform
         const double ctr0 = swizzle_f64<kKeep | (5 << 5)>(myCtr), ctr1 = swizzle_f64<kKeep | (0 << 5)>(myCtr),
                      ctr2 = swizzle_f64<kKeep | (7 << 5)>(myCtr);
@@ -1515,14 +1533,19 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     const double dxB = cell_pos(m.g.baseX, m.g.res, i0f + a) - nx0;
     const bool visA = (dxA * dxA + dy2) <= hc.rf2;  // CircleIterator::isInside (cell_in_disc)
     const bool visB = (dxB * dxB + dy2) <= hc.rf2;
-    const float eA = m.elev[static_cast<size_t>(i0d + a) * m.g.cols + (j0d + bq)];
-    const float eB = m.elev[static_cast<size_t>(i0f + a) * m.g.cols + (j0d + bq)];
-    const float eMidA = m.elev[static_cast<size_t>(i0d + 1) * m.g.cols + (j0d + 1)];
-    const float eMidB = m.elev[static_cast<size_t>(i0f + 1) * m.g.cols + (j0d + 1)];
+    // (32-bit cell offsets from the uniform layer base: bits_supported bounds the layer below 2 GiB)
+    const unsigned colsU = static_cast<unsigned>(m.g.cols);
+    const unsigned laneCell = __umul24(static_cast<unsigned>(a), colsU) + static_cast<unsigned>(bq);
+    const unsigned boxA = __umul24(static_cast<unsigned>(i0d), colsU) + static_cast<unsigned>(j0d);
+    const unsigned boxB = __umul24(static_cast<unsigned>(i0f), colsU) + static_cast<unsigned>(j0d);
+    const float eA = load_cell(m.elev, boxA + laneCell);
+    const float eB = load_cell(m.elev, boxB + laneCell);
+    const float eMidA = load_cell(m.elev, boxA + colsU + 1u);
+    const float eMidB = load_cell(m.elev, boxB + colsU + 1u);
     stamp(pc, cyc, 3);
     WinRows<NRL, KW> w;
     win_finish<NRL, KW>(jw0, grp, w);
-    const CentroidScan sc = rows_from_bits<G, NRL, KW>(sm, w, g, iw0, jw0);
+    const CentroidScan sc = rows_from_bits<G, NRL, KW>(sm, w, g, iw0, jw0, &ye.rmask);
     stamp(pc, cyc, 4);
     // ---- checkDefaultFoothold: the lanes owning the box's three window rows test their Df bits under the members ----
     const unsigned mA = static_cast<unsigned>(g.ballot(visA)), mB = static_cast<unsigned>(g.ballot(visB));
@@ -1587,45 +1610,100 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     no.y = ny;
     no.z = 0.0f;
     if (!defaultOk) {
-        LegCtx c;
-        c.cyc = cyc;
-        c.cx = cx;
-        c.cy = ny;
-        c.nv = ls.polyKind == 0 ? 4 : 6;
+        nominal_invalid(no, cx, ny, 2);
         const double r = static_cast<double>(ls.Rf);
-        c.rect = ls.polyKind == 0;
-        c.xhi = nx2 + r;
-        c.xlo = nx2 - r;
-        c.yhi = ny + 0.5 * r;
-        c.ylo = ny - 0.5 * r;
-        c.vx = sh.polyX[leg];
-        c.vy = sh.polyY[leg];
-        c.footDa = sh.footDa;
-        c.footDb = sh.footDb;
-        c.footOff = sh.footOff;
-        c.R2 = lk.R2;
-        c.nRings = lk.nRings;
-        c.nCand = lk.nCand;
-        c.ti0 = c.tj0 = 0;
-        c.ici = ici;
-        c.icj = icj;
-        if (!c.rect) {  // hexagon vertices from the NOMINAL track's position (build-defined, App. E)
-            if (g.sub == 0) {
-                double* vx = sh.polyX[leg];
-                double* vy = sh.polyY[leg];
-                const double hx = 0.5 * r, hy = (0.5 * r) * 0.8660254037844386;
-                vx[0] = nx2 + r;   vy[0] = ny;
-                vx[1] = nx2 + hx;  vy[1] = ny - hy;
-                vx[2] = nx2 - hx;  vy[2] = ny - hy;
-                vx[3] = nx2 - r;   vy[3] = ny;
-                vx[4] = nx2 - hx;  vy[4] = ny + hy;
-                vx[5] = nx2 + hx;  vy[5] = ny + hy;
+        int wi = 0, wj = 0;
+        bool found = false, searched = false;
+        // The usual search as straight-line code: reference rectangle, one-cell foot disc, and the candidates of the
+        // first two rounds (ranks 0-15: rings 0-2, whose cells the iterator does not filter when nRings >= 4).  Same
+        // evaluation as spiral_bits: x interval as in rectangle_index_bounds, columns from the y entry, pass rows
+        // P = ~F | (~C & inside) in the leg's LDS, lowest set ballot bit = first valid cell in spiral order.
+        if (__ballot(ls.polyKind != 0 || lk.nRings < 4 || lk.nCand < 16) == 0ull && pc.nFoot <= 1) {  // uniform over the searching legs
+            const double xhi = nx2 + r, xlo = nx2 - r;  // getSearchPolygon around the NOMINAL track (cpp:2496-2517)
+            double qh = floor((m.g.baseX - xhi) * m.g.rinv), ql = floor((m.g.baseX - xlo) * m.g.rinv);
+            qh = fmin(fmax(qh, -1.0e9), 1.0e9);
+            ql = fmin(fmax(ql, -1.0e9), 1.0e9);
+            const int eH = static_cast<int>(qh), eL = static_cast<int>(ql);
+            // lane q & 3: 0 P(eH), 1 P(eH + 1) with P(i) = x_i < xhi;  2 Q(eL + 1), 3 Q(eL) with Q(i) = x_i >= xlo
+            const bool isLo = (g.sub & 2) != 0;
+            const int odd = g.sub & 1;
+            const int tLo = eL + 1 - odd, tHi = eH + odd;
+            const int tq = isLo ? tLo : tHi;
+            const double lim = isLo ? xlo : xhi;
+            const double xt = cell_pos(m.g.baseX, m.g.res, tq);
+            const bool predLo = xt >= lim, predHi = xt < lim;
+            const bool pred = isLo ? predLo : predHi;
+            const unsigned pb = static_cast<unsigned>(g.ballot(pred));
+            const int iA1 = (pb & 2u) ? eH + 1 : eH + 2, iB1 = (pb & 8u) ? eL : eL - 1;
+            const int iA = (pb & 1u) ? eH : iA1, iB = (pb & 4u) ? eL + 1 : iB1;
+            const int NR = lb.rows;
+#pragma unroll
+            for (int k = 0; k < NRL; ++k) {
+                const int ri = g.sub + G * k;
+                const int i = iw0 + ri;
+                const unsigned inside = (i >= iA && i <= iB) ? ye.pmask : 0u;
+                if (ri < NR) lb.a[ri] = ~w.F[k][0] | (~w.C[k][0] & inside);
             }
             pose_sync<G>();
+            const int rowW = ici - iw0, colW = icj - jw0;  // the centre inside the window (winH, winH)
+            int eWin = 0;
+#pragma unroll
+            for (int round = 0; round < kLutHeadRounds; ++round) {
+                const int e = head.dij[round];
+                const int di = static_cast<int16_t>(e & 0xFFFF), dj = e >> 16;
+                const bool inMap = in_range(ici + di, icj + dj, m.g.rows, m.g.cols);
+                const bool ok = !found && inMap && win_bit<KW>(lb.a, NR, rowW + di, colW + dj) != 0u;
+                const unsigned mask = static_cast<unsigned>(g.ballot(ok));
+                const int l = __builtin_ctz(mask | 0x100u);
+                const int eSel = g.bcast(e, l & 7);
+                eWin = (!found && mask != 0u) ? eSel : eWin;
+                found = found || mask != 0u;
+            }
+            wi = ici + static_cast<int16_t>(eWin & 0xFFFF);
+            wj = icj + (eWin >> 16);
+            searched = lk.nCand <= G * kLutHeadRounds;  // nothing beyond the two rounds
+            pose_sync<G>();
         }
-        nominal_invalid(no, cx, ny, 2);
-        int wi = 0, wj = 0;
-        if (spiral_bits<G, NRL, KW>(m, pc, lut, head, c, w, lb, g, iw0, jw0, wi, wj, &yeIn)) {  // cpp:2022
+        if (!found && !searched) {  // other polygons, larger foot discs, small search radii, or no hit in the first two rounds
+            LegCtx c;
+            c.cyc = cyc;
+            c.cx = cx;
+            c.cy = ny;
+            c.nv = ls.polyKind == 0 ? 4 : 6;
+            c.rect = ls.polyKind == 0;
+            c.xhi = nx2 + r;
+            c.xlo = nx2 - r;
+            c.yhi = ny + 0.5 * r;
+            c.ylo = ny - 0.5 * r;
+            c.vx = sh.polyX[leg];
+            c.vy = sh.polyY[leg];
+            c.footDa = sh.footDa;
+            c.footDb = sh.footDb;
+            c.footOff = sh.footOff;
+            c.R2 = lk.R2;
+            c.nRings = lk.nRings;
+            c.nCand = lk.nCand;
+            c.ti0 = c.tj0 = 0;
+            c.ici = ici;
+            c.icj = icj;
+            if (!c.rect) {  // hexagon vertices from the NOMINAL track's position (build-defined, App. E)
+                if (g.sub == 0) {
+                    double* vx = sh.polyX[leg];
+                    double* vy = sh.polyY[leg];
+                    const double hx = 0.5 * r, hy = (0.5 * r) * 0.8660254037844386;
+                    vx[0] = nx2 + r;   vy[0] = ny;
+                    vx[1] = nx2 + hx;  vy[1] = ny - hy;
+                    vx[2] = nx2 - hx;  vy[2] = ny - hy;
+                    vx[3] = nx2 - r;   vy[3] = ny;
+                    vx[4] = nx2 - hx;  vy[4] = ny + hy;
+                    vx[5] = nx2 + hx;  vy[5] = ny + hy;
+                }
+                pose_sync<G>();
+            }
+            found = spiral_bits<G, NRL, KW>(m, pc, lut, head, c, w, lb, g, iw0, jw0, wi, wj, &yeIn);  // cpp:2022
+            pose_sync<G>();
+        }
+        if (found) {
             no.valid = 1;
             no.source = 1;
             no.row = wi;
@@ -1633,7 +1711,6 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
             no.x = cell_pos(m.g.baseX, m.g.res, wi);  // cpp:2105-2107
             no.y = cell_pos(m.g.baseY, m.g.res, wj);
         }
-        pose_sync<G>();
     }
     stamp(pc, cyc, 8);
     if (g.sub == 0) {  // what flush_unit needs to rebuild this leg's four records
@@ -1684,7 +1761,7 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
     hc.rf2 = in_vgpr(pc.rf2);
     hc.cornerEps = in_vgpr(pc.cornerEps);
     hc.oneMinusEps = in_vgpr(1.0 - pc.cornerEps);
-    hc.drift = in_vgpr(pc.drift);
+    hc.drift = kMid ? in_vgpr(pc.drift) : pc.drift;  // (the generic variants run at their register cap: nothing extra parked)
     constexpr int kPoseThreads = 4 * G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = static_cast<int>(threadIdx.x);
@@ -1725,6 +1802,12 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
             ls.biasX = pc.biasX[leg];
             ls.biasY = pc.biasY[leg];
         }
+    }
+    // (loaded values parked here: inside the cycle loop the compiler would wait for "all outstanding loads" at their
+    // first use in every iteration)
+    if constexpr (kMid) {
+        ls.biasX = in_vgpr(ls.biasX);
+        ls.biasY = in_vgpr(ls.biasY);
     }
     for (int k = tid % kPoseThreads; k < pc.nFoot; k += kPoseThreads) {
         sh.footDa[k] = pc.footDa[k];
@@ -1775,7 +1858,8 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
     // the track whose feet-polygon centre this lane evaluates: 3x3-only kernels: the track of the lane's corner
     // (LaneRole); generic kernels: lane t evaluates track t
     const int myTrack = kMid ? lane_track(g.sub) : (g.sub < 2 ? g.sub : 2);
-    const LaneRole role = make_lane_role(g.sub, pc.rf, ls.lk.lx, pc.cornerEps, static_cast<double>(mArg.g.rows));
+    LaneRole role{};
+    if constexpr (kMid) role = make_lane_role(g.sub, pc.rf, ls.lk.lx, pc.cornerEps, static_cast<double>(mArg.g.rows));
     uint32_t okBits = 0u;  // cycleOk of the cycles since the last flush (3x3-only kernels: stored by flush_unit)
 
     for (int cyc = 0; cyc < nCycles; ++cyc) {
@@ -1983,6 +2067,10 @@ static BitsShape bits_shape(int winH) {
 
 bool bits_supported(const PlanConsts& pc, const MapGeom& g) {
     if (pc.noBits != 0 || pc.winH <= 0) return false;
+    // 32-bit offsets into layers and planes (load_cell / load_group), 24-bit multiplies of rows and strides
+    if (g.rows >= (1 << 24) - 2 || g.cols >= (1 << 24) - 64) return false;
+    if (static_cast<double>(g.rows) * g.cols * 4.0 >= 2147483648.0 - 65536.0) return false;
+    if ((static_cast<double>(g.rows) + 2.0) * ((g.cols + 31) / 32 + 2 * kBitPadW) * 16.0 >= 2147483648.0) return false;
     const BitsShape sp = bits_shape(pc.winH);
     if (sp.lanes == 0) return false;
     if (pc.groupOverride != 0 && pc.groupOverride != (sp.lanes == 8 ? 8 : 65)) return false;
