@@ -37,4 +37,7 @@ print("cycle-to-cycle", np.mean(t[:,1:,0]-t[:,:-1,0]))
 print("kernel span per block", np.mean(t[:,n-1 if n<8 else 7,10]-t[:,0,0]))
 
 print("prologue: entry -> statics/LUT/stance", np.mean(t[:,1,12]-t[:,1,11]), " gate", np.mean(t[:,1,13]-t[:,1,12]), " ytab fill", np.mean(t[:,1,14]-t[:,1,13]), " first cycle start after entry", np.mean(t[:,0,0]-t[:,1,11]))
+if t[:,3,11].any():
+    print("prologue detail: entry -> pose arrived", np.mean(t[:,3,11]-t[:,1,11]), " -> rank-table head", np.mean(t[:,3,12]-t[:,3,11]), " -> per-leg constants", np.mean(t[:,3,13]-t[:,3,12]),
+          " -> offset table copied", np.mean(t[:,3,14]-t[:,3,13]), " -> stance in LDS", np.mean(t[:,1,12]-t[:,3,14]))
 print("flush", np.mean(t[:,2,12]-t[:,2,11]), " last commit -> flush start", np.mean(t[:,2,11]-t[:,7,10]))

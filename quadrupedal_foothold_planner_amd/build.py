@@ -31,6 +31,8 @@ FLAGS = [
     "-fno-fast-math",
     "-Wall",
     "-Wno-unused-function",
+    # leading scalar kernel arguments arrive in SGPRs at wave launch (gfx950 kernarg preload) instead of by s_load
+    "-mllvm", "-amdgpu-kernarg-preload-count=16",
 ]
 
 # what the last build_engine() call in this process did: "compiled" | "up-to-date"

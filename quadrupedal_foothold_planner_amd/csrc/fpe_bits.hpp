@@ -1101,28 +1101,35 @@ __device__ __forceinline__ void fill_yentry(const MapGeom& mg, const PlanConsts&
     int flags = fabs(ny) <= 1e6 ? 2 : 0;
     e.ny = ny;
     // foot-disc box (CircleIterator::findSubmapParameters, y axis), getIndex(centre), centroid rectangle
-    // (getSubmapInformation, y axis: corners centre +- 0.5 * ly).  The five indices are predicted without the f64
-    // division (index_of_fast's test); when any lane of the wavefront is too close to a cell boundary the wavefront
-    // takes the true divisions (a real branch: the if-converted form would pay five divisions per entry)
-    const double tly = bound_axis(ny + pc.rf, mg.orgY, mg.posY, mg.lenY);
-    const double bry = bound_axis(ny - pc.rf, mg.orgY, mg.posY, mg.lenY);
-    const double tlr = bound_axis(ny + 0.5 * ly, mg.orgY, mg.posY, mg.lenY);
-    const double brr = bound_axis(ny - 0.5 * ly, mg.orgY, mg.posY, mg.lenY);
-    const double xs[5] = {tly, bry, ny, tlr, brr};
+    // (getSubmapInformation, y axis: corners centre +- 0.5 * ly).
+    // Predicted, as in the x pass of the chain (PlanConsts::cornerEps): a corner strictly inside the map whose quotient
+    // is farther than cornerEps from an integer has the index -trunc(quotient) and stays within the map, whatever
+    // boundPositionToRange's rewrite and the index division do to the last bits.  When any lane of the wavefront is
+    // too close to a cell boundary or to the map's edge, the wavefront evaluates the reference's own expressions (a
+    // real branch: the if-converted form would pay five divisions per entry).
+    const double xs0[5] = {ny + pc.rf, ny - pc.rf, ny, ny + 0.5 * ly, ny - 0.5 * ly};
     int idx[5];
-    bool tie = false;
+    bool safe = true;
+    const double colsD = static_cast<double>(mg.cols);
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        const double qf = ((xs[k] - mg.orgY) - mg.posY) * mg.rinv;
+        const double qf = ((xs0[k] - mg.orgY) - mg.posY) * mg.rinv;
         const double kk = trunc(qf);
         const double fr = fabs(qf - kk);
-        const double eps = fabs(qf) * 4.5e-16 + 1e-290;
-        tie |= !(fr > eps && fr < 1.0 - eps);
+        safe = safe & (fr > pc.cornerEps) & (fr < 1.0 - pc.cornerEps);
+        if (k != 2) safe = safe & (qf < -pc.cornerEps) & (qf > pc.cornerEps - colsD);
         idx[k] = -static_cast<int>(kk);
     }
-    if (__ballot(tie) != 0ull) {
+    bool cornersWithin = true;  // checkIfPositionWithinMap of the centroid rectangle's bounded corners (y axis)
+    if (__ballot(!safe) != 0ull) {
+        const double tly = bound_axis(xs0[0], mg.orgY, mg.posY, mg.lenY);
+        const double bry = bound_axis(xs0[1], mg.orgY, mg.posY, mg.lenY);
+        const double tlr = bound_axis(xs0[3], mg.orgY, mg.posY, mg.lenY);
+        const double brr = bound_axis(xs0[4], mg.orgY, mg.posY, mg.lenY);
+        const double xs[5] = {tly, bry, ny, tlr, brr};
 #pragma unroll
         for (int k = 0; k < 5; ++k) idx[k] = index_of(xs[k], mg.orgY, mg.posY, mg.res);
+        cornersWithin = within_axis(tlr, mg.orgY, mg.posY, mg.lenY) && within_axis(brr, mg.orgY, mg.posY, mg.lenY);
     }
     e.j0d = idx[0];
     e.njd = idx[1] - idx[0] + 1;
@@ -1131,7 +1138,7 @@ __device__ __forceinline__ void fill_yentry(const MapGeom& mg, const PlanConsts&
     const int j1r = idx[4];
     e.j0r = j0r;
     e.njr = j1r - j0r + 1;
-    bool okY = within_axis(tlr, mg.orgY, mg.posY, mg.lenY) && within_axis(brr, mg.orgY, mg.posY, mg.lenY) && j0r >= 0 && j0r < mg.cols;
+    bool okY = cornersWithin && j0r >= 0 && j0r < mg.cols;
     const double cornerY = cell_pos(mg.baseY, mg.res, j0r) - (-(0.5 * mg.res));
     const double subLenY = static_cast<double>(e.njr) * mg.res;
     const double subOrgY = 0.5 * subLenY;
@@ -1739,10 +1746,26 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
 #define FPE_BITS_GENERIC_WAVES 3  // measured on cfg-4: 2 -> 1.36 ms, 3 -> 1.25 ms (27 spilled VGPRs), 4 -> 1.46 ms (69 spilled)
 #endif
 template <int NRL, bool kMid>
-__global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bits_kernel(DevMap mArg, BitMap bm, PlanConsts pc, SpiralLut lut,
-                                                          const fpe_pose* __restrict__ poses, int B, int nCycles, fpe_plan_out out) {
+// (the pose pointer and the counts lead the argument list: scalar arguments at the head of the kernarg segment are
+// preloaded into SGPRs at wave launch, -amdgpu-kernarg-preload-count, so the pose loads can be issued at once)
+__global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bits_kernel(const fpe_pose* __restrict__ poses, int B, int nCycles,
+                                                          DevMap mArg, BitMap bm, PlanConsts pc, SpiralLut lut, fpe_plan_out out) {
     constexpr int G = 8;
     constexpr int NR = G * NRL;
+    constexpr int kPoseThreads = 4 * G;
+    const int tid = static_cast<int>(threadIdx.x);
+    const int slot = tid / kPoseThreads;
+    const int leg = (tid / G) & 3;
+    // the pose first: its address needs nothing but the preloaded arguments, and everything else waits for it
+    int b = blockIdx.x * 2 + slot;
+    const bool live = b < B;  // the padding pose of the last block runs the chain on pose B-1, stores nothing
+    if (!live) b = B - 1;
+    const fpe_pose* pp = poses + b;
+    const double x0 = pp->position[0], y0 = pp->position[1], z0 = pp->position[2];
+    const int gait = pp->gait;
+    const float rOverride = pp->leg_search_radius[leg];
+    const int polyKindIn = pp->leg_polygon_kind[leg];
+    __builtin_amdgcn_sched_barrier(0);  // (the loads above stay ahead of the kernel-argument fetches below)
     stamp(pc, 1, 11);
     // the map geometry doubles are operands of vector f64 arithmetic only: parked in VGPRs (see plan_chained_kernel)
     DevMap m = mArg;
@@ -1762,11 +1785,7 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
     hc.cornerEps = in_vgpr(pc.cornerEps);
     hc.oneMinusEps = in_vgpr(1.0 - pc.cornerEps);
     hc.drift = kMid ? in_vgpr(pc.drift) : pc.drift;  // (the generic variants run at their register cap: nothing extra parked)
-    constexpr int kPoseThreads = 4 * G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = static_cast<int>(threadIdx.x);
-    const int slot = tid / kPoseThreads;
-    const int leg = (tid / G) & 3;
     const Grp<G> g(tid);
     const size_t legBytes = 4 * static_cast<size_t>(legbits_words(NR, 1, pc.nHW, false));
     const size_t poseBytes = sizeof(PoseShared) + 4 * legBytes + sizeof(YEntry) * 4 * 8 + (kMid ? sizeof(Unit) * 4 * 8 : 0);
@@ -1776,21 +1795,20 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
     YEntry* ytab = reinterpret_cast<YEntry*>(base + sizeof(PoseShared) + 4 * legBytes) + leg * 8;  // [cycle & 7] of this leg
     Unit* units = reinterpret_cast<Unit*>(base + sizeof(PoseShared) + 4 * legBytes + sizeof(YEntry) * 4 * 8) + leg * 8;
 
-    int b = blockIdx.x * 2 + slot;
-    const bool live = b < B;  // the padding pose of the last block runs the chain on pose B-1, stores nothing
-    if (!live) b = B - 1;
-    const fpe_pose* pp = poses + b;
-    const double x0 = pp->position[0], y0 = pp->position[1], z0 = pp->position[2];
-    const int gait = pp->gait;
     const LutHead head = load_lut_head(lut, g);
+#ifdef FPE_TRACE
+    asm volatile("" ::"v"(x0), "v"(gait));
+    stamp(pc, 3, 11);  // pose arrived
+    asm volatile("" ::"v"(head.dij[0]), "v"(head.ring[1]));
+    stamp(pc, 3, 12);  // rank-table head arrived
+#endif
     LegStatic ls;
     {
-        const float rOverride = pp->leg_search_radius[leg];
         if (__ballot(rOverride > 0.0f) != 0ull) {  // some leg of the wavefront overrides the search radius (build-defined)
             ls = make_leg_static(pc, pp, leg, m.g.res, lut);
         } else {  // the reference's single searchRadius_: constants precomputed on the host
             ls.Rf = pc.searchRadius;
-            ls.polyKind = pp->leg_polygon_kind[leg];
+            ls.polyKind = polyKindIn;
             ls.radiusOk = true;
             const double R = static_cast<double>(pc.searchRadius);
             ls.lk.Rf = pc.searchRadius;
@@ -1799,8 +1817,12 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
             ls.lk.nCand = pc.defNCand;
             ls.lk.lx = static_cast<double>(pc.searchRadius * 2);
             ls.lk.ly = static_cast<double>(pc.searchRadius);
-            ls.biasX = pc.biasX[leg];
-            ls.biasY = pc.biasY[leg];
+            // (two selects on the leg's bits: a run-time index into the kernel-argument array is a dependent global load)
+            const bool odd = (leg & 1) != 0, high = (leg & 2) != 0;
+            const double bxLo = odd ? pc.biasX[1] : pc.biasX[0], bxHi = odd ? pc.biasX[3] : pc.biasX[2];
+            const double byLo = odd ? pc.biasY[1] : pc.biasY[0], byHi = odd ? pc.biasY[3] : pc.biasY[2];
+            ls.biasX = high ? bxHi : bxLo;
+            ls.biasY = high ? byHi : byLo;
         }
     }
     // (loaded values parked here: inside the cycle loop the compiler would wait for "all outstanding loads" at their
@@ -1809,11 +1831,21 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
         ls.biasX = in_vgpr(ls.biasX);
         ls.biasY = in_vgpr(ls.biasY);
     }
-    for (int k = tid % kPoseThreads; k < pc.nFoot; k += kPoseThreads) {
-        sh.footDa[k] = pc.footDa[k];
-        sh.footDb[k] = pc.footDb[k];
-        sh.footOff[k] = 0;
+    stamp(pc, 3, 13);  // per-leg constants
+    if constexpr (kMid) {  // launched for one-cell foot discs only: the table is the single offset (0, 0)
+        if (tid % kPoseThreads == 0) {
+            sh.footDa[0] = 0;
+            sh.footDb[0] = 0;
+            sh.footOff[0] = 0;
+        }
+    } else {
+        for (int k = tid % kPoseThreads; k < pc.nFoot; k += kPoseThreads) {
+            sh.footDa[k] = pc.footDa[k];
+            sh.footDb[k] = pc.footDb[k];
+            sh.footOff[k] = 0;
+        }
     }
+    stamp(pc, 3, 14);  // offset table copied
     // initial stance (cpp:350-378) and first-gait shift (setFirstGait, cpp:2679-2699)
     if (g.sub == 0) {
         double sx = (leg == 0 || leg == 3) ? pc.LbHalf : -pc.LbHalf;
@@ -1839,10 +1871,35 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
     if (out.pose_status) {
         // getGaitCycleSearchGridMap's getSubmap in the first cycle (opt_gate_cycle0), its four corners on four lanes
         const double gx = polygon_center_x(sh.cur[0]) + pc.step, gy = y0 + 0.0;  // cpp:2327-2329
-        const Box gb{gx, gy, 0.5 * pc.isosLen, 0.5 * pc.isosWid};
-        Corners<G, 8> gc;
-        gc.eval(m.g, g, gb, gb, gb, gb, 0x0u);
-        const Submap gs = submap_from_corners(m.g, gc.template bbox<0>(g), gc.box_within(0), gx, gy);
+        Submap gs;
+        {
+            // lane q & 3: 0 top-left x, 1 top-left y, 2 bottom-right x, 3 bottom-right y — predicted as in the x pass
+            // of the chain; the reference's own expressions when any lane is near a cell boundary or the map's edge
+            const bool isY = (g.sub & 1) != 0, isBR = (g.sub & 2) != 0;
+            const double ctr = isY ? gy : gx, halfExt = isY ? 0.5 * pc.isosWid : 0.5 * pc.isosLen;
+            const double org = isY ? m.g.orgY : m.g.orgX, pos = isY ? m.g.posY : m.g.posX;
+            const double cells = isY ? static_cast<double>(mArg.g.cols) : static_cast<double>(mArg.g.rows);
+            const double vq = isBR ? ctr - halfExt : ctr + halfExt;
+            const double qf = ((vq - org) - pos) * m.g.rinv;
+            const double kq = trunc(qf);
+            const double fr = fabs(qf - kq);
+            const bool safe = (fr > pc.cornerEps) & (fr < 1.0 - pc.cornerEps) & (qf < -pc.cornerEps) & (qf > pc.cornerEps - cells);
+            if (__ballot(!safe) == 0ull) {
+                const int idxq = -static_cast<int>(kq);
+                constexpr int kKeep = (~(G - 1)) & 0x1F;
+                BBox gbb;
+                gbb.i0 = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (0 << 5));
+                gbb.j0 = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (1 << 5));
+                gbb.ni = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (2 << 5)) - gbb.i0 + 1;
+                gbb.nj = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (3 << 5)) - gbb.j0 + 1;
+                gs = submap_from_corners(m.g, gbb, true, gx, gy);
+            } else {
+                const Box gb{gx, gy, 0.5 * pc.isosLen, 0.5 * pc.isosWid};
+                Corners<G, 8> gc;
+                gc.eval(m.g, g, gb, gb, gb, gb, 0x0u);
+                gs = submap_from_corners(m.g, gc.template bbox<0>(g), gc.box_within(0), gx, gy);
+            }
+        }
         if (live && leg == 0 && g.sub == 0)
             out.pose_status[b] = (centre_usable(gx, gy) && gs.ok) ? 0 : static_cast<uint8_t>(FPE_POSE_OPT_SUBMAP_FAILED);
     }
@@ -2108,8 +2165,7 @@ hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts&
 #define FPE_LAUNCH_BITS(NRL, MID)                                                                                            \
     hipLaunchKernelGGL((plan_bits_kernel<NRL, MID>), dim3((B + 1) / 2), block,                                              \
                        2 * (sizeof(PoseShared) + 16 * legbits_words(8 * NRL, 1, pc.nHW, false) + sizeof(YEntry) * 32 +                \
-                            (MID ? sizeof(Unit) * 32 : 0)), stream, m, bm, pc, lut,                                                 \
-                       d_poses, B, nCycles, d_out)
+                            (MID ? sizeof(Unit) * 32 : 0)), stream, d_poses, B, nCycles, m, bm, pc, lut, d_out)
 #define FPE_LAUNCH_BITS_SEQ(NRL, KW)                                                                                         \
     hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW>), dim3(B), block,                                                      \
                        sizeof(PoseShared) + ((4 * sizeof(LegStatic) + 15) & ~static_cast<size_t>(15)) +                                  \

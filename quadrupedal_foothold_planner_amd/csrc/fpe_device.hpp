@@ -24,6 +24,7 @@ struct SpiralLut {
     const uint8_t* ring;       // ring index of entry k
     const int32_t* ringStart;  // [maxRing + 2]
     int32_t maxRing;
+    int32_t total;             // ringStart[maxRing + 1]: entries of the whole table (spares the kernels a dependent load)
 };
 
 constexpr int kMaxFootOffsets = 128;

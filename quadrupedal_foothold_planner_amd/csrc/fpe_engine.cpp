@@ -238,7 +238,9 @@ struct fpe_engine {
     float maxLegSearchRadius = 0.0f;  // fpe_set_max_leg_search_radius
     fpe::Tuning tuning;               // fpe_set_tuning; seeded from the environment once, in fpe_create
 
-    fpe::SpiralLut lut() const { return fpe::SpiralLut{d_di, d_dj, d_ring, d_ringStart, maxRing}; }
+    fpe::SpiralLut lut() const {
+        return fpe::SpiralLut{d_di, d_dj, d_ring, d_ringStart, maxRing, ringStart.empty() ? 0 : ringStart[static_cast<size_t>(maxRing) + 1]};
+    }
 };
 
 namespace {

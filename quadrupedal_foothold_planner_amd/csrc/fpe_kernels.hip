@@ -134,9 +134,18 @@ __device__ __forceinline__ CornerVal corner_quantity(const MapGeom& g, int k, co
     const double v = isBR ? c - h : c + h;
     const double bnd = raw ? c : bound_axis(v, org, pos, len);
     CornerVal r;
-    // index_of_fast: hipcc if-converts its rare exact-division fallback into straight-line code; measured
-    // faster here than either a per-lane or a wave-uniform branch (0.0766 vs 0.0783 ms per launch)
-    r.idx = index_of_fast(bnd, org, pos, g.res, g.rinv);
+    // index_of_fast's test with a wave-uniform fallback: when any lane's predicted quotient is within rounding
+    // distance of an integer the wavefront takes the true division (hipcc if-converts index_of_fast's own rare branch,
+    // i.e. every call pays the division sequence)
+    {
+        const double n = (bnd - org) - pos;
+        const double qf = n * g.rinv;
+        double k2 = trunc(qf);
+        const double fr = fabs(qf - k2);
+        const double eps = fabs(qf) * 4.5e-16 + 1e-290;
+        if (__ballot(!(fr > eps && fr < 1.0 - eps)) != 0ull) k2 = trunc(n / g.res);
+        r.idx = -static_cast<int>(k2);
+    }
     r.within = raw || within_axis(bnd, org, pos, len);
     return r;
 }
@@ -573,7 +582,7 @@ struct LutHead {
 template <int G>
 __device__ __forceinline__ LutHead load_lut_head(const SpiralLut& lut, const Grp<G>& g) {
     LutHead h;
-    const int total = lut.ringStart[lut.maxRing + 1];
+    const int total = lut.total;
 #pragma unroll
     for (int r = 0; r < kLutHeadRounds; ++r) {
         const int k = min(r * G + g.sub, total - 1);
