@@ -145,3 +145,16 @@ def test_build_is_atomic_and_reports_what_it_did():
     path = fbuild.build_engine()
     assert os.path.exists(path) and fbuild.LAST_ACTION in ("compiled", "up-to-date")
     assert not [f for f in os.listdir(os.path.dirname(path)) if f.endswith(".so.tmp")], "a temporary build output was left behind"
+
+
+def test_three_operation_division_by_three_is_exact(tmp_path):
+    """getPolygonCenter's x / 3.0 (cpp:2461-2462) is evaluated by the kernels as q = x * c, r = fma(-3, q, x),
+    q + r * c with c = RN(1/3) (fpe_kernels.hip::div3; proof in its comment).  The same sequence on the CPU must equal the
+    division bit for bit: 20 M random doubles plus mantissa patterns next to the quotient's rounding boundaries."""
+    import subprocess
+
+    src = os.path.join(os.path.dirname(__file__), "probe", "div3_check.c")
+    exe = str(tmp_path / "div3_check")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm"], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.strip()
+    assert out == "0", f"{out} mismatches between the three-operation form and x / 3.0"
