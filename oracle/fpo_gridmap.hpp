@@ -176,6 +176,15 @@ struct GridMap {
         SubmapInfo info;
         isSuccess = getSubmapInformation(info, p, len, length, position, res, size);
         if (!isSuccess) return sub;
+        // GridMap::getSubmap then asks getBufferRegionsForSubmap for the region's buffer pieces, which fails when
+        // top-left + size reaches past the map (GridMapMath.cpp: `(index + submapBufferSize > bufferSize).any()`).
+        // That happens when a corner bounded onto the map's far edge rounds to the index `size` ((eps - len) / res with
+        // len / res a hair above the integer, e.g. 280 * 0.04 / 0.04): without the test the copy below would read one
+        // row / column past the layer.
+        if (info.topLeft.i + info.size.i > size.i || info.topLeft.j + info.size.j > size.j) {
+            isSuccess = false;
+            return sub;
+        }
         sub.setGeometry(info.length, res, info.position);
         sub.trav.resize((size_t)sub.size.i * sub.size.j);
         for (int j = 0; j < sub.size.j; ++j)

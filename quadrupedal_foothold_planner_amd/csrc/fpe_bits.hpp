@@ -1138,7 +1138,7 @@ __device__ __forceinline__ void fill_yentry(const MapGeom& mg, const PlanConsts&
     const int j1r = idx[4];
     e.j0r = j0r;
     e.njr = j1r - j0r + 1;
-    bool okY = cornersWithin && j0r >= 0 && j0r < mg.cols;
+    bool okY = cornersWithin && j0r >= 0 && j0r < mg.cols && j1r < mg.cols;  // top-left in range, region fits the buffer (getSubmap)
     const double cornerY = cell_pos(mg.baseY, mg.res, j0r) - (-(0.5 * mg.res));
     const double subLenY = static_cast<double>(e.njr) * mg.res;
     const double subOrgY = 0.5 * subLenY;
@@ -1302,7 +1302,7 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
         sm.ni = rbox.ni;
         sm.nj = rbox.nj;
         {
-            const bool okX = (wbits & 0xCu) == 0xCu && sm.i0 >= 0 && sm.i0 < m.g.rows;
+            const bool okX = (wbits & 0xCu) == 0xCu && sm.i0 >= 0 && sm.i0 < m.g.rows && sm.i0 + sm.ni <= m.g.rows;  // (region fits the buffer)
             const double cornerX = cell_pos(m.g.baseX, m.g.res, sm.i0) - (-(0.5 * m.g.res));
             const double subLenX = static_cast<double>(sm.ni) * m.g.res;
             const double subOrgX = 0.5 * subLenX;

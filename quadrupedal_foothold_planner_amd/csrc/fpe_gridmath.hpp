@@ -159,6 +159,7 @@ FPE_HD Submap submap_info(const MapGeom& g, double px, double py, double lx, dou
     const int j1 = index_of_fast(bry, g.orgY, g.posY, g.res, g.rinv);
     if (!(within_axis(brx, g.orgX, g.posX, g.lenX) && within_axis(bry, g.orgY, g.posY, g.lenY))) return s;
     if (!in_range(s.i0, s.j0, g.rows, g.cols)) return s;  // getPositionFromIndex(topLeft) range check
+    if (i1 >= g.rows || j1 >= g.cols) return s;            // getBufferRegionsForSubmap: the region must fit the buffer
     const double cornerX = cell_pos(g.baseX, g.res, s.i0) - (-(0.5 * g.res));
     const double cornerY = cell_pos(g.baseY, g.res, s.j0) - (-(0.5 * g.res));
     s.ni = i1 - s.i0 + 1;

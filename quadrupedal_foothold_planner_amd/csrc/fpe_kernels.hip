@@ -231,6 +231,9 @@ __device__ __forceinline__ Submap submap_from_corners(const MapGeom& g, const BB
     s.baseX = s.baseY = 0.0;
     if (!allWithin) return s;
     if (!in_range(s.i0, s.j0, g.rows, g.cols)) return s;  // getPositionFromIndex(topLeft) range check
+    // getBufferRegionsForSubmap: the region must fit the buffer — a corner bounded onto the far edge can round to the
+    // index `size` (oracle/fpo_gridmap.hpp::getSubmap)
+    if (s.i0 + s.ni > g.rows || s.j0 + s.nj > g.cols) return s;
     const double cornerX = cell_pos(g.baseX, g.res, s.i0) - (-(0.5 * g.res));
     const double cornerY = cell_pos(g.baseY, g.res, s.j0) - (-(0.5 * g.res));
     const double subLenX = static_cast<double>(s.ni) * g.res;

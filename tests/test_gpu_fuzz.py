@@ -67,11 +67,12 @@ def make_case(seed):
 def test_random_differential_campaign():
     planner = FootholdPlanner(0)
     n_cases = int(os.environ.get("FPE_FUZZ_CASES", "120"))
+    seed0 = int(os.environ.get("FPE_FUZZ_SEED", "20000"))
     src = np.zeros(4, np.int64)
     codes = np.zeros(7, np.int64)
     kernels = {}
     for k in range(n_cases):
-        c = make_case(20000 + k)
+        c = make_case(seed0 + k)
         # group "0" = automatic dispatch (the bit-window kernels where they apply); a forced grouping runs the direct kernels
         planner.set_tuning(plan_group=int(c["group"]), literal_discs=int(c["literal"]), no_bits=int(not c["bits"]))
         planner.params = c["params"]
@@ -85,7 +86,7 @@ def test_random_differential_campaign():
         try:
             util.assert_plan_equal(eng, ora)
         except AssertionError as e:
-            raise AssertionError(f"case seed {20000 + k} (res {c['res']}, group {c['group']}, literal {c['literal']}): {e}")
+            raise AssertionError(f"case seed {seed0 + k} (res {c['res']}, group {c['group']}, literal {c['literal']}): {e}")
         src += np.bincount(eng["nominal"]["source"].ravel(), minlength=4)[:4]
         codes += np.bincount(eng["centroid"]["code"].ravel(), minlength=7)[:7]
     planner.close()

@@ -173,6 +173,22 @@ def test_poses_near_and_outside_the_border(planner):
     assert (eng["centroid"]["code"] == 6).any(), "some legs must fall outside the map"
 
 
+def test_centroid_rectangle_reaching_the_index_past_the_far_edge(planner):
+    """Random-campaign case 502981 (round 2): 280 columns at 4 cm centred at y = 4.8865..., legs next to the low-y edge.
+    The rectangle's bounded bottom-right corner rounds to column 280 = size(1); grid_map's getSubmap fails there
+    (getBufferRegionsForSubmap), so the centroid result is code 6 — the bit-window kernels used to scan the in-map
+    columns while the direct kernels and the oracle read one cell past the row (tests/test_oracle_kat.py has the
+    arithmetic).  Both kernel families must agree with the oracle now."""
+    from tests.test_gpu_fuzz import make_case
+    c = make_case(502981)
+    for no_bits in (0, 1):
+        with planner.tuning(plan_group=0, literal_discs=0, no_bits=no_bits):
+            planner.params = c["params"]
+            eng, ora = util.run_both(planner, c["trav"], c["elev"], c["res"], c["poses"], c["n"], position=c["pos"], threads=8)
+            util.assert_plan_equal(eng, ora)
+    assert (ora["centroid"]["code"][5, 0] == 6).any()
+
+
 def test_open_loop_checkFoothold_with_arbitrary_polygons(planner):
     set_params(planner)
     trav, elev = synth.rough_map(400, 400, 0.02, seed=71)

@@ -363,3 +363,39 @@ def test_kat_spiral_skips_empty_rings_when_the_centre_is_outside_the_map():
     ok, i, j = omap.get_index(4.0, 0.0)
     assert (not ok) and (i, j) == (-2, 1)
     assert [tuple(c) for c in omap.spiral_cells(4.0, 0.0, 4.0)] == [(0, 0), (0, 2), (0, 1), (1, 1)]
+
+
+def test_kat_submap_reaching_the_index_past_the_far_edge_fails():
+    """A map of 280 columns at 4 cm centred at y = 4.886504903968108 (a random-campaign case): a centroid rectangle whose
+    bottom-right corner is bounded onto the far (low-y) edge gets the column index -(int)(((y - org) - pos) / 0.04) = 280
+    = size(1), one past the last column — the bounded position's rounding carries the quotient a hair past -280.
+    grid_map's getSubmap then fails in getBufferRegionsForSubmap (the region does not fit the buffer), i.e. cpp:1628-1631
+    returns with the result untouched (code 6) instead of scanning a column that does not exist.  The index is evaluated
+    here with plain Python floats, independently of both implementations (the same request on a map centred at y = 0
+    gives 279); a rectangle that stays inside the same map succeeds."""
+    res, rows, cols = 0.04, 40, 280
+    len_y = cols * res
+    org_y = 0.5 * len_y
+    eps0 = 10.0 * np.finfo(np.float64).eps
+
+    def far_edge_index(pos_y):
+        y_corner = pos_y - org_y - 0.3                # a bottom-right corner below the map
+        shifted = (y_corner - pos_y) + org_y          # boundPositionToRange (SURVEY App. A.2)
+        eps = eps0 * abs(y_corner) if abs(y_corner) > 1.0 else eps0
+        if shifted <= 0:
+            shifted = eps
+        y_bounded = (shifted + pos_y) - org_y
+        return -int(((y_bounded - org_y) - pos_y) / res)   # getIndexFromPosition
+
+    pos_y = 4.886504903968108
+    assert far_edge_index(pos_y) == cols and far_edge_index(0.0) == cols - 1
+    trav = np.ones((rows, cols), np.float32)
+    trav[:, -3:] = 0.1                                # blocked cells next to the edge: a scan would count them
+    omap = fpo.OracleMap(trav, np.zeros_like(trav), res, (0.0, pos_y))
+    p = yaml_params()
+    R = 0.3
+    y = pos_y - org_y + 0.5 * R - 0.05                # centre inside the map, rectangle (width R) overhanging the edge by 5 cm
+    out = omap.centroid_method(p, 0.0, y, R)
+    assert out["code"] == 6, out
+    out2 = omap.centroid_method(p, 0.0, y + 0.2, R)   # 20 cm further inside: the rectangle fits
+    assert out2["code"] != 6, out2
