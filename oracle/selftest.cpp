@@ -70,6 +70,43 @@ int main(int argc, char** argv) {
     CentroidResult c;
     checkFootholdUseCentroidMethod(m, {1e300, 0.0}, 0.1f, p, c);
     if (c.code != 6) return 3;
+    // other geometries: resolutions that are not dyadic fractions, off-origin maps, poses along every edge — a corner
+    // bounded onto the far edge can round to the index `size` there (getSubmap must fail, not copy past the layer;
+    // the 280-column 4 cm map centred at y = 4.8865 is random-campaign case 502981)
+    const double resList[5] = {0.04, 0.03, 0.025, 0.0125, 0.02};
+    for (int gcase = 0; gcase < 10; ++gcase) {
+        GridMap g;
+        const double r2 = resList[gcase % 5];
+        const int rw = gcase == 0 ? 213 : 60 + static_cast<int>(u(rng) * 120), cl = gcase == 0 ? 280 : 60 + static_cast<int>(u(rng) * 120);
+        g.size = {rw, cl};
+        g.res = r2;
+        g.length = {rw * r2, cl * r2};
+        g.position = gcase == 0 ? Vec2{-4.887825252429465, 4.886504903968108} : Vec2{(u(rng) - 0.5) * 12.0, (u(rng) - 0.5) * 12.0};
+        g.trav.resize((size_t)rw * cl);
+        g.elev.resize((size_t)rw * cl);
+        for (size_t k = 0; k < g.trav.size(); ++k) {
+            g.trav[k] = u(rng) < 0.03 ? std::numeric_limits<float>::quiet_NaN() : static_cast<float>(0.3 + 0.7 * u(rng));
+            g.elev[k] = static_cast<float>(0.2 * u(rng));
+        }
+        Params q = p;
+        q.searchRadius = static_cast<float>(5.4 * r2);
+        q.footRadius = static_cast<float>(r2);
+        for (int b = 0; b < 80; ++b) {
+            PoseSpec ps;
+            const int edge = b % 4;  // walk the poses along the four edges, inside and outside
+            const double tpos = u(rng) - 0.5, off = (u(rng) - 0.5) * 0.6;
+            ps.pose[0] = g.position.x + (edge < 2 ? (edge == 0 ? 0.5 : -0.5) * g.length.x + off : tpos * g.length.x);
+            ps.pose[1] = g.position.y + (edge >= 2 ? (edge == 2 ? 0.5 : -0.5) * g.length.y + off : tpos * g.length.y);
+            ps.pose[2] = 0.0;
+            ps.gait = b % 2;
+            for (int l = 0; l < 4; ++l) {
+                ps.legRadius[l] = 0.0f;
+                ps.legPoly[l] = (b % 7 == 0) ? 1 : 0;
+            }
+            planGlobalFootholds(g, q, ps, 4, out);
+            for (const auto& rr : out.nominal) { valid += rr.valid; ++legs; }
+        }
+    }
     std::printf("selftest ok: %ld valid of %ld legs\n", valid, legs);
     return 0;
 }
