@@ -536,6 +536,35 @@ __device__ __forceinline__ bool window_column_rows(const MapGeom& mg, const LegC
     return !g.any(over);
 }
 
+// Distance (columns) from window column cj to the nearest set bit of a row of KW words; >= 1 << 20 when the row is empty.
+template <int KW>
+__device__ __forceinline__ int nearest_set_bit_distance(const uint32_t* row, int cj) {
+    int best = 1 << 20;
+#pragma unroll
+    for (int q = 0; q < KW; ++q) {
+        const int rel = cj - 32 * q;  // the centre column relative to this word
+        const unsigned left = row[q] & bits_to(rel), right = row[q] & bits_from(rel);
+        const int dl = left ? rel - (31 - __builtin_clz(left)) : (1 << 20);
+        const int dr = right ? __builtin_ctz(right) - rel : (1 << 20);
+        best = min(best, min(dl, dr));
+    }
+    return best;
+}
+// Minimum of a small non-negative value (< 128; larger values count as 127) over the lanes of a group, by ballots.
+template <int G>
+__device__ __forceinline__ int group_min7(const Grp<G>& g, int v) {
+    v = min(v, 127);
+    unsigned long long cand = g.ballot(true);
+    int r = 0;
+#pragma unroll
+    for (int b = 6; b >= 0; --b) {
+        const unsigned long long zero = g.ballot(((v >> b) & 1) == 0) & cand;
+        if (zero) cand = zero;
+        else r |= 1 << b;
+    }
+    return r;
+}
+
 // checkCandidateFoothold (cpp:2085-2114) on the window's bit rows: first valid cell in SpiralIterator order.
 template <int G, int NRL, int KW>
 __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head, const LegCtx& c,
@@ -708,62 +737,165 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
         pose_sync<G>();
         E = lb.h0;
     }
-    // (3) candidates in rank order, lane = rank; lowest set ballot bit = argmin of rank
-    const int M = c.nCand;
-    int round = 0;
-    int nDi = 0, nDj = 0, nR = c.nRings;
-    for (int base = 0; base < M; base += G, ++round) {
-        const int k = base + g.sub;
-        bool ok = false;
-        int i = 0, j = 0;
-        int di = 0, dj = 0, r = c.nRings;
-        if (round < kLutHeadRounds) {
-            if (k < M) {
+    // Two forms of the candidate scan, chosen per kernel shape by measurement (A/B on the BASELINE configurations):
+    // 96-bit windows (0.5 cm maps: thousands of candidates, searches that run for tens of rounds) take the straight-line
+    // rounds with the ring skip (cfg-5: 0.98 -> 0.76 ms); the 8-lane kernels take the straight-line rounds without it
+    // (cfg-4: -1.5 %; the skip costs registers the generic variant does not have: +12 %); the 64-bit windows keep the
+    // branchy rounds (cfg-3 loses 6 % / 14 % with the other two: its searches are rare and short).
+    constexpr bool kFlatRounds = KW >= 3 || G == 8;
+    constexpr bool kRingSkip = KW >= 3;
+    if constexpr (kFlatRounds) {
+        // (3) candidates in rank order, lane = rank; lowest set ballot bit = argmin of rank.  Straight-line per round
+        // (per-lane `if` chains are compiled into exec-mask branches): lanes beyond the table and cells outside the map carry
+        // ok = false through unconditional, clamped evaluations; the disc filter of the outer rings and the per-candidate
+        // polygon test of an unfolded polygon sit behind wave-uniform branches.
+        const int M = c.nCand;
+        // (2b) Where the scan can start.  A candidate needs its E bit, and the iterator's ring of a cell is
+        // trunc(sqrt(di^2 + dj^2)) (fpe_host.cpp::build_spiral_table): the nearest E bit of every window row (lane = row)
+        // gives the lowest ring rho that holds any E bit at all.  Ranks below ringStart[rho] cannot be valid: the scan
+        // starts at the round containing ringStart[rho], and a window without an E bit inside the search radius has no
+        // candidate — the searches that used to walk every round to the end (a pose stuck on bad terrain repeats them in
+        // every remaining cycle; with one wavefront per pose such poses set the kernel's duration).
+        int startBase = 0;
+        if constexpr (kRingSkip) {
+            int ringRow = 1 << 20;
+    #pragma unroll
+            for (int k = 0; k < NRL; ++k) {
+                const int ri = g.sub + G * k;
+                const int a = abs(ri - (c.ici - iw0));
+                const int d = nearest_set_bit_distance<KW>(E + min(ri, NR - 1) * KW, c.icj - jw0);
+                const int n2 = a * a + d * d;  // <= 2 * 127^2 when in reach: exact in f32
+                int rr = static_cast<int>(__builtin_sqrtf(static_cast<float>(min(n2, 1 << 16))));
+                rr = (rr + 1) * (rr + 1) <= n2 ? rr + 1 : rr;  // v_sqrt_f32 is 1 ulp: settle floor(sqrt(n2)) exactly
+                rr = rr * rr > n2 ? rr - 1 : rr;
+                if (ri < NR && d < (1 << 20)) ringRow = min(ringRow, rr);
+            }
+            const int rho = group_min7<G>(g, ringRow);
+            if (rho > c.nRings) return false;
+            if (__ballot(rho >= 2) != 0ull) {  // uniform: the usual search (a pass bit in rings 0-1) needs no table lookup
+                const int first = lut.ringStart[min(rho, lut.maxRing)];
+                startBase = rho >= 2 ? (first / G) * G : 0;
+            }
+        }
+        int round = startBase / G;
+        int nDi = 0, nDj = 0, nR = c.nRings;
+        if (__ballot(round >= kLutHeadRounds) != 0ull) {  // uniform: a late start reads its first round's entries here
+            const int kn = min(startBase + g.sub, M - 1);
+            nDi = lut.di[kn];
+            nDj = lut.dj[kn];
+            nR = lut.ring[kn];
+        }
+        for (int base = startBase; base < M; base += G, ++round) {
+            const int k = base + g.sub;
+            const bool live = k < M;
+            int di, dj, r;
+            if (round < kLutHeadRounds) {  // uniform
                 const int e = round == 0 ? head.dij[0] : head.dij[1];
                 di = static_cast<int16_t>(e & 0xFFFF);
                 dj = e >> 16;
                 r = round == 0 ? head.ring[0] : head.ring[1];
+            } else {
+                di = nDi;
+                dj = nDj;
+                r = nR;
             }
-        } else {
-            di = nDi;
-            dj = nDj;
-            r = nR;
-        }
-        if (round + 1 >= kLutHeadRounds) {
-            const int kn = k + G;
-            nR = c.nRings;
-            if (kn < M) {
+            if (round + 1 >= kLutHeadRounds) {
+                // uniform: the next round's table entries, untouched until then (their latency is this round's work);
+                // clamped index instead of a lane-dependent branch
+                const int kn = min(k + G, M - 1);
                 nDi = lut.di[kn];
                 nDj = lut.dj[kn];
                 nR = lut.ring[kn];
             }
-        }
-        if (k < M) {
-            i = c.ici + di;
-            j = c.icj + dj;
-            ok = in_range(i, j, m.g.rows, m.g.cols);
-            // SpiralIterator::generateRing filters rings nRings-1 and nRings by isInside; the centre cell (ring 0)
-            // is pushed unfiltered by the constructor
-            if (ok && r >= 1 && (r == c.nRings || r + 1 == c.nRings)) ok = cell_in_disc(m.g, i, j, c.cx, c.cy, c.R2);
-            if (ok) ok = win_bit<KW>(E, NR, i - iw0, j - jw0) != 0u;
-            if (ok && !polyFolded) {
-                // arbitrary polygon not folded into P: every FINITE cell of the foot disc must lie inside it (cpp:2138)
-                for (int f = 0; f < pc.nFoot; ++f) {
-                    const int qi = i + c.footDa[f], qj = j + c.footDb[f];
-                    if (win_bit<KW>(lb.f, NR, qi - iw0, qj - jw0) == 0u) continue;
-                    if (!polygon_inside_fast(c.vx, c.vy, c.nv, cell_pos(m.g.baseX, m.g.res, qi), cell_pos(m.g.baseY, m.g.res, qj))) {
-                        ok = false;
-                        break;
+            const int i = c.ici + di, j = c.icj + dj;
+            bool ok = live & in_range(i, j, m.g.rows, m.g.cols);
+            // SpiralIterator::generateRing filters rings nRings-1 and nRings by isInside; the centre cell (ring 0) is
+            // pushed unfiltered by the constructor
+            const bool outer = (r >= 1) & ((r == c.nRings) | (r + 1 == c.nRings));
+            if (__ballot(ok & outer) != 0ull) {
+                const bool inDisc = cell_in_disc(m.g, i, j, c.cx, c.cy, c.R2);
+                ok = ok & (!outer | inDisc);
+            }
+            ok = ok & (win_bit<KW>(E, NR, i - iw0, j - jw0) != 0u);
+            if (!polyFolded && __ballot(ok) != 0ull) {
+                if (ok) {
+                    // arbitrary polygon not folded into P: every FINITE cell of the foot disc must lie inside it (cpp:2138)
+                    for (int f = 0; f < pc.nFoot; ++f) {
+                        const int qi = i + c.footDa[f], qj = j + c.footDb[f];
+                        if (win_bit<KW>(lb.f, NR, qi - iw0, qj - jw0) == 0u) continue;
+                        if (!polygon_inside_fast(c.vx, c.vy, c.nv, cell_pos(m.g.baseX, m.g.res, qi), cell_pos(m.g.baseY, m.g.res, qj))) {
+                            ok = false;
+                            break;
+                        }
                     }
                 }
             }
+            const unsigned long long mask = g.ballot(ok);
+            if (mask) {
+                const int l = __builtin_ctzll(mask);
+                wi = g.bcast(i, l);
+                wj = g.bcast(j, l);
+                return true;
+            }
         }
-        const unsigned long long mask = g.ballot(ok);
-        if (mask) {
-            const int l = __builtin_ctzll(mask);
-            wi = g.bcast(i, l);
-            wj = g.bcast(j, l);
-            return true;
+    } else {
+        // (3) candidates in rank order, lane = rank; lowest set ballot bit = argmin of rank
+        const int M = c.nCand;
+        int round = 0;
+        int nDi = 0, nDj = 0, nR = c.nRings;
+        for (int base = 0; base < M; base += G, ++round) {
+            const int k = base + g.sub;
+            bool ok = false;
+            int i = 0, j = 0;
+            int di = 0, dj = 0, r = c.nRings;
+            if (round < kLutHeadRounds) {
+                if (k < M) {
+                    const int e = round == 0 ? head.dij[0] : head.dij[1];
+                    di = static_cast<int16_t>(e & 0xFFFF);
+                    dj = e >> 16;
+                    r = round == 0 ? head.ring[0] : head.ring[1];
+                }
+            } else {
+                di = nDi;
+                dj = nDj;
+                r = nR;
+            }
+            if (round + 1 >= kLutHeadRounds) {
+                const int kn = k + G;
+                nR = c.nRings;
+                if (kn < M) {
+                    nDi = lut.di[kn];
+                    nDj = lut.dj[kn];
+                    nR = lut.ring[kn];
+                }
+            }
+            if (k < M) {
+                i = c.ici + di;
+                j = c.icj + dj;
+                ok = in_range(i, j, m.g.rows, m.g.cols);
+                // SpiralIterator::generateRing filters rings nRings-1 and nRings by isInside; the centre cell (ring 0)
+                // is pushed unfiltered by the constructor
+                if (ok && r >= 1 && (r == c.nRings || r + 1 == c.nRings)) ok = cell_in_disc(m.g, i, j, c.cx, c.cy, c.R2);
+                if (ok) ok = win_bit<KW>(E, NR, i - iw0, j - jw0) != 0u;
+                if (ok && !polyFolded) {
+                    // arbitrary polygon not folded into P: every FINITE cell of the foot disc must lie inside it (cpp:2138)
+                    for (int f = 0; f < pc.nFoot; ++f) {
+                        const int qi = i + c.footDa[f], qj = j + c.footDb[f];
+                        if (win_bit<KW>(lb.f, NR, qi - iw0, qj - jw0) == 0u) continue;
+                        if (!polygon_inside_fast(c.vx, c.vy, c.nv, cell_pos(m.g.baseX, m.g.res, qi), cell_pos(m.g.baseY, m.g.res, qj))) {
+                            ok = false;
+                            break;
+                        }
+                    }
+                }
+            }
+            const unsigned long long mask = g.ballot(ok);
+            if (mask) {
+                const int l = __builtin_ctzll(mask);
+                wi = g.bcast(i, l);
+                wj = g.bcast(j, l);
+                return true;
+            }
         }
     }
     return false;
@@ -1998,6 +2130,7 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
                                                               const fpe_pose* __restrict__ poses, int B, int nCycles, fpe_plan_out out) {
     constexpr int G = 64;
     constexpr int NR = G * NRL;
+    stamp(pc, 6, 14);  // (profiling builds: lifetime of the wavefront, with the stamp after the cycle loop)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = static_cast<int>(threadIdx.x);
     const Grp<G> g(tid);
@@ -2084,6 +2217,7 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
         if (tid == 0 && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = cycleOk ? 1 : 0;
         adjY += pc.drift;  // cpp:1578
     }
+    stamp(pc, 6, 15);
 }
 
 // ---- host side of the bit-window path --------------------------------------------------------------------------
