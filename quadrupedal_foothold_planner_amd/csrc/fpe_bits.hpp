@@ -571,6 +571,11 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                             const WinRows<NRL, KW>& w, const LegBits& lb, const Grp<G>& g, int iw0, int jw0, int& wi, int& wj,
                             const YEntry* ye = nullptr) {
     const int NR = lb.rows;  // allocated window rows (lanes beyond them hold nothing a search can touch)
+    // Every candidate has |di|, |dj| <= nRings.  A centre so far off the map that none of them is inside it — poses that
+    // walked off the map, or a feet polygon degenerated by the centroid track's "no case" (0,0,0) results — has no valid
+    // candidate; without this test such a leg scans every round with in_range false, in every phase of every remaining
+    // cycle (cfg-3: 122 of a pose's 128 searches, 1.3 of its 2.5 M clocks, and the kernel waits for its slowest pose).
+    if (c.ici + c.nRings < 0 || c.ici - c.nRings >= m.g.rows || c.icj + c.nRings < 0 || c.icj - c.nRings >= m.g.cols) return false;
     bool polyFolded = true;  // the polygon test is part of P (rectangle: always; other polygons: see below)
     // (1) per row: P = cells that do NOT fail checkCirclePolygonFoothold's per-cell test (cpp:2132-2138)
     if (c.rect) {
@@ -742,8 +747,13 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
     // rounds with the ring skip (cfg-5: 0.98 -> 0.76 ms); the 8-lane kernels take the straight-line rounds without it
     // (cfg-4: -1.5 %; the skip costs registers the generic variant does not have: +12 %); the 64-bit windows keep the
     // branchy rounds (cfg-3 loses 6 % / 14 % with the other two: its searches are rare and short).
+#ifdef FPE_SKIP_ALL
+    constexpr bool kFlatRounds = true;
+    constexpr bool kRingSkip = KW >= 2;
+#else
     constexpr bool kFlatRounds = KW >= 3 || G == 8;
     constexpr bool kRingSkip = KW >= 3;
+#endif
     if constexpr (kFlatRounds) {
         // (3) candidates in rank order, lane = rank; lowest set ballot bit = argmin of rank.  Straight-line per round
         // (per-lane `if` chains are compiled into exec-mask branches): lanes beyond the table and cells outside the map carry
@@ -759,11 +769,15 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
         int startBase = 0;
         if constexpr (kRingSkip) {
             int ringRow = 1 << 20;
-    #pragma unroll
+#pragma unroll
             for (int k = 0; k < NRL; ++k) {
                 const int ri = g.sub + G * k;
                 const int a = abs(ri - (c.ici - iw0));
-                const int d = nearest_set_bit_distance<KW>(E + min(ri, NR - 1) * KW, c.icj - jw0);
+                uint32_t rowIn[KW];  // the row's E bits on columns inside the map (cells outside it pass every test but are no candidates)
+#pragma unroll
+                for (int q = 0; q < KW; ++q) rowIn[q] = E[min(ri, NR - 1) * KW + q] & range_word(-jw0, m.g.cols - 1 - jw0, q);
+                const bool rowInMap = static_cast<unsigned>(iw0 + ri) < static_cast<unsigned>(m.g.rows);
+                const int d = rowInMap ? nearest_set_bit_distance<KW>(rowIn, c.icj - jw0) : (1 << 20);
                 const int n2 = a * a + d * d;  // <= 2 * 127^2 when in reach: exact in f32
                 int rr = static_cast<int>(__builtin_sqrtf(static_cast<float>(min(n2, 1 << 16))));
                 rr = (rr + 1) * (rr + 1) <= n2 ? rr + 1 : rr;  // v_sqrt_f32 is 1 ulp: settle floor(sqrt(n2)) exactly
@@ -1040,7 +1054,18 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
             nominal_invalid(no, c.cx, c.cy, 2);
             int wi = 0, wj = 0;
             pose_sync<G>();
-            if (spiral_bits<G, NRL, KW>(m, pc, lut, head, c, w, lb, g, iw0, jw0, wi, wj)) {  // cpp:2022
+#ifdef FPE_TRACE
+            const long long tSp0 = __builtin_readcyclecounter();
+#endif
+            const bool spFound = spiral_bits<G, NRL, KW>(m, pc, lut, head, c, w, lb, g, iw0, jw0, wi, wj);
+#ifdef FPE_TRACE
+            if (g.sub == 0 && G == 64) {
+                sh.pad[0] += static_cast<int>((__builtin_readcyclecounter() - tSp0) >> 4);
+                sh.pad[1] += 1;
+                sh.pad[2] += spFound ? 0 : 1;
+            }
+#endif
+            if (spFound) {  // cpp:2022
                 no.valid = 1;
                 no.source = 1;
                 no.row = wi;
@@ -2135,6 +2160,9 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
     const int tid = static_cast<int>(threadIdx.x);
     const Grp<G> g(tid);
     PoseShared& sh = *reinterpret_cast<PoseShared*>(smem);
+#ifdef FPE_TRACE
+    if (tid < 4) sh.pad[tid] = 0;
+#endif
     // per-leg constants of the pose, computed once (lane = leg) instead of once per leg and phase: a division and a
     // dependent rank-table load each
     LegStatic* lsTab = reinterpret_cast<LegStatic*>(smem + sizeof(PoseShared));
@@ -2218,6 +2246,11 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
         adjY += pc.drift;  // cpp:1578
     }
     stamp(pc, 6, 15);
+#ifdef FPE_TRACE
+    stamp_value(pc, 6, 13, static_cast<long long>(sh.pad[0]) << 4);  // clocks inside the spiral search,
+    stamp_value(pc, 6, 12, sh.pad[1]);                               // searches, and searches without a hit
+    stamp_value(pc, 6, 11, sh.pad[2]);
+#endif
 }
 
 // ---- host side of the bit-window path --------------------------------------------------------------------------
