@@ -749,10 +749,10 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
     // branchy rounds (cfg-3 loses 6 % / 14 % with the other two: its searches are rare and short).
 #ifdef FPE_SKIP_ALL
     constexpr bool kFlatRounds = true;
-    constexpr bool kRingSkip = KW >= 2;
+    constexpr bool kRingSkip = true;
 #else
-    constexpr bool kFlatRounds = KW >= 3 || G == 8;
-    constexpr bool kRingSkip = KW >= 3;
+    constexpr bool kFlatRounds = true;
+    constexpr bool kRingSkip = KW >= 2;
 #endif
     if constexpr (kFlatRounds) {
         // (3) candidates in rank order, lane = rank; lowest set ballot bit = argmin of rank.  Straight-line per round
