@@ -428,37 +428,74 @@ __device__ __forceinline__ float centroid_height_bits(const PlanConsts& pc, cons
 }
 
 // 64-lane kernels: the three mean heights of a leg (centre disc, default-track disc, centroid result; cpp:2520-2554)
-// in ONE pass.  Each disc's visited elevations were compacted into its own LDS array in CircleIterator order
-// (ordered_push); here lanes 0-15 walk the first array, 16-31 the second, 32-63 the third — the same instruction
-// stream performs the three strictly sequential f32 sums side by side, and the f32 division runs once.
+// in ONE pass over three LDS arrays of terms in CircleIterator order; the f32 division runs once.
+// Ordered f32 sum of a disc's visited elevations (getFootholdMeanHeight, cpp:2520-2554) prepared for a serial pass of
+// PURE additions: what the reference decides per element is decided here while the elements still sit on different
+// lanes — the element's term (the value, or -0.0f when >= 10, cpp:2539: s + (-0.0f) == s for every s) is what gets
+// compacted into LDS, the count of summed elements is a ballot popcount, and `last` (the mean's fallback when nothing
+// was summed, cpp:2547-2551) is the value of the highest visited lane of the last non-empty round.
+struct TermSum {
+    float* terms;  // >= (cells of the disc bounding box) floats, 16-byte aligned
+    int n;         // elements visited
+    int cnt;       // elements < 10
+    float last;
+};
 template <int G>
-__device__ __forceinline__ void heights3_finish(const Grp<G>& g, const float* hs, int nA, int nB, int nC, double h, float& zA,
-                                                float& zB, float& zC) {
-    const int d = min(g.sub >> 4, 2);
-    const int n = d == 0 ? nA : (d == 1 ? nB : nC);
-    const float* p = hs + d * kBitsMaxBoxCells;
-    float sum = 0.0f, last = 0.0f;
-    int cnt = 0;
-    const int nMax = max(nA, max(nB, nC));
-    for (int t = 0; t < nMax; t += 4) {
-        const float4 q = *reinterpret_cast<const float4*>(p + t);
-        if (t + 0 < n) ordered_step(q.x, sum, last, cnt);
-        if (t + 1 < n) ordered_step(q.y, sum, last, cnt);
-        if (t + 2 < n) ordered_step(q.z, sum, last, cnt);
-        if (t + 3 < n) ordered_step(q.w, sum, last, cnt);
+__device__ __forceinline__ void term_push(const Grp<G>& g, TermSum& ts, bool vis, float v) {
+    const unsigned long long mask = g.ballot(vis);
+    const int rank = __builtin_popcountll(mask & ((1ull << g.sub) - 1ull));
+    const bool inc = v < 10;
+    if (vis) ts.terms[ts.n + rank] = inc ? v : -0.0f;
+    ts.n += __builtin_popcountll(mask);
+    ts.cnt += __builtin_popcountll(g.ballot(vis && inc));
+    if (mask) ts.last = g.bcast(v, 63 - __builtin_clzll(mask));
+}
+template <int G>
+__device__ __forceinline__ void push_disc(const Grp<G>& g, TermSum& ts, const DiscLoads& d) {
+#pragma unroll
+    for (int r = 0; r < disc_rounds<G>(); ++r) {
+        const float v = __builtin_isfinite(d.e[r]) ? d.e[r] : 0.0f;  // cpp:2532-2537
+        term_push(g, ts, d.vis[r] != 0, v);
     }
+}
+// The three sums of a leg side by side: lanes 0-15 walk the first array, 16-31 the second, 32-63 the third — the same
+// instruction stream for all three.  Eight terms per pass (two 16-byte LDS reads, eight dependent additions); the arrays
+// are padded with -0.0f to the common length first (they hold kBitsMaxBoxCells, a multiple of 8, floats each).
+template <int G>
+__device__ __forceinline__ void heights3_finish(const Grp<G>& g, float* hs, const TermSum& A, const TermSum& B, const TermSum& C, double h,
+                                                float& zA, float& zB, float& zC) {
+    static_assert(kBitsMaxBoxCells % 8 == 0, "heights3_finish reads whole groups of eight");
+    const int nMax = max(A.n, max(B.n, C.n));
+    const int padEnd = (nMax + 7) & ~7;
+    {
+        const int kA = A.n + g.sub, kB = B.n + g.sub, kC = C.n + g.sub;
+        if (kA < padEnd) hs[kA] = -0.0f;
+        if (kB < padEnd) hs[kBitsMaxBoxCells + kB] = -0.0f;
+        if (kC < padEnd) hs[2 * kBitsMaxBoxCells + kC] = -0.0f;
+    }
+    pose_sync<G>();
+    const int d = min(g.sub >> 4, 2);
+    const float* p = hs + d * kBitsMaxBoxCells;
+    float sum = 0.0f;
+    for (int t0 = 0; t0 < padEnd; t0 += 8) {
+        const float4 q0 = *reinterpret_cast<const float4*>(p + t0), q1 = *reinterpret_cast<const float4*>(p + t0 + 4);
+        sum = sum + q0.x;
+        sum = sum + q0.y;
+        sum = sum + q0.z;
+        sum = sum + q0.w;
+        sum = sum + q1.x;
+        sum = sum + q1.y;
+        sum = sum + q1.z;
+        sum = sum + q1.w;
+    }
+    const int cntBC = d == 1 ? B.cnt : C.cnt;
+    const int cnt = d == 0 ? A.cnt : cntBC;
+    const float lastBC = d == 1 ? B.last : C.last;
+    const float last = d == 0 ? A.last : lastBC;
     const float z = finish_mean(sum, last, cnt, h);
     zA = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), 0));
     zB = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), 16));
     zC = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), 32));
-}
-template <int G>
-__device__ __forceinline__ void push_disc(const Grp<G>& g, OrderedSum& os, const DiscLoads& d) {
-#pragma unroll
-    for (int r = 0; r < disc_rounds<G>(); ++r) {
-        const float v = __builtin_isfinite(d.e[r]) ? d.e[r] : 0.0f;  // cpp:2532-2537
-        ordered_push(g, os, d.vis[r] != 0, v);
-    }
 }
 
 // The reference rectangle in index space.  Cell centres x_i = base + res * (-i) are non-increasing in i, so
@@ -1022,13 +1059,13 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
         pose_sync<G>();  // lb doubles as scratch below
         bool unused;
         float zCentre = 0.0f;
-        OrderedSum osA{nullptr, 0}, osB{nullptr, 0}, osC{nullptr, 0};
+        TermSum osA{nullptr, 0, 0, 0.0f}, osB{nullptr, 0, 0, 0.0f}, osC{nullptr, 0, 0, 0.0f};
         if constexpr (G == 64) {
             // the three ordered height sums run side by side at the end of the leg (heights3_finish): here the visited
             // elevations of the two discs around known centres are only compacted into LDS
-            osA.scratch = lb.hs;
-            osB.scratch = lb.hs + kBitsMaxBoxCells;
-            osC.scratch = lb.hs + 2 * kBitsMaxBoxCells;
+            osA.terms = lb.hs;
+            osB.terms = lb.hs + kBitsMaxBoxCells;
+            osC.terms = lb.hs + 2 * kBitsMaxBoxCells;
             push_disc(g, osA, dc);
             if (dfltUsable) push_disc(g, osB, dd);
         } else {
@@ -1079,11 +1116,12 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
         if constexpr (G == 64) {
             if (cp.needDisc != 0) {
                 const float v = __builtin_isfinite(cp.e[0]) ? cp.e[0] : 0.0f;
-                ordered_push(g, osC, cp.vis[0] != 0, v);
+                term_push(g, osC, cp.vis[0] != 0, v);
             }
-            pose_sync<G>();
+            stamp(pc, cyc, 11);
             float zB, zC;
-            heights3_finish(g, lb.hs, osA.n, osB.n, osC.n, pc.h, zCentre, zB, zC);
+            heights3_finish(g, lb.hs, osA, osB, osC, pc.h, zCentre, zB, zC);
+            stamp(pc, cyc, 12);
             if (dfltUsable) zDefault = zB;
             if (cp.needDisc != 0) cp.o.z = zC;
             else if (cp.o.code == 0) cp.o.z = zCentre;  // whole region valid: the height at the centre (cpp:1687)
@@ -1106,6 +1144,7 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
             sh.nxt[1][leg][0] = co.x;  sh.nxt[1][leg][1] = co.y;  sh.nxt[1][leg][2] = static_cast<double>(co.z);
             sh.nxt[2][leg][0] = no.x;  sh.nxt[2][leg][1] = no.y;  sh.nxt[2][leg][2] = static_cast<double>(no.z);
         }
+        stamp(pc, cyc, 13);
         if (live) {
             const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
             if (out.nominal) store_foothold(out.nominal + o, no, leg, cyc);
