@@ -702,12 +702,19 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
     // (2) erosion with the foot-disc offset table: E bit (row, col) = AND_k P(row + da_k, col + db_k)
     const uint32_t* E = lb.a;
     if (pc.nFoot > 1 && pc.nHW > 0) {
+        // the two small tables in registers, fetched once (indexed inside the loops below they are a scalar load and a
+        // wait per iteration): hwList[4] as one word, hwIdx[16] as two
+        uint32_t hwListW;
+        unsigned long long hwIdxLo, hwIdxHi;
+        __builtin_memcpy(&hwListW, pc.hwList, 4);
+        __builtin_memcpy(&hwIdxLo, pc.hwIdx, 8);
+        __builtin_memcpy(&hwIdxHi, pc.hwIdx + 8, 8);
         // row-interval form: the disc's row +-a holds the columns [-w(a), w(a)], so
         //   E(row) = AND_a H_w(a)(P(row + a)) & H_w(a)(P(row - a)),   H_w(x) bit j = AND_{|t| <= w} x bit j + t,
         // and H_w is built by doubling (x & x>>1, & >>2, ...) — a handful of shifts per distinct width instead of one
         // shift per offset (45 offsets on a 0.5 cm map)
         for (int hw = 0; hw < pc.nHW; ++hw) {
-            const int wdt = pc.hwList[hw];
+            const int wdt = static_cast<int>((hwListW >> (8 * hw)) & 0xFFu);
             const int L = 2 * wdt + 1;
 #pragma unroll
             for (int k = 0; k < NRL; ++k) {
@@ -741,7 +748,8 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
 #pragma unroll
             for (int q = 0; q < KW; ++q) e[q] = ~0u;
             for (int a = 0; a <= pc.footReach; ++a) {
-                const uint32_t* hrow = lb.h0 + pc.hwIdx[a] * lb.hStride;
+                const int hwOfRow = static_cast<int>(((a < 8 ? hwIdxLo : hwIdxHi) >> (8 * (a & 7))) & 0xFFu);
+                const uint32_t* hrow = lb.h0 + hwOfRow * lb.hStride;
                 const uint32_t* up = hrow + min(max(ri - a, 0), NR - 1) * KW;
                 const uint32_t* dn = hrow + min(max(ri + a, 0), NR - 1) * KW;
 #pragma unroll
