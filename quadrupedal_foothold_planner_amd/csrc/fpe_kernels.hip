@@ -816,16 +816,22 @@ __device__ __forceinline__ void disc_issue(const DevMap& m, const PlanConsts& pc
         d.vis[r] = false;
         d.e[r] = 0.0f;
         d.t[r] = 0.0f;
-        if (t < nb) {
-            int a, bq;
-            divmod_small(t, bb.nj, njInv, a, bq);
-            const int i = bb.i0 + a, j = bb.j0 + bq;
-            if (in_range(i, j, m.g.rows, m.g.cols) && cell_in_disc(m.g, i, j, cx, cy, pc.rf2)) {
-                d.vis[r] = true;
-                const size_t off = static_cast<size_t>(i) * m.g.cols + j;
-                d.e[r] = m.elev[off];
-                if (kCheck) d.t[r] = m.trav[off];
-            }
+        if (__ballot(t < nb) == 0ull) continue;  // wave-uniform: a round past every box of the wavefront
+        // one level of control flow per round (nested per-lane tests are compiled into exec-mask mazes): the cell of slot t
+        // by the branch-free form of divmod_small (estimate off by at most one), membership evaluated for every lane
+        const int njS = max(bb.nj, 1);
+        int a = static_cast<int>(static_cast<float>(t) * njInv);
+        int bq = t - a * njS;
+        const int fix = (bq >= njS ? 1 : 0) - (bq < 0 ? 1 : 0);
+        a += fix;
+        bq -= fix * njS;
+        const int i = bb.i0 + a, j = bb.j0 + bq;
+        const bool vis = (t < nb) & in_range(i, j, m.g.rows, m.g.cols) & cell_in_disc(m.g, i, j, cx, cy, pc.rf2);
+        d.vis[r] = vis;
+        if (vis) {
+            const size_t off = static_cast<size_t>(i) * m.g.cols + j;
+            d.e[r] = m.elev[off];
+            if (kCheck) d.t[r] = m.trav[off];
         }
     }
 }
