@@ -573,6 +573,19 @@ __device__ __forceinline__ bool window_column_rows(const MapGeom& mg, const LegC
     return !g.any(over);
 }
 
+// Inclusive OR-scan over the 64 lanes of a wavefront (lane l gets the OR of lanes 0..l): four shifts inside the 16-lane
+// DPP rows, then the last lane of a row into the next row, then lane 31 into the upper half.
+__device__ __forceinline__ unsigned wave_or_scan(unsigned v) {
+    int x = static_cast<int>(v);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);   // row_shr:1
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);   // row_shr:2
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);   // row_shr:4
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);   // row_shr:8
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return static_cast<unsigned>(x);
+}
+
 // Distance (columns) from window column cj to the nearest set bit of a row of KW words; >= 1 << 20 when the row is empty.
 template <int KW>
 __device__ __forceinline__ int nearest_set_bit_distance(const uint32_t* row, int cj) {
@@ -641,38 +654,52 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             folded = window_column_rows<G, KW>(m.g, c, g, jw0, lb.colRows);
             if (folded) {
                 pose_sync<G>();
-                int lo[(32 * KW + G - 1) / G], hi[(32 * KW + G - 1) / G];
+                // Column intervals -> row masks without a ballot per row.  Column c is inside for the rows [lo_c, hi_c): it
+                // ENTERS at row lo_c and LEAVES at row hi_c.  Each column sets its bit in the "enters" word of its first
+                // row and in the "leaves" word of its end row (LDS atomic OR; two scratch row arrays that are free here);
+                // an inclusive OR-scan over the rows (lane = row: four row shifts and two row broadcasts per word) then
+                // gives, for every row, the columns that have entered and the columns that have left:
+                //     inside(row) = entered(row) & ~left(row)
+                // — the same set as the per-row comparison i >= lo_c && i < hi_c, by construction.
+                uint32_t* entersAt = lb.f;
+                uint32_t* leavesAt = lb.h0;
+                for (int idx = g.sub; idx < NR * KW; idx += G) {
+                    entersAt[idx] = 0u;
+                    leavesAt[idx] = 0u;
+                }
+                pose_sync<G>();
 #pragma unroll
                 for (int u = 0; u < (32 * KW + G - 1) / G; ++u) {
                     const int col = g.sub + G * u;
-                    const bool live = col < 32 * KW;
-                    lo[u] = live ? lb.colRows[2 * min(col, 32 * KW - 1)] : 0;
-                    hi[u] = live ? lb.colRows[2 * min(col, 32 * KW - 1) + 1] : 0;
+                    if (col < 32 * KW) {
+                        const int rl = lb.colRows[2 * col] - iw0, rh = lb.colRows[2 * col + 1] - iw0;  // window rows [rl, rh)
+                        const uint32_t bit = 1u << (col & 31);
+                        const int wq = col >> 5;
+                        if (rl < rh && rh > 0 && rl < NR) {
+                            atomicOr(&entersAt[max(rl, 0) * KW + wq], bit);
+                            if (rh < NR) atomicOr(&leavesAt[rh * KW + wq], bit);
+                        }
+                    }
                 }
+                pose_sync<G>();
                 unsigned inside[NRL][KW];
-#pragma unroll
-                for (int k = 0; k < NRL; ++k)
-#pragma unroll
-                    for (int q = 0; q < KW; ++q) inside[k][q] = 0u;
                 // rows a candidate's foot disc can touch: within nRings + footReach rows of the centre row (winH)
                 const int reachRows = min(c.nRings + pc.footReach, pc.winH);
                 const int rowLo = pc.winH - reachRows, rowHi = min(pc.winH + reachRows + 1, NR);  // NR: allocated rows
+                unsigned carryIn[KW], carryOut[KW];
+#pragma unroll
+                for (int q = 0; q < KW; ++q) carryIn[q] = carryOut[q] = 0u;
 #pragma unroll
                 for (int k = 0; k < NRL; ++k) {
-                    const int rBeg = max(rowLo - G * k, 0), rEnd = min(rowHi - G * k, G);
-                    for (int r = rBeg; r < rEnd; ++r) {
-                        const int i = iw0 + r + G * k;
-                        unsigned wd[KW];
+                    const int ri = g.sub + G * k;
 #pragma unroll
-                        for (int u = 0; u < (32 * KW + G - 1) / G; ++u) {
-                            const unsigned long long mk = __ballot(i >= lo[u] && i < hi[u]);
-                            if (2 * u < KW) wd[2 * u] = static_cast<unsigned>(mk);
-                            if (2 * u + 1 < KW) wd[2 * u + 1] = static_cast<unsigned>(mk >> 32);
-                        }
-                        if (g.sub == r) {
-#pragma unroll
-                            for (int q = 0; q < KW; ++q) inside[k][q] = wd[q];
-                        }
+                    for (int q = 0; q < KW; ++q) {
+                        unsigned en = ri < NR ? entersAt[ri * KW + q] : 0u, lv = ri < NR ? leavesAt[ri * KW + q] : 0u;
+                        en = wave_or_scan(en) | carryIn[q];
+                        lv = wave_or_scan(lv) | carryOut[q];
+                        carryIn[q] = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(en), 63));
+                        carryOut[q] = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(lv), 63));
+                        inside[k][q] = (ri >= rowLo && ri < rowHi) ? (en & ~lv) : 0u;
                     }
                 }
 #pragma unroll
