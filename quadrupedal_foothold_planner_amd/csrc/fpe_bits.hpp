@@ -545,19 +545,29 @@ __device__ __forceinline__ bool window_column_rows(const MapGeom& mg, const LegC
     for (int b = g.sub; b < 32 * KW; b += G) {
         const double py = cell_pos(mg.baseY, mg.res, jw0 + b);
         double X[2] = {ninf, ninf};
-        int n = 0;
+        // the (at most two) edges that straddle py, found with comparisons only; their abscissae afterwards — two division
+        // sequences per column pass instead of one per polygon edge (the lanes' columns straddle different edges)
+        int n = 0, e0 = 0, e1 = 0;
         for (int i = 0, j = c.nv - 1; i < c.nv; j = i++) {
-            if ((c.vy[i] > py) != (c.vy[j] > py)) {
-                const double ex = c.vx[j] - c.vx[i];
-                const double t = py - c.vy[i];
-                double xi = c.vx[i];
-                if (!(ex == 0.0 && fabs(t) <= DBL_MAX)) xi = ex * t / (c.vy[j] - c.vy[i]) + c.vx[i];  // polygon_inside_fast
-                if (n == 0) X[0] = xi;
-                else if (n == 1) X[1] = xi;
-                ++n;
-            }
+            const bool cross = (c.vy[i] > py) != (c.vy[j] > py);
+            e1 = (cross && n == 1) ? i : e1;
+            e0 = (cross && n == 0) ? i : e0;
+            n += cross ? 1 : 0;
         }
         over |= n > 2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (n > u) {
+                const int i = u == 0 ? e0 : e1;
+                const int j = i == 0 ? c.nv - 1 : i - 1;
+                const double vxi = c.vx[i], vyi = c.vy[i], vxj = c.vx[j], vyj = c.vy[j];
+                const double ex = vxj - vxi;
+                const double t = py - vyi;
+                double xi = vxi;
+                if (!(ex == 0.0 && fabs(t) <= DBL_MAX)) xi = ex * t / (vyj - vyi) + vxi;  // polygon_inside_fast
+                X[u] = xi;
+            }
+        }
         int t[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
