@@ -849,7 +849,24 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
         // candidate — the searches that used to walk every round to the end (a pose stuck on bad terrain repeats them in
         // every remaining cycle; with one wavefront per pose such poses set the kernel's duration).
         int startBase = 0;
+        bool nearHit = false;
         if constexpr (kRingSkip) {
+            // the usual search has a pass bit within three rows and columns of the centre (ring <= 4: among the first 49
+            // ranks, i.e. in the first round of 64): one ballot spares it the ring computation below
+            bool near = false;
+#pragma unroll
+            for (int k = 0; k < NRL; ++k) {
+                const int ri = g.sub + G * k;
+                const int cj = c.icj - jw0;
+                uint32_t bits = 0u;
+#pragma unroll
+                for (int q = 0; q < KW; ++q)
+                    bits |= E[min(ri, NR - 1) * KW + q] & range_word(max(cj - 3, -jw0), min(cj + 3, m.g.cols - 1 - jw0), q);
+                near |= ri < NR && abs(ri - (c.ici - iw0)) <= 3 && bits != 0u && static_cast<unsigned>(iw0 + ri) < static_cast<unsigned>(m.g.rows);
+            }
+            nearHit = g.any(near);
+        }
+        if (kRingSkip && !nearHit) {
             int ringRow = 1 << 20;
 #pragma unroll
             for (int k = 0; k < NRL; ++k) {
