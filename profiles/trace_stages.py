@@ -41,3 +41,5 @@ if t[:,3,11].any():
     print("prologue detail: entry -> pose arrived", np.mean(t[:,3,11]-t[:,1,11]), " -> rank-table head", np.mean(t[:,3,12]-t[:,3,11]), " -> per-leg constants", np.mean(t[:,3,13]-t[:,3,12]),
           " -> offset table copied", np.mean(t[:,3,14]-t[:,3,13]), " -> stance in LDS", np.mean(t[:,1,12]-t[:,3,14]))
 print("flush", np.mean(t[:,2,12]-t[:,2,11]), " last commit -> flush start", np.mean(t[:,2,11]-t[:,7,10]))
+life = t[:, 2, 12] - t[:, 1, 11]
+print("wavefront lifetime (entry -> last flush) over the first 256 blocks: mean", life.mean(), "median", np.median(life), "p90", np.percentile(life, 90), "max", life.max(), " mean/max", life.mean() / life.max())

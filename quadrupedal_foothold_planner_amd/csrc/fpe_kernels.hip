@@ -77,9 +77,16 @@ struct Grp {
         return (m >> gbase) & ((1ull << (G & 63)) - 1ull);
     }
     __device__ __forceinline__ bool any(bool p) const { return ballot(p) != 0ull; }
+    // Value of lane l of the group.  Every caller derives l from a group ballot (or passes a constant), so l is uniform
+    // over the group; with one group per wavefront that is a v_readlane (no LDS round trip) instead of a ds_bpermute.
     template <class T>
     __device__ __forceinline__ T bcast(T v, int l) const {
-        return __shfl(v, gbase + l);
+        if constexpr (G == 64 && sizeof(T) == 4) {
+            const int r = __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), __builtin_amdgcn_readfirstlane(l));
+            return __builtin_bit_cast(T, r);
+        } else {
+            return __shfl(v, gbase + l);
+        }
     }
 };
 
@@ -204,6 +211,8 @@ struct Corners {
         if constexpr (G <= 32) {
             constexpr int pattern = ((~(G - 1)) & 0x1F) | ((ID % L) << 5);
             return __builtin_amdgcn_ds_swizzle(idx[ID / L], pattern);
+        } else if constexpr (G == 64) {
+            return __builtin_amdgcn_readlane(idx[ID / L], ID % L);  // one group per wavefront: a fixed lane, a scalar result
         } else {
             return g.bcast(idx[ID / L], ID % L);
         }
