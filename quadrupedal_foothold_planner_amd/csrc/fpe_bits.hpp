@@ -626,7 +626,9 @@ __device__ __forceinline__ int group_min7(const Grp<G>& g, int v) {
 }
 
 // checkCandidateFoothold (cpp:2085-2114) on the window's bit rows: first valid cell in SpiralIterator order.
-template <int G, int NRL, int KW>
+// kOneCellFoot: the caller is a 3x3-only kernel, launched for one-cell foot discs only (launch_plan_bits): the erosion
+// is compiled out (its code and live scalars cost the chain of those kernels 1 us of register allocation otherwise).
+template <int G, int NRL, int KW, bool kOneCellFoot = false>
 __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const LutHead& head, const LegCtx& c,
                             const WinRows<NRL, KW>& w, const LegBits& lb, const Grp<G>& g, int iw0, int jw0, int& wi, int& wj,
                             const YEntry* ye = nullptr) {
@@ -738,7 +740,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
     pose_sync<G>();
     // (2) erosion with the foot-disc offset table: E bit (row, col) = AND_k P(row + da_k, col + db_k)
     const uint32_t* E = lb.a;
-    if (pc.nFoot > 1 && pc.nHW > 0) {
+    if (!kOneCellFoot && pc.nFoot > 1 && pc.nHW > 0) {
         // the two small tables in registers, fetched once (indexed inside the loops below they are a scalar load and a
         // wait per iteration): hwList[4] as one word, hwIdx[16] as two
         uint32_t hwListW;
@@ -797,7 +799,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                 if (ri < NR) lb.a[ri * KW + q] = e[q];  // the P rows are dead: E takes their place
         }
         pose_sync<G>();
-    } else if (pc.nFoot > 1) {
+    } else if (!kOneCellFoot && pc.nFoot > 1) {
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
             const int ri = g.sub + G * k;
@@ -1622,7 +1624,7 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
             nominal_invalid(no, c.cx, c.cy, 2);
             int wi = 0, wj = 0;
             pose_sync<G>();
-            if (spiral_bits<G, NRL, KW>(m, pc, lut, head, c, w, lb, g, iw0, jw0, wi, wj, &ye)) {  // cpp:2022
+            if (spiral_bits<G, NRL, KW, kMid>(m, pc, lut, head, c, w, lb, g, iw0, jw0, wi, wj, &ye)) {  // cpp:2022
                 no.valid = 1;
                 no.source = 1;
                 no.row = wi;
@@ -1965,7 +1967,7 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
                 }
                 pose_sync<G>();
             }
-            found = spiral_bits<G, NRL, KW>(m, pc, lut, head, c, w, lb, g, iw0, jw0, wi, wj, &yeIn);  // cpp:2022
+            found = spiral_bits<G, NRL, KW, true>(m, pc, lut, head, c, w, lb, g, iw0, jw0, wi, wj, &yeIn);  // cpp:2022
             pose_sync<G>();
         }
         if (found) {
