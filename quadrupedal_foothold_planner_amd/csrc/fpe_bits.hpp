@@ -1298,9 +1298,15 @@ __device__ __forceinline__ float unit_mean9(const float* e, uint32_t vis, double
     return finish_mean(sum, last, cnt, h);
 }
 // One (leg, cycle) unit per lane: heights and the four output records of that unit.
-__device__ __forceinline__ void flush_unit(const DevMap& m, const PlanConsts& pc, const Unit& u, const YEntry& ye, int b, int cyc,
+__device__ __forceinline__ void flush_unit(const DevMap& m, const PlanConsts& pc, const Unit& uLds, const YEntry& yeLds, int b, int cyc,
                                            int leg, int nCycles, uint32_t okBits, const fpe_plan_out& out) {
     const MapGeom& mg = m.g;
+    // the unit and its y entry in registers by one batch of 16-byte LDS reads (read field by field the reads are
+    // interleaved with their uses: a dozen serial round trips)
+    Unit u;
+    YEntry ye;
+    __builtin_memcpy(&u, &uLds, sizeof(Unit));
+    __builtin_memcpy(&ye, &yeLds, sizeof(YEntry));
     // the centroid result's own cell, when the chain left its elevation to be read here (issued first: the three
     // height sums below cover the round trip)
     float eC = u.eC;
