@@ -1919,19 +1919,19 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
             }
             pose_sync<G>();
             const int rowW = ici - iw0, colW = icj - jw0;  // the centre inside the window (winH, winH)
-            int eWin = 0;
-#pragma unroll
-            for (int round = 0; round < kLutHeadRounds; ++round) {
-                const int e = head.dij[round];
-                const int di = static_cast<int16_t>(e & 0xFFFF), dj = e >> 16;
-                const bool inMap = in_range(ici + di, icj + dj, m.g.rows, m.g.cols);
-                const bool ok = !found && inMap && win_bit<KW>(lb.a, NR, rowW + di, colW + dj) != 0u;
-                const unsigned mask = static_cast<unsigned>(g.ballot(ok));
-                const int l = __builtin_ctz(mask | 0x100u);
-                const int eSel = g.bcast(e, l & 7);
-                eWin = (!found && mask != 0u) ? eSel : eWin;
-                found = found || mask != 0u;
-            }
+            static_assert(kLutHeadRounds == 2, "both register rounds are evaluated side by side");
+            // both rounds' pass bits in flight together, one broadcast of the winning entry
+            const int e0 = head.dij[0], e1 = head.dij[1];
+            const int di0 = static_cast<int16_t>(e0 & 0xFFFF), dj0 = e0 >> 16, di1 = static_cast<int16_t>(e1 & 0xFFFF), dj1 = e1 >> 16;
+            const unsigned bit0 = win_bit<KW>(lb.a, NR, rowW + di0, colW + dj0), bit1 = win_bit<KW>(lb.a, NR, rowW + di1, colW + dj1);
+            const bool ok0 = in_range(ici + di0, icj + dj0, m.g.rows, m.g.cols) & (bit0 != 0u);
+            const bool ok1 = in_range(ici + di1, icj + dj1, m.g.rows, m.g.cols) & (bit1 != 0u);
+            const unsigned m0 = static_cast<unsigned>(g.ballot(ok0)), m1 = static_cast<unsigned>(g.ballot(ok1));
+            const bool first = m0 != 0u;
+            const unsigned mSel = first ? m0 : m1;
+            const int eMine = first ? e0 : e1;
+            const int eWin = g.bcast(eMine, __builtin_ctz(mSel | 0x100u) & 7);
+            found = (m0 | m1) != 0u;
             wi = ici + static_cast<int16_t>(eWin & 0xFFFF);
             wj = icj + (eWin >> 16);
             searched = lk.nCand <= G * kLutHeadRounds;  // nothing beyond the two rounds
