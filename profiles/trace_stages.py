@@ -43,3 +43,11 @@ if t[:,3,11].any():
 print("flush", np.mean(t[:,2,12]-t[:,2,11]), " last commit -> flush start", np.mean(t[:,2,11]-t[:,7,10]))
 life = t[:, 2, 12] - t[:, 1, 11]
 print("wavefront lifetime (entry -> last flush) over the first 256 blocks: mean", life.mean(), "median", np.median(life), "p90", np.percentile(life, 90), "max", life.max(), " mean/max", life.mean() / life.max())
+# cold start: the same stages for the first cycle against the later ones (instruction and data caches are cold per launch)
+nc = min(n, 8)
+print("cycle total by cycle index:", " ".join(f"{tot[:, c].mean():.0f}" for c in range(nc)))
+prev = 0
+for p in pts[1:]:
+    dt = t[:, :nc, p] - t[:, :nc, prev]
+    print(f"  {names[prev]:22s} -> {names[p]:22s} cycle 0 {dt[:,0].mean():7.0f}  cycle 1 {dt[:,1].mean() if nc>1 else 0:7.0f}  cycles 2.. {dt[:,2:].mean() if nc>2 else 0:7.0f}")
+    prev = p

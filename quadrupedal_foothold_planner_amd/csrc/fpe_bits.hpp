@@ -1767,6 +1767,11 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     const double nx0 = swizzle_f64<kKeep | (5 << 5)>(nxq);  // default track
     const double nx2 = swizzle_f64<kKeep | (7 << 5)>(nxq);  // nominal track (search polygon)
     const int j0d = ye.j0d, icj = ye.jc;
+    // the window rows are requested before anything else looks at the indices (win_issue clamps whatever it is given;
+    // the rare path below discards them): the round trip runs under the box tests, the ballot and the submap arithmetic
+    const int iw0 = ici - pc.winH, jw0 = icj - pc.winH;
+    uint4 grp[NRL][KW + 1];
+    win_issue<G, NRL, KW>(bm, m.g, g, iw0, jw0, grp);
     // both foot-disc boxes: 3x3 and clear of the map's outermost rows / columns (not clamped, inside the map)
     // (bitwise: a short-circuit chain is compiled into exec-mask branches)
     const int lowest = min(min(i0d, i0f), j0d), lastRow = max(i0d, i0f) + 4;
@@ -1793,11 +1798,8 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
         sm.baseX = subPosX + (subOrgX - 0.5 * m.g.res);
         sm.baseY = ye.sbaseY;
     }
-    const int iw0 = ici - pc.winH, jw0 = icj - pc.winH;
     stamp(pc, cyc, 2);
-    // ---- one memory round trip: window rows, and the elevation of both discs (lane = cell t of the 3x3 boxes) ----
-    uint4 grp[NRL][KW + 1];
-    win_issue<G, NRL, KW>(bm, m.g, g, iw0, jw0, grp);
+    // ---- same round trip: the elevation of both discs (lane = cell t of the 3x3 boxes) ----
     const int t = g.sub + (g.sub >= 4 ? 1 : 0);
     const int a = t >= 6 ? 2 : (t >= 3 ? 1 : 0);
     const int bq = t - 3 * a;
