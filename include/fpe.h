@@ -184,6 +184,36 @@ int fpe_upload_map_device(fpe_handle h, const fpe_map_desc* desc, const float* d
                           const float* d_elevation, void* stream);
 int fpe_map_info(fpe_handle h, fpe_map_desc* out); /* geometry of the current snapshot */
 
+/* ---- the producer of the map: elevation layer -> traversability layer -----------------
+ * The reference starts leggedrobotics/traversability_estimation (launch/mapping.launch:12-13,
+ * launch/all.launch:21-22, README.md:29) and subscribes to its output (cpp:188); package and filter
+ * configuration are not part of the reference, no version is pinned.  These entry points restate that package's
+ * published default chain (grid_map_filters NormalVectorsFilter, area method; SlopeFilter, StepFilter,
+ * RoughnessFilter; traversability = (1/3)(slope + step + roughness) on float layers) as disc stencils on the
+ * device, so that `elevation message -> traversability -> fpe_upload_map_device -> fpe_plan_device` never leaves
+ * HBM.  PARITY UNPINNED: the arithmetic contract is the build's own oracle (oracle/fpo_filters.cpp). */
+typedef struct fpe_filter_params {
+    double normal_radius;        /* NormalVectorsFilter radius [m]                      (0.05) */
+    double slope_critical;       /* SlopeFilter critical_value [rad]                    (1.0)  */
+    double step_critical;        /* StepFilter critical_value [m]                       (0.12) */
+    double step_first_radius;    /* StepFilter first_window_radius [m]                  (0.08) */
+    double step_second_radius;   /* StepFilter second_window_radius [m]                 (0.08) */
+    int32_t step_critical_cells; /* StepFilter critical_cell_number                     (4)    */
+    int32_t reserved;
+    double roughness_critical;   /* RoughnessFilter critical_value [m]                  (0.05) */
+    double roughness_radius;     /* RoughnessFilter estimation_radius [m]               (0.05) */
+} fpe_filter_params;
+int fpe_filter_params_defaults(fpe_filter_params* out);
+#define FPE_FILTER_LAYERS 8 /* surface_normal_x, _y, _z, traversability_slope, step_height, traversability_step,
+                               traversability_roughness, traversability — each rows*cols floats */
+/* Host buffers: `elevation` in desc's layout (storage order, start index); `traversability` (required) and `layers`
+ * (optional, FPE_FILTER_LAYERS * rows * cols floats) come back CANONICAL (row-major, start index 0).  Synchronous. */
+int fpe_traversability(fpe_handle h, const fpe_map_desc* desc, const fpe_filter_params* fp, const float* elevation,
+                       float* traversability, float* layers);
+/* Device buffers, asynchronous on `stream`; d_layers optional (scratch from the engine's pool when null). */
+int fpe_traversability_device(fpe_handle h, const fpe_map_desc* desc, const fpe_filter_params* fp, const float* d_elevation,
+                              float* d_traversability, float* d_layers, void* stream);
+
 /* Name and shape of the kernel a chained plan with these parameters launches on the current map (evidence for
  * benchmarks and profiles; e.g. "plan_bits_kernel<2, true> (8 lanes per leg, 13 x 13 bit window, 3x3-only fast path)"). */
 int fpe_describe_plan(fpe_handle h, const fpe_params* params, char* buf, int32_t n);

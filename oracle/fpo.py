@@ -49,6 +49,24 @@ QUERY_DTYPE = np.dtype(
 )
 
 
+# fpo_filters.cpp: FilterParams (the producer's default chain)
+FILTER_PARAMS_DTYPE = np.dtype(
+    [
+        ("normalRadius", "<f8"),
+        ("slopeCritical", "<f8"),
+        ("stepCritical", "<f8"),
+        ("stepFirstRadius", "<f8"),
+        ("stepSecondRadius", "<f8"),
+        ("stepCriticalCells", "<i4"),
+        ("pad", "<i4"),
+        ("roughnessCritical", "<f8"),
+        ("roughnessRadius", "<f8"),
+    ],
+    align=True,
+)
+FILTER_LAYERS = ("normal_x", "normal_y", "normal_z", "slope", "step_height", "step", "roughness", "traversability")
+
+
 class _Map(C.Structure):
     _fields_ = [
         ("rows", C.c_int32),
@@ -65,7 +83,7 @@ def build(force=False):
     """Compile the oracle with the committed Makefile (g++, -ffp-contract=off)."""
     if force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-        for f in ("fpo_gridmap.hpp", "fpo_planner.hpp", "fpo_planner.cpp", "fpo_capi.cpp", "Makefile")
+        for f in ("fpo_gridmap.hpp", "fpo_planner.hpp", "fpo_planner.cpp", "fpo_capi.cpp", "fpo_filters.cpp", "Makefile")
     ):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _LIB_PATH
@@ -99,6 +117,8 @@ def lib():
         L.fpo_polygon_inside.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
         L.fpo_polygon_center.argtypes = [C.c_void_p, C.c_void_p]
         L.fpo_constants.argtypes = [C.c_void_p, C.c_void_p]
+        L.fpo_filter_defaults.argtypes = [C.c_void_p]
+        L.fpo_filters.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         assert L.fpo_sizeof(0) == PARAMS_DTYPE.itemsize
         assert L.fpo_sizeof(1) == POSE_DTYPE.itemsize
         assert L.fpo_sizeof(2) == LEG_DTYPE.itemsize
@@ -251,3 +271,22 @@ def constants(params):
     lib().fpo_constants(_ptr(params), _ptr(out))
     return {"LbHalf": out[0], "WbHalfNeg": out[1], "WbHalfPos": out[2], "biasX": out[3:7].copy(),
             "biasY": out[7:11].copy(), "stepHalf": out[11], "step": out[12], "stepQuarter": out[13]}
+
+
+def filter_defaults():
+    fp = np.zeros(1, FILTER_PARAMS_DTYPE)
+    assert lib().fpo_filter_defaults(_ptr(fp)) == 0
+    return fp
+
+
+def traversability_filters(elevation, resolution, position=(0.0, 0.0), params=None):
+    """elevation: rows x cols float32 (row-major numpy, start index 0) -> dict of the eight layers, same shape."""
+    elev = np.asarray(elevation, np.float32)
+    rows, cols = elev.shape
+    fp = filter_defaults() if params is None else params
+    src = np.asfortranarray(elev)  # grid_map::Matrix is column-major
+    out = np.empty((8, cols, rows), np.float32)  # each layer column-major = the transpose, row-major
+    rc = lib().fpo_filters(rows, cols, float(resolution), float(position[0]), float(position[1]),
+                           src.ctypes.data_as(C.c_void_p), _ptr(fp), _ptr(out))
+    assert rc == 0
+    return {name: np.ascontiguousarray(out[k].T) for k, name in enumerate(FILTER_LAYERS)}

@@ -100,6 +100,23 @@ class PlanOut(C.Structure):
     ]
 
 
+class FilterParams(C.Structure):
+    """fpe_filter_params (include/fpe.h): the producer's default filter chain."""
+    _fields_ = [
+        ("normal_radius", C.c_double),
+        ("slope_critical", C.c_double),
+        ("step_critical", C.c_double),
+        ("step_first_radius", C.c_double),
+        ("step_second_radius", C.c_double),
+        ("step_critical_cells", C.c_int32),
+        ("reserved", C.c_int32),
+        ("roughness_critical", C.c_double),
+        ("roughness_radius", C.c_double),
+    ]
+
+
+FILTER_LAYERS = ("normal_x", "normal_y", "normal_z", "slope", "step_height", "step", "roughness", "traversability")
+
 # every symbol include/fpe.h declares (tests check the library exports each of them)
 EXPORTED_SYMBOLS = [
     "fpe_params_yaml",
@@ -111,6 +128,9 @@ EXPORTED_SYMBOLS = [
     "fpe_upload_map",
     "fpe_upload_map_device",
     "fpe_map_info",
+    "fpe_filter_params_defaults",
+    "fpe_traversability",
+    "fpe_traversability_device",
     "fpe_set_max_leg_search_radius",
     "fpe_set_tuning",
     "fpe_describe_plan",
@@ -165,6 +185,9 @@ def lib():
     L.fpe_destroy.argtypes = [vp]
     L.fpe_upload_map.argtypes = [vp, C.POINTER(MapDesc), vp, vp]
     L.fpe_upload_map_device.argtypes = [vp, C.POINTER(MapDesc), vp, vp, vp]
+    L.fpe_filter_params_defaults.argtypes = [C.POINTER(FilterParams)]
+    L.fpe_traversability.argtypes = [vp, C.POINTER(MapDesc), C.POINTER(FilterParams), vp, vp, vp]
+    L.fpe_traversability_device.argtypes = [vp, C.POINTER(MapDesc), C.POINTER(FilterParams), vp, vp, vp, vp]
     L.fpe_map_info.argtypes = [vp, C.POINTER(MapDesc)]
     L.fpe_set_max_leg_search_radius.argtypes = [vp, f32]
     L.fpe_set_tuning.argtypes = [vp, C.c_char_p, i32]

@@ -101,6 +101,17 @@ struct BitMap {
     int32_t nw;          // ceil(cols / 32)
 };
 
+// Producer filters (fpe_filters.hpp): parameters of the published default chain and the eight
+// canonical row-major output layers in HBM.
+struct FilterConsts {
+    double normalRadius, slopeCritical, stepCritical, stepFirstRadius, stepSecondRadius;
+    int32_t stepCriticalCells;
+    double roughnessCritical, roughnessRadius;
+};
+struct FilterLayers {
+    float *nx, *ny, *nz, *slope, *stepHeight, *step, *rough, *trav;
+};
+
 // Tile flag bits (one byte per cell in LDS).
 enum : uint8_t {
     kFlagInMap = 1,      // cell index inside the map

@@ -35,6 +35,9 @@ hipError_t launch_build_bitmap(const float* d_trav, int rows, int cols, float th
                                uint32_t* d_words, hipStream_t stream);
 bool bits_supported(const PlanConsts& pc, const MapGeom& g);
 void describe_plan_kernel(const PlanConsts& pc, const MapGeom& g, char* buf, size_t n);
+// producer filters (fpe_filters.hpp part of fpe_kernels.hip)
+bool filters_supported(const FilterConsts& fc, const MapGeom& g);
+hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float* d_elev, const FilterLayers& L, hipStream_t stream);
 hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut,
                             const fpe_pose* d_poses, int B, int nCycles, const fpe_plan_out& d_out, hipStream_t stream);
 }  // namespace fpe
@@ -516,6 +519,94 @@ int fpe_upload_map(fpe_handle h, const fpe_map_desc* desc, const float* traversa
 int fpe_upload_map_device(fpe_handle h, const fpe_map_desc* desc, const float* d_traversability,
                           const float* d_elevation, void* stream) {
     return upload_common(h, desc, d_traversability, d_elevation, true, static_cast<hipStream_t>(stream));
+}
+
+int fpe_filter_params_defaults(fpe_filter_params* out) {
+    if (!out) return fail(FPE_E_INVALID_ARG, "null out");
+    std::memset(out, 0, sizeof(*out));
+    out->normal_radius = 0.05;
+    out->slope_critical = 1.0;
+    out->step_critical = 0.12;
+    out->step_first_radius = 0.08;
+    out->step_second_radius = 0.08;
+    out->step_critical_cells = 4;
+    out->roughness_critical = 0.05;
+    out->roughness_radius = 0.05;
+    return FPE_OK;
+}
+
+namespace {
+int filters_common(fpe_engine* h, const fpe_map_desc* desc, const fpe_filter_params* fp, const float* elev, bool onDevice,
+                   float* trav, float* layers, hipStream_t stream) {
+    if (!h || !fp || !elev || !trav) return fail(FPE_E_INVALID_ARG, "null argument");
+    int rc = check_desc(desc);
+    if (rc != FPE_OK) return rc;
+    const double radii[4] = {fp->normal_radius, fp->step_first_radius, fp->step_second_radius, fp->roughness_radius};
+    for (double r : radii)
+        if (!(r > 0.0) || !std::isfinite(r)) return fail(FPE_E_INVALID_ARG, "filter radius must be positive and finite");
+    if (!(fp->slope_critical > 0.0) || !(fp->step_critical > 0.0) || !(fp->roughness_critical > 0.0) || fp->step_critical_cells <= 0)
+        return fail(FPE_E_INVALID_ARG, "filter critical values must be positive");
+    const fpe::MapGeom g = fpe::make_geom(desc->rows, desc->cols, desc->resolution, desc->position[0], desc->position[1]);
+    const fpe::FilterConsts fc{fp->normal_radius, fp->slope_critical, fp->step_critical, fp->step_first_radius, fp->step_second_radius,
+                               fp->step_critical_cells, fp->roughness_critical, fp->roughness_radius};
+    if (!fpe::filters_supported(fc, g)) return fail(FPE_E_UNSUPPORTED, "filter radius spans more cells than the stencil tables hold");
+    FPE_HIP(hipSetDevice(h->device));
+    const size_t n = static_cast<size_t>(desc->rows) * desc->cols;
+    const bool canonical = desc->storage_order == 1 && desc->start_index[0] == 0 && desc->start_index[1] == 0;
+    // pooled scratch: the canonical elevation (when the source is a host buffer or in message layout) and the eight layers
+    struct Scratch {
+        std::shared_ptr<BufferPool> pool;
+        std::vector<std::pair<size_t, float*>> bufs;
+        ~Scratch() {
+            for (auto& b : bufs) pool->give(b.first, b.second, true);
+        }
+    } scratch{h->pool, {}};
+    auto take = [&](size_t units, float** out) -> hipError_t {
+        hipError_t e = alloc_units(*h->pool, units, out);
+        if (e == hipSuccess) scratch.bufs.emplace_back(units, *out);
+        return e;
+    };
+    const float* d_elev = elev;
+    if (!onDevice || !canonical) {
+        float* canon = nullptr;
+        FPE_HIP(take(n, &canon));
+        const float* dsrc = elev;
+        if (!onDevice) {
+            float* staging = canon;
+            if (!canonical) FPE_HIP(take(n, &staging));
+            FPE_HIP(hipMemcpyAsync(staging, elev, n * sizeof(float), hipMemcpyHostToDevice, stream));
+            dsrc = staging;
+        }
+        if (!canonical)
+            FPE_HIP(fpe::launch_canonicalise(dsrc, canon, desc->rows, desc->cols, desc->start_index[0], desc->start_index[1],
+                                             desc->storage_order, stream));
+        d_elev = canon;
+    }
+    float* d_layers = onDevice ? layers : nullptr;
+    if (!d_layers) FPE_HIP(take(8 * n, &d_layers));
+    const fpe::FilterLayers L{d_layers, d_layers + n, d_layers + 2 * n, d_layers + 3 * n, d_layers + 4 * n, d_layers + 5 * n,
+                              d_layers + 6 * n, d_layers + 7 * n};
+    FPE_HIP(fpe::launch_filters(g, fc, d_elev, L, stream));
+    if (onDevice) {
+        if (trav != L.trav) FPE_HIP(hipMemcpyAsync(trav, L.trav, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        // pooled scratch is handed back marked dirty: the next taker synchronises the device before reuse (BufferPool)
+    } else {
+        FPE_HIP(hipMemcpyAsync(trav, L.trav, n * sizeof(float), hipMemcpyDeviceToHost, stream));
+        if (layers) FPE_HIP(hipMemcpyAsync(layers, d_layers, 8 * n * sizeof(float), hipMemcpyDeviceToHost, stream));
+        FPE_HIP(hipStreamSynchronize(stream));
+    }
+    return FPE_OK;
+}
+}  // namespace
+
+int fpe_traversability(fpe_handle h, const fpe_map_desc* desc, const fpe_filter_params* fp, const float* elevation,
+                       float* traversability, float* layers) {
+    return filters_common(h, desc, fp, elevation, false, traversability, layers, nullptr);
+}
+
+int fpe_traversability_device(fpe_handle h, const fpe_map_desc* desc, const fpe_filter_params* fp, const float* d_elevation,
+                              float* d_traversability, float* d_layers, void* stream) {
+    return filters_common(h, desc, fp, d_elevation, true, d_traversability, d_layers, static_cast<hipStream_t>(stream));
 }
 
 int fpe_map_info(fpe_handle h, fpe_map_desc* out) {

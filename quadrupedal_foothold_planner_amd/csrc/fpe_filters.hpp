@@ -1,0 +1,287 @@
+// fpe_filters.hpp — part three of the fpe_kernels.hip translation unit: the PRODUCER of the path's input
+// (SURVEY.md §8(f) N3), elevation layer -> traversability layer, as disc stencils on the canonical map in HBM.
+//
+// The reference starts the producer and subscribes to its output (launch/mapping.launch:12-13, launch/all.launch:21-22,
+// FootholdPlanner.cpp:188); the package itself (leggedrobotics/traversability_estimation, README.md:29) and its filter
+// configuration are not under /root/reference and no version is pinned, so this is a restatement of that package's
+// published default chain (grid_map_filters NormalVectorsFilter, area method; traversability_estimation_filters
+// SlopeFilter, StepFilter, RoughnessFilter; the (1/3)-weighted MathExpressionFilter).  PARITY UNPINNED; the arithmetic
+// contract is oracle/fpo_filters.cpp (same f64 expression order, float layers, filters read the rounded normals back).
+//
+// Every filter is a walk over CircleIterator(cell centre, radius) per cell.  One workgroup = one 16 x 16 tile of cells,
+// one cell per lane.  The source tile plus a halo of H = floor(r / res) + 1 cells goes through LDS once; the iterator's
+// per-axis quantities — the bounding rows / columns of findSubmapParameters and the squared centre distances of
+// isInside — depend on (cell row, row offset) and (cell column, column offset) only and are tabulated in LDS by the
+// workgroup, so a visit costs one LDS read, one f64 add and one compare before the filter's own arithmetic.
+// Bound: f64 VALU (the published filters gather f64 points and a 3 x 3 covariance per cell), not HBM: 4 B read and
+// 4 B written per cell and layer against some thousand f64 operations per cell.
+// (included inside namespace fpe of fpe_kernels.hip, like fpe_bits.hpp)
+#pragma once
+
+namespace {
+
+constexpr int kFT = 16;        // tile edge of the disc stencils
+constexpr int kFilterMaxH = 24;  // largest halo the tables are sized for (e.g. r 0.115 m at 0.5 cm)
+
+struct DiscLds {
+    float* tile;        // (kFT + 2H)^2 source cells, row-major, NaN outside the map
+    double *xP, *yP;    // positions of the tile's rows / columns (halo included)
+    double *dx2, *dy2;  // [kFT][2H + 1] squared centre distance per axis
+    int *bi0, *bi1, *bj0, *bj1;  // [kFT] bounding rows / columns of the cell's iterator
+    int H, W;
+};
+__host__ __device__ inline size_t disc_lds_bytes(int H) {
+    const int W = kFT + 2 * H;
+    return static_cast<size_t>(W) * W * 4 + 2 * static_cast<size_t>(W) * 8 + 2 * static_cast<size_t>(kFT) * (2 * H + 1) * 8 + 4 * kFT * 4 + 16;
+}
+__device__ __forceinline__ DiscLds disc_carve(char* base, int H) {
+    DiscLds d;
+    d.H = H;
+    d.W = kFT + 2 * H;
+    char* p = base;
+    d.xP = reinterpret_cast<double*>(p); p += d.W * 8;
+    d.yP = reinterpret_cast<double*>(p); p += d.W * 8;
+    d.dx2 = reinterpret_cast<double*>(p); p += kFT * (2 * H + 1) * 8;
+    d.dy2 = reinterpret_cast<double*>(p); p += kFT * (2 * H + 1) * 8;
+    d.bi0 = reinterpret_cast<int*>(p); p += kFT * 4;
+    d.bi1 = reinterpret_cast<int*>(p); p += kFT * 4;
+    d.bj0 = reinterpret_cast<int*>(p); p += kFT * 4;
+    d.bj1 = reinterpret_cast<int*>(p); p += kFT * 4;
+    d.tile = reinterpret_cast<float*>(p);
+    return d;
+}
+// Tables and source tile of the workgroup's cells [ti0, ti0 + kFT) x [tj0, tj0 + kFT); ends with a barrier.
+__device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, const float* __restrict__ src, int ti0, int tj0, double r) {
+    const int H = d.H, W = d.W, t = threadIdx.x, D = 2 * H + 1;
+    for (int k = t; k < 2 * W; k += 256) {
+        if (k < W) d.xP[k] = cell_pos(g.baseX, g.res, ti0 - H + k);
+        else d.yP[k - W] = cell_pos(g.baseY, g.res, tj0 - H + (k - W));
+    }
+    for (int k = t; k < W * W; k += 256) {
+        const int i = ti0 - H + k / W, j = tj0 - H + k % W;
+        d.tile[k] = in_range(i, j, g.rows, g.cols) ? src[static_cast<size_t>(i) * g.cols + j] : __builtin_nanf("");
+    }
+    __syncthreads();
+    if (t < 2 * kFT) {  // CircleIterator::findSubmapParameters per axis (circle_bbox), clamped onto the halo
+        const bool isRow = t < kFT;
+        const int l = isRow ? t : t - kFT;
+        const int idx = (isRow ? ti0 : tj0) + l, n = isRow ? g.rows : g.cols;
+        const double c = isRow ? d.xP[l + H] : d.yP[l + H];
+        const double org = isRow ? g.orgX : g.orgY, pos = isRow ? g.posX : g.posY, len = isRow ? g.lenX : g.lenY;
+        int a = index_of(bound_axis(c + r, org, pos, len), org, pos, g.res);
+        int b = index_of(bound_axis(c - r, org, pos, len), org, pos, g.res);
+        a = max(a, max(idx - H, 0));
+        b = min(b, min(idx + H, n - 1));
+        (isRow ? d.bi0 : d.bj0)[l] = a;
+        (isRow ? d.bi1 : d.bj1)[l] = b;
+    }
+    for (int k = t; k < 2 * kFT * D; k += 256) {  // CircleIterator::isInside, per axis
+        const bool isRow = k < kFT * D;
+        const int e = isRow ? k : k - kFT * D;
+        const int l = e / D, o = e % D;
+        const double* P = isRow ? d.xP : d.yP;
+        const double dd = P[l + o] - P[l + H];
+        (isRow ? d.dx2 : d.dy2)[e] = dd * dd;
+    }
+    __syncthreads();
+}
+// The cell's iterator walk, in CircleIterator order (rows outer, columns inner): f(x, y, value) per member cell.
+template <class F>
+__device__ __forceinline__ void disc_walk(const DiscLds& d, int li, int lj, int ti0, int tj0, double r2, F&& f) {
+    const int H = d.H, W = d.W, D = 2 * H + 1;
+    const int i = ti0 + li, j = tj0 + lj;
+    const int i0 = d.bi0[li], i1 = d.bi1[li], j0 = d.bj0[lj], j1 = d.bj1[lj];
+    const int dyBase = lj * D + (H - j), colBase = H - tj0;
+    for (int ii = i0; ii <= i1; ++ii) {
+        const int ri = ii - ti0 + H;
+        const double a = d.dx2[li * D + (ii - i + H)];
+        const double x = d.xP[ri];
+        const int rowBase = ri * W + colBase;
+        for (int jj = j0; jj <= j1; ++jj)
+            if (a + d.dy2[dyBase + jj] <= r2) f(x, d.yP[colBase + jj], d.tile[rowBase + jj]);
+    }
+}
+
+// One Jacobi rotation of the symmetric 3 x 3 eigenproblem on the (p, q) pair; r is the third index.
+__device__ __forceinline__ void jacobi_rotate(double& app, double& aqq, double& apq, double& arp, double& arq, double (&vp)[3], double (&vq)[3]) {
+    if (apq == 0.0) return;
+    const double theta = (aqq - app) / (2.0 * apq);
+    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    const double c = 1.0 / sqrt(t * t + 1.0);
+    const double s = t * c;
+    app = app - t * apq;
+    aqq = aqq + t * apq;
+    apq = 0.0;
+    const double rp = arp, rq = arq;
+    arp = c * rp - s * rq;
+    arq = s * rp + c * rq;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const double a = vp[m], b = vq[m];
+        vp[m] = c * a - s * b;
+        vq[m] = s * a + c * b;
+    }
+}
+
+// NormalVectorsFilter (area method) + SlopeFilter.
+__global__ __launch_bounds__(256) void filter_normals_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double r, int H, double slopeCritical) {
+    extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
+    const DiscLds d = disc_carve(ldsRaw, H);
+    const int ti0 = blockIdx.y * kFT, tj0 = blockIdx.x * kFT;
+    disc_setup(d, g, elev, ti0, tj0, r);
+    const int li = threadIdx.x / kFT, lj = threadIdx.x % kFT;
+    const int i = ti0 + li, j = tj0 + lj;
+    if (i >= g.rows || j >= g.cols) return;
+    const size_t cell = static_cast<size_t>(i) * g.cols + j;
+    const float nanf = __builtin_nanf("");
+    float ox = nanf, oy = nanf, oz = nanf, os = nanf;
+    if (isfinite(d.tile[(li + H) * d.W + lj + H])) {
+        const double r2 = r * r;
+        int np = 0;
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        disc_walk(d, li, lj, ti0, tj0, r2, [&](double x, double y, float z) {
+            if (isfinite(z)) { ++np; sx += x; sy += y; sz += static_cast<double>(z); }
+        });
+        const double nd = static_cast<double>(np);
+        const double mx = sx / nd, my = sy / nd, mz = sz / nd;
+        double a00 = 0.0, a01 = 0.0, a02 = 0.0, a11 = 0.0, a12 = 0.0, a22 = 0.0;
+        disc_walk(d, li, lj, ti0, tj0, r2, [&](double x, double y, float z) {
+            if (isfinite(z)) {
+                const double dx = x - mx, dy = y - my, dz = static_cast<double>(z) - mz;
+                a00 += dx * dx; a01 += dx * dy; a02 += dx * dz;
+                a11 += dy * dy; a12 += dy * dz; a22 += dz * dz;
+            }
+        });
+        double v0[3] = {1.0, 0.0, 0.0}, v1[3] = {0.0, 1.0, 0.0}, v2[3] = {0.0, 0.0, 1.0};  // columns of V
+        for (int sweep = 0; sweep < 12; ++sweep) {
+            const double off = fabs(a01) + fabs(a02) + fabs(a12);
+            if (off == 0.0) break;
+            jacobi_rotate(a00, a11, a01, a02, a12, v0, v1);  // (p, q, r) = (0, 1, 2)
+            jacobi_rotate(a00, a22, a02, a01, a12, v0, v2);  // (0, 2, 1)
+            jacobi_rotate(a11, a22, a12, a01, a02, v1, v2);  // (1, 2, 0)
+        }
+        // the eigenvector of the smallest eigenvalue (first of equals); rank-deficient covariance -> z axis
+        double wS = a00, ex = v0[0], ey = v0[1], ez = v0[2];
+        if (a11 < wS) { wS = a11; ex = v1[0]; ey = v1[1]; ez = v1[2]; }
+        if (a22 < wS) { wS = a22; ex = v2[0]; ey = v2[1]; ez = v2[2]; }
+        const double wL = fmax(fmax(fmax(a00, 0.0), a11), a22);
+        if (!(wS > 3.0 * DBL_EPSILON * wL)) { ex = 0.0; ey = 0.0; ez = 1.0; }
+        if (ez < 0.0) { ex = -ex; ey = -ey; ez = -ez; }
+        ox = static_cast<float>(ex);
+        oy = static_cast<float>(ey);
+        oz = static_cast<float>(ez);
+        const double slope = acos(static_cast<double>(oz));  // SlopeFilter reads the float layer
+        os = slope < slopeCritical ? static_cast<float>(1.0 - slope / slopeCritical) : 0.0f;
+    }
+    L.nx[cell] = ox;
+    L.ny[cell] = oy;
+    L.nz[cell] = oz;
+    L.slope[cell] = os;
+}
+
+// RoughnessFilter: needs the finished normal layers.
+__global__ __launch_bounds__(256) void filter_roughness_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double r, int H, double critical) {
+    extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
+    const DiscLds d = disc_carve(ldsRaw, H);
+    const int ti0 = blockIdx.y * kFT, tj0 = blockIdx.x * kFT;
+    disc_setup(d, g, elev, ti0, tj0, r);
+    const int li = threadIdx.x / kFT, lj = threadIdx.x % kFT;
+    const int i = ti0 + li, j = tj0 + lj;
+    if (i >= g.rows || j >= g.cols) return;
+    const size_t cell = static_cast<size_t>(i) * g.cols + j;
+    float out = __builtin_nanf("");
+    const float fx = L.nx[cell];
+    if (isfinite(fx)) {
+        const double normalX = fx, normalY = L.ny[cell], normalZ = L.nz[cell];
+        const double r2 = r * r;
+        int np = 0;
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        disc_walk(d, li, lj, ti0, tj0, r2, [&](double x, double y, float z) {
+            if (isfinite(z)) { ++np; sx += x; sy += y; sz += static_cast<double>(z); }
+        });
+        const double nd = static_cast<double>(np);
+        const double mx = sx / nd, my = sy / nd, mz = sz / nd;
+        const double planeParameter = mx * normalX + my * normalY + mz * normalZ;
+        double sum = 0.0;
+        disc_walk(d, li, lj, ti0, tj0, r2, [&](double x, double y, float z) {
+            if (isfinite(z)) {
+                const double dist = normalX * x + normalY * y + normalZ * static_cast<double>(z) - planeParameter;
+                sum += dist * dist;
+            }
+        });
+        const double roughness = sqrt(sum / (nd - 1.0));
+        out = roughness < critical ? static_cast<float>(1.0 - roughness / critical) : 0.0f;
+    }
+    L.rough[cell] = out;
+}
+
+// StepFilter, first iteration: step_height = max - min over the first window.
+__global__ __launch_bounds__(256) void filter_step1_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double r, int H) {
+    extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
+    const DiscLds d = disc_carve(ldsRaw, H);
+    const int ti0 = blockIdx.y * kFT, tj0 = blockIdx.x * kFT;
+    disc_setup(d, g, elev, ti0, tj0, r);
+    const int li = threadIdx.x / kFT, lj = threadIdx.x % kFT;
+    const int i = ti0 + li, j = tj0 + lj;
+    if (i >= g.rows || j >= g.cols) return;
+    float out = __builtin_nanf("");
+    if (isfinite(d.tile[(li + H) * d.W + lj + H])) {
+        float hi = -__builtin_huge_valf(), lo = __builtin_huge_valf();
+        disc_walk(d, li, lj, ti0, tj0, r * r, [&](double, double, float z) {
+            if (isfinite(z)) { hi = fmaxf(hi, z); lo = fminf(lo, z); }
+        });
+        out = static_cast<float>(static_cast<double>(hi) - static_cast<double>(lo));  // the centre is a member: init holds
+    }
+    L.stepHeight[static_cast<size_t>(i) * g.cols + j] = out;
+}
+
+// StepFilter, second iteration, and the weighted sum of the three filters.
+__global__ __launch_bounds__(256) void filter_step2_kernel(MapGeom g, FilterLayers L, double r, int H, double critical, int nCritical) {
+    extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
+    const DiscLds d = disc_carve(ldsRaw, H);
+    const int ti0 = blockIdx.y * kFT, tj0 = blockIdx.x * kFT;
+    disc_setup(d, g, L.stepHeight, ti0, tj0, r);
+    const int li = threadIdx.x / kFT, lj = threadIdx.x % kFT;
+    const int i = ti0 + li, j = tj0 + lj;
+    if (i >= g.rows || j >= g.cols) return;
+    const size_t cell = static_cast<size_t>(i) * g.cols + j;
+    int nCells = 0;
+    float stepMaxF = 0.0f;
+    bool valid = false;
+    disc_walk(d, li, lj, ti0, tj0, r * r, [&](double, double, float sh) {
+        if (isfinite(sh)) {
+            valid = true;
+            stepMaxF = fmaxf(stepMaxF, sh);
+            nCells += static_cast<double>(sh) > critical ? 1 : 0;
+        }
+    });
+    float out = __builtin_nanf("");
+    if (valid) {
+        const double stepMax = static_cast<double>(stepMaxF);
+        const double step = fmin(stepMax, static_cast<double>(nCells) / static_cast<double>(nCritical) * stepMax);
+        out = step < critical ? static_cast<float>(1.0 - step / critical) : 0.0f;
+    }
+    L.step[cell] = out;
+    const float third = 1.0f / 3.0f;  // MathExpressionFilter on float matrices: (1.0 / 3.0) * (slope + step + roughness)
+    L.trav[cell] = third * ((L.slope[cell] + out) + L.rough[cell]);
+}
+
+__host__ inline int filter_halo(double r, double res) { return static_cast<int>(r / res) + 1; }
+
+}  // namespace
+
+bool filters_supported(const FilterConsts& fc, const MapGeom& g) {
+    const double rmax = std::fmax(std::fmax(fc.normalRadius, fc.roughnessRadius), std::fmax(fc.stepFirstRadius, fc.stepSecondRadius));
+    return filter_halo(rmax, g.res) <= kFilterMaxH;
+}
+// Four launches on `stream`: normals + slope, roughness, step heights, step + weighted sum.
+hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float* d_elev, const FilterLayers& L, hipStream_t stream) {
+    const dim3 grid((g.cols + kFT - 1) / kFT, (g.rows + kFT - 1) / kFT), block(256);
+    const int hN = filter_halo(fc.normalRadius, g.res), hR = filter_halo(fc.roughnessRadius, g.res);
+    const int h1 = filter_halo(fc.stepFirstRadius, g.res), h2 = filter_halo(fc.stepSecondRadius, g.res);
+    hipLaunchKernelGGL(filter_normals_kernel, grid, block, disc_lds_bytes(hN), stream, g, d_elev, L, fc.normalRadius, hN, fc.slopeCritical);
+    hipLaunchKernelGGL(filter_roughness_kernel, grid, block, disc_lds_bytes(hR), stream, g, d_elev, L, fc.roughnessRadius, hR, fc.roughnessCritical);
+    hipLaunchKernelGGL(filter_step1_kernel, grid, block, disc_lds_bytes(h1), stream, g, d_elev, L, fc.stepFirstRadius, h1);
+    hipLaunchKernelGGL(filter_step2_kernel, grid, block, disc_lds_bytes(h2), stream, g, L, fc.stepSecondRadius, h2, fc.stepCritical, fc.stepCriticalCells);
+    return hipGetLastError();
+}

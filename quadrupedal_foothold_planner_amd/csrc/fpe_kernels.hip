@@ -835,7 +835,8 @@ __device__ __forceinline__ void disc_issue(const DevMap& m, const PlanConsts& pc
         a += fix;
         bq -= fix * njS;
         const int i = bb.i0 + a, j = bb.j0 + bq;
-        const bool vis = (t < nb) & in_range(i, j, m.g.rows, m.g.cols) & cell_in_disc(m.g, i, j, cx, cy, pc.rf2);
+        const bool inMap = in_range(i, j, m.g.rows, m.g.cols), inDisc = cell_in_disc(m.g, i, j, cx, cy, pc.rf2);
+        const bool vis = (t < nb) & inMap & inDisc;
         d.vis[r] = vis;
         if (vis) {
             const size_t off = static_cast<size_t>(i) * m.g.cols + j;
@@ -1008,7 +1009,7 @@ struct RowShape {
     static constexpr int C4 = (G >= 64) ? 6 : (kMid ? 2 : 3);
     typedef RowLoads<CH, C4> Loads;
 };
-constexpr int kRowOverreadBytes = 6 * 16;  // widest row read (C4 = 6); the layers carry this much tail padding
+[[maybe_unused]] constexpr int kRowOverreadBytes = 6 * 16;  // widest row read (C4 = 6); the layers carry this much tail padding
 template <int G, int CH, int C4>
 __device__ __forceinline__ void rows_issue(const DevMap& m, const Submap& s, const Grp<G>& g, RowLoads<CH, C4>& rl) {
     rl.pipelined = s.ok && s.ni <= CH * G && s.nj <= 4 * C4;
@@ -1947,6 +1948,8 @@ hipError_t launch_canonicalise(const float* d_src, float* d_dst, int rows, int c
 
 // ---- part two of this translation unit: the bit-window kernels ---------------------------------------------
 #include "fpe_bits.hpp"
+// ---- part three: the producer's filters (elevation -> traversability) ----------------------------------------
+#include "fpe_filters.hpp"
 
 hipError_t set_max_lds(size_t planBytes, size_t searchBytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_chained_kernel<16>),

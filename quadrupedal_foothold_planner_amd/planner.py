@@ -90,6 +90,39 @@ class FootholdPlanner:
                                                     C.c_void_p(stream or 0)))
         self.rows, self.cols, self.resolution = rows, cols, float(resolution)
 
+    # ---- the producer of the map (launch/mapping.launch:12-13) ----------------------
+    def filter_params(self, **overrides):
+        fp = _capi.FilterParams()
+        self._check(self._lib.fpe_filter_params_defaults(C.byref(fp)))
+        for k, v in overrides.items():
+            setattr(fp, k, v)
+        return fp
+
+    def traversability_from_elevation(self, elevation, resolution, position=(0.0, 0.0), start_index=(0, 0), storage_order="row",
+                                      params=None, want_layers=False):
+        """Elevation layer (host array in the message's layout) -> traversability layer (rows x cols, canonical) through
+        the device filters; with want_layers also the dict of all FPE_FILTER_LAYERS layers."""
+        elev = np.ascontiguousarray(elevation, dtype=np.float32)
+        rows, cols = elev.shape if storage_order == "row" else elev.shape[::-1]
+        d = MapDesc(rows, cols, float(resolution), (C.c_double * 2)(*map(float, position)),
+                    (C.c_int32 * 2)(*map(int, start_index)), 1 if storage_order == "row" else 0)
+        fp = params if params is not None else self.filter_params()
+        trav = np.empty((rows, cols), np.float32)
+        layers = np.empty((len(_capi.FILTER_LAYERS), rows, cols), np.float32) if want_layers else None
+        self._check(self._lib.fpe_traversability(self._h, C.byref(d), C.byref(fp), ptr(elev), ptr(trav),
+                                                 ptr(layers) if want_layers else None))
+        if want_layers:
+            return trav, {name: layers[k] for k, name in enumerate(_capi.FILTER_LAYERS)}
+        return trav
+
+    def traversability_device(self, d_elev_ptr, d_trav_ptr, rows, cols, resolution, position=(0.0, 0.0), params=None,
+                              d_layers_ptr=0, stream=None):
+        """Device-resident form (canonical row-major layers), asynchronous on `stream`."""
+        d = MapDesc(rows, cols, float(resolution), (C.c_double * 2)(*map(float, position)), (C.c_int32 * 2)(0, 0), 1)
+        fp = params if params is not None else self.filter_params()
+        self._check(self._lib.fpe_traversability_device(self._h, C.byref(d), C.byref(fp), C.c_void_p(d_elev_ptr),
+                                                        C.c_void_p(d_trav_ptr), C.c_void_p(d_layers_ptr or 0), C.c_void_p(stream or 0)))
+
     def map_info(self):
         d = MapDesc()
         self._check(self._lib.fpe_map_info(self._h, C.byref(d)))

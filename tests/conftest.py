@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+try:  # load torch's bundled HIP runtime BEFORE libfpe.so brings in /opt/rocm's: in the other order torch finds no GPU
+    import torch  # noqa: F401  (only the tests that own device buffers and streams through torch use it)
+except Exception:  # pragma: no cover
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,0 +1,121 @@
+"""SURVEY §8(f) N3 — the producer's filters on the device (fpe_traversability[_device], csrc/fpe_filters.hpp) against
+the oracle's restatement (oracle/fpo_filters.cpp) on the same seeded elevation layers.
+
+Bar: the layers are float, computed through f64 like the published filters.  Engine and oracle run the same expression
+order, so the layers agree bit for bit except where the device's and the host's `acos` differ in the last place of the f64
+slope (the float result may then round the other way): every layer within ONE float ulp, and bit-identical on all but a
+handful of cells.  Holes (NaN) must coincide exactly."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import fpo
+from quadrupedal_foothold_planner_amd import _capi, synth
+from quadrupedal_foothold_planner_amd.planner import FootholdPlanner
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def planner():
+    p = FootholdPlanner(0)
+    yield p
+    p.close()
+
+
+def oracle_params(fp):
+    o = fpo.filter_defaults()
+    o["normalRadius"], o["slopeCritical"], o["stepCritical"] = fp.normal_radius, fp.slope_critical, fp.step_critical
+    o["stepFirstRadius"], o["stepSecondRadius"], o["stepCriticalCells"] = fp.step_first_radius, fp.step_second_radius, fp.step_critical_cells
+    o["roughnessCritical"], o["roughnessRadius"] = fp.roughness_critical, fp.roughness_radius
+    return o
+
+
+def assert_layers_equal(eng, ora, max_ulp_cells=1e-4):
+    for name in _capi.FILTER_LAYERS:
+        a, b = eng[name], ora[name]
+        assert a.shape == b.shape, name
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f"{name}: holes differ"
+        ok = ~np.isnan(a)
+        ai, bi = a[ok].view(np.int32).astype(np.int64), b[ok].view(np.int32).astype(np.int64)
+        d = np.abs(ai - bi)
+        assert d.max(initial=0) <= 1, f"{name}: {int((d > 1).sum())} cells differ by more than one float ulp (max {int(d.max())})"
+        assert (d != 0).mean() <= max_ulp_cells, f"{name}: {int((d != 0).sum())} of {d.size} cells not bit-identical"
+
+
+@pytest.mark.parametrize("rows,cols,res,seed", [(160, 144, 0.02, 21), (150, 170, 0.01, 22), (96, 112, 0.005, 23), (130, 90, 0.03, 24)])
+def test_filter_chain_matches_the_oracle(planner, rows, cols, res, seed):
+    _, elev = synth.rough_map(rows, cols, res, seed)
+    trav, layers = planner.traversability_from_elevation(elev, res, want_layers=True)
+    ora = fpo.traversability_filters(elev, res)
+    assert np.array_equal(trav, layers["traversability"], equal_nan=True)
+    assert_layers_equal(layers, ora)
+    t = ora["traversability"]
+    assert np.isfinite(t).mean() > 0.9 and np.nanmin(t) < 0.5 < 0.9 < np.nanmax(t)  # the terrain spans the planner's thresholds
+
+
+def test_off_origin_map_message_layout_and_other_parameters(planner):
+    """Column-major message buffer with a circular-buffer start index, a map far from the origin, non-default radii and
+    critical values (radii that are no multiple of the resolution)."""
+    rows, cols, res = 120, 100, 0.02
+    _, elev = synth.rough_map(rows, cols, res, 31)
+    pos = (123.456, -78.9)
+    fp = planner.filter_params(normal_radius=0.07, slope_critical=0.8, step_critical=0.1, step_first_radius=0.05,
+                               step_second_radius=0.11, step_critical_cells=6, roughness_critical=0.03, roughness_radius=0.045)
+    si, sj = 37, 81
+    msg = np.ascontiguousarray(np.roll(np.roll(elev, si, axis=0), sj, axis=1).T)  # (cols, rows): column-major buffer
+    trav, layers = planner.traversability_from_elevation(msg, res, position=pos, start_index=(si, sj), storage_order="col",
+                                                         params=fp, want_layers=True)
+    ora = fpo.traversability_filters(elev, res, position=pos, params=oracle_params(fp))
+    assert_layers_equal(layers, ora)
+
+
+def test_map_border_holes_and_flat_ground(planner):
+    rows, cols, res = 64, 80, 0.02
+    elev = np.zeros((rows, cols), np.float32)
+    elev[:, 40:] = 0.2
+    elev[10:14, 5:9] = np.nan
+    elev[0, 0] = np.nan
+    elev[rows - 1, cols - 1] = np.nan
+    trav, layers = planner.traversability_from_elevation(elev, res, want_layers=True)
+    ora = fpo.traversability_filters(elev, res)
+    assert_layers_equal(layers, ora, max_ulp_cells=0.0)
+    assert np.all(trav[20:, :30] == layers["traversability"][20:, :30]) and np.nanmax(trav[30:50, 2:30]) > 0.9999
+
+
+def test_device_resident_chain_feeds_the_planner(planner):
+    """elevation (HBM) -> fpe_traversability_device -> fpe_upload_map_device -> plan: the same plan as uploading the
+    oracle's traversability layer from the host."""
+    import torch
+    from tests import util
+    rows, cols, res = 300, 300, 0.02
+    _, elev = synth.rough_map(rows, cols, res, 41)
+    d_elev = torch.from_numpy(elev).cuda()
+    d_trav = torch.empty_like(d_elev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        planner.traversability_device(d_elev.data_ptr(), d_trav.data_ptr(), rows, cols, res, stream=s.cuda_stream)
+        planner.upload_map_device(d_trav.data_ptr(), d_elev.data_ptr(), rows, cols, res, stream=s.cuda_stream)
+    s.synchronize()
+    ora_trav = fpo.traversability_filters(elev, res)["traversability"]
+    got = d_trav.cpu().numpy()
+    ok = ~np.isnan(ora_trav)
+    assert np.array_equal(np.isnan(got), ~ok) and np.abs(got[ok].view(np.int32).astype(np.int64) - ora_trav[ok].view(np.int32)).max() <= 1
+    planner.params = _capi.params_yaml()
+    poses = synth.poses_in_map(64, rows * res, cols * res, 6, 0.18, seed=42, margin=0.7)
+    eng = planner.plan(poses, 6)
+    om = fpo.OracleMap(got, elev, res)  # the device's own layer: the plan must match the oracle run on it
+    ora = om.plan(util.to_oracle_params(planner.params), util.to_oracle_poses(poses), 6, threads=4)
+    ora["pose_status"] = om.pose_status(util.to_oracle_params(planner.params), util.to_oracle_poses(poses))
+    util.assert_plan_equal(eng, ora)
+
+
+def test_filter_argument_errors(planner):
+    elev = np.zeros((8, 8), np.float32)
+    with pytest.raises(Exception):
+        planner.traversability_from_elevation(elev, 0.02, params=planner.filter_params(normal_radius=0.0))
+    with pytest.raises(Exception):
+        planner.traversability_from_elevation(elev, 0.02, params=planner.filter_params(step_critical_cells=0))
+    with pytest.raises(Exception):  # a halo of more cells than the stencil tables hold
+        planner.traversability_from_elevation(elev, 0.001, params=planner.filter_params(step_first_radius=0.2))
