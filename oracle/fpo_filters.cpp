@@ -59,6 +59,10 @@ static void jacobi3(double a[3][3], double w[3], double v[3][3]) {
             const int p = P[k], q = Q[k], r = R[k];
             const double apq = a[p][q];
             if (apq == 0.0) continue;
+            if (std::fabs(apq) <= 2.3e-18 * (std::fabs(a[p][p]) + std::fabs(a[q][q]))) {  // negligible: no rotation
+                a[p][q] = a[q][p] = 0.0;
+                continue;
+            }
             const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
             const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
             const double c = 1.0 / std::sqrt(t * t + 1.0);

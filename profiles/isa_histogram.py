@@ -46,7 +46,7 @@ while i < len(lines):
         mm = re.search(r"sgpr_spill_count (\d+)|SGPRSpill: (\d+)|; SGPR spills?: (\d+)", lines[i])
         i += 1
     occ = re.search(r"; Occupancy: (\d+)", lines[i]).group(1) if i < len(lines) else "?"
-    demangled = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0]
+    demangled = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().replace("(anonymous namespace)::", "").split("(")[0]
     print(demangled)
     print(f"  static instructions: {sum(cls.values())}  {dict(sorted(cls.items()))}")
     print(f"  VGPRs {info.get('NumVgprs')}, scratch {info.get('ScratchSize')} B/lane, occupancy {occ} waves/SIMD")

@@ -1,0 +1,26 @@
+"""The producer's filter chain (fpe_traversability_device) on larger layers: per-launch time by resolution.
+usage on the GPU box: python3 profiles/probe_filters.py   (or under rocprofv3 --kernel-trace --stats for the per-kernel split)"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, '.')
+from quadrupedal_foothold_planner_amd import synth
+from quadrupedal_foothold_planner_amd.planner import FootholdPlanner
+pl = FootholdPlanner(0)
+s = torch.cuda.current_stream()
+for rows, res in ((1000, 0.02), (2000, 0.01), (2000, 0.005)):
+    _, elev = synth.rough_map(rows, rows, res, 5)
+    d_e = torch.from_numpy(elev).cuda()
+    d_t = torch.empty_like(d_e)
+    d_l = torch.empty(8 * rows * rows, dtype=torch.float32, device='cuda')
+    def run():
+        pl.traversability_device(d_e.data_ptr(), d_t.data_ptr(), rows, rows, res, d_layers_ptr=d_l.data_ptr(), stream=s.cuda_stream)
+    for _ in range(2): run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record(s)
+    for _ in range(5): run()
+    e1.record(s); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    t = d_t.cpu().numpy()
+    print(f"{rows}x{rows} @ {res} m: {ms:.3f} ms per chain, {rows*rows/ms/1e6:.2f} Gcell/s, {36*rows*rows/ms/1e6:.1f} GB/s by layers; "
+          f"traversability mean {np.nanmean(t):.3f}, below 0.7: {np.nanmean(t < 0.7):.3f}, holes {np.isnan(t).mean():.4f}")

@@ -7,6 +7,7 @@ for c in headline cfg2 cfg3 cfg4 cfg5; do python3 profiles/summarise.py r2p_$c r
 cp gpurun_out/r2p_bench_full.json profiles/round2_bench_line_full.json
 cp gpurun_out/r2p_pytest.log profiles/round2_gpu_pytest_durations.log
 [ -f gpurun_out/r2p_batch_scaling.txt ] && cp gpurun_out/r2p_batch_scaling.txt profiles/round2_batch_scaling.txt
+[ -d gpurun_out/prof_filters ] && python3 profiles/summarise_filters.py > profiles/round2_filters.txt
 python3 - <<'PY'
 import csv, glob, json
 def mean_counter(d, name, kern):

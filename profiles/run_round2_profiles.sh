@@ -15,4 +15,7 @@ FPE_BENCH_SHARE_GPU=1 python3 bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-b
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/r2p_ol_fetch -o ol -- python3 bench.py --steps 5 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/r2p_ol_write -o ol -- python3 bench.py --steps 5 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2p_ol_stats -o ol -- python3 bench.py --steps 5 --no-cpu-baseline > /dev/null 2>&1
+# the producer's filter chain (N3): per-kernel split by resolution
+rm -rf gpurun_out/prof_filters
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_filters -o f -- python3 profiles/probe_filters.py > gpurun_out/probe_filters.txt 2>&1
 ls gpurun_out | grep r2p_ | wc -l

@@ -86,25 +86,42 @@ __device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, c
     __syncthreads();
 }
 // The cell's iterator walk, in CircleIterator order (rows outer, columns inner): f(x, y, value) per member cell.
+// isInside is monotone in the column distance on either side of the centre column (the squared distances are rounded
+// monotonically), so the members of a row are one interval; its ends follow from the previous row's by a few tests
+// instead of one test per cell of the bounding box.  Same members, same order as testing every cell.
 template <class F>
 __device__ __forceinline__ void disc_walk(const DiscLds& d, int li, int lj, int ti0, int tj0, double r2, F&& f) {
     const int H = d.H, W = d.W, D = 2 * H + 1;
     const int i = ti0 + li, j = tj0 + lj;
-    const int i0 = d.bi0[li], i1 = d.bi1[li], j0 = d.bj0[lj], j1 = d.bj1[lj];
-    const int dyBase = lj * D + (H - j), colBase = H - tj0;
+    const int i0 = d.bi0[li], i1 = d.bi1[li];
+    const int maxL = j - d.bj0[lj], maxR = d.bj1[lj] - j;  // the bounding box's columns either side of the centre column
+    const int dyC = lj * D + H, dxC = li * D + H - i;       // dy2[dyC + dj], dx2[dxC + ii]
+    const int colBase = H - tj0;
+    int wL = 0, wR = 0;
     for (int ii = i0; ii <= i1; ++ii) {
+        const double a = d.dx2[dxC + ii];
+        if (!(a <= r2)) continue;  // (a + 0 <= r2: the centre column, dy2 = 0 exactly)
+        wR = min(wR, maxR);
+        wL = min(wL, maxL);
+        while (wR > 0 && !(a + d.dy2[dyC + wR] <= r2)) --wR;
+        while (wR < maxR && a + d.dy2[dyC + wR + 1] <= r2) ++wR;
+        while (wL > 0 && !(a + d.dy2[dyC - wL] <= r2)) --wL;
+        while (wL < maxL && a + d.dy2[dyC - wL - 1] <= r2) ++wL;
         const int ri = ii - ti0 + H;
-        const double a = d.dx2[li * D + (ii - i + H)];
         const double x = d.xP[ri];
         const int rowBase = ri * W + colBase;
-        for (int jj = j0; jj <= j1; ++jj)
-            if (a + d.dy2[dyBase + jj] <= r2) f(x, d.yP[colBase + jj], d.tile[rowBase + jj]);
+#pragma unroll 4
+        for (int jj = j - wL; jj <= j + wR; ++jj) f(x, d.yP[colBase + jj], d.tile[rowBase + jj]);
     }
 }
 
 // One Jacobi rotation of the symmetric 3 x 3 eigenproblem on the (p, q) pair; r is the third index.
 __device__ __forceinline__ void jacobi_rotate(double& app, double& aqq, double& apq, double& arp, double& arq, double (&vp)[3], double (&vq)[3]) {
     if (apq == 0.0) return;
+    if (fabs(apq) <= 2.3e-18 * (fabs(app) + fabs(aqq))) {  // a rotation by less than 2^-58: nothing moves in double precision
+        apq = 0.0;
+        return;
+    }
     const double theta = (aqq - app) / (2.0 * apq);
     const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
     const double c = 1.0 / sqrt(t * t + 1.0);
@@ -123,8 +140,10 @@ __device__ __forceinline__ void jacobi_rotate(double& app, double& aqq, double& 
     }
 }
 
-// NormalVectorsFilter (area method) + SlopeFilter.
-__global__ __launch_bounds__(256) void filter_normals_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double r, int H, double slopeCritical) {
+// NormalVectorsFilter (area method) + SlopeFilter; with fuseRough also the RoughnessFilter of the same radius (same
+// members in the same order, hence the same point count and mean: one walk and one tile load less than its own launch).
+__global__ __launch_bounds__(256) void filter_normals_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double r, int H, double slopeCritical,
+                                                              int fuseRough, double roughCritical) {
     extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
     const DiscLds d = disc_carve(ldsRaw, H);
     const int ti0 = blockIdx.y * kFT, tj0 = blockIdx.x * kFT;
@@ -134,7 +153,7 @@ __global__ __launch_bounds__(256) void filter_normals_kernel(MapGeom g, const fl
     if (i >= g.rows || j >= g.cols) return;
     const size_t cell = static_cast<size_t>(i) * g.cols + j;
     const float nanf = __builtin_nanf("");
-    float ox = nanf, oy = nanf, oz = nanf, os = nanf;
+    float ox = nanf, oy = nanf, oz = nanf, os = nanf, orough = nanf;
     if (isfinite(d.tile[(li + H) * d.W + lj + H])) {
         const double r2 = r * r;
         int np = 0;
@@ -172,11 +191,25 @@ __global__ __launch_bounds__(256) void filter_normals_kernel(MapGeom g, const fl
         oz = static_cast<float>(ez);
         const double slope = acos(static_cast<double>(oz));  // SlopeFilter reads the float layer
         os = slope < slopeCritical ? static_cast<float>(1.0 - slope / slopeCritical) : 0.0f;
+        if (fuseRough) {  // RoughnessFilter::update with the float normals just written
+            const double normalX = ox, normalY = oy, normalZ = oz;
+            const double planeParameter = mx * normalX + my * normalY + mz * normalZ;
+            double sum = 0.0;
+            disc_walk(d, li, lj, ti0, tj0, r2, [&](double x, double y, float z) {
+                if (isfinite(z)) {
+                    const double dist = normalX * x + normalY * y + normalZ * static_cast<double>(z) - planeParameter;
+                    sum += dist * dist;
+                }
+            });
+            const double roughness = sqrt(sum / (nd - 1.0));
+            orough = roughness < roughCritical ? static_cast<float>(1.0 - roughness / roughCritical) : 0.0f;
+        }
     }
     L.nx[cell] = ox;
     L.ny[cell] = oy;
     L.nz[cell] = oz;
     L.slope[cell] = os;
+    if (fuseRough) L.rough[cell] = orough;
 }
 
 // RoughnessFilter: needs the finished normal layers.
@@ -274,13 +307,17 @@ bool filters_supported(const FilterConsts& fc, const MapGeom& g) {
     const double rmax = std::fmax(std::fmax(fc.normalRadius, fc.roughnessRadius), std::fmax(fc.stepFirstRadius, fc.stepSecondRadius));
     return filter_halo(rmax, g.res) <= kFilterMaxH;
 }
-// Four launches on `stream`: normals + slope, roughness, step heights, step + weighted sum.
+// Three launches on `stream` (four when the roughness radius differs from the normals'): normals + slope [+ roughness],
+// [roughness,] step heights, step + weighted sum.
 hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float* d_elev, const FilterLayers& L, hipStream_t stream) {
     const dim3 grid((g.cols + kFT - 1) / kFT, (g.rows + kFT - 1) / kFT), block(256);
     const int hN = filter_halo(fc.normalRadius, g.res), hR = filter_halo(fc.roughnessRadius, g.res);
     const int h1 = filter_halo(fc.stepFirstRadius, g.res), h2 = filter_halo(fc.stepSecondRadius, g.res);
-    hipLaunchKernelGGL(filter_normals_kernel, grid, block, disc_lds_bytes(hN), stream, g, d_elev, L, fc.normalRadius, hN, fc.slopeCritical);
-    hipLaunchKernelGGL(filter_roughness_kernel, grid, block, disc_lds_bytes(hR), stream, g, d_elev, L, fc.roughnessRadius, hR, fc.roughnessCritical);
+    const int fuse = fc.roughnessRadius == fc.normalRadius ? 1 : 0;  // the published default chain: both 0.05 m
+    hipLaunchKernelGGL(filter_normals_kernel, grid, block, disc_lds_bytes(hN), stream, g, d_elev, L, fc.normalRadius, hN, fc.slopeCritical, fuse,
+                       fc.roughnessCritical);
+    if (!fuse)
+        hipLaunchKernelGGL(filter_roughness_kernel, grid, block, disc_lds_bytes(hR), stream, g, d_elev, L, fc.roughnessRadius, hR, fc.roughnessCritical);
     hipLaunchKernelGGL(filter_step1_kernel, grid, block, disc_lds_bytes(h1), stream, g, d_elev, L, fc.stepFirstRadius, h1);
     hipLaunchKernelGGL(filter_step2_kernel, grid, block, disc_lds_bytes(h2), stream, g, L, fc.stepSecondRadius, h2, fc.stepCritical, fc.stepCriticalCells);
     return hipGetLastError();
