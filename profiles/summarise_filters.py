@@ -16,3 +16,28 @@ for m, name in enumerate(names):
     for r in rows[m * per:(m + 1) * per]:
         acc[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].split("::")[-1]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print(name + ": " + ", ".join(f"{k} {sum(v) / len(v):.1f} us x{len(v)}" for k, v in acc.items()))
+
+# counters (one rocprofv3 --pmc pass per group), per launch and kernel, the 2000x2000 @ 0.01 m map (launches 8..14 of each kernel)
+import json
+cnt = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/prof_filters_pmc_*/**/*counter_collection.csv", recursive=True):
+    byk = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "filter_" in r["Kernel_Name"]:
+            byk[(r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].split("::")[-1], r["Counter_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    for (k, c), v in byk.items():
+        v.sort()
+        n = len(v) // 3
+        cnt[k][c] = [x for _, x in v[n:2 * n]]
+if cnt:
+    cal = json.load(open("profiles/round2_headline_counters.json"))["calibration"]
+    print("\ncounters per launch, 2000x2000 @ 0.01 m (mean over the map's launches):")
+    for k, c in cnt.items():
+        m = {name: sum(v) / len(v) for name, v in c.items() if v}
+        w = m.get("SQ_WAVES", 0.0)
+        line = f"{k}: waves {w:.0f}"
+        if w and "SQ_INSTS_VALU" in m: line += f", VALU instructions per wavefront {m['SQ_INSTS_VALU'] / w:.0f}, SALU {m.get('SQ_INSTS_SALU', 0) / w:.0f}, LDS {m.get('SQ_INSTS_LDS', 0) / w:.0f}"
+        if w and "SQ_WAVE_CYCLES" in m and "SQ_ACTIVE_INST_VALU" in m:
+            line += f"; wavefront lifetime {4 * m['SQ_WAVE_CYCLES'] / w:.0f} clk, VALU-active {4 * m['SQ_ACTIVE_INST_VALU'] / w:.0f} clk per wavefront"
+        if "FETCH_SIZE" in m: line += f"; fabric read {m['FETCH_SIZE'] * 1024 * cal['fetch_factor'] / 1e6:.1f} MB, written {m.get('WRITE_SIZE', 0) * 1024 * cal['write_factor'] / 1e6:.1f} MB (algorithmic: 16 MB per layer)"
+        print(line)

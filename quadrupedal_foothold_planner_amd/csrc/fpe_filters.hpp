@@ -59,7 +59,10 @@ __device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, c
     }
     for (int k = t; k < W * W; k += 256) {
         const int i = ti0 - H + k / W, j = tj0 - H + k % W;
-        d.tile[k] = in_range(i, j, g.rows, g.cols) ? src[static_cast<size_t>(i) * g.cols + j] : __builtin_nanf("");
+        // invalid cells (GridMap::isValid = isfinite) enter the tile as quiet NaNs: the walks test `z == z`, and the
+        // float max / min of the step filter skip them by themselves
+        const float v = in_range(i, j, g.rows, g.cols) ? src[static_cast<size_t>(i) * g.cols + j] : __builtin_nanf("");
+        d.tile[k] = isfinite(v) ? v : __builtin_nanf("");
     }
     __syncthreads();
     if (t < 2 * kFT) {  // CircleIterator::findSubmapParameters per axis (circle_bbox), clamped onto the halo
@@ -110,9 +113,31 @@ __device__ __forceinline__ void disc_walk(const DiscLds& d, int li, int lj, int 
         const int ri = ii - ti0 + H;
         const double x = d.xP[ri];
         const int rowBase = ri * W + colBase;
-#pragma unroll 4
-        for (int jj = j - wL; jj <= j + wR; ++jj) f(x, d.yP[colBase + jj], d.tile[rowBase + jj]);
+        int jj = j - wL;
+        const int jEnd = j + wR;
+        for (; jj + 3 <= jEnd; jj += 4) {  // four members' LDS reads in flight before the first is consumed
+            const float z0 = d.tile[rowBase + jj], z1 = d.tile[rowBase + jj + 1], z2 = d.tile[rowBase + jj + 2], z3 = d.tile[rowBase + jj + 3];
+            const double y0 = d.yP[colBase + jj], y1 = d.yP[colBase + jj + 1], y2 = d.yP[colBase + jj + 2], y3 = d.yP[colBase + jj + 3];
+            f(x, y0, z0);
+            f(x, y1, z1);
+            f(x, y2, z2);
+            f(x, y3, z3);
+        }
+        for (; jj <= jEnd; ++jj) f(x, d.yP[colBase + jj], d.tile[rowBase + jj]);
     }
+}
+
+// v_max_f32 / v_min_f32 return the other operand when one is a quiet NaN (IEEE mode); written as instructions because
+// fmaxf / fminf are compiled with a canonicalising v_max(x, x) in front of every operand.
+__device__ __forceinline__ float max_skip_nan(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float min_skip_nan(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // One Jacobi rotation of the symmetric 3 x 3 eigenproblem on the (p, q) pair; r is the third index.
@@ -261,7 +286,8 @@ __global__ __launch_bounds__(256) void filter_step1_kernel(MapGeom g, const floa
     if (isfinite(d.tile[(li + H) * d.W + lj + H])) {
         float hi = -__builtin_huge_valf(), lo = __builtin_huge_valf();
         disc_walk(d, li, lj, ti0, tj0, r * r, [&](double, double, float z) {
-            if (isfinite(z)) { hi = fmaxf(hi, z); lo = fminf(lo, z); }
+            hi = max_skip_nan(hi, z);
+            lo = min_skip_nan(lo, z);
         });
         out = static_cast<float>(static_cast<double>(hi) - static_cast<double>(lo));  // the centre is a member: init holds
     }
@@ -269,7 +295,7 @@ __global__ __launch_bounds__(256) void filter_step1_kernel(MapGeom g, const floa
 }
 
 // StepFilter, second iteration, and the weighted sum of the three filters.
-__global__ __launch_bounds__(256) void filter_step2_kernel(MapGeom g, FilterLayers L, double r, int H, double critical, int nCritical) {
+__global__ __launch_bounds__(256) void filter_step2_kernel(MapGeom g, FilterLayers L, double r, int H, double critical, float critDown, int nCritical) {
     extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
     const DiscLds d = disc_carve(ldsRaw, H);
     const int ti0 = blockIdx.y * kFT, tj0 = blockIdx.x * kFT;
@@ -278,16 +304,16 @@ __global__ __launch_bounds__(256) void filter_step2_kernel(MapGeom g, FilterLaye
     const int i = ti0 + li, j = tj0 + lj;
     if (i >= g.rows || j >= g.cols) return;
     const size_t cell = static_cast<size_t>(i) * g.cols + j;
+    // double(sh) > critical for a float sh is sh > critDown = critical rounded DOWN to float (launch_filters); NaN (invalid)
+    // compares false
     int nCells = 0;
-    float stepMaxF = 0.0f;
-    bool valid = false;
+    float seen = -1.0f;  // step heights are >= +0: the maximum over the valid members, -1 when there is none
     disc_walk(d, li, lj, ti0, tj0, r * r, [&](double, double, float sh) {
-        if (isfinite(sh)) {
-            valid = true;
-            stepMaxF = fmaxf(stepMaxF, sh);
-            nCells += static_cast<double>(sh) > critical ? 1 : 0;
-        }
+        seen = max_skip_nan(seen, sh);
+        nCells += sh > critDown ? 1 : 0;
     });
+    const bool valid = seen >= 0.0f;
+    const float stepMaxF = valid ? seen : 0.0f;
     float out = __builtin_nanf("");
     if (valid) {
         const double stepMax = static_cast<double>(stepMaxF);
@@ -319,6 +345,9 @@ hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float*
     if (!fuse)
         hipLaunchKernelGGL(filter_roughness_kernel, grid, block, disc_lds_bytes(hR), stream, g, d_elev, L, fc.roughnessRadius, hR, fc.roughnessCritical);
     hipLaunchKernelGGL(filter_step1_kernel, grid, block, disc_lds_bytes(h1), stream, g, d_elev, L, fc.stepFirstRadius, h1);
-    hipLaunchKernelGGL(filter_step2_kernel, grid, block, disc_lds_bytes(h2), stream, g, L, fc.stepSecondRadius, h2, fc.stepCritical, fc.stepCriticalCells);
+    float critDown = static_cast<float>(fc.stepCritical);
+    if (static_cast<double>(critDown) > fc.stepCritical) critDown = std::nextafterf(critDown, -HUGE_VALF);
+    hipLaunchKernelGGL(filter_step2_kernel, grid, block, disc_lds_bytes(h2), stream, g, L, fc.stepSecondRadius, h2, fc.stepCritical, critDown,
+                       fc.stepCriticalCells);
     return hipGetLastError();
 }
