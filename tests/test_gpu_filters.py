@@ -111,6 +111,35 @@ def test_device_resident_chain_feeds_the_planner(planner):
     util.assert_plan_equal(eng, ora)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_layers_and_parameters(planner, seed):
+    """Differential campaign: random size, resolution, map position, hole density, terrain (steps, slopes, noise, spikes
+    of +-inf) and filter parameters — radii on and off multiples of the resolution, windows larger than the map."""
+    rng = np.random.default_rng(9000 + seed)
+    rows, cols = int(rng.integers(5, 90)), int(rng.integers(5, 90))
+    res = float(rng.choice([0.005, 0.01, 0.02, 0.025, 0.04]))
+    ii, jj = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
+    elev = (rng.uniform(0, 0.4) * np.sin(ii * res * rng.uniform(2, 30)) + rng.uniform(-0.5, 0.5) * jj * res
+            + rng.normal(0, rng.choice([0.0, 1e-4, 5e-3]), (rows, cols))).astype(np.float32)
+    for _ in range(int(rng.integers(0, 4))):  # risers
+        k = int(rng.integers(0, rows))
+        elev[k:, :] += np.float32(rng.uniform(0.02, 0.3))
+    elev[rng.random((rows, cols)) < rng.choice([0.0, 0.02, 0.3, 0.9])] = np.nan
+    if seed % 4 == 1:
+        elev[rng.random((rows, cols)) < 0.01] = np.inf  # GridMap::isValid is isfinite
+        elev[rng.random((rows, cols)) < 0.01] = -np.inf
+    pos = (float(rng.uniform(-50, 50)), float(rng.uniform(-50, 50))) if seed % 2 else (0.0, 0.0)
+    k = rng.uniform(1.0, 6.0, 4)
+    snap = lambda r: float(np.round(r / res) * res) if rng.random() < 0.5 else float(r)  # exactly n cells, or not
+    fp = planner.filter_params(normal_radius=snap(k[0] * res), roughness_radius=snap(k[0] * res) if seed % 3 else snap(k[1] * res),
+                               step_first_radius=snap(k[2] * res), step_second_radius=snap(k[3] * res),
+                               slope_critical=float(rng.uniform(0.3, 1.5)), step_critical=float(rng.choice([0.12, 0.125, 0.05])),
+                               step_critical_cells=int(rng.integers(1, 9)), roughness_critical=float(rng.uniform(0.01, 0.1)))
+    _, layers = planner.traversability_from_elevation(elev, res, position=pos, params=fp, want_layers=True)
+    ora = fpo.traversability_filters(elev, res, position=pos, params=oracle_params(fp))
+    assert_layers_equal(layers, ora, max_ulp_cells=5e-3)
+
+
 def test_filter_argument_errors(planner):
     elev = np.zeros((8, 8), np.float32)
     with pytest.raises(Exception):
