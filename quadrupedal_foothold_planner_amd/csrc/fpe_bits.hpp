@@ -1217,18 +1217,18 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
                 sf.row = no.row; sf.col = no.col; sf.z = no.z;
                 sf.valid = static_cast<uint8_t>(no.valid); sf.source = static_cast<uint8_t>(no.source);
                 sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
-                out.selected[o] = sf;
+                store_record<false>(out.selected + o, sf);
             }
             if (out.centroid) {
                 fpe_centroid_foothold cf;
                 cf.x = co.x; cf.y = co.y; cf.z = co.z; cf.row = co.row; cf.col = co.col;
                 cf.code = static_cast<uint8_t>(co.code); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
-                out.centroid[o] = cf;
+                store_record<false>(out.centroid + o, cf);
             }
             if (out.default_next) {
-                out.default_next[o * 3 + 0] = nx0;
-                out.default_next[o * 3 + 1] = ny;
-                out.default_next[o * 3 + 2] = static_cast<double>(zDefault);
+                store_record<false>(out.default_next + o * 3 + 0, static_cast<double>(nx0));
+                store_record<false>(out.default_next + o * 3 + 1, static_cast<double>(ny));
+                store_record<false>(out.default_next + o * 3 + 2, static_cast<double>(zDefault));
             }
         }
     }
@@ -1337,14 +1337,14 @@ __device__ __forceinline__ void flush_unit(const DevMap& m, const PlanConsts& pc
         f.source = static_cast<uint8_t>(source);
         f.foot_id = static_cast<uint8_t>(leg);
         f.gait_cycle_id = static_cast<uint8_t>(cyc);
-        out.nominal[o] = f;
+        store_record<true>(out.nominal + o, f);
     }
     if (out.selected) {
         fpe_selected_foothold sf;
         sf.row = u.nomRow; sf.col = u.nomCol; sf.z = zN;
         sf.valid = static_cast<uint8_t>(valid); sf.source = static_cast<uint8_t>(source);
         sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
-        out.selected[o] = sf;
+        store_record<true>(out.selected + o, sf);
     }
     if (out.centroid) {
         fpe_centroid_foothold cf;
@@ -1352,12 +1352,12 @@ __device__ __forceinline__ void flush_unit(const DevMap& m, const PlanConsts& pc
         cf.y = code == 0 ? ye.ny : (code == 1 ? ye.yA : (code <= 4 ? ye.yB : 0.0));
         cf.z = zC; cf.row = u.cenRow; cf.col = u.cenCol;
         cf.code = static_cast<uint8_t>(code); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
-        out.centroid[o] = cf;
+        store_record<true>(out.centroid + o, cf);
     }
     if (out.default_next) {
-        out.default_next[o * 3 + 0] = u.defX;
-        out.default_next[o * 3 + 1] = ye.ny;
-        out.default_next[o * 3 + 2] = static_cast<double>(zB);
+        store_record<true>(out.default_next + o * 3 + 0, u.defX);
+        store_record<true>(out.default_next + o * 3 + 1, ye.ny);
+        store_record<true>(out.default_next + o * 3 + 2, static_cast<double>(zB));
     }
 }
 
@@ -1675,24 +1675,24 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
     }
     if (g.sub == 0 && live) {
         const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
-        if (out.nominal) store_foothold(out.nominal + o, no, leg, cyc);
+        if (out.nominal) store_foothold<true>(out.nominal + o, no, leg, cyc);
         if (out.selected) {
             fpe_selected_foothold sf;
             sf.row = no.row; sf.col = no.col; sf.z = no.z;
             sf.valid = static_cast<uint8_t>(no.valid); sf.source = static_cast<uint8_t>(no.source);
             sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
-            out.selected[o] = sf;
+            store_record<true>(out.selected + o, sf);
         }
         if (out.centroid) {
             fpe_centroid_foothold cf;
             cf.x = co.x; cf.y = co.y; cf.z = co.z; cf.row = co.row; cf.col = co.col;
             cf.code = static_cast<uint8_t>(co.code); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
-            out.centroid[o] = cf;
+            store_record<true>(out.centroid + o, cf);
         }
         if (out.default_next) {
-            out.default_next[o * 3 + 0] = nx0;
-            out.default_next[o * 3 + 1] = ny;
-            out.default_next[o * 3 + 2] = static_cast<double>(zDefault);
+            store_record<true>(out.default_next + o * 3 + 0, static_cast<double>(nx0));
+            store_record<true>(out.default_next + o * 3 + 1, static_cast<double>(ny));
+            store_record<true>(out.default_next + o * 3 + 2, static_cast<double>(zDefault));
         }
     }
 }

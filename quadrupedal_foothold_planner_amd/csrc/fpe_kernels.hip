@@ -1275,6 +1275,32 @@ __device__ void spiral_search(const DevMap& m, const PlanConsts& pc, const Spira
     }
 }
 
+// Result records of the 8-lane kernels leave as streaming stores (nt): nothing on the device reads them back within the
+// launch, and a record left dirty in the L2 displaces map lines and is only written out when the kernel ends (14 MB per
+// headline launch behind the last wavefront).  Measured: headline 30.25 -> 29.1 us, cfg-4 1.193 -> 1.151 ms.  The
+// one-wavefront-per-pose kernels store one 32-byte record per leg from a single lane: streamed, those partial lines cost
+// more than they save (cfg-3 +4 %, cfg-5 +1.5 %), so they keep ordinary stores (kStream = false).
+typedef unsigned int fpe_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int fpe_v2u __attribute__((ext_vector_type(2)));
+template <bool kStream, class T>
+__device__ __forceinline__ void store_record(T* dst, const T& v) {
+    static_assert(sizeof(T) % 8 == 0, "records are stored in 8- or 16-byte pieces");
+    if constexpr (!kStream) {
+        *dst = v;
+    } else if constexpr (sizeof(T) % 16 == 0) {
+        fpe_v4u w[sizeof(T) / 16];
+        __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+        for (unsigned k = 0; k < sizeof(T) / 16; ++k) __builtin_nontemporal_store(w[k], reinterpret_cast<fpe_v4u*>(dst) + k);
+    } else {
+        fpe_v2u w[sizeof(T) / 8];
+        __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+        for (unsigned k = 0; k < sizeof(T) / 8; ++k) __builtin_nontemporal_store(w[k], reinterpret_cast<fpe_v2u*>(dst) + k);
+    }
+}
+
+template <bool kStream = false>
 __device__ __forceinline__ void store_foothold(fpe_foothold* dst, const NominalOut& o, int leg, int cycle) {
     fpe_foothold f;
     f.row = o.row;
@@ -1286,7 +1312,7 @@ __device__ __forceinline__ void store_foothold(fpe_foothold* dst, const NominalO
     f.source = static_cast<uint8_t>(o.source);
     f.foot_id = static_cast<uint8_t>(leg);
     f.gait_cycle_id = static_cast<uint8_t>(cycle);
-    *dst = f;
+    store_record<kStream>(dst, f);
 }
 
 // getPolygonCenter (cpp:2421-2463): feet[leg][xyz] in LDS.  Only the centre's x is computed: the next
@@ -1503,18 +1529,18 @@ __device__ __forceinline__ void leg_phase(const DevMap& m, const PlanConsts& pc,
                     sf.row = no.row; sf.col = no.col; sf.z = no.z;
                     sf.valid = static_cast<uint8_t>(no.valid); sf.source = static_cast<uint8_t>(no.source);
                     sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
-                    out.selected[o] = sf;
+                    store_record<false>(out.selected + o, sf);
                 }
                 if (out.centroid) {
                     fpe_centroid_foothold cf;
                     cf.x = co.x; cf.y = co.y; cf.z = co.z; cf.row = co.row; cf.col = co.col;
                     cf.code = static_cast<uint8_t>(co.code); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
-                    out.centroid[o] = cf;
+                    store_record<false>(out.centroid + o, cf);
                 }
                 if (out.default_next) {
-                    out.default_next[o * 3 + 0] = nx0;
-                    out.default_next[o * 3 + 1] = ny;
-                    out.default_next[o * 3 + 2] = static_cast<double>(zDefault);
+                    store_record<false>(out.default_next + o * 3 + 0, static_cast<double>(nx0));
+                    store_record<false>(out.default_next + o * 3 + 1, static_cast<double>(ny));
+                    store_record<false>(out.default_next + o * 3 + 2, static_cast<double>(zDefault));
                 }
             }
         }
