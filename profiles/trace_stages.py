@@ -51,3 +51,16 @@ for p in pts[1:]:
     dt = t[:, :nc, p] - t[:, :nc, prev]
     print(f"  {names[prev]:22s} -> {names[p]:22s} cycle 0 {dt[:,0].mean():7.0f}  cycle 1 {dt[:,1].mean() if nc>1 else 0:7.0f}  cycles 2.. {dt[:,2:].mean() if nc>2 else 0:7.0f}")
     prev = p
+# which wavefronts are the slow ones: lifetime against the per-cycle stage that varies
+order = np.argsort(life)
+cyc_tot = t[:, :nc, 10] - t[:, :nc, 0]
+sp = t[:, :nc, 8] - t[:, :nc, 7]
+xp = t[:, :nc, 2] - t[:, :nc, 1]
+print("slowest 8 wavefronts: lifetime, sum of cycle totals, spiral stage per cycle, x pass per cycle")
+for bidx in order[-8:]:
+    print(f"  block {bidx}: {life[bidx]:.0f} {cyc_tot[bidx].sum():.0f}  spiral {' '.join(f'{v:.0f}' for v in sp[bidx])}  x {' '.join(f'{v:.0f}' for v in xp[bidx])}")
+print("fastest 4:")
+for bidx in order[:4]:
+    print(f"  block {bidx}: {life[bidx]:.0f} {cyc_tot[bidx].sum():.0f}  spiral {' '.join(f'{v:.0f}' for v in sp[bidx])}  x {' '.join(f'{v:.0f}' for v in xp[bidx])}")
+print("correlation of lifetime with the summed spiral stage", np.corrcoef(life, sp.sum(1))[0, 1], " with the summed x pass", np.corrcoef(life, xp.sum(1))[0, 1])
+print("spiral stage histogram (clk):", np.histogram(sp, bins=[0, 200, 600, 1000, 1400, 1800, 2500, 4000, 100000])[0])

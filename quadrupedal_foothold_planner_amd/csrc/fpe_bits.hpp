@@ -1817,6 +1817,33 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     const float eB = load_cell(m.elev, boxB + laneCell);
     const float eMidA = load_cell(m.elev, boxA + colsU + 1u);
     const float eMidB = load_cell(m.elev, boxB + colsU + 1u);
+    // In the shadow of that round trip: the rows of the search rectangle, which only a spiral search uses — but most
+    // wavefronts have one leg in eight that needs it (88 % of the headline's cycles), and these forty instructions
+    // would otherwise sit on the dependent chain behind the default check.  (Moving the candidates' window addresses
+    // and the chain-independent unit fields up here as well changed nothing.)
+    const bool fastSpiral = __ballot(ls.polyKind != 0 || lk.nRings < 4 || lk.nCand < 16) == 0ull && pc.nFoot <= 1;  // uniform
+    int iA = 0, iB = -1;
+    if (fastSpiral) {
+        const double r = static_cast<double>(ls.Rf);
+        const double xhi = nx2 + r, xlo = nx2 - r;  // getSearchPolygon around the NOMINAL track (cpp:2496-2517)
+        double qh = floor((m.g.baseX - xhi) * m.g.rinv), ql = floor((m.g.baseX - xlo) * m.g.rinv);
+        qh = fmin(fmax(qh, -1.0e9), 1.0e9);
+        ql = fmin(fmax(ql, -1.0e9), 1.0e9);
+        const int eH = static_cast<int>(qh), eL = static_cast<int>(ql);
+        // lane q & 3: 0 P(eH), 1 P(eH + 1) with P(i) = x_i < xhi;  2 Q(eL + 1), 3 Q(eL) with Q(i) = x_i >= xlo
+        const bool isLo = (g.sub & 2) != 0;
+        const int odd = g.sub & 1;
+        const int tLo = eL + 1 - odd, tHi = eH + odd;
+        const int tq = isLo ? tLo : tHi;
+        const double lim = isLo ? xlo : xhi;
+        const double xt = cell_pos(m.g.baseX, m.g.res, tq);
+        const bool predLo = xt >= lim, predHi = xt < lim;
+        const bool pred = isLo ? predLo : predHi;
+        const unsigned pb = static_cast<unsigned>(g.ballot(pred));
+        const int iA1 = (pb & 2u) ? eH + 1 : eH + 2, iB1 = (pb & 8u) ? eL : eL - 1;
+        iA = (pb & 1u) ? eH : iA1;
+        iB = (pb & 4u) ? eL + 1 : iB1;
+    }
     stamp(pc, cyc, 3);
     WinRows<NRL, KW> w;
     win_finish<NRL, KW>(jw0, grp, w);
@@ -1893,24 +1920,7 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
         // first two rounds (ranks 0-15: rings 0-2, whose cells the iterator does not filter when nRings >= 4).  Same
         // evaluation as spiral_bits: x interval as in rectangle_index_bounds, columns from the y entry, pass rows
         // P = ~F | (~C & inside) in the leg's LDS, lowest set ballot bit = first valid cell in spiral order.
-        if (__ballot(ls.polyKind != 0 || lk.nRings < 4 || lk.nCand < 16) == 0ull && pc.nFoot <= 1) {  // uniform over the searching legs
-            const double xhi = nx2 + r, xlo = nx2 - r;  // getSearchPolygon around the NOMINAL track (cpp:2496-2517)
-            double qh = floor((m.g.baseX - xhi) * m.g.rinv), ql = floor((m.g.baseX - xlo) * m.g.rinv);
-            qh = fmin(fmax(qh, -1.0e9), 1.0e9);
-            ql = fmin(fmax(ql, -1.0e9), 1.0e9);
-            const int eH = static_cast<int>(qh), eL = static_cast<int>(ql);
-            // lane q & 3: 0 P(eH), 1 P(eH + 1) with P(i) = x_i < xhi;  2 Q(eL + 1), 3 Q(eL) with Q(i) = x_i >= xlo
-            const bool isLo = (g.sub & 2) != 0;
-            const int odd = g.sub & 1;
-            const int tLo = eL + 1 - odd, tHi = eH + odd;
-            const int tq = isLo ? tLo : tHi;
-            const double lim = isLo ? xlo : xhi;
-            const double xt = cell_pos(m.g.baseX, m.g.res, tq);
-            const bool predLo = xt >= lim, predHi = xt < lim;
-            const bool pred = isLo ? predLo : predHi;
-            const unsigned pb = static_cast<unsigned>(g.ballot(pred));
-            const int iA1 = (pb & 2u) ? eH + 1 : eH + 2, iB1 = (pb & 8u) ? eL : eL - 1;
-            const int iA = (pb & 1u) ? eH : iA1, iB = (pb & 4u) ? eL + 1 : iB1;
+        if (fastSpiral) {
             const int NR = lb.rows;
 #pragma unroll
             for (int k = 0; k < NRL; ++k) {
