@@ -1016,6 +1016,17 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
     return false;
 }
 
+// One-wavefront-per-pose kernels: what a leg's four output records are made of, staged in LDS by the leg's lane 0 and
+// written out for a few cycles at a time by one lane per (cycle, leg) — full records side by side instead of eight
+// single-lane store instructions per leg (8 % of a leg's clocks on cfg-3).
+struct SeqRec {
+    double nomX, nomY, cenX, cenY, defX, defY;
+    float nomZ, cenZ, defZ;
+    int32_t nomRow, nomCol, cenRow, cenCol;
+    uint32_t flags;  // nominal valid | source << 8 | centroid code << 16
+};
+static_assert(sizeof(SeqRec) == 80 && sizeof(SeqRec) % 16 == 0, "SeqRec layout");
+
 // One swing leg of one phase on the bit window: the three tracks' next positions, the centroid method
 // (cpp:1605-1997) and checkFoothold (cpp:2001-2036) around the centroid track's position, the mean heights.
 // kDirect: the results stay in registers (LegCommit) for a commit decided by wave ballot (8-lane kernels); otherwise
@@ -1024,7 +1035,7 @@ template <int G, int NRL, int KW, bool kMid, bool kDirect>
 __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut,
                                                const LutHead& head, PoseShared& sh, const LegBits& lb, const Grp<G>& g, int leg,
                                                const LegStatic& ls, double y0, double adjY, double advance, int cyc, int nCycles,
-                                               int b, bool live, const fpe_plan_out& out, LegCommit* lc) {
+                                               int b, bool live, const fpe_plan_out& out, LegCommit* lc, SeqRec* recs = nullptr) {
     const float Rf = ls.Rf;
     const int polyKind = ls.polyKind;
     const LegConst& lk = ls.lk;
@@ -1209,7 +1220,14 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
             sh.nxt[2][leg][0] = no.x;  sh.nxt[2][leg][1] = no.y;  sh.nxt[2][leg][2] = static_cast<double>(no.z);
         }
         stamp(pc, cyc, 13);
-        if (live) {
+        if (live && recs) {  // staged: flush_seqrec writes the records of a few cycles at a time
+            SeqRec r;
+            r.nomX = no.x; r.nomY = no.y; r.cenX = co.x; r.cenY = co.y; r.defX = nx0; r.defY = ny;
+            r.nomZ = no.z; r.cenZ = co.z; r.defZ = zDefault;
+            r.nomRow = no.row; r.nomCol = no.col; r.cenRow = co.row; r.cenCol = co.col;
+            r.flags = static_cast<uint32_t>(no.valid) | (static_cast<uint32_t>(no.source) << 8) | (static_cast<uint32_t>(co.code) << 16);
+            recs[leg] = r;
+        } else if (live) {
             const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
             if (out.nominal) store_foothold(out.nominal + o, no, leg, cyc);
             if (out.selected) {
@@ -1263,6 +1281,38 @@ struct Unit {
     uint32_t written;
 };
 static_assert(sizeof(Unit) == 144 && sizeof(Unit) % 16 == 0, "Unit layout");
+
+__device__ __forceinline__ void flush_seqrec(const SeqRec& rLds, int b, int cyc, int leg, int nCycles, const fpe_plan_out& out) {
+    SeqRec r;
+    __builtin_memcpy(&r, &rLds, sizeof(SeqRec));
+    const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
+    const uint8_t valid = static_cast<uint8_t>(r.flags & 0xFFu), source = static_cast<uint8_t>((r.flags >> 8) & 0xFFu);
+    if (out.nominal) {
+        fpe_foothold f;
+        f.row = r.nomRow; f.col = r.nomCol; f.x = r.nomX; f.y = r.nomY; f.z = r.nomZ;
+        f.valid = valid; f.source = source;
+        f.foot_id = static_cast<uint8_t>(leg); f.gait_cycle_id = static_cast<uint8_t>(cyc);
+        store_record<true>(out.nominal + o, f);
+    }
+    if (out.selected) {
+        fpe_selected_foothold sf;
+        sf.row = r.nomRow; sf.col = r.nomCol; sf.z = r.nomZ;
+        sf.valid = valid; sf.source = source;
+        sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
+        store_record<true>(out.selected + o, sf);
+    }
+    if (out.centroid) {
+        fpe_centroid_foothold cf;
+        cf.x = r.cenX; cf.y = r.cenY; cf.z = r.cenZ; cf.row = r.cenRow; cf.col = r.cenCol;
+        cf.code = static_cast<uint8_t>((r.flags >> 16) & 0xFFu); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
+        store_record<true>(out.centroid + o, cf);
+    }
+    if (out.default_next) {
+        store_record<true>(out.default_next + o * 3 + 0, r.defX);
+        store_record<true>(out.default_next + o * 3 + 1, r.defY);
+        store_record<true>(out.default_next + o * 3 + 2, static_cast<double>(r.defZ));
+    }
+}
 
 // 3x3 form: lane s holds cell s + (s >= 4) of the box, every lane the middle cell (disc_issue); else the direct pass.
 template <bool kWant>
@@ -2273,7 +2323,7 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
 // row, KW words per row; the swing legs of a phase are searched one after the other (see plan_sequential_kernel) ----
 template <int NRL, int KW>
 __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap bm, PlanConsts pc, SpiralLut lut,
-                                                              const fpe_pose* __restrict__ poses, int B, int nCycles, fpe_plan_out out) {
+                                                              const fpe_pose* __restrict__ poses, int B, int nCycles, fpe_plan_out out, int recSlots) {
     constexpr int G = 64;
     constexpr int NR = G * NRL;
     stamp(pc, 6, 14);  // (profiling builds: lifetime of the wavefront, with the stamp after the cycle loop)
@@ -2290,6 +2340,10 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
     constexpr size_t kLsBytes = (4 * sizeof(LegStatic) + 15) & ~static_cast<size_t>(15);
     // rows actually allocated: the window's 2 winH + 1 (not 64 * NRL) — LDS bounds the occupancy of these kernels
     const LegBits lb = make_legbits(smem + sizeof(PoseShared) + kLsBytes, min(2 * pc.winH + 1, NR), KW, pc.nHW, true);
+    // staged output records: recSlots (a power of two, sized by the launch to keep the LDS within the occupancy budget)
+    // cycles of four legs behind the row arrays
+    SeqRec* recBase = reinterpret_cast<SeqRec*>(
+        smem + ((sizeof(PoseShared) + kLsBytes + 4 * static_cast<size_t>(legbits_words(min(2 * pc.winH + 1, NR), KW, pc.nHW, true)) + 15) & ~static_cast<size_t>(15)));
     const int b = blockIdx.x;
     if (b >= B) return;
     const bool live = true;
@@ -2346,7 +2400,8 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
                 if (!((mask >> leg) & 1u)) continue;
                 const LegStatic ls = lsTab[leg];
                 stamp(pc, cyc, 1);
-                leg_phase_bits<G, NRL, KW, false, false>(m, bm, pc, lut, head, sh, lb, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out, nullptr);
+                leg_phase_bits<G, NRL, KW, false, false>(m, bm, pc, lut, head, sh, lb, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out, nullptr,
+                                                         recBase + 4 * (cyc & (recSlots - 1)));
                 stamp(pc, cyc, 9);
             }
             pose_sync<16>();
@@ -2365,6 +2420,15 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
         }
         if (tid == 0 && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = cycleOk ? 1 : 0;
         adjY += pc.drift;  // cpp:1578
+        {   // the staged records of the last recSlots cycles: lane = (cycle slot, leg)
+            const int slot = cyc & (recSlots - 1);
+            if (slot == recSlots - 1 || cyc == nCycles - 1) {
+                pose_sync<16>();
+                const int s = tid >> 2, c = (cyc - slot) + s;
+                if (tid < 4 * recSlots && c <= cyc) flush_seqrec(recBase[tid], b, c, tid & 3, nCycles, out);
+                pose_sync<16>();  // the slots are rewritten next
+            }
+        }
     }
     stamp(pc, 6, 15);
 #ifdef FPE_TRACE
@@ -2455,10 +2519,15 @@ hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts&
                        2 * (sizeof(PoseShared) + 16 * legbits_words(8 * NRL, 1, pc.nHW, false) + sizeof(YEntry) * 32 +                \
                             (MID ? sizeof(Unit) * 32 : 0)), stream, d_poses, B, nCycles, m, bm, pc, lut, d_out)
 #define FPE_LAUNCH_BITS_SEQ(NRL, KW)                                                                                         \
-    hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW>), dim3(B), block,                                                      \
-                       sizeof(PoseShared) + ((4 * sizeof(LegStatic) + 15) & ~static_cast<size_t>(15)) +                                  \
-                           4 * legbits_words(2 * pc.winH + 1 < 64 * NRL ? 2 * pc.winH + 1 : 64 * NRL, KW, pc.nHW, true),        \
-                       stream, m, bm, pc, lut, d_poses, B, nCycles, d_out)
+    do {                                                                                                                     \
+        const size_t base = (sizeof(PoseShared) + ((4 * sizeof(LegStatic) + 15) & ~static_cast<size_t>(15)) +                            \
+                             4 * legbits_words(2 * pc.winH + 1 < 64 * NRL ? 2 * pc.winH + 1 : 64 * NRL, KW, pc.nHW, true) + 15) &        \
+                            ~static_cast<size_t>(15);                                                                                 \
+        int recSlots = 8; /* cycles of staged records: as many as keep sixteen blocks per CU (10 KiB each) */                      \
+        while (recSlots > 1 && base + recSlots * 4 * sizeof(SeqRec) > 10240) recSlots >>= 1;                                         \
+        hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW>), dim3(B), block, base + recSlots * 4 * sizeof(SeqRec), stream, m, bm, pc, \
+                           lut, d_poses, B, nCycles, d_out, recSlots);                                                                \
+    } while (0)
     if (sp.lanes == 8) {
         if (sp.nrl == 2 && mid) FPE_LAUNCH_BITS(2, true);
         else if (sp.nrl == 2) FPE_LAUNCH_BITS(2, false);
