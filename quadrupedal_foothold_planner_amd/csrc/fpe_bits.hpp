@@ -198,6 +198,7 @@ __device__ __forceinline__ CentroidScan rows_from_bits(const Submap& s, const Wi
     const int ni = s.ni, nj = s.nj;
     const int c0 = s.j0 - jw0, c1 = c0 + nj - 1;  // window columns of the rectangle
     unsigned long long blk[2] = {0ull, 0ull};      // bit = window row
+    unsigned blk32 = 0u;                           // (windows of up to 32 rows: one 32-bit word)
     bool anyBelow = false;
 #pragma unroll
     for (int k = 0; k < NRL; ++k) {
@@ -211,10 +212,19 @@ __device__ __forceinline__ CentroidScan rows_from_bits(const Submap& s, const Wi
         const bool blocked = liveRow && 2 * cnt > nj;
         const unsigned long long mk = g.ballot(blocked);
         constexpr int kPerWord = 64 / G;  // ballots of G lanes packed into a 64-bit word
-        if constexpr (G == 64) blk[k & 1] |= mk;
+        if constexpr (G * NRL <= 32) blk32 |= static_cast<unsigned>(mk) << (G * k);
+        else if constexpr (G == 64) blk[k & 1] |= mk;
         else blk[(k / kPerWord) & 1] |= mk << (G * (k % kPerWord));
     }
     const int off = s.i0 - iw0;
+    if constexpr (G * NRL <= 32) {  // the 8-lane shapes: 32-bit shifts and bit scans instead of 64-bit ones
+        const unsigned rel = blk32 >> (off & 31);
+        const unsigned relIn = (static_cast<unsigned>(off) < 32u) ? rel : 0u;
+        r0.minRow = relIn ? __builtin_ctz(relIn) : 0;
+        r0.maxRow = relIn ? 31 - __builtin_clz(relIn) : 0;
+        r0.whole = s.ok && ni * nj > 0 && !g.any(anyBelow);
+        return r0;
+    }
     if constexpr (G * NRL <= 64) {  // the whole window in one word
         const unsigned long long rel = blk[0] >> (off & 63);
         const unsigned long long relIn = (static_cast<unsigned>(off) < 64u) ? rel : 0ull;
