@@ -42,6 +42,23 @@ def test_params_defaults_match_yaml_and_code():
     assert c["defaultFootholdThreshold"] == np.float32(0.7)
 
 
+def test_filter_defaults_match_between_engine_and_oracle():
+    """fpe_filter_params_defaults (no device needed) and the oracle's defaults are the same published chain, field by
+    field, and the two records have the same layout."""
+    import ctypes as C
+
+    fp = _capi.FilterParams()
+    assert _capi.lib().fpe_filter_params_defaults(C.byref(fp)) == 0
+    o = fpo.filter_defaults()[0]
+    assert C.sizeof(fp) == fpo.FILTER_PARAMS_DTYPE.itemsize
+    pairs = [("normal_radius", "normalRadius"), ("slope_critical", "slopeCritical"), ("step_critical", "stepCritical"),
+             ("step_first_radius", "stepFirstRadius"), ("step_second_radius", "stepSecondRadius"),
+             ("step_critical_cells", "stepCriticalCells"), ("roughness_critical", "roughnessCritical"), ("roughness_radius", "roughnessRadius")]
+    for a, b in pairs:
+        assert getattr(fp, a) == o[b], (a, b)
+    assert bytes(fp) == o.tobytes()
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import torch
 
