@@ -46,10 +46,12 @@ __global__ __launch_bounds__(256) void build_bitmap_kernel(const float* __restri
             o.y = static_cast<unsigned>(bDf >> (32 * lane));
             o.z = static_cast<unsigned>(bC >> (32 * lane));
             o.w = static_cast<unsigned>(bF >> (32 * lane));
-            words[static_cast<size_t>(i + 1) * strideW + w + kBitPadW] = o;
+            words[bit_group_index(i, w, strideW)] = o;
         }
     }
 }
+
+// (bit_group_index: fpe_device.hpp — the tiled plane layout, shared with win_issue)
 
 // 64-lane kernels: upper bound of a CircleIterator bounding box (cells) whose elevations are compacted into LDS
 constexpr int kBitsMaxBoxCells = 128;
@@ -161,9 +163,19 @@ __device__ __forceinline__ void win_issue(const BitMap& bm, const MapGeom& mg, c
     for (int k = 0; k < NRL; ++k) {
         int i = iw0 + g.sub + G * k;
         i = max(-1, min(i, mg.rows));
+#if FPE_BITS_TILED
+        // tile (row group, word) = one 128-byte line holding 8 consecutive rows: the lanes that own rows of one row
+        // group read different 16-byte pieces of the SAME line (8-lane kernels: one or two lines per load instruction
+        // instead of eight; one-wavefront-per-pose kernels: eight or nine instead of 64)
+        const unsigned r1 = static_cast<unsigned>(i + 1);
+        const unsigned first = ((__umul24(r1 >> 3, static_cast<unsigned>(bm.strideW)) + static_cast<unsigned>(w0 + kBitPadW)) << 3) + (r1 & 7u);
+#pragma unroll
+        for (int q = 0; q <= KW; ++q) grp[k][q] = load_group(bm.words, first + 8u * static_cast<unsigned>(q));
+#else
         const unsigned first = __umul24(static_cast<unsigned>(i + 1), static_cast<unsigned>(bm.strideW)) + static_cast<unsigned>(w0 + kBitPadW);
 #pragma unroll
         for (int q = 0; q <= KW; ++q) grp[k][q] = load_group(bm.words, first + static_cast<unsigned>(q));
+#endif
     }
 }
 template <int NRL, int KW>
@@ -2452,7 +2464,11 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
 size_t bitmap_words(int rows, int cols, int* strideW, int* nw) {
     *nw = (cols + 31) / 32;
     *strideW = *nw + 2 * kBitPadW;
+#if FPE_BITS_TILED
+    return static_cast<size_t>(bit_row_groups(rows)) * 8 * (*strideW) * 4;  // 4-byte units (4 planes per word group, 8 rows per tile)
+#else
     return static_cast<size_t>(rows + 2) * (*strideW) * 4;  // 4-byte units (4 planes per word group)
+#endif
 }
 
 hipError_t launch_build_bitmap(const float* d_trav, int rows, int cols, float thrDefault, float thrCandidate, uint32_t* d_words,
@@ -2489,7 +2505,7 @@ bool bits_supported(const PlanConsts& pc, const MapGeom& g) {
     // 32-bit offsets into layers and planes (load_cell / load_group), 24-bit multiplies of rows and strides
     if (g.rows >= (1 << 24) - 2 || g.cols >= (1 << 24) - 64) return false;
     if (static_cast<double>(g.rows) * g.cols * 4.0 >= 2147483648.0 - 65536.0) return false;
-    if ((static_cast<double>(g.rows) + 2.0) * ((g.cols + 31) / 32 + 2 * kBitPadW) * 16.0 >= 2147483648.0) return false;
+    if ((static_cast<double>(g.rows) + 16.0) * ((g.cols + 31) / 32 + 2 * kBitPadW) * 16.0 >= 2147483648.0) return false;
     const BitsShape sp = bits_shape(pc.winH);
     if (sp.lanes == 0) return false;
     if (pc.groupOverride != 0 && pc.groupOverride != (sp.lanes == 8 ? 8 : 65)) return false;

@@ -92,14 +92,29 @@ constexpr int kMaxHW = 4;
 // Bit planes of one map snapshot for one (defaultFootholdThreshold, candidateFootholdThreshold) pair
 // (fpe_bits.hpp).  One uint4 per 32 columns of a row: x = D  (trav < thrDefault, raw compare: NaN 0, -inf 1),
 // y = Df (finite && trav < thrDefault), z = C (finite && trav < thrCandidate), w = F (finite); bit b of a word =
-// column 32 * word + b.  Rows -1 and `rows`, kBitPadW word groups left of column 0 and everything right of the last
-// column are zero ("not in the map"), so a window hanging over the map edge reads zeros without a bounds test.
+// column 32 * word + b.  TILED: the groups of 8 consecutive rows x one word are one 128-byte line (a search window
+// is a few dozen rows of one or two words: row-major planes spend a line per window row, 32-64 bytes of it used);
+// tiles in row-major tile order.  Rows -1 and `rows`, kBitPadW word groups left of column 0 and everything right of
+// the last column are zero ("not in the map"), so a window hanging over the map edge reads zeros without a bounds test.
+#ifndef FPE_BITS_TILED
+#define FPE_BITS_TILED 1  // 0: row-major planes (round-2 layout, kept for A/B measurements)
+#endif
 constexpr int kBitPadW = 4;
 struct BitMap {
-    const uint4* words;  // [(rows + 2) * strideW]; group of (row i, word w) at (i + 1) * strideW + w + kBitPadW
+    const uint4* words;  // group of (row i, word w) at bit_group_index(i, w, strideW)
     int32_t strideW;     // nw + 2 * kBitPadW
     int32_t nw;          // ceil(cols / 32)
 };
+// row groups (tiles of 8 rows) covering the rows -1 .. rows
+__host__ __device__ constexpr int bit_row_groups(int rows) { return ((rows + 1) >> 3) + 1; }
+__host__ __device__ __forceinline__ size_t bit_group_index(int i, int w, int strideW) {
+#if FPE_BITS_TILED
+    const int r1 = i + 1;
+    return ((static_cast<size_t>(r1 >> 3) * strideW + static_cast<size_t>(w + kBitPadW)) << 3) + static_cast<size_t>(r1 & 7);
+#else
+    return static_cast<size_t>(i + 1) * strideW + static_cast<size_t>(w + kBitPadW);
+#endif
+}
 
 // Producer filters (fpe_filters.hpp): parameters of the published default chain and the eight
 // canonical row-major output layers in HBM.
