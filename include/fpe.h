@@ -116,8 +116,9 @@ typedef struct fpe_selected_foothold {
 /* fpe_plan_out.pose_status bits */
 #define FPE_POSE_OPT_SUBMAP_FAILED 1u /* getGaitCycleSearchGridMap (cpp:2307-2349) fails in the FIRST gait cycle:
                                          getSubmap(next feet centre, isos_.length x isos_.width) — the reference's
-                                         service handler returns false there (cpp:920-934).  Exact for cycle 0
-                                         only: from cycle 1 on the opt track's feet depend on NLopt (not rebuilt). */
+                                         service handler returns false there (cpp:920-934).  This bit of the PLAN kernels
+                                         covers cycle 0; later cycles follow the opt track's own feet: fpe_plan_opt*
+                                         (fpe_opt_out.gate_fail_cycle), which the fpe_plan_service* calls run. */
 
 /* Output buffers of a chained plan; any pointer may be NULL (that product is skipped).
  * Index convention: record (b, g, leg) at ((b * n_cycles) + g) * 4 + leg. */
@@ -130,6 +131,71 @@ typedef struct fpe_plan_out {
     fpe_selected_foothold* selected; /* [B * n_cycles * 4] 16-byte form of `nominal` (multi-GPU exchange record) */
     uint8_t* pose_status;            /* [B] FPE_POSE_* bits */
 } fpe_plan_out;
+
+/* ---- the "opt" track: cpp:54-148 objective + constraints, cpp:913-1319 per-cycle driver,
+ * cpp:1485-1570 commit, cpp:2307-2408 getGaitCycleSearchGridMap, cpp:2557-2568 getMapIndex ---------------------------
+ * Reproduced exactly (bit for bit against the oracle): the gait-cycle submap gaitMap_, the four next default
+ * positions, nominalIndex, checkFootholdUseCentroidMethod ON gaitMap_ with traversableBeginRow / traversableEndRow,
+ * centroidIndex, the integer bounds xBounds, t1..t4, the objective and the eight constraints, positions and heights
+ * taken from gaitMap_ at the optimiser's (truncated) x, the commit rule, lfCurrentRow / rhCurrentRow.
+ * BUILD-DEFINED: the optimiser.  The reference runs NLopt's LN_COBYLA (yaml:60); NLopt is absent from this image and
+ * unpinned by the reference, and COBYLA's iterates are not reproducible.  In its place: exhaustive search of the same
+ * objective under the same constraints (tolerance ctol) over the INTEGER points of the same box — the reference
+ * truncates x to int before using it (cpp:1287-1312) — feasible points by objective, else the point of least
+ * constraint violation; deterministic tie-breaks (oracle/fpo_opt.cpp::solveLattice states the rule). */
+typedef struct fpe_opt_params {
+    double w1, w2, w3, w4, wr, wc;         /* nlopt/w1..wc, cpp:297-303 */
+    int32_t use_inequality_constraints;    /* nlopt/useInequalityConstraits, cpp:306 (code default 0, yaml 1) */
+    int32_t reserved;
+    double ctol;                           /* cpp:34: 1e-2 */
+    double hip_lower_scale, hip_upper_scale;   /* cpp:48: 0.9, 1.1 */
+    double skew_lower_scale, skew_upper_scale; /* cpp:49: 0.8, 1.2 */
+    double lf_current_row0, rh_current_row0;   /* file-scope lfCurrentRow / rhCurrentRow (cpp:36) at entry of the call:
+                                                  0 at node start, afterwards whatever the previous call left — the
+                                                  adapter carries fpe_opt_cycle.lf/rh_current_row of the last cycle */
+} fpe_opt_params;
+int fpe_opt_params_yaml(fpe_opt_params* out);          /* yaml:53-63 + cpp:28-51 */
+int fpe_opt_params_code_defaults(fpe_opt_params* out); /* cpp:297-307 (constraints off) */
+
+/* RF/RH/LH/LF_footholdResult_opt of one cycle (cpp:1283-1314): record (b, g, leg) at ((b * n_cycles) + g) * 4 + leg. */
+typedef struct fpe_opt_foothold {
+    double x, y;      /* gaitMap_.getPosition((int)x[2k], (int)x[2k+1]) */
+    float z;          /* getFootholdMeanHeight ON gaitMap_ (cpp:1290) */
+    int32_t row, col; /* the truncated optimiser variables: an index of gaitMap_ */
+    uint8_t foot_id, gait_cycle_id;
+    uint8_t committed; /* the cycle committed (cpp:1332): the record is part of global_footholds_opt (cpp:1515-1532) */
+    uint8_t pad;
+} fpe_opt_foothold;
+
+/* The optimisation problem of one gait cycle of one pose and its solution: record (b, g) at b * n_cycles + g.
+ * Index order of the 8-vectors: LF, RH, RF, LH x (row, col) — the reference's x (cpp:50-51, 1058-1059). */
+typedef struct fpe_opt_cycle {
+    int32_t gait_top_left[2], gait_size[2]; /* gaitMap_ (cpp:2345) inside gridmap_: index of its cell (0,0); rows, cols */
+    int32_t nominal_index[8];               /* cpp:965-976 */
+    int32_t centroid_index[8];              /* cpp:1030-1041 */
+    int32_t traversable_row[2][4];          /* cpp:1009-1013 / cpp:1608-1609: begin, end row x RF,RH,LH,LF (rows of gaitMap_);
+                                               0 where the reference leaves its (uninitialised) storage untouched */
+    int32_t x_lower[8], x_upper[8];         /* xBounds, cpp:1057-1076 */
+    int32_t x[8];                           /* the optimiser's x as the reference uses it: truncated to int */
+    double minf;                            /* objective at x */
+    double lf_current_row, rh_current_row;  /* the values this cycle's objective and constraints 7-8 used */
+    uint8_t centroid_code[4];               /* checkFootholdUseCentroidMethod on gaitMap_, RF,RH,LH,LF (fpe_centroid_foothold.code) */
+    uint8_t gate_failed;                    /* getGaitCycleSearchGridMap returned false in THIS cycle (cpp:931-934) */
+    uint8_t committed;
+    uint8_t solver_status;                  /* 0 feasible optimum; 1 NLopt precondition (lb > ub or x0 outside the box: the
+                                               reference's call throws, x stays x0); 2 least-violation point of an
+                                               infeasible problem; 3 box too large to enumerate (x0 kept) */
+    uint8_t pad;
+} fpe_opt_cycle;
+
+/* Outputs of the opt track; any pointer may be NULL.  Cycles from a pose's failing gate on (and every cycle of a
+ * walk-gait pose: the opt track is the reference's, i.e. trot only) are zero records. */
+typedef struct fpe_opt_out {
+    fpe_opt_foothold* footholds; /* [B * n_cycles * 4] */
+    fpe_opt_cycle* cycles;       /* [B * n_cycles] */
+    uint8_t* gate_fail_cycle;    /* [B] first cycle whose getGaitCycleSearchGridMap failed — the cycle in which the
+                                    reference's service handler returns false (cpp:931-934); 255 = none */
+} fpe_opt_out;
 
 /* One open-loop checkFoothold call (hpp:94-100) with an arbitrary polygon (grid_map::Polygon). */
 #define FPE_MAX_POLYGON_VERTICES 8
@@ -167,7 +233,9 @@ int fpe_destroy(fpe_handle h);
  * defaults once, in fpe_create).  Keys: "plan_group" (0 automatic; 4/8/16/64 lanes per leg, 65 = one
  * wavefront per pose), "literal_discs" (1: force the literal CircleIterator walk), "no_mid_variant"
  * (1: never launch the 3x3-only kernel variants), "no_bits" (1: never launch the bit-window kernels).
- * Not thread-safe against concurrent plan calls on the same engine. */
+ * Thread-safe: every plan / search call copies the knobs once, under the engine's lock, so a concurrent call runs
+ * entirely with the values before or entirely with the values after a change (one key per call: callers that change
+ * several keys while other threads plan get each key's change at its own moment). */
 int fpe_set_tuning(fpe_handle h, const char* key, int32_t value);
 const char* fpe_last_error(fpe_handle h); /* thread-local text of the last failure on this thread */
 const char* fpe_version(void);
@@ -179,7 +247,9 @@ int fpe_upload_map(fpe_handle h, const fpe_map_desc* desc, const float* traversa
 /* Same with DEVICE pointers (e.g. a map RCCL-broadcast from rank 0); async on `stream`.  Ordering is the
  * engine's job, not the caller's: a plan / search on ANY stream waits (GPU-side) for the upload of the snapshot it
  * uses, and the layer buffers of a snapshot retired while asynchronous launches may still read it are recycled only
- * behind a device synchronisation performed by the NEXT upload — plans never pay for it. */
+ * behind a device synchronisation performed by the NEXT upload — plans never pay for it: the upload also builds the
+ * search bit planes for the threshold pairs the previous snapshot was planned with, and a plan that needs planes for
+ * a pair never seen before allocates fresh memory rather than wait for a recycled buffer. */
 int fpe_upload_map_device(fpe_handle h, const fpe_map_desc* desc, const float* d_traversability,
                           const float* d_elevation, void* stream);
 int fpe_map_info(fpe_handle h, fpe_map_desc* out); /* geometry of the current snapshot */
@@ -226,14 +296,23 @@ int fpe_set_max_leg_search_radius(fpe_handle h, float radius);
 /* ---- chained plan: replaces the body of the per-cycle loop of globalFootholdPlan (cpp:762-1579)
  * — getDefaultFootholds, getFootholdSearchGridMap, 4x checkFootholdUseCentroidMethod (cpp:818-821),
  * 4x std::thread(checkFoothold) + join (cpp:863-909), the commit rule (cpp:1323-1576) and the
- * lateral drift (cpp:1578) — for B independent initial poses.  The NLopt "opt" track
- * (cpp:913-1319) is not part of the path. */
+ * lateral drift (cpp:1578) — for B independent initial poses.  The "opt" track (cpp:913-1319) does not feed
+ * these products; it is a launch of its own (fpe_plan_opt*). */
 int fpe_plan(fpe_handle h, const fpe_params* params, const fpe_pose* poses, int32_t B, int32_t n_cycles,
              const fpe_plan_out* out);
 /* Device-resident variant: d_poses and every non-NULL pointer of d_out are DEVICE pointers; the
  * launch is asynchronous on `stream` (a hipStream_t; NULL = default stream). */
 int fpe_plan_device(fpe_handle h, const fpe_params* params, const fpe_pose* d_poses, int32_t B,
                     int32_t n_cycles, const fpe_plan_out* d_out, void* stream);
+
+/* ---- the opt track of the same batch: replaces cpp:913-1319 + cpp:1485-1568 of the cycle loop ----------------
+ * cycle_ok = fpe_plan_out.cycle_ok of the SAME poses / parameters / map (the opt track commits with the nominal
+ * track's validity, cpp:1323-1332).  Host variant: cycle_ok may be NULL — the engine then runs the chained plan
+ * itself first.  Device variant: asynchronous on `stream`, ordered after the plan launch that wrote d_cycle_ok. */
+int fpe_plan_opt(fpe_handle h, const fpe_params* params, const fpe_opt_params* opt, const fpe_pose* poses, int32_t B,
+                 int32_t n_cycles, const uint8_t* cycle_ok, const fpe_opt_out* out);
+int fpe_plan_opt_device(fpe_handle h, const fpe_params* params, const fpe_opt_params* opt, const fpe_pose* d_poses,
+                        int32_t B, int32_t n_cycles, const uint8_t* d_cycle_ok, const fpe_opt_out* d_out, void* stream);
 
 /* ---- open-loop per-leg search: replaces checkFoothold (cpp:2001-2036) one call per query ------ */
 int fpe_search_legs(fpe_handle h, const fpe_params* params, const fpe_leg_query* queries, int32_t n,
@@ -243,8 +322,9 @@ int fpe_search_legs_device(fpe_handle h, const fpe_params* params, const fpe_leg
 
 /* ---- service-shaped call: one pose, response content of plan_global_footholds (cpp:539-1602) --
  * Returns FPE_E_SERVICE_FALSE (response zeroed) where the reference's handler returns false because
- * getGaitCycleSearchGridMap fails in the first gait cycle (cpp:920-934): the next feet centre lies off
- * the map.  Later cycles of that gate depend on the NLopt opt track, which is not rebuilt. */
+ * getGaitCycleSearchGridMap fails (cpp:920-934) — in ANY gait cycle: the service calls run the opt track's chain
+ * (yaml optimiser parameters unless fpe_plan_service_opt passes others) next to the plan.  From the second cycle on
+ * the gate follows the opt track's feet, i.e. the build-defined optimiser (see fpe_opt_params). */
 int fpe_plan_service(fpe_handle h, const fpe_params* params, const double initial_position[3],
                      uint8_t gait_cycles, fpe_global_footholds* response);
 
@@ -270,9 +350,11 @@ int fpe_plan_service_ex(fpe_handle h, const fpe_params* params, const double ini
  *   feet_distance / cog_speed: footholdsKPI_ (hpp:732-745), two entries per COMMITTED cycle
  *             (getHipDistance cpp:2571-2584, getCogSpeed cpp:2587-2623 with gaitCycle_ = 1.0, cpp:332). */
 typedef struct fpe_track_report {
-    int32_t n_path; /* = gait_cycles */
+    int32_t n_path; /* nominal: gait_cycles.  centroid: 2 x gait_cycles — the opt track's getFootholdSearchGridMap call is
+                       handed centroidFeetCenterPath too (cpp:946), so every cycle appends the centroid track's centre
+                       and then the opt track's */
     int32_t n_kpi;  /* = 2 x committed cycles */
-    double feet_center_path[255][3];
+    double feet_center_path[2 * 255][3];
     double feet_distance[2 * 255];
     double cog_speed[2 * 255];
 } fpe_track_report;
@@ -281,6 +363,19 @@ int fpe_plan_service_report(fpe_handle h, const fpe_params* params, const double
                             uint8_t gait_cycles, fpe_global_footholds* response, fpe_global_footholds* centroid,
                             double* default_footholds, int32_t* n_default_rows, fpe_track_report* nominal_report,
                             fpe_track_report* centroid_report);
+
+/* fpe_plan_service_report plus the opt track's products; every pointer after `response` may be
+ * NULL, `opt` NULL = fpe_opt_params_yaml.
+ *   opt_msg:    content of global_footholds_opt for THIS call (cpp:737-755 stance entries, cpp:1510-1532 per committed
+ *               cycle; bookkeeping as the centroid message: success = any cycle committed, gait_cycles never written);
+ *   opt_report: footholdsKPI_.feetDistance_opt / cogSpeed_opt (cpp:1488-1499); feet_center_path holds the opt
+ *               track's feet centres (the entries it interleaves into the centroid path);
+ *   opt_cycles: [gait_cycles] the per-cycle problems and solutions. */
+int fpe_plan_service_opt(fpe_handle h, const fpe_params* params, const fpe_opt_params* opt, const double initial_position[3],
+                         uint8_t gait_cycles, fpe_global_footholds* response, fpe_global_footholds* centroid,
+                         double* default_footholds, int32_t* n_default_rows, fpe_track_report* nominal_report,
+                         fpe_track_report* centroid_report, fpe_global_footholds* opt_msg, fpe_track_report* opt_report,
+                         fpe_opt_cycle* opt_cycles);
 
 /* ---- several GPUs in ONE process (fpe_multi.cpp) ----------------------------------------------
  * north_star: "a batch of candidate body trajectories is the parallel axis and shards across the 8 GPUs of one

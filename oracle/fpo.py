@@ -48,6 +48,40 @@ QUERY_DTYPE = np.dtype(
     align=True,
 )
 
+# fpo_opt.cpp: OptParams / the per-cycle record and the per-leg result of the opt track; the two record
+# layouts are the engine's fpe_opt_cycle / fpe_opt_foothold (include/fpe.h)
+OPT_PARAMS_DTYPE = np.dtype(
+    [("w1", "<f8"), ("w2", "<f8"), ("w3", "<f8"), ("w4", "<f8"), ("wr", "<f8"), ("wc", "<f8"),
+     ("useInequalityConstraits", "<i4"), ("pad", "<i4"), ("ctol", "<f8"),
+     ("hipLowerScale", "<f8"), ("hipUpperScale", "<f8"), ("skewLowerScale", "<f8"), ("skewUpperScale", "<f8"),
+     ("lfCurrentRow0", "<f8"), ("rhCurrentRow0", "<f8")],
+    align=True,
+)
+OPT_FOOTHOLD_DTYPE = np.dtype(
+    [("x", "<f8"), ("y", "<f8"), ("z", "<f4"), ("row", "<i4"), ("col", "<i4"), ("foot_id", "u1"), ("gait_cycle_id", "u1"),
+     ("committed", "u1"), ("pad", "u1")],
+    align=True,
+)
+OPT_CYCLE_DTYPE = np.dtype(
+    [("gait_top_left", "<i4", (2,)), ("gait_size", "<i4", (2,)), ("nominal_index", "<i4", (8,)), ("centroid_index", "<i4", (8,)),
+     ("traversable_row", "<i4", (2, 4)), ("x_lower", "<i4", (8,)), ("x_upper", "<i4", (8,)), ("x", "<i4", (8,)),
+     ("minf", "<f8"), ("lf_current_row", "<f8"), ("rh_current_row", "<f8"), ("centroid_code", "u1", (4,)),
+     ("gate_failed", "u1"), ("committed", "u1"), ("solver_status", "u1"), ("pad", "u1")],
+    align=True,
+)
+
+
+def opt_params_yaml():
+    """nlopt/* of foothold_planner.yaml:53-63 plus the file-scope constants of FootholdPlanner.cpp:28-51."""
+    op = np.zeros(1, OPT_PARAMS_DTYPE)
+    for k in ("w1", "w2", "w3", "w4", "wr", "wc"):
+        op[k] = 1.0
+    op["useInequalityConstraits"] = 1
+    op["ctol"] = 1e-2
+    op["hipLowerScale"], op["hipUpperScale"] = 0.9, 1.1
+    op["skewLowerScale"], op["skewUpperScale"] = 0.8, 1.2
+    return op
+
 
 # fpo_filters.cpp: FilterParams (the producer's default chain, SURVEY §8(f) N3)
 FILTER_PARAMS_DTYPE = np.dtype(
@@ -83,7 +117,7 @@ def build(force=False):
     """Compile the oracle with the committed Makefile (g++, -ffp-contract=off)."""
     if force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-        for f in ("fpo_gridmap.hpp", "fpo_planner.hpp", "fpo_planner.cpp", "fpo_capi.cpp", "fpo_filters.cpp", "Makefile")
+        for f in ("fpo_gridmap.hpp", "fpo_planner.hpp", "fpo_planner.cpp", "fpo_opt.cpp", "fpo_capi.cpp", "fpo_filters.cpp", "Makefile")
     ):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _LIB_PATH
@@ -117,6 +151,10 @@ def lib():
         L.fpo_polygon_inside.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
         L.fpo_polygon_center.argtypes = [C.c_void_p, C.c_void_p]
         L.fpo_constants.argtypes = [C.c_void_p, C.c_void_p]
+        L.fpo_plan_opt.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 4
+        L.fpo_plan_opt_products.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 5
+        L.fpo_solve_lattice.argtypes = [C.c_void_p] * 5 + [C.c_double] * 5 + [C.c_void_p] * 2
+        L.fpo_centroid_on_submap.argtypes = [C.c_void_p, C.c_void_p] + [C.c_double] * 6 + [C.c_float, C.c_void_p, C.c_void_p]
         L.fpo_filter_defaults.argtypes = [C.c_void_p]
         L.fpo_filters.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         assert L.fpo_sizeof(0) == PARAMS_DTYPE.itemsize
@@ -125,6 +163,9 @@ def lib():
         assert L.fpo_sizeof(3) == CENTROID_DTYPE.itemsize
         assert L.fpo_sizeof(4) == QUERY_DTYPE.itemsize
         assert L.fpo_sizeof(5) == C.sizeof(_Map)
+        assert L.fpo_sizeof(6) == OPT_PARAMS_DTYPE.itemsize
+        assert L.fpo_sizeof(7) == OPT_FOOTHOLD_DTYPE.itemsize == 32
+        assert L.fpo_sizeof(8) == OPT_CYCLE_DTYPE.itemsize == 240
         _lib = L
     return _lib
 
@@ -208,6 +249,42 @@ class OracleMap:
                          "cog_speed": speed[k][: counts[2 * k + 1]].copy()}
         return out
 
+    # ---- the opt track ---------------------------------------------------------
+    def plan_opt(self, params, opt_params, poses, n_cycles, cycle_ok):
+        """cycle_ok: [B, n_cycles] of the nominal plan.  Returns {"footholds" [B, n, 4], "cycles" [B, n], "gate_fail_cycle" [B]}."""
+        params = np.ascontiguousarray(params, dtype=PARAMS_DTYPE).reshape(1)
+        op = np.ascontiguousarray(opt_params, dtype=OPT_PARAMS_DTYPE).reshape(1)
+        poses = np.ascontiguousarray(poses, dtype=POSE_DTYPE)
+        B = poses.shape[0]
+        ok = np.ascontiguousarray(cycle_ok, dtype=np.uint8).reshape(B, n_cycles)
+        out = {"footholds": np.zeros((B, n_cycles, 4), OPT_FOOTHOLD_DTYPE), "cycles": np.zeros((B, n_cycles), OPT_CYCLE_DTYPE),
+               "gate_fail_cycle": np.zeros(B, np.uint8)}
+        rc = lib().fpo_plan_opt(self._h, _ptr(params), _ptr(op), _ptr(poses), B, n_cycles, _ptr(ok), _ptr(out["footholds"]),
+                                _ptr(out["cycles"]), _ptr(out["gate_fail_cycle"]))
+        assert rc == 0
+        return out
+
+    def plan_opt_products(self, params, opt_params, pose, n_cycles, cycle_ok):
+        params = np.ascontiguousarray(params, dtype=PARAMS_DTYPE).reshape(1)
+        op = np.ascontiguousarray(opt_params, dtype=OPT_PARAMS_DTYPE).reshape(1)
+        pose = np.ascontiguousarray(pose, dtype=POSE_DTYPE).reshape(1)
+        ok = np.ascontiguousarray(cycle_ok, dtype=np.uint8).reshape(n_cycles)
+        n = max(int(n_cycles), 1)
+        path, dist, speed, counts = np.zeros((n, 3)), np.zeros(2 * n), np.zeros(2 * n), np.zeros(3, np.int32)
+        lib().fpo_plan_opt_products(self._h, _ptr(params), _ptr(op), _ptr(pose), int(n_cycles), _ptr(ok), _ptr(path), _ptr(dist),
+                                    _ptr(speed), _ptr(counts))
+        return {"path": path[: counts[0]].copy(), "feet_distance": dist[: counts[1]].copy(), "cog_speed": speed[: counts[1]].copy(),
+                "gate_fail_cycle": int(counts[2])}
+
+    def centroid_on_submap(self, params, sub_centre, sub_length, x, y, search_radius):
+        """checkFootholdUseCentroidMethod on getSubmap(sub_centre, sub_length) of this map (the opt track's use)."""
+        params = np.ascontiguousarray(params, dtype=PARAMS_DTYPE).reshape(1)
+        out = np.zeros(1, dtype=CENTROID_DTYPE)
+        o6 = np.zeros(6, dtype=np.int32)
+        ok = lib().fpo_centroid_on_submap(self._h, _ptr(params), sub_centre[0], sub_centre[1], sub_length[0], sub_length[1], x, y,
+                                          search_radius, _ptr(out), _ptr(o6))
+        return bool(ok), out[0], {"code": int(o6[0]), "begin_row": int(o6[1]), "end_row": int(o6[2]), "row": int(o6[3]), "col": int(o6[4])}
+
     def search_legs(self, params, queries):
         params = np.ascontiguousarray(params, dtype=PARAMS_DTYPE).reshape(1)
         queries = np.ascontiguousarray(queries, dtype=QUERY_DTYPE)
@@ -250,6 +327,16 @@ class OracleMap:
         pl = np.zeros(4, dtype=np.float64)
         ok = lib().fpo_submap_info(self._h, x, y, lx, ly, _ptr(o), _ptr(pl))
         return bool(ok), o, pl
+
+
+def solve_lattice(opt_params, nominal_index, centroid_index, lo, up, length_base, skew, resolution, lf_row=0.0, rh_row=0.0):
+    """The build-defined optimiser of the opt track alone: returns (status, x[8], minf)."""
+    op = np.ascontiguousarray(opt_params, dtype=OPT_PARAMS_DTYPE).reshape(1)
+    a = [np.ascontiguousarray(v, dtype=np.int32).reshape(8) for v in (nominal_index, centroid_index, lo, up)]
+    x, minf = np.zeros(8), np.zeros(1)
+    st = lib().fpo_solve_lattice(_ptr(op), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), float(length_base), float(skew),
+                                 float(resolution), float(lf_row), float(rh_row), _ptr(x), _ptr(minf))
+    return int(st), x, float(minf[0])
 
 
 def polygon_inside(vx, vy, x, y):

@@ -287,6 +287,118 @@ unsigned long long fpo_plan_as_written(const void* mapHandle, const Params* para
     return n;
 }
 
+// ---- the opt track (fpo_opt.cpp) ------------------------------------------------------------------------------
+struct fpo_opt_foothold {  // 32 bytes: RF/RH/LH/LF_footholdResult_opt (cpp:1283-1314)
+    double x, y;
+    float z;
+    int32_t row, col;  // (int)x[2k], (int)x[2k+1]: the gaitMap_ index the position was taken from (cpp:1287-1312)
+    uint8_t foot_id, gait_cycle_id, committed, pad;
+};
+struct fpo_opt_cycle {  // 240 bytes; same layout as fpe_opt_cycle (include/fpe.h)
+    int32_t gait_top_left[2], gait_size[2];
+    int32_t nominal_index[8], centroid_index[8];
+    int32_t traversable_row[2][4];
+    int32_t x_lower[8], x_upper[8];
+    int32_t x[8];
+    double minf, lf_current_row, rh_current_row;
+    uint8_t centroid_code[4];
+    uint8_t gate_failed, committed, solver_status, pad;
+};
+
+// cycleOk: [B * nCycles] footholdValidation_ of the nominal track (from fpo_plan).  footholds: [B * nCycles * 4],
+// cycles: [B * nCycles], gateFailCycle: [B] (255 = none).  Cycles from the failing one on stay zero.
+int fpo_plan_opt(const void* mapHandle, const Params* params, const OptParams* op, const PoseSpec* poses, int B, int nCycles,
+                 const uint8_t* cycleOk, fpo_opt_foothold* footholds, fpo_opt_cycle* cycles, uint8_t* gateFailCycle) {
+    const GridMap& map = *static_cast<const GridMap*>(mapHandle);
+    OptOutput out;
+    for (int b = 0; b < B; ++b) {
+        planOptTrack(map, *params, *op, poses[b], nCycles, cycleOk + (size_t)b * nCycles, out);
+        if (gateFailCycle) gateFailCycle[b] = out.gateFailCycle < 0 ? 255 : static_cast<uint8_t>(out.gateFailCycle);
+        for (int g = 0; g < nCycles; ++g) {
+            const OptCycle& oc = out.cycles[(size_t)g];
+            const bool ran = poses[b].gait == 0 && (out.gateFailCycle < 0 || g < out.gateFailCycle);
+            if (cycles) {
+                fpo_opt_cycle& r = cycles[(size_t)b * nCycles + g];
+                std::memset(&r, 0, sizeof(r));
+                r.gate_failed = oc.gateFailed;
+                if (ran) {
+                    for (int k = 0; k < 2; ++k) { r.gait_top_left[k] = oc.gaitTopLeft[k]; r.gait_size[k] = oc.gaitSize[k]; }
+                    for (int k = 0; k < 8; ++k) {
+                        r.nominal_index[k] = oc.nominalIndex[k]; r.centroid_index[k] = oc.centroidIndex[k];
+                        r.x_lower[k] = oc.xLower[k]; r.x_upper[k] = oc.xUpper[k];
+                        r.x[k] = static_cast<int32_t>(oc.x[k]);
+                    }
+                    for (int k = 0; k < 4; ++k) {
+                        r.traversable_row[0][k] = oc.traversableRow[0][k]; r.traversable_row[1][k] = oc.traversableRow[1][k];
+                        r.centroid_code[k] = oc.centroidCode[k];
+                    }
+                    r.minf = oc.minf; r.lf_current_row = oc.lfCurrentRow; r.rh_current_row = oc.rhCurrentRow;
+                    r.committed = oc.committed; r.solver_status = oc.solverStatus;
+                }
+            }
+            if (footholds) {
+                static const int slot[4] = {2, 1, 3, 0};  // position of RF,RH,LH,LF in the optimiser's order LF,RH,RF,LH
+                for (int l = 0; l < 4; ++l) {
+                    fpo_opt_foothold& f = footholds[((size_t)b * nCycles + g) * 4 + l];
+                    std::memset(&f, 0, sizeof(f));
+                    f.foot_id = static_cast<uint8_t>(l);
+                    f.gait_cycle_id = static_cast<uint8_t>(g);
+                    if (!ran) continue;
+                    f.x = oc.result[l].x; f.y = oc.result[l].y; f.z = static_cast<float>(oc.result[l].z);
+                    f.row = static_cast<int32_t>(oc.x[2 * slot[l]]); f.col = static_cast<int32_t>(oc.x[2 * slot[l] + 1]);
+                    f.committed = oc.committed;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+// Evaluation products of ONE pose's opt track: path [nCycles x 3] (feet centres pushed onto centroidFeetCenterPath,
+// cpp:946), dist / speed [2 * nCycles]; counts = {nPath, nKpi, gateFailCycle (-1 none)}.
+int fpo_plan_opt_products(const void* mapHandle, const Params* params, const OptParams* op, const PoseSpec* pose, int nCycles,
+                          const uint8_t* cycleOk, double* path, double* dist, double* speed, int32_t* counts) {
+    const GridMap& map = *static_cast<const GridMap*>(mapHandle);
+    OptOutput out;
+    planOptTrack(map, *params, *op, *pose, nCycles, cycleOk, out);
+    counts[0] = (int32_t)out.feetCenterPath.size();
+    counts[1] = (int32_t)out.feetDistance.size();
+    counts[2] = out.gateFailCycle;
+    for (size_t i = 0; i < out.feetCenterPath.size(); ++i) {
+        path[3 * i] = out.feetCenterPath[i].x; path[3 * i + 1] = out.feetCenterPath[i].y; path[3 * i + 2] = out.feetCenterPath[i].z;
+    }
+    for (size_t i = 0; i < out.feetDistance.size(); ++i) {
+        dist[i] = out.feetDistance[i];
+        speed[i] = out.cogSpeed[i];
+    }
+    return 0;
+}
+
+// the build-defined optimiser alone (tests: hand-made problems)
+int fpo_solve_lattice(const OptParams* op, const int32_t* nominalIndex, const int32_t* centroidIndex, const int32_t* lo,
+                      const int32_t* up, double lengthBase, double skew, double mapResolution, double lfCurrentRow,
+                      double rhCurrentRow, double* x, double* minf) {
+    return solveLattice(*op, nominalIndex, centroidIndex, lo, up, lengthBase, skew, mapResolution, lfCurrentRow, rhCurrentRow, x, minf);
+}
+
+// checkFootholdUseCentroidMethod on a SUBMAP of the map (the opt track's use, cpp:1010): the submap is
+// getSubmap(subCentre, subLength); out6 = {code, beginRow, endRow, row, col, submapOk}.
+int fpo_centroid_on_submap(const void* mapHandle, const Params* params, double sx, double sy, double slx, double sly, double x,
+                           double y, float searchRadius, fpo_centroid* out, int32_t* out6) {
+    const GridMap& map = *static_cast<const GridMap*>(mapHandle);
+    bool ok = false;
+    GridMap sub = map.getSubmap({sx, sy}, {slx, sly}, ok, nullptr, true);
+    std::memset(out, 0, sizeof(*out));
+    for (int k = 0; k < 6; ++k) out6[k] = 0;
+    if (!ok) return 0;
+    CentroidResult r;
+    int b = 0, e = 0;
+    checkFootholdUseCentroidMethod(sub, {x, y}, searchRadius, *params, r, &map, &b, &e);
+    out->x = r.x; out->y = r.y; out->z = r.z; out->row = r.row; out->col = r.col; out->code = r.code;
+    out6[0] = r.code; out6[1] = b; out6[2] = e; out6[3] = r.row; out6[4] = r.col; out6[5] = 1;
+    return 1;
+}
+
 int fpo_sizeof(int which) {
     switch (which) {
         case 0: return (int)sizeof(Params);
@@ -295,6 +407,9 @@ int fpo_sizeof(int which) {
         case 3: return (int)sizeof(fpo_centroid);
         case 4: return (int)sizeof(fpo_query);
         case 5: return (int)sizeof(fpo_map);
+        case 6: return (int)sizeof(OptParams);
+        case 7: return (int)sizeof(fpo_opt_foothold);
+        case 8: return (int)sizeof(fpo_opt_cycle);
     }
     return -1;
 }

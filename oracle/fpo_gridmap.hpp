@@ -171,7 +171,10 @@ struct GridMap {
     // GridMap::getSubmap(position, length, isSuccess): geometry via getSubmapInformation +
     // setGeometry(SubmapGeometry), data copied cell by cell ("traversability" only is needed by
     // cpp:1650).  cpp:1627.
-    GridMap getSubmap(const Vec2& p, const Vec2& len, bool& isSuccess, SubmapInfo* infoOut = nullptr) const {
+    // withElevation: also copy the "elevation" layer (upstream copies every layer; the centroid method reads the
+    // traversability only, the opt track's gait-cycle submap is asked for heights too, cpp:1290-1314).
+    GridMap getSubmap(const Vec2& p, const Vec2& len, bool& isSuccess, SubmapInfo* infoOut = nullptr,
+                      bool withElevation = false) const {
         GridMap sub;
         SubmapInfo info;
         isSuccess = getSubmapInformation(info, p, len, length, position, res, size);
@@ -190,6 +193,12 @@ struct GridMap {
         for (int j = 0; j < sub.size.j; ++j)
             for (int i = 0; i < sub.size.i; ++i)
                 sub.trav[(size_t)i + (size_t)j * sub.size.i] = travAt({info.topLeft.i + i, info.topLeft.j + j});
+        if (withElevation && !elev.empty()) {
+            sub.elev.resize((size_t)sub.size.i * sub.size.j);
+            for (int j = 0; j < sub.size.j; ++j)
+                for (int i = 0; i < sub.size.i; ++i)
+                    sub.elev[(size_t)i + (size_t)j * sub.size.i] = elevAt({info.topLeft.i + i, info.topLeft.j + j});
+        }
         if (infoOut) *infoOut = info;
         isSuccess = true;
         return sub;

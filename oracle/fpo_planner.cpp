@@ -186,9 +186,18 @@ void checkFoothold(const GridMap& map, const Vec2& center, float footRadius, flo
 }
 
 // cpp:1605-1997.  `searchRadius` is searchRadius_ in the reference (cpp:1616-1617).
+// `gridmap` is the map the rectangle is cut from — gridmap_ for the centroid track (cpp:818-821), the gait-cycle submap
+// gaitMap_ for the opt track (cpp:1010-1013); the result's height is always measured on the member gridmap_
+// (`heightMap`, cpp:1687, 1820).  traversableBeginRow / traversableEndRow (cpp:1608-1609): first / last row of the
+// traversable band in `gridmap`'s rows; the reference leaves them untouched on the paths that set no result (getSubmap
+// failure, no case) — there the caller's storage is uninitialised (Eigen::MatrixXi(2,4), cpp:1009): oracle-defined 0.
 void checkFootholdUseCentroidMethod(const GridMap& gridmap, const Vec2& p, float searchRadius,
-                                    const Params& prm, CentroidResult& out) {
+                                    const Params& prm, CentroidResult& out, const GridMap* heightMapIn,
+                                    int* traversableBeginRow, int* traversableEndRow) {
+    const GridMap& heightMap = heightMapIn ? *heightMapIn : gridmap;
     out = CentroidResult();
+    if (traversableBeginRow) *traversableBeginRow = 0;
+    if (traversableEndRow) *traversableEndRow = 0;
     if (!centreUsable(p)) {  // oracle-defined, see centreUsable
         out.code = 6;
         return;
@@ -214,8 +223,22 @@ void checkFootholdUseCentroidMethod(const GridMap& gridmap, const Vec2& p, float
     }
     const int topRow = 0, bottomRow = map.size.i - 1, rightCol = map.size.j - 1;  // cpp:1679-1682
 
+    // cpp:1692-1710 (and the same block in every case): the band's first / last row of the rectangle, mapped to rows of
+    // `gridmap` through the position of the rectangle's cell (row, 1).  One Position is reused for both conversions
+    // (a failed getPosition leaves it as it was; the reference's local is uninitialised before the first: oracle (0,0)).
+    auto bandRows = [&](int beginRow, int endRow) {
+        if (!traversableBeginRow && !traversableEndRow) return;
+        Vec2 q{0, 0};
+        Idx2 i2;
+        map.getPosition({beginRow, 1}, q);
+        gridmap.getIndex(q, i2);
+        if (traversableBeginRow) *traversableBeginRow = i2.i;
+        map.getPosition({endRow, 1}, q);
+        gridmap.getIndex(q, i2);
+        if (traversableEndRow) *traversableEndRow = i2.i;
+    };
     auto finish = [&](const Vec2& q, uint8_t code) {
-        out.z = getFootholdMeanHeight(gridmap, q, prm.footRadius, prm.h);  // on gridmap_ (cpp:1687, 1820)
+        out.z = getFootholdMeanHeight(heightMap, q, prm.footRadius, prm.h);  // on gridmap_ (cpp:1687, 1820)
         out.x = q.x;
         out.y = q.y;
         out.code = code;
@@ -227,6 +250,7 @@ void checkFootholdUseCentroidMethod(const GridMap& gridmap, const Vec2& p, float
 
     if (wholeRegionValid) {  // cpp:1684-1689
         finish(p, 0);
+        bandRows(topRow, bottomRow);  // cpp:1692-1693
         return;
     }
     // cpp:1717-1750: row scan.  The reference's LineIterator end index (row, size(1)) reads one
@@ -248,20 +272,24 @@ void checkFootholdUseCentroidMethod(const GridMap& gridmap, const Vec2& p, float
         newIndex.i = static_cast<int>(std::floor((maxRow + bottomRow + 1) * 0.5));
         newIndex.j = static_cast<int>(std::floor((rightCol + 1) * 0.5));
         code = 1;
+        bandRows(maxRow + 1, bottomRow);  // cpp:1794-1795
     } else if (minRow != topRow && maxRow != bottomRow) {  // case 2, cpp:1843-1886
         if ((minRow - topRow) >= (bottomRow - maxRow)) {
             newIndex.i = static_cast<int>(std::ceil(minRow * 0.5));
             newIndex.j = static_cast<int>(std::floor((rightCol + 0) * 0.5));
             code = 2;
+            bandRows(topRow, minRow - 1);  // cpp:1858-1859
         } else {
             newIndex.i = static_cast<int>(std::floor((maxRow + bottomRow) * 0.5));
             newIndex.j = static_cast<int>(std::floor((rightCol + 0) * 0.5));
             code = 3;
+            bandRows(maxRow + 1, bottomRow);  // cpp:1889-1890
         }
     } else if (minRow != topRow && maxRow == bottomRow) {  // case 3, cpp:1944-1952
         newIndex.i = static_cast<int>(std::ceil(minRow * 0.5));
         newIndex.j = static_cast<int>(std::floor((rightCol + 0) * 0.5));
         code = 4;
+        bandRows(topRow, minRow - 1);  // cpp:1960-1961
     } else {
         out.code = 5;  // minRow == topRow && maxRow == bottomRow: no branch, result stays (0,0,0)
         return;

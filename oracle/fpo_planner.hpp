@@ -7,7 +7,8 @@
 // typing and expression order.  Deliberate divergences:
 //   * maps are passed by const reference, not by value (hpp:94-143 deep-copy every layer);
 //   * the centroid row scan stays in bounds (cpp:1719-1720 reads one cell past the last column);
-//   * no ROS publishing / logging / NLopt "opt" track (cpp:913-1319: does not feed the response).
+//   * no ROS publishing / logging; the "opt" track (cpp:913-1319) is restated in fpo_opt.cpp with a BUILD-DEFINED
+//     optimiser in NLopt's place (NLopt is absent and unpinned).
 // Build-defined extensions (NOT in the reference): batch of poses, 4-phase walk
 // gait, per-leg search radius / polygon kind.  With gait = trot, radius override <= 0 and polygon
 // kind 0 the code path is exactly the reference's.
@@ -85,7 +86,8 @@ float getFootholdMeanHeight(const GridMap& map, const Vec2& center, float radius
 void checkFoothold(const GridMap& map, const Vec2& center, float footRadius, float searchRadius,
                    const Polygon& polygon, const Params& p, LegResult& out);
 void checkFootholdUseCentroidMethod(const GridMap& map, const Vec2& defaultFoothold, float searchRadius,
-                                    const Params& p, CentroidResult& out);
+                                    const Params& p, CentroidResult& out, const GridMap* heightMap = nullptr,
+                                    int* traversableBeginRow = nullptr, int* traversableEndRow = nullptr);
 Point3 getPolygonCenter(const Point3& rf, const Point3& rh, const Point3& lh, const Point3& lf);
 bool getGaitCycleSearchGridMap(const GridMap& gridmap, const Params& p, const Point3 optCurrent[4], double initialPoseY,
                                double ajustedPoseY);
@@ -102,7 +104,7 @@ struct PlanOutput {
     std::vector<uint8_t> cycleOk;     // footholdValidation_ per cycle (cpp:1323)
     Point3 stance[4];                 // RF/RH/LH/LF_initialPosition_ (cpp:350-378)
     // getGaitCycleSearchGridMap (cpp:2307-2349) fails in the FIRST gait cycle => the reference's service handler
-    // returns false (cpp:920-934).  Only cycle 0 is restated: later cycles use the NLopt track's feet.
+    // returns false (cpp:920-934).  Later cycles: planOptTrack (the opt track's own chain).
     uint8_t optGate0Failed = 0;
     // Evaluation products of the centroid ([0]) and nominal ([1]) tracks (trot only):
     //   feetCenterPath: one pose per planned cycle = getPolygonCenter of the track's CURRENT feet,
@@ -115,6 +117,44 @@ struct PlanOutput {
 };
 void planGlobalFootholds(const GridMap& map, const Params& p, const PoseSpec& pose, int nCycles,
                          PlanOutput& out);
+
+// --- the opt track (fpo_opt.cpp; SURVEY.md §8(f) N4: cpp:54-148, 913-1319, 1485-1570, 2307-2408, 2557-2568) -----------
+// nlopt/* ROS parameters (cpp:297-307, yaml:53-63) and the file-scope constants of cpp:28-51.
+struct OptParams {
+    double w1, w2, w3, w4, wr, wc;       // cpp:297-303
+    int useInequalityConstraits;         // cpp:306 (code default false, yaml true)
+    int pad;
+    double ctol;                         // cpp:34: 1e-2
+    double hipLowerScale, hipUpperScale;    // cpp:48: 0.9, 1.1
+    double skewLowerScale, skewUpperScale;  // cpp:49: 0.8, 1.2
+    double lfCurrentRow0, rhCurrentRow0;    // cpp:36 at entry of the call: 0 at node start, else what the previous call left
+};
+constexpr long long kMaxLatticePoints = 1ll << 24;  // build-defined optimiser: row points it will enumerate
+struct OptCycle {
+    uint8_t gateFailed = 0;    // getGaitCycleSearchGridMap returned false (cpp:931-934): the service returns false
+    uint8_t committed = 0;     // the cycle committed (cycleOk)
+    uint8_t solverStatus = 0;  // solveLattice
+    uint8_t centroidCode[4] = {0, 0, 0, 0};  // checkFootholdUseCentroidMethod on gaitMap_, RF,RH,LH,LF
+    int gaitTopLeft[2] = {0, 0}, gaitSize[2] = {0, 0};  // gaitMap_ inside gridmap_
+    int nominalIndex[8] = {0}, centroidIndex[8] = {0};  // LF,RH,RF,LH x (row, col) on gaitMap_ (cpp:965-976, 1030-1041)
+    int traversableRow[2][4] = {{0}};                   // begin / end row x RF,RH,LH,LF (cpp:1009-1013)
+    int xLower[8] = {0}, xUpper[8] = {0};               // xBounds (cpp:1057-1076)
+    double x[8] = {0};                                  // the optimiser's result (LF,RH,RF,LH x (row, col))
+    double minf = 0;
+    double lfCurrentRow = 0, rhCurrentRow = 0;          // the values this cycle's objective used
+    Point3 result[4];                                   // RF,RH,LH,LF_footholdResult_opt (cpp:1283-1314)
+};
+struct OptOutput {
+    std::vector<OptCycle> cycles;
+    int gateFailCycle = -1;              // first cycle whose gate failed, -1 none
+    std::vector<Point3> feetCenterPath;  // this track's feet centres, pushed onto centroidFeetCenterPath (cpp:946)
+    std::vector<double> feetDistance, cogSpeed;  // footholdsKPI_.feetDistance_opt / cogSpeed_opt (cpp:1488-1499)
+};
+int solveLattice(const OptParams& op, const int* nominalIndex, const int* centroidIndex, const int* xLower, const int* xUpper,
+                 double lengthBase, double skew, double mapResolution, double lfCurrentRow, double rhCurrentRow, double* x,
+                 double* minf);
+void planOptTrack(const GridMap& gridmap_, const Params& p, const OptParams& op, const PoseSpec& pose, int nCycles,
+                  const uint8_t* cycleOk, OptOutput& out);
 
 // "As-written" cost EMULATION: the reference passes grid_map::GridMap BY
 // VALUE (hpp:94,110,124,140,262,288), i.e. deep-copies every layer at each of those call sites.  When

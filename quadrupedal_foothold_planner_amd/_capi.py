@@ -71,10 +71,31 @@ GLOBAL_FOOTHOLDS_DTYPE = np.dtype(
 
 
 TRACK_REPORT_DTYPE = np.dtype(
-    [("n_path", "<i4"), ("n_kpi", "<i4"), ("feet_center_path", "<f8", (255, 3)), ("feet_distance", "<f8", (510,)),
+    [("n_path", "<i4"), ("n_kpi", "<i4"), ("feet_center_path", "<f8", (510, 3)), ("feet_distance", "<f8", (510,)),
      ("cog_speed", "<f8", (510,))],
     align=True,
 )
+# the opt track (include/fpe.h: fpe_opt_params, fpe_opt_foothold, fpe_opt_cycle)
+OPT_PARAMS_DTYPE = np.dtype(
+    [("w1", "<f8"), ("w2", "<f8"), ("w3", "<f8"), ("w4", "<f8"), ("wr", "<f8"), ("wc", "<f8"),
+     ("use_inequality_constraints", "<i4"), ("reserved", "<i4"), ("ctol", "<f8"),
+     ("hip_lower_scale", "<f8"), ("hip_upper_scale", "<f8"), ("skew_lower_scale", "<f8"), ("skew_upper_scale", "<f8"),
+     ("lf_current_row0", "<f8"), ("rh_current_row0", "<f8")],
+    align=True,
+)
+OPT_FOOTHOLD_DTYPE = np.dtype(
+    [("x", "<f8"), ("y", "<f8"), ("z", "<f4"), ("row", "<i4"), ("col", "<i4"), ("foot_id", "u1"), ("gait_cycle_id", "u1"),
+     ("committed", "u1"), ("pad", "u1")],
+    align=True,
+)
+OPT_CYCLE_DTYPE = np.dtype(
+    [("gait_top_left", "<i4", (2,)), ("gait_size", "<i4", (2,)), ("nominal_index", "<i4", (8,)), ("centroid_index", "<i4", (8,)),
+     ("traversable_row", "<i4", (2, 4)), ("x_lower", "<i4", (8,)), ("x_upper", "<i4", (8,)), ("x", "<i4", (8,)),
+     ("minf", "<f8"), ("lf_current_row", "<f8"), ("rh_current_row", "<f8"), ("centroid_code", "u1", (4,)),
+     ("gate_failed", "u1"), ("committed", "u1"), ("solver_status", "u1"), ("pad", "u1")],
+    align=True,
+)
+assert OPT_FOOTHOLD_DTYPE.itemsize == 32 and OPT_CYCLE_DTYPE.itemsize == 240 and OPT_PARAMS_DTYPE.itemsize == 112
 
 
 class MapDesc(C.Structure):
@@ -98,6 +119,10 @@ class PlanOut(C.Structure):
         ("selected", C.c_void_p),
         ("pose_status", C.c_void_p),
     ]
+
+
+class OptOut(C.Structure):
+    _fields_ = [("footholds", C.c_void_p), ("cycles", C.c_void_p), ("gate_fail_cycle", C.c_void_p)]
 
 
 class FilterParams(C.Structure):
@@ -141,6 +166,11 @@ EXPORTED_SYMBOLS = [
     "fpe_plan_service",
     "fpe_plan_service_ex",
     "fpe_plan_service_report",
+    "fpe_plan_service_opt",
+    "fpe_opt_params_yaml",
+    "fpe_opt_params_code_defaults",
+    "fpe_plan_opt",
+    "fpe_plan_opt_device",
     "fpe_multi_create",
     "fpe_multi_destroy",
     "fpe_multi_device_count",
@@ -199,6 +229,11 @@ def lib():
     L.fpe_plan_service.argtypes = [vp, vp, vp, C.c_uint8, vp]
     L.fpe_plan_service_ex.argtypes = [vp, vp, vp, C.c_uint8, vp, vp, vp, vp]
     L.fpe_plan_service_report.argtypes = [vp, vp, vp, C.c_uint8, vp, vp, vp, vp, vp, vp]
+    L.fpe_plan_service_opt.argtypes = [vp, vp, vp, vp, C.c_uint8] + [vp] * 9
+    L.fpe_opt_params_yaml.argtypes = [vp]
+    L.fpe_opt_params_code_defaults.argtypes = [vp]
+    L.fpe_plan_opt.argtypes = [vp, vp, vp, vp, i32, i32, vp, C.POINTER(OptOut)]
+    L.fpe_plan_opt_device.argtypes = [vp, vp, vp, vp, i32, i32, vp, C.POINTER(OptOut), vp]
     L.fpe_multi_create.argtypes = [vp, i32, C.POINTER(vp)]
     L.fpe_multi_destroy.argtypes = [vp]
     L.fpe_multi_device_count.argtypes = [vp]
@@ -230,6 +265,18 @@ def params_yaml():
 def params_code_defaults():
     p = np.zeros(1, dtype=PARAMS_DTYPE)
     assert lib().fpe_params_code_defaults(ptr(p)) == FPE_OK
+    return p
+
+
+def opt_params_yaml():
+    p = np.zeros(1, dtype=OPT_PARAMS_DTYPE)
+    assert lib().fpe_opt_params_yaml(ptr(p)) == FPE_OK
+    return p
+
+
+def opt_params_code_defaults():
+    p = np.zeros(1, dtype=OPT_PARAMS_DTYPE)
+    assert lib().fpe_opt_params_code_defaults(ptr(p)) == FPE_OK
     return p
 
 

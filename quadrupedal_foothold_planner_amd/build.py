@@ -19,7 +19,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libfpe.so")
 LOCK_PATH = os.path.join(_HERE, ".libfpe.lock")
 SOURCES = ["fpe_kernels.hip", "fpe_engine.cpp", "fpe_host.cpp", "fpe_multi.cpp"]
-HEADERS = ["fpe_gridmath.hpp", "fpe_device.hpp", "fpe_host.hpp", "fpe_bits.hpp", "fpe_filters.hpp", os.path.join("..", "..", "include", "fpe.h")]
+HEADERS = ["fpe_gridmath.hpp", "fpe_device.hpp", "fpe_host.hpp", "fpe_bits.hpp", "fpe_filters.hpp", "fpe_opt.hpp", os.path.join("..", "..", "include", "fpe.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950",
@@ -47,7 +47,11 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(f) > t for f in _inputs() if os.path.exists(f))
+    # a listed input that is missing (renamed / deleted header) is an error of the tree, never "up to date"
+    missing = [f for f in _inputs() if not os.path.exists(f)]
+    if missing:
+        raise FileNotFoundError(f"engine source listed in build.py is missing: {missing}")
+    return any(os.path.getmtime(f) > t for f in _inputs())
 
 
 def build_engine(force=False, verbose=False):

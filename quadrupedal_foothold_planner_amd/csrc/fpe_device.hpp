@@ -127,6 +127,21 @@ struct FilterLayers {
     float *nx, *ny, *nz, *slope, *stepHeight, *step, *rough, *trav;
 };
 
+// Opt track (fpe_opt.hpp): the file-scope NLopt globals of the reference (cpp:28-51) and what
+// initialize() / gridmapCallback derive for them, with the reference's typing (fpe_host.cpp::derive_opt_constants).
+struct OptConsts {
+    double w1, w2, w3, w4, wr, wc;
+    double ctol;
+    double lengthBase, skew, mapResolution;  // cpp:497-498, 514
+    double t1, t2, t3, t4;                   // cpp:1156-1159
+    double lfRow0, rhRow0;                   // lfCurrentRow / rhCurrentRow at entry of the call (cpp:36)
+    int32_t useConstraints;
+    int32_t colLoA, colUpA;                  // xBounds of x2 = x8 (cpp:1063-1064)
+    int32_t colLoB, colUpB;                  // xBounds of x4 = x6 (cpp:1065-1066)
+    int32_t pad;
+};
+constexpr long long kMaxLatticePoints = 1ll << 24;  // row points the build-defined optimiser enumerates (oracle: same)
+
 // Tile flag bits (one byte per cell in LDS).
 enum : uint8_t {
     kFlagInMap = 1,      // cell index inside the map

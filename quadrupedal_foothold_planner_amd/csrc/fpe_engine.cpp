@@ -40,6 +40,9 @@ bool filters_supported(const FilterConsts& fc, const MapGeom& g);
 hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float* d_elev, const FilterLayers& L, hipStream_t stream);
 hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut,
                             const fpe_pose* d_poses, int B, int nCycles, const fpe_plan_out& d_out, hipStream_t stream);
+// opt track (fpe_opt.hpp part of fpe_kernels.hip)
+hipError_t launch_opt_track(const DevMap& m, const PlanConsts& pc, const OptConsts& oc, const fpe_pose* d_poses, int B, int nCycles,
+                            const uint8_t* d_cycleOk, const fpe_opt_out& d_out, hipStream_t stream);
 }  // namespace fpe
 
 namespace {
@@ -68,29 +71,40 @@ int fail_hip(hipError_t e, const char* what) {
 // after every launch would put a 3-4 us bubble between back-to-back plan kernels (measured).
 struct BufferPool {
     struct Entry {
-        size_t n;      // 4-byte units
+        size_t n;      // capacity in 4-byte units
         float* p;
         bool dirty;    // retired while asynchronous (device-API) work may still have been reading it
     };
     std::mutex mu;
     std::vector<Entry> free;
-    float* take(size_t n, bool* dirty) {
+    // Best fit: the smallest pooled buffer that holds n units and is not more than twice as large (a map stream whose
+    // size changes from message to message keeps recycling instead of falling back to hipMalloc / hipFree, which
+    // synchronise the device).  *cap receives the buffer's real capacity: the caller hands THAT back to give().
+    // cleanOnly: skip buffers that need a device synchronisation before reuse (the plan path never pays for one).
+    float* take(size_t n, bool* dirty, size_t* cap, bool cleanOnly = false) {
         std::lock_guard<std::mutex> lk(mu);
-        for (size_t k = 0; k < free.size(); ++k)
-            if (free[k].n == n) {
-                float* p = free[k].p;
-                *dirty = free[k].dirty;
-                free.erase(free.begin() + static_cast<long>(k));
-                return p;
-            }
-        *dirty = false;
-        return nullptr;
+        size_t best = free.size();
+        for (size_t k = 0; k < free.size(); ++k) {
+            if (free[k].n < n || free[k].n > 2 * n + 1024) continue;
+            if (cleanOnly && free[k].dirty) continue;
+            if (best == free.size() || free[k].n < free[best].n) best = k;
+        }
+        if (best == free.size()) {
+            *dirty = false;
+            *cap = 0;
+            return nullptr;
+        }
+        float* p = free[best].p;
+        *dirty = free[best].dirty;
+        *cap = free[best].n;
+        free.erase(free.begin() + static_cast<long>(best));
+        return p;
     }
     void give(size_t n, float* p, bool dirty = false) {
         float* drop = nullptr;
         {
             std::lock_guard<std::mutex> lk(mu);
-            if (free.size() >= 10) {  // two snapshots' worth (layers + bit planes) plus the upload staging layer
+            if (free.size() >= 12) {  // two snapshots' worth (layers + bit planes) plus the upload staging layer
                 drop = free.front().p;
                 free.erase(free.begin());
             }
@@ -167,20 +181,33 @@ struct CtxLease {  // returns the context to the pool on every exit path
 };
 inline size_t align256(size_t n) { return (n + 255) & ~static_cast<size_t>(255); }
 
-// Bit planes of a snapshot for one (defaultFootholdThreshold, candidateFootholdThreshold) pair, built lazily by
-// the first plan that needs them (one HBM-bound pass over the traversability layer) and kept with the snapshot.
+// Bit planes of a snapshot for one (defaultFootholdThreshold, candidateFootholdThreshold) pair: built by the upload
+// for the pairs the previous snapshot was planned with (the upload already owns the pool's synchronisation), lazily by
+// the first plan for a pair never seen before.  Shared: a call keeps the set it launched with alive, so the snapshot
+// can evict its least recently used set when a fifth pair arrives (no silent change of kernels).
 struct MaskSet {
     float thrD = 0.0f, thrC = 0.0f;
     uint32_t* d_words = nullptr;
-    size_t n = 0;  // in 4-byte units (BufferPool size key)
+    size_t cap = 0;  // capacity in 4-byte units (what goes back to the pool)
     int strideW = 0, nw = 0;
     hipEvent_t ready = nullptr;
-    bool readyDone = false;  // guarded by MapSnapshot::mu
+    std::atomic<bool> readyDone{false};
+    std::atomic<bool> asyncUsed{false};
+    std::atomic<unsigned long long> lastUse{0};
+    std::shared_ptr<BufferPool> pool;
+    ~MaskSet() {
+        if (ready) {
+            (void)hipEventSynchronize(ready);
+            (void)hipEventDestroy(ready);
+        }
+        if (d_words) pool ? pool->give(cap, reinterpret_cast<float*>(d_words), asyncUsed.load(std::memory_order_acquire)) : (void)hipFree(d_words);
+    }
 };
 
 struct MapSnapshot {
     fpe::MapGeom g;
     size_t n = 0;
+    size_t capTrav = 0, capElev = 0;  // pooled capacities of the two layers
     float* d_trav = nullptr;
     float* d_elev = nullptr;
     std::shared_ptr<BufferPool> pool;
@@ -191,7 +218,8 @@ struct MapSnapshot {
     std::atomic<bool> readyDone{false};
     std::atomic<bool> asyncUsed{false};
     std::mutex mu;
-    std::vector<MaskSet> masks;
+    std::vector<std::shared_ptr<MaskSet>> masks;
+    unsigned long long useClock = 0;  // guarded by mu
 
     hipError_t wait_ready(hipStream_t s) {
         if (!ready || readyDone.load(std::memory_order_acquire)) return hipSuccess;
@@ -208,15 +236,11 @@ struct MapSnapshot {
             (void)hipEventSynchronize(ready);  // the upload itself (normally long complete)
             (void)hipEventDestroy(ready);
         }
-        for (MaskSet& ms : masks) {
-            if (ms.ready) {
-                (void)hipEventSynchronize(ms.ready);
-                (void)hipEventDestroy(ms.ready);
-            }
-            if (ms.d_words) pool ? pool->give(ms.n, reinterpret_cast<float*>(ms.d_words), dirty) : (void)hipFree(ms.d_words);
-        }
-        if (d_trav) pool ? pool->give(n, d_trav, dirty) : (void)hipFree(d_trav);
-        if (d_elev) pool ? pool->give(n, d_elev, dirty) : (void)hipFree(d_elev);
+        for (auto& ms : masks)
+            if (dirty) ms->asyncUsed.store(true, std::memory_order_release);
+        masks.clear();
+        if (d_trav) pool ? pool->give(capTrav, d_trav, dirty) : (void)hipFree(d_trav);
+        if (d_elev) pool ? pool->give(capElev, d_elev, dirty) : (void)hipFree(d_elev);
     }
 };
 
@@ -250,10 +274,12 @@ namespace {
 
 // Device allocation in 4-byte units with the tail padding every pooled buffer carries (the row scan reads whole
 // 16-byte groups past the end of a layer, fpe_kernels.hip::rows_issue), so any pooled buffer can serve any role.
-hipError_t alloc_units(BufferPool& pool, size_t n, float** out) {
+// *cap: the capacity to hand back to the pool.  cleanOnly: never synchronise the device (the plan path).
+hipError_t alloc_units(BufferPool& pool, size_t n, float** out, size_t* cap, bool cleanOnly = false) {
     bool dirty = false;
-    *out = pool.take(n, &dirty);
+    *out = pool.take(n, &dirty, cap, cleanOnly);
     if (*out) return dirty ? hipDeviceSynchronize() : hipSuccess;  // see BufferPool: asynchronous readers may be in flight
+    *cap = n;
     return hipMalloc(reinterpret_cast<void**>(out), n * sizeof(float) + kLayerPadBytes);
 }
 
@@ -264,7 +290,29 @@ struct CallPlan {
     size_t planLds = 0, searchLds = 0;
     bool useBits = false;
     fpe::BitMap bits{nullptr, 0, 0};
+    std::shared_ptr<MaskSet> mask;  // the bit planes this call launches with (kept alive past an eviction)
 };
+
+// Bit planes of `snap` for a threshold pair: queued on `stream`, event recorded.  cleanOnly as in alloc_units.
+int build_mask(MapSnapshot& snap, float thrD, float thrC, hipStream_t stream, bool cleanOnly, std::shared_ptr<MaskSet>& out) {
+    auto ms = std::make_shared<MaskSet>();
+    ms->thrD = thrD;
+    ms->thrC = thrC;
+    ms->pool = snap.pool;
+    const size_t need = fpe::bitmap_words(snap.g.rows, snap.g.cols, &ms->strideW, &ms->nw);
+    float* buf = nullptr;
+    FPE_HIP(alloc_units(*snap.pool, need, &buf, &ms->cap, cleanOnly));
+    ms->d_words = reinterpret_cast<uint32_t*>(buf);
+    hipError_t e = fpe::launch_build_bitmap(snap.d_trav, snap.g.rows, snap.g.cols, thrD, thrC, ms->d_words, stream);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ms->ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ms->ready, stream);
+    if (e != hipSuccess) {
+        ms->asyncUsed.store(true);  // the build may be queued: hand the buffer back dirty
+        return fail_hip(e, "bit-plane build");
+    }
+    out = std::move(ms);
+    return FPE_OK;
+}
 
 int prepare_call(fpe_engine* h, const fpe_params* params, float maxRadius, CallPlan& cp, hipStream_t stream, bool wantBits) {
     if (!h || !params) return fail(FPE_E_INVALID_ARG, "null handle or params");
@@ -294,37 +342,28 @@ int prepare_call(fpe_engine* h, const fpe_params* params, float maxRadius, CallP
     cp.useBits = wantBits && fpe::bits_supported(pc, snap.g);
     if (cp.useBits) {
         std::lock_guard<std::mutex> lk(snap.mu);
-        MaskSet* found = nullptr;
-        for (MaskSet& ms : snap.masks)
-            if (std::memcmp(&ms.thrD, &pc.thrDefault, 4) == 0 && std::memcmp(&ms.thrC, &pc.thrCandidate, 4) == 0) found = &ms;
-        if (!found && snap.masks.size() >= 4) {
-            // more threshold pairs than a snapshot keeps planes for (sets are never evicted while the snapshot
-            // lives: another call may be reading them): this call runs the direct kernels
-            cp.useBits = false;
-            return FPE_OK;
-        }
+        std::shared_ptr<MaskSet> found;
+        for (auto& ms : snap.masks)
+            if (std::memcmp(&ms->thrD, &pc.thrDefault, 4) == 0 && std::memcmp(&ms->thrC, &pc.thrCandidate, 4) == 0) found = ms;
         if (!found) {
-            MaskSet ms;
-            ms.thrD = pc.thrDefault;
-            ms.thrC = pc.thrCandidate;
-            ms.n = fpe::bitmap_words(snap.g.rows, snap.g.cols, &ms.strideW, &ms.nw);
-            float* buf = nullptr;
-            FPE_HIP(alloc_units(*snap.pool, ms.n, &buf));
-            ms.d_words = reinterpret_cast<uint32_t*>(buf);
-            hipError_t e = fpe::launch_build_bitmap(snap.d_trav, snap.g.rows, snap.g.cols, pc.thrDefault, pc.thrCandidate,
-                                                    ms.d_words, stream);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&ms.ready, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventRecord(ms.ready, stream);
-            if (e != hipSuccess) {
-                snap.pool->give(ms.n, buf, true);
-                return fail_hip(e, "bit-plane build");
+            // a pair this snapshot has not been planned with (the upload pre-builds the pairs of the previous snapshot).
+            // cleanOnly: a plan never synchronises the device for a recycled buffer — it allocates instead.
+            rc = build_mask(snap, pc.thrDefault, pc.thrCandidate, stream, true, found);
+            if (rc != FPE_OK) return rc;
+            if (snap.masks.size() >= 4) {  // least recently used set out (calls in flight keep theirs alive)
+                size_t lru = 0;
+                for (size_t k = 1; k < snap.masks.size(); ++k)
+                    if (snap.masks[k]->lastUse.load() < snap.masks[lru]->lastUse.load()) lru = k;
+                if (snap.asyncUsed.load(std::memory_order_acquire)) snap.masks[lru]->asyncUsed.store(true);
+                snap.masks.erase(snap.masks.begin() + static_cast<long>(lru));
             }
-            snap.masks.push_back(ms);
-            found = &snap.masks.back();
+            snap.masks.push_back(found);
         }
+        found->lastUse.store(++snap.useClock);
+        cp.mask = found;
         cp.bits = fpe::BitMap{reinterpret_cast<const uint4*>(found->d_words), found->strideW, found->nw};
-        if (!found->readyDone) {
-            if (hipEventQuery(found->ready) == hipSuccess) found->readyDone = true;
+        if (!found->readyDone.load(std::memory_order_acquire)) {
+            if (hipEventQuery(found->ready) == hipSuccess) found->readyDone.store(true, std::memory_order_release);
             else FPE_HIP(hipStreamWaitEvent(stream, found->ready, 0));
         }
     }
@@ -356,8 +395,8 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
     snap->g = fpe::make_geom(desc->rows, desc->cols, desc->resolution, desc->position[0], desc->position[1]);
     snap->n = n;
     snap->pool = h->pool;
-    FPE_HIP(alloc_units(*h->pool, n, &snap->d_trav));
-    FPE_HIP(alloc_units(*h->pool, n, &snap->d_elev));
+    FPE_HIP(alloc_units(*h->pool, n, &snap->d_trav, &snap->capTrav));
+    FPE_HIP(alloc_units(*h->pool, n, &snap->d_elev, &snap->capElev));
     const bool canonical = desc->storage_order == 1 && desc->start_index[0] == 0 && desc->start_index[1] == 0;
     const float* src[2] = {trav, elev};
     float* dst[2] = {snap->d_trav, snap->d_elev};
@@ -365,15 +404,15 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
     // must not hipMalloc/hipFree per message), and returned to the pool on every exit path
     struct Staging {
         std::shared_ptr<BufferPool> pool;
-        size_t n;
+        size_t cap = 0;
         float* p = nullptr;
         ~Staging() {
-            if (p) pool->give(n, p);
+            if (p) pool->give(cap, p);
         }
-    } stagingGuard{h->pool, n};
+    } stagingGuard{h->pool};
     float*& staging = stagingGuard.p;
     if (!srcOnDevice && !canonical) {
-        FPE_HIP(alloc_units(*h->pool, n, &staging));
+        FPE_HIP(alloc_units(*h->pool, n, &staging, &stagingGuard.cap));
     }
     for (int l = 0; l < 2; ++l) {
         if (canonical) {
@@ -394,6 +433,30 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
     // asynchronous; host-source uploads have been synchronised above, the event is then already complete)
     FPE_HIP(hipEventCreateWithFlags(&snap->ready, hipEventDisableTiming));
     FPE_HIP(hipEventRecord(snap->ready, stream));
+    // Bit planes for the threshold pairs the CURRENT snapshot was planned with, built here on the upload's stream: the
+    // upload is the 10-20 Hz path that may take a recycled ("dirty") buffer behind a device synchronisation; the first
+    // plan on the new map then finds its planes and pays nothing (include/fpe.h: "plans never pay for it").
+    {
+        std::shared_ptr<MapSnapshot> cur;
+        {
+            std::lock_guard<std::mutex> lk(h->mu);
+            cur = h->map;
+        }
+        if (cur) {
+            std::vector<std::pair<float, float>> pairs;
+            {
+                std::lock_guard<std::mutex> lk(cur->mu);
+                for (auto& ms : cur->masks) pairs.emplace_back(ms->thrD, ms->thrC);
+            }
+            for (auto& pr : pairs) {
+                std::shared_ptr<MaskSet> ms;
+                rc = build_mask(*snap, pr.first, pr.second, stream, false, ms);
+                if (rc != FPE_OK) return rc;
+                ms->lastUse.store(++snap->useClock);
+                snap->masks.push_back(std::move(ms));
+            }
+        }
+    }
     std::shared_ptr<MapSnapshot> old;
     {
         std::lock_guard<std::mutex> lk(h->mu);
@@ -562,8 +625,9 @@ int filters_common(fpe_engine* h, const fpe_map_desc* desc, const fpe_filter_par
         }
     } scratch{h->pool, {}};
     auto take = [&](size_t units, float** out) -> hipError_t {
-        hipError_t e = alloc_units(*h->pool, units, out);
-        if (e == hipSuccess) scratch.bufs.emplace_back(units, *out);
+        size_t cap = 0;
+        hipError_t e = alloc_units(*h->pool, units, out, &cap);
+        if (e == hipSuccess) scratch.bufs.emplace_back(cap, *out);
         return e;
     };
     const float* d_elev = elev;
@@ -648,12 +712,32 @@ int fpe_plan_device(fpe_handle h, const fpe_params* params, const fpe_pose* d_po
     rc = launch_plan(h, cp, d_poses, B, n_cycles, *d_out, st);
     if (rc != FPE_OK) return rc;
     cp.snap->note_async_use();  // asynchronous launch: the snapshot's buffers are recycled only behind a device sync
+    if (cp.mask) cp.mask->asyncUsed.store(true, std::memory_order_release);
     return FPE_OK;
 }
 
-int fpe_plan(fpe_handle h, const fpe_params* params, const fpe_pose* poses, int32_t B, int32_t n_cycles,
-             const fpe_plan_out* out) {
-    if (!poses || !out) return fail(FPE_E_INVALID_ARG, "null argument");
+namespace {
+// Constants of the opt track for this map, checked (fpe_host.cpp::derive_opt_constants).
+int prepare_opt(const fpe_params* params, const fpe_opt_params* opt, const CallPlan& cp, float maxRadius, fpe::OptConsts& oc) {
+    fpe_opt_params yaml;
+    if (!opt) {
+        fpe_opt_params_yaml(&yaml);
+        opt = &yaml;
+    }
+    const int rc = fpe::derive_opt_constants(*params, *opt, cp.snap->g, cp.pc, oc);
+    if (rc != FPE_OK) return fail(rc, "opt parameters: weights / scales / tolerance must be finite");
+    // checkFootholdUseCentroidMethod on the gait-cycle submap keeps its blocked-row mask in 128 bits
+    const double rows = 2.0 * static_cast<double>(std::max(maxRadius, params->searchRadius)) / cp.snap->g.res + 3.0;
+    if (rows > 128.0) return fail(FPE_E_UNSUPPORTED, "opt track: the foot search rectangle spans more than 128 rows");
+    return FPE_OK;
+}
+
+// The host-buffer form of the plan and / or the opt track: one device arena, the launches back to back on one
+// stream, the results copied out.  `out` NULL: no plan products are returned (the plan still runs when the opt track
+// needs its cycle flags and the caller gave none).
+int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt, const fpe_pose* poses, int32_t B, int32_t n_cycles,
+              const fpe_plan_out* out, const uint8_t* cycleOkIn, const fpe_opt_out* oout) {
+    if (!poses || (!out && !oout)) return fail(FPE_E_INVALID_ARG, "null argument");
     if (B <= 0 || n_cycles <= 0 || n_cycles > 255) return fail(FPE_E_INVALID_ARG, "B and n_cycles must be in [1, ..] / [1, 255]");
     float maxRadius = 0.0f;
     for (int b = 0; b < B; ++b) {
@@ -667,30 +751,57 @@ int fpe_plan(fpe_handle h, const fpe_params* params, const fpe_pose* poses, int3
                 return fail(FPE_E_INVALID_ARG, "unknown polygon kind");
         }
     }
-    // one device arena + one pinned arena: [poses | nominal | centroid | default | cycle_ok | stance | selected | status]
+    fpe_plan_out none;
+    std::memset(&none, 0, sizeof(none));
+    const fpe_plan_out& po = out ? *out : none;
+    const bool runPlan = out != nullptr || (oout && !cycleOkIn);
+    const bool needOkDev = po.cycle_ok != nullptr || oout != nullptr;  // device copy of the cycle flags
+    // one device arena + one pinned arena:
+    // [poses | nominal | centroid | default | cycle_ok | stance | selected | status | opt footholds | opt cycles | gate]
     const size_t nRec = static_cast<size_t>(B) * n_cycles * 4;
+    const size_t nCyc = static_cast<size_t>(B) * n_cycles;
     const size_t szPose = align256(static_cast<size_t>(B) * sizeof(fpe_pose));
-    const size_t szNom = out->nominal ? align256(nRec * sizeof(fpe_foothold)) : 0;
-    const size_t szCen = out->centroid ? align256(nRec * sizeof(fpe_centroid_foothold)) : 0;
-    const size_t szDef = out->default_next ? align256(nRec * 3 * sizeof(double)) : 0;
-    const size_t szOk = out->cycle_ok ? align256(static_cast<size_t>(B) * n_cycles) : 0;
-    const size_t szSt = out->stance ? align256(static_cast<size_t>(B) * 12 * sizeof(double)) : 0;
-    const size_t szSel = out->selected ? align256(nRec * sizeof(fpe_selected_foothold)) : 0;
-    const size_t szPs = out->pose_status ? align256(static_cast<size_t>(B)) : 0;
-    const size_t total = szPose + szNom + szCen + szDef + szOk + szSt + szSel + szPs;
+    const size_t szNom = po.nominal ? align256(nRec * sizeof(fpe_foothold)) : 0;
+    const size_t szCen = po.centroid ? align256(nRec * sizeof(fpe_centroid_foothold)) : 0;
+    const size_t szDef = po.default_next ? align256(nRec * 3 * sizeof(double)) : 0;
+    const size_t szOk = needOkDev ? align256(nCyc) : 0;
+    const size_t szSt = po.stance ? align256(static_cast<size_t>(B) * 12 * sizeof(double)) : 0;
+    const size_t szSel = po.selected ? align256(nRec * sizeof(fpe_selected_foothold)) : 0;
+    const size_t szPs = po.pose_status ? align256(static_cast<size_t>(B)) : 0;
+    const size_t szOf = (oout && oout->footholds) ? align256(nRec * sizeof(fpe_opt_foothold)) : 0;
+    const size_t szOc = (oout && oout->cycles) ? align256(nCyc * sizeof(fpe_opt_cycle)) : 0;
+    const size_t szOg = (oout && oout->gate_fail_cycle) ? align256(static_cast<size_t>(B)) : 0;
+    const size_t total = szPose + szNom + szCen + szDef + szOk + szSt + szSel + szPs + szOf + szOc + szOg;
     if (!h) return fail(FPE_E_INVALID_ARG, "null handle or params");
     CtxLease lease(h->ctxPool);
     CallCtx& cx = *lease.ctx;
     FPE_HIP(hipSetDevice(h->device));
     FPE_HIP(cx.reserve(total));
     CallPlan cp;
-    int rc = prepare_call(h, params, maxRadius, cp, cx.stream, true);
+    int rc = prepare_call(h, params, maxRadius, cp, cx.stream, runPlan);
     if (rc != FPE_OK) return rc;
+    fpe::OptConsts oc;
+    if (oout) {
+        rc = prepare_opt(params, opt, cp, maxRadius, oc);
+        if (rc != FPE_OK) return rc;
+    }
     unsigned char* dp = cx.dev;
     unsigned char* hp = cx.pinned;
+    size_t off = szPose;
+    const size_t oNom = off; off += szNom;
+    const size_t oCen = off; off += szCen;
+    const size_t oDef = off; off += szDef;
+    const size_t oOk = off; off += szOk;
+    const size_t oSt = off; off += szSt;
+    const size_t oSel = off; off += szSel;
+    const size_t oPs = off; off += szPs;
+    const size_t oOf = off; off += szOf;
+    const size_t oOc = off; off += szOc;
+    const size_t oOg = off;
     std::memcpy(hp, poses, static_cast<size_t>(B) * sizeof(fpe_pose));
-    // Small calls (the plan_global_footholds service: one pose) skip both DMA copies: the kernel reads the
-    // poses from, and writes its few KB of results straight into, the pinned (coherent, device-mapped) host
+    if (oout && cycleOkIn) std::memcpy(hp + oOk, cycleOkIn, nCyc);
+    // Small calls (the plan_global_footholds service: one pose) skip both DMA copies: the kernels read the
+    // poses from, and write their few KB of results straight into, the pinned (coherent, device-mapped) host
     // arena — two copy-engine round trips (~10 us each) less on a call whose kernel runs ~25 us.
     const bool zeroCopy = total <= kZeroCopyBytes;
     if (zeroCopy) {
@@ -699,38 +810,74 @@ int fpe_plan(fpe_handle h, const fpe_params* params, const fpe_pose* poses, int3
         dp = static_cast<unsigned char*>(mapped);
     } else {
         FPE_HIP(hipMemcpyAsync(dp, hp, static_cast<size_t>(B) * sizeof(fpe_pose), hipMemcpyHostToDevice, cx.stream));
+        if (oout && cycleOkIn) FPE_HIP(hipMemcpyAsync(dp + oOk, hp + oOk, nCyc, hipMemcpyHostToDevice, cx.stream));
     }
-    size_t off = szPose;
-    const size_t oNom = off; off += szNom;
-    const size_t oCen = off; off += szCen;
-    const size_t oDef = off; off += szDef;
-    const size_t oOk = off; off += szOk;
-    const size_t oSt = off; off += szSt;
-    const size_t oSel = off; off += szSel;
-    const size_t oPs = off;
-    fpe_plan_out d;
-    std::memset(&d, 0, sizeof(d));
-    if (out->nominal) d.nominal = reinterpret_cast<fpe_foothold*>(dp + oNom);
-    if (out->centroid) d.centroid = reinterpret_cast<fpe_centroid_foothold*>(dp + oCen);
-    if (out->default_next) d.default_next = reinterpret_cast<double*>(dp + oDef);
-    if (out->cycle_ok) d.cycle_ok = dp + oOk;
-    if (out->stance) d.stance = reinterpret_cast<double*>(dp + oSt);
-    if (out->selected) d.selected = reinterpret_cast<fpe_selected_foothold*>(dp + oSel);
-    if (out->pose_status) d.pose_status = dp + oPs;
-    // every (pose, cycle, leg) record is written by the kernel (trot: all legs each cycle; walk: each
-    // leg in its phase), so the buffers need no clearing
-    rc = launch_plan(h, cp, reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, d, cx.stream);
-    if (rc != FPE_OK) return rc;
+    if (runPlan) {
+        fpe_plan_out d;
+        std::memset(&d, 0, sizeof(d));
+        if (po.nominal) d.nominal = reinterpret_cast<fpe_foothold*>(dp + oNom);
+        if (po.centroid) d.centroid = reinterpret_cast<fpe_centroid_foothold*>(dp + oCen);
+        if (po.default_next) d.default_next = reinterpret_cast<double*>(dp + oDef);
+        if (needOkDev) d.cycle_ok = dp + oOk;
+        if (po.stance) d.stance = reinterpret_cast<double*>(dp + oSt);
+        if (po.selected) d.selected = reinterpret_cast<fpe_selected_foothold*>(dp + oSel);
+        if (po.pose_status) d.pose_status = dp + oPs;
+        // every (pose, cycle, leg) record is written by the kernel (trot: all legs each cycle; walk: each
+        // leg in its phase), so the buffers need no clearing
+        rc = launch_plan(h, cp, reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, d, cx.stream);
+        if (rc != FPE_OK) return rc;
+    }
+    if (oout) {
+        fpe_opt_out od;
+        std::memset(&od, 0, sizeof(od));
+        if (oout->footholds) od.footholds = reinterpret_cast<fpe_opt_foothold*>(dp + oOf);
+        if (oout->cycles) od.cycles = reinterpret_cast<fpe_opt_cycle*>(dp + oOc);
+        if (oout->gate_fail_cycle) od.gate_fail_cycle = dp + oOg;
+        FPE_HIP(fpe::launch_opt_track(dev_map(*cp.snap), cp.pc, oc, reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, dp + oOk, od,
+                                      cx.stream));
+    }
     if (total > szPose && !zeroCopy)  // results: one D2H copy of the whole result arena into pinned memory
         FPE_HIP(hipMemcpyAsync(hp + szPose, dp + szPose, total - szPose, hipMemcpyDeviceToHost, cx.stream));
     FPE_HIP(hipStreamSynchronize(cx.stream));
-    if (out->nominal) std::memcpy(out->nominal, hp + oNom, nRec * sizeof(fpe_foothold));
-    if (out->centroid) std::memcpy(out->centroid, hp + oCen, nRec * sizeof(fpe_centroid_foothold));
-    if (out->default_next) std::memcpy(out->default_next, hp + oDef, nRec * 3 * sizeof(double));
-    if (out->cycle_ok) std::memcpy(out->cycle_ok, hp + oOk, static_cast<size_t>(B) * n_cycles);
-    if (out->stance) std::memcpy(out->stance, hp + oSt, static_cast<size_t>(B) * 12 * sizeof(double));
-    if (out->selected) std::memcpy(out->selected, hp + oSel, nRec * sizeof(fpe_selected_foothold));
-    if (out->pose_status) std::memcpy(out->pose_status, hp + oPs, static_cast<size_t>(B));
+    if (po.nominal) std::memcpy(po.nominal, hp + oNom, nRec * sizeof(fpe_foothold));
+    if (po.centroid) std::memcpy(po.centroid, hp + oCen, nRec * sizeof(fpe_centroid_foothold));
+    if (po.default_next) std::memcpy(po.default_next, hp + oDef, nRec * 3 * sizeof(double));
+    if (po.cycle_ok) std::memcpy(po.cycle_ok, hp + oOk, nCyc);
+    if (po.stance) std::memcpy(po.stance, hp + oSt, static_cast<size_t>(B) * 12 * sizeof(double));
+    if (po.selected) std::memcpy(po.selected, hp + oSel, nRec * sizeof(fpe_selected_foothold));
+    if (po.pose_status) std::memcpy(po.pose_status, hp + oPs, static_cast<size_t>(B));
+    if (szOf) std::memcpy(oout->footholds, hp + oOf, nRec * sizeof(fpe_opt_foothold));
+    if (szOc) std::memcpy(oout->cycles, hp + oOc, nCyc * sizeof(fpe_opt_cycle));
+    if (szOg) std::memcpy(oout->gate_fail_cycle, hp + oOg, static_cast<size_t>(B));
+    return FPE_OK;
+}
+}  // namespace
+
+int fpe_plan(fpe_handle h, const fpe_params* params, const fpe_pose* poses, int32_t B, int32_t n_cycles,
+             const fpe_plan_out* out) {
+    if (!out) return fail(FPE_E_INVALID_ARG, "null argument");
+    return plan_host(h, params, nullptr, poses, B, n_cycles, out, nullptr, nullptr);
+}
+
+int fpe_plan_opt(fpe_handle h, const fpe_params* params, const fpe_opt_params* opt, const fpe_pose* poses, int32_t B,
+                 int32_t n_cycles, const uint8_t* cycle_ok, const fpe_opt_out* out) {
+    if (!out) return fail(FPE_E_INVALID_ARG, "null argument");
+    return plan_host(h, params, opt, poses, B, n_cycles, nullptr, cycle_ok, out);
+}
+
+int fpe_plan_opt_device(fpe_handle h, const fpe_params* params, const fpe_opt_params* opt, const fpe_pose* d_poses, int32_t B,
+                        int32_t n_cycles, const uint8_t* d_cycle_ok, const fpe_opt_out* d_out, void* stream) {
+    if (!d_poses || !d_out || !d_cycle_ok) return fail(FPE_E_INVALID_ARG, "null argument");
+    if (B <= 0 || n_cycles <= 0 || n_cycles > 255) return fail(FPE_E_INVALID_ARG, "B and n_cycles must be in [1, ..] / [1, 255]");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    CallPlan cp;
+    int rc = prepare_call(h, params, 0.0f, cp, st, false);
+    if (rc != FPE_OK) return rc;
+    fpe::OptConsts oc;
+    rc = prepare_opt(params, opt, cp, std::max(params->searchRadius, cp.pc.maxSearchRadius), oc);
+    if (rc != FPE_OK) return rc;
+    FPE_HIP(fpe::launch_opt_track(dev_map(*cp.snap), cp.pc, oc, d_poses, B, n_cycles, d_cycle_ok, *d_out, st));
+    cp.snap->note_async_use();
     return FPE_OK;
 }
 
@@ -796,6 +943,15 @@ int fpe_plan_service_ex(fpe_handle h, const fpe_params* params, const double ini
 int fpe_plan_service_report(fpe_handle h, const fpe_params* params, const double initial_position[3], uint8_t gait_cycles,
                             fpe_global_footholds* response, fpe_global_footholds* centroid, double* default_footholds,
                             int32_t* n_default_rows, fpe_track_report* nominal_report, fpe_track_report* centroid_report) {
+    return fpe_plan_service_opt(h, params, nullptr, initial_position, gait_cycles, response, centroid, default_footholds, n_default_rows,
+                                nominal_report, centroid_report, nullptr, nullptr, nullptr);
+}
+
+int fpe_plan_service_opt(fpe_handle h, const fpe_params* params, const fpe_opt_params* opt, const double initial_position[3],
+                         uint8_t gait_cycles, fpe_global_footholds* response, fpe_global_footholds* centroid,
+                         double* default_footholds, int32_t* n_default_rows, fpe_track_report* nominal_report,
+                         fpe_track_report* centroid_report, fpe_global_footholds* opt_msg, fpe_track_report* opt_report,
+                         fpe_opt_cycle* opt_cycles) {
     if (!initial_position || !response) return fail(FPE_E_INVALID_ARG, "null argument");
     if (default_footholds && !n_default_rows) return fail(FPE_E_INVALID_ARG, "n_default_rows is required with default_footholds");
     fpe_pose pose;
@@ -807,6 +963,7 @@ int fpe_plan_service_report(fpe_handle h, const fpe_params* params, const double
     double stance[12];
     std::vector<fpe_foothold> nominal(static_cast<size_t>(N) * 4);
     std::vector<fpe_centroid_foothold> cen(static_cast<size_t>(N) * 4);
+    std::vector<fpe_opt_foothold> optf(static_cast<size_t>(N) * 4);
     std::vector<double> dflt(static_cast<size_t>(N) * 12);
     std::vector<uint8_t> ok(static_cast<size_t>(N));
     if (N == 0) {
@@ -829,27 +986,36 @@ int fpe_plan_service_report(fpe_handle h, const fpe_params* params, const double
         out.nominal = nominal.data();
         out.cycle_ok = ok.data();
         out.stance = stance;
-        uint8_t poseStatus = 0;
-        out.pose_status = &poseStatus;
         if (centroid || centroid_report) out.centroid = cen.data();
         if (default_footholds) out.default_next = dflt.data();
-        int rc = fpe_plan(h, params, &pose, 1, N, &out);
+        // the opt track's chain next to the plan (same stream, same call): its gate decides the handler's return value in
+        // EVERY cycle (cpp:920-934), its feet centres are part of the centroid path (cpp:946)
+        fpe_opt_out oout;
+        std::memset(&oout, 0, sizeof(oout));
+        uint8_t gateFail = 255;
+        oout.gate_fail_cycle = &gateFail;
+        oout.footholds = optf.data();
+        oout.cycles = opt_cycles;
+        int rc = plan_host(h, params, opt, &pose, 1, N, &out, nullptr, &oout);
         if (rc != FPE_OK) return rc;
-        if (poseStatus & FPE_POSE_OPT_SUBMAP_FAILED) {
-            // getGaitCycleSearchGridMap fails in the first gait cycle: the reference's handler logs "Failed to get
-            // gait-cycle search gridmap." and returns false before anything is appended beyond the stance
-            // (cpp:920-934); the ROS response is never assigned (cpp:1588 is not reached)
+        if (gateFail != 255) {
+            // getGaitCycleSearchGridMap fails in cycle gateFail: the reference's handler logs "Failed to get gait-cycle
+            // search gridmap." and returns false (cpp:931-934); the ROS response is never assigned (cpp:1588 is not reached)
             std::memset(response, 0, sizeof(*response));
             if (centroid) std::memset(centroid, 0, sizeof(*centroid));
             if (n_default_rows) *n_default_rows = 0;
             if (nominal_report) std::memset(nominal_report, 0, sizeof(*nominal_report));
             if (centroid_report) std::memset(centroid_report, 0, sizeof(*centroid_report));
-            return fail(FPE_E_SERVICE_FALSE, "getGaitCycleSearchGridMap: getSubmap failed in the first gait cycle (cpp:931-934)");
+            if (opt_msg) std::memset(opt_msg, 0, sizeof(*opt_msg));
+            if (opt_report) std::memset(opt_report, 0, sizeof(*opt_report));
+            return fail(FPE_E_SERVICE_FALSE, "getGaitCycleSearchGridMap: getSubmap failed in gait cycle " + std::to_string(static_cast<int>(gateFail)) +
+                                                 " (cpp:931-934)");
         }
     }
     fpe::assemble_global_footholds(nominal.data(), ok.data(), stance, N, response);
     if (centroid) fpe::assemble_centroid_footholds(cen.data(), ok.data(), stance, N, centroid);
-    if (nominal_report || centroid_report) {
+    if (opt_msg) fpe::assemble_opt_footholds(optf.data(), ok.data(), stance, N, opt_msg);
+    if (nominal_report || centroid_report || opt_report) {
         if (!params) return fail(FPE_E_INVALID_ARG, "null params");
         std::vector<double> xyz(static_cast<size_t>(N) * 12);
         if (nominal_report) {
@@ -860,13 +1026,25 @@ int fpe_plan_service_report(fpe_handle h, const fpe_params* params, const double
             }
             fpe::assemble_track_report(xyz.data(), ok.data(), stance, N, *params, nominal_report);
         }
-        if (centroid_report) {
+        if (centroid_report || opt_report) {
+            std::unique_ptr<fpe_track_report> optRep(new (std::nothrow) fpe_track_report);
+            if (!optRep) return fail(FPE_E_NOMEM, "out of host memory");
             for (size_t k = 0; k < static_cast<size_t>(N) * 4; ++k) {
-                xyz[k * 3] = cen[k].x;
-                xyz[k * 3 + 1] = cen[k].y;
-                xyz[k * 3 + 2] = static_cast<double>(cen[k].z);
+                xyz[k * 3] = optf[k].x;
+                xyz[k * 3 + 1] = optf[k].y;
+                xyz[k * 3 + 2] = static_cast<double>(optf[k].z);
             }
-            fpe::assemble_track_report(xyz.data(), ok.data(), stance, N, *params, centroid_report);
+            fpe::assemble_track_report(xyz.data(), ok.data(), stance, N, *params, optRep.get());
+            if (opt_report) std::memcpy(opt_report, optRep.get(), sizeof(*opt_report));
+            if (centroid_report) {
+                for (size_t k = 0; k < static_cast<size_t>(N) * 4; ++k) {
+                    xyz[k * 3] = cen[k].x;
+                    xyz[k * 3 + 1] = cen[k].y;
+                    xyz[k * 3 + 2] = static_cast<double>(cen[k].z);
+                }
+                fpe::assemble_track_report(xyz.data(), ok.data(), stance, N, *params, centroid_report);
+                fpe::interleave_centroid_path(centroid_report, *optRep);  // cpp:946: the opt track pushes onto the same path
+            }
         }
     }
     if (default_footholds) {

@@ -418,6 +418,83 @@ void assemble_track_report(const double* resultXYZ /*[nCycles][4][3]*/, const ui
     }
 }
 
+int derive_opt_constants(const fpe_params& p, const fpe_opt_params& op, const MapGeom& g, const PlanConsts& pc, OptConsts& oc) {
+    const double vals[] = {op.w1, op.w2, op.w3, op.w4, op.wr, op.wc, op.ctol, op.hip_lower_scale, op.hip_upper_scale,
+                           op.skew_lower_scale, op.skew_upper_scale, op.lf_current_row0, op.rh_current_row0};
+    for (double v : vals)
+        if (!std::isfinite(v)) return FPE_E_INVALID_ARG;
+    oc.w1 = op.w1; oc.w2 = op.w2; oc.w3 = op.w3; oc.w4 = op.w4; oc.wr = op.wr; oc.wc = op.wc;
+    oc.ctol = op.ctol;
+    const double lengthBase = static_cast<double>(p.length);  // cpp:497: lengthBase = laikagoKinematics_.lengthBase (float)
+    const double skew = static_cast<double>(p.skew);          // cpp:498
+    const double mapResolution = g.res;                       // cpp:514
+    oc.lengthBase = lengthBase;
+    oc.skew = skew;
+    oc.mapResolution = mapResolution;
+    const double hip_lower_scale = op.hip_lower_scale, hip_upper_scale = op.hip_upper_scale;
+    const double skew_lower_scale = op.skew_lower_scale, skew_upper_scale = op.skew_upper_scale;
+    oc.t1 = lengthBase * hip_lower_scale/mapResolution;   // cpp:1156
+    oc.t2 = lengthBase * hip_upper_scale/mapResolution;   // cpp:1157
+    oc.t3 = 2* skew * skew_lower_scale/mapResolution;     // cpp:1158
+    oc.t4 = 2* skew * skew_upper_scale/mapResolution;     // cpp:1159
+    oc.lfRow0 = op.lf_current_row0;
+    oc.rhRow0 = op.rh_current_row0;
+    oc.useConstraints = op.use_inequality_constraints ? 1 : 0;
+    // footSearchRect_.width = searchRadius_ (an f32 value in a double, cpp:385); .col = width / mapResolution, a double
+    // (cpp:529, hpp:704-705); Eigen::MatrixXi assignments truncate toward zero (cpp:1063-1066)
+    const double footSearchRectWidth = p.searchRadius;
+    const double footSearchRectCol = footSearchRectWidth/mapResolution;
+    const double a = footSearchRectCol, b = pc.isosWid/mapResolution - footSearchRectCol, c = pc.isosWid/mapResolution;
+    if (!(std::fabs(a) < 2.0e9) || !(std::fabs(b) < 2.0e9) || !(std::fabs(c) < 2.0e9)) return FPE_E_INVALID_ARG;
+    oc.colLoA = 0;
+    oc.colUpA = static_cast<int>(a);
+    oc.colLoB = static_cast<int>(b);
+    oc.colUpB = static_cast<int>(c);
+    oc.pad = 0;
+    return FPE_OK;
+}
+
+void assemble_opt_footholds(const fpe_opt_foothold* opt, const uint8_t* cycleOk, const double* stance, int nCycles,
+                            fpe_global_footholds* msg) {
+    std::memset(msg, 0, sizeof(*msg));
+    int n = 0;
+    for (int l = 0; l < 4; ++l) {  // cpp:737-755: the initial stance, gait_cycle_id 0
+        fpe_msg_foothold& f = msg->footholds[n++];
+        f.x = stance[l * 3 + 0];
+        f.y = stance[l * 3 + 1];
+        f.z = stance[l * 3 + 2];
+        f.foot_id = static_cast<uint8_t>(l);
+        f.gait_cycle_id = 0;
+    }
+    for (int g = 0; g < nCycles; ++g) {
+        if (!cycleOk[g]) continue;
+        msg->gait_cycles_succeed = static_cast<uint8_t>(g + 1);  // cpp:1511
+        msg->success = 1;                                        // cpp:1512
+        for (int l = 0; l < 4; ++l) {
+            const fpe_opt_foothold& s = opt[g * 4 + l];
+            fpe_msg_foothold& f = msg->footholds[n++];
+            f.x = s.x;
+            f.y = s.y;
+            f.z = static_cast<double>(s.z);
+            f.foot_id = static_cast<uint8_t>(l);
+            f.gait_cycle_id = static_cast<uint8_t>(g);
+        }
+    }
+    msg->n_footholds = n;
+}
+
+void interleave_centroid_path(fpe_track_report* cen, const fpe_track_report& opt) {
+    const int n = cen->n_path < opt.n_path ? cen->n_path : opt.n_path;
+    for (int g = n - 1; g >= 0; --g) {
+        for (int k = 0; k < 3; ++k) {
+            const double c = cen->feet_center_path[g][k];
+            cen->feet_center_path[2 * g][k] = c;
+            cen->feet_center_path[2 * g + 1][k] = opt.feet_center_path[g][k];
+        }
+    }
+    cen->n_path = 2 * n;
+}
+
 }  // namespace fpe
 
 // ---- C ABI: host-only entry points -----------------------------------------------------------------
@@ -455,6 +532,26 @@ int fpe_params_code_defaults(fpe_params* p) {  // readParameters, cpp:255-290
     p->h = 0.01;
     p->lateralDrift = -0.007;
     return FPE_OK;
+}
+
+int fpe_opt_params_yaml(fpe_opt_params* p) {  // foothold_planner.yaml:53-63, FootholdPlanner.cpp:34, 48-49
+    if (!p) return FPE_E_INVALID_ARG;
+    std::memset(p, 0, sizeof(*p));
+    p->w1 = p->w2 = p->w3 = p->w4 = 1.0;
+    p->wr = p->wc = 1.0;
+    p->use_inequality_constraints = 1;
+    p->ctol = 1e-2;
+    p->hip_lower_scale = 0.9;
+    p->hip_upper_scale = 1.1;
+    p->skew_lower_scale = 0.8;
+    p->skew_upper_scale = 1.2;
+    return FPE_OK;
+}
+
+int fpe_opt_params_code_defaults(fpe_opt_params* p) {  // readParameters, cpp:297-307
+    const int rc = fpe_opt_params_yaml(p);
+    if (rc == FPE_OK) p->use_inequality_constraints = 0;
+    return rc;
 }
 
 int fpe_spiral_offsets(int32_t n_rings, int32_t* out, int32_t max_cells) {

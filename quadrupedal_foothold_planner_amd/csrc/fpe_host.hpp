@@ -41,6 +41,11 @@ int spiral_rings(float searchRadius, double resolution);
 
 int validate_params(const fpe_params& p);
 
+// Opt track: the file-scope NLopt globals (cpp:28-51, 497-498, 514), the constraint thresholds
+// t1..t4 (cpp:1156-1159) and the column bounds of xBounds (cpp:1063-1066, 528-529), with the reference's typing.
+// FPE_E_INVALID_ARG when a weight / scale / tolerance is not finite.
+int derive_opt_constants(const fpe_params& p, const fpe_opt_params& op, const MapGeom& g, const PlanConsts& pc, OptConsts& out);
+
 // GlobalFootholds message content from one pose's plan outputs (cpp:591-699, 1378-1396, 1574).
 void assemble_global_footholds(const fpe_foothold* nominal, const uint8_t* cycleOk, const double* stance,
                                int nCycles, fpe_global_footholds* msg);
@@ -49,5 +54,11 @@ void assemble_centroid_footholds(const fpe_centroid_foothold* centroid, const ui
                                  int nCycles, fpe_global_footholds* msg);
 void assemble_track_report(const double* resultXYZ, const uint8_t* cycleOk, const double* stance, int nCycles,
                            const fpe_params& params, fpe_track_report* rep);
+// optGlobalFootholdsMsg_ content of one call (cpp:737-755, 1510-1532): bookkeeping as the centroid message
+void assemble_opt_footholds(const fpe_opt_foothold* opt, const uint8_t* cycleOk, const double* stance, int nCycles,
+                            fpe_global_footholds* msg);
+// centroidFeetCenterPath as the reference fills it (cpp:792 and cpp:946): per cycle the centroid track's feet centre,
+// then the opt track's
+void interleave_centroid_path(fpe_track_report* centroid, const fpe_track_report& opt);
 
 }  // namespace fpe

@@ -1977,6 +1977,8 @@ hipError_t launch_canonicalise(const float* d_src, float* d_dst, int rows, int c
 // ---- part three: the producer's filters (elevation -> traversability) ----------------------------------------
 #include "fpe_filters.hpp"
 
+#include "fpe_opt.hpp"
+
 hipError_t set_max_lds(size_t planBytes, size_t searchBytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_chained_kernel<16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(planBytes));

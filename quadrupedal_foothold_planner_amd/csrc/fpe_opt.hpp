@@ -1,0 +1,458 @@
+// fpe_opt.hpp — part three of the kernel translation unit (included at the end of fpe_kernels.hip, inside namespace
+// fpe): the OPT TRACK of globalFootholdPlan.
+//
+// Reference: cpp:54-88 nloptFunc, cpp:92-148 nloptConstraint1..8, cpp:913-1319 the per-cycle driver, cpp:1485-1568 the
+// commit, cpp:2307-2408 getGaitCycleSearchGridMap, cpp:2557-2568 getMapIndex.  One wavefront per pose, gait cycles in
+// sequence (the track's feet chain like the other tracks'); inside a cycle
+//   * the gait-cycle submap gaitMap_ = gridmap_.getSubmap(next feet centre, isos_.length x isos_.width) as a MapGeom
+//     of its own plus its top-left index in the map (no copy: cells are read from the map's layers);
+//   * checkFootholdUseCentroidMethod ON gaitMap_ for the four legs side by side, 16 lanes per leg (lane = row of the
+//     leg's rectangle), with traversableBeginRow / traversableEndRow (cpp:1608-1609);
+//   * the BUILD-DEFINED optimiser (NLopt is absent and unpinned — include/fpe.h): the literal objective and
+//     constraints evaluated on every integer point of the box, lane = point, wave-wide lexicographic minimum of
+//     (violation, objective, enumeration order) — the same rule, expression for expression, as
+//     oracle/fpo_opt.cpp::solveLattice;
+//   * positions and mean heights taken from gaitMap_ (its own geometry: a CircleIterator on a submap is clamped to the
+//     submap and measures distances to the SUBMAP's cell centres), the commit with the nominal track's validity.
+// Everything is the reference's f64 expression order (-ffp-contract=off); this is a secondary product, written for
+// exactness first: the hot path is fpe_bits.hpp.
+#pragma once
+
+namespace {
+
+// GridMap::getSubmap(position, length) as geometry only: the submap's own MapGeom (setGeometry(SubmapGeometry): size,
+// length = size * res, position = top-left corner - length / 2) and its top-left index.  ok = isSuccess.
+struct SubGeom {
+    MapGeom g;
+    int i0, j0;
+    bool ok;
+};
+__device__ __forceinline__ SubGeom opt_submap(const MapGeom& g, double px, double py, double lx, double ly) {
+    SubGeom r;
+    const Submap s = submap_info(g, px, py, lx, ly);
+    r.ok = s.ok;
+    r.i0 = s.i0;
+    r.j0 = s.j0;
+    const int ni = s.ok ? s.ni : 1, nj = s.ok ? s.nj : 1;
+    const double cornerX = cell_pos(g.baseX, g.res, s.i0) - (-(0.5 * g.res));
+    const double cornerY = cell_pos(g.baseY, g.res, s.j0) - (-(0.5 * g.res));
+    const double subLenX = static_cast<double>(ni) * g.res, subLenY = static_cast<double>(nj) * g.res;
+    r.g = make_geom(ni, nj, g.res, cornerX - 0.5 * subLenX, cornerY - 0.5 * subLenY);
+    return r;
+}
+
+// getFootholdMeanHeight (cpp:2520-2554) on a map given by its geometry `g` whose cell (i, j) is cell (offI + i, offJ + j)
+// of the elevation layer: one lane, cells in CircleIterator order (row-major over the bounding box).
+__device__ float opt_mean_height(const MapGeom& g, const float* elev, int ld, int offI, int offJ, double cx, double cy, double rf,
+                                 double rf2, double h) {
+    float iHeight = 0.0f, meanHeight = 0.0f;
+    int n = 0;
+    if (!centre_usable(cx, cy)) return static_cast<float>(meanHeight + h);
+    const BBox bb = circle_bbox(g, cx, cy, rf);
+    for (int a = 0; a < bb.ni; ++a)
+        for (int b = 0; b < bb.nj; ++b) {
+            const int i = bb.i0 + a, j = bb.j0 + b;
+            if (!in_range(i, j, g.rows, g.cols) || !cell_in_disc(g, i, j, cx, cy, rf2)) continue;
+            const float e = elev[static_cast<size_t>(offI + i) * ld + (offJ + j)];
+            iHeight = __builtin_isfinite(e) ? e : 0.0f;  // cpp:2532-2537
+            if (iHeight < 10) {                            // cpp:2539
+                n++;
+                meanHeight = meanHeight + iHeight;
+            }
+        }
+    if (n != 0) meanHeight = meanHeight / n;
+    else meanHeight = iHeight;
+    return static_cast<float>(meanHeight + h);
+}
+
+// nloptFunc, cpp:54-88 — the reference's expression, term for term (abs = std::abs(double): fabs).
+__device__ __forceinline__ double opt_objective(const double (&x)[8], const OptConsts& oc, const int (&nominalIndex)[8],
+                                                const int (&centroidIndex)[8], double lfCurrentRow, double rhCurrentRow) {
+    const double w1 = oc.w1, w2 = oc.w2, w3 = oc.w3, w4 = oc.w4, wr = oc.wr, wc = oc.wc;
+    const double lengthBase = oc.lengthBase, skew = oc.skew, mapResolution = oc.mapResolution;
+#define abs fabs
+    return (
+            w1*( wr*(abs(x[0]-nominalIndex[0])) + wc*(abs(x[1]-nominalIndex[1])) +
+                 wr*(abs(x[2]-nominalIndex[2])) + wc*(abs(x[3]-nominalIndex[3])) +
+                 wr*(abs(x[4]-nominalIndex[4])) + wc*(abs(x[5]-nominalIndex[5])) +
+                 wr*(abs(x[6]-nominalIndex[6])) + wc*(abs(x[7]-nominalIndex[7])) ) +
+            w2*( wr*(abs(x[0]-centroidIndex[0])) + wc*(abs(x[1]-centroidIndex[1])) +
+                 wr*(abs(x[2]-centroidIndex[2])) + wc*(abs(x[3]-centroidIndex[3])) +
+                 wr*(abs(x[4]-centroidIndex[4])) + wc*(abs(x[5]-centroidIndex[5])) +
+                 wr*(abs(x[6]-centroidIndex[6])) + wc*(abs(x[7]-centroidIndex[7])) ) +
+            w3*( abs(abs(x[0]-x[2]) - lengthBase/mapResolution) +
+                 abs(abs(x[4]-x[6]) - lengthBase/mapResolution) ) +
+            w4*( abs(abs(0.5*abs(x[0]-x[2]) - 0.5*abs(x[4]-x[6])) - 2*skew/mapResolution) +
+                 abs(abs(0.5*abs(x[4]-x[6]) - 0.5*abs(lfCurrentRow - rhCurrentRow)) - 2*skew/mapResolution) )
+            );
+#undef abs
+}
+
+// nloptConstraint1..8, cpp:92-148, folded into (every value <= ctol, largest value) — solveLattice's key.
+__device__ __forceinline__ double opt_violation(const double (&x)[8], const OptConsts& oc, double lfCurrentRow, double rhCurrentRow) {
+    const double t1 = oc.t1, t2 = oc.t2, t3 = oc.t3, t4 = oc.t4;
+#define abs fabs
+    const double c[8] = {
+        ( t1 - abs(x[0] - x[2]) ),
+        ( abs(x[0] - x[2]) - t2 ),
+        ( t1 - abs(x[4] - x[6]) ),
+        ( abs(x[4] - x[6]) - t2 ),
+        ( t3 - 0.5*abs( abs(x[0] - x[2]) - abs(x[4] - x[6]) ) ),
+        ( 0.5*abs( abs(x[0] - x[2]) - abs(x[4] - x[6]) ) - t4 ),
+        ( t3 - 0.5*abs( abs(x[4] - x[6]) - abs(lfCurrentRow - rhCurrentRow) ) ),
+        ( 0.5*abs( abs(x[4] - x[6]) - abs(lfCurrentRow - rhCurrentRow) ) - t4 ),
+    };
+#undef abs
+    bool feasible = true;
+    double resmax = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        feasible = feasible && c[q] <= oc.ctol;
+        resmax = c[q] > resmax ? c[q] : resmax;
+    }
+    return feasible ? 0.0 : resmax;
+}
+
+// wave-wide lexicographic minimum of (key, f, t): every lane ends with the winner
+__device__ __forceinline__ void opt_wave_min(double& key, double& f, unsigned& t) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double k2 = __shfl_xor(key, off), f2 = __shfl_xor(f, off);
+        const unsigned t2 = __shfl_xor(t, off);
+        const bool take = k2 < key || (k2 == key && (f2 < f || (f2 == f && t2 < t)));
+        key = take ? k2 : key;
+        f = take ? f2 : f;
+        t = take ? t2 : t;
+    }
+}
+
+// oracle/fpo_opt.cpp::solveLattice on a wavefront (lane = lattice point).  All arguments are wave-uniform.
+__device__ int opt_solve(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8],
+                         double lfRow, double rhRow, int lane, double (&x)[8], double& minf) {
+    const double inf = __builtin_huge_val();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = cIdx[k];  // cpp:1180-1183
+    minf = opt_objective(x, oc, nIdx, cIdx, lfRow, rhRow);
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bad = bad || lo[k] > up[k] || x[k] < lo[k] || x[k] > up[k];
+    if (bad) return 1;
+    // columns x[1], x[3], x[5], x[7]: each the minimiser of the objective over its interval, smallest integer on ties
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        constexpr int kk[4] = {1, 3, 5, 7};
+        const int k = kk[c];
+        double key = 0.0, bestF = inf;
+        unsigned bestV = 0xFFFFFFFFu;
+        for (int v = lo[k] + lane; v <= up[k]; v += 64) {
+            x[k] = v;
+            const double f = opt_objective(x, oc, nIdx, cIdx, lfRow, rhRow);
+            if (f < bestF) {
+                bestF = f;
+                bestV = static_cast<unsigned>(v - lo[k]);
+            }
+        }
+        opt_wave_min(key, bestF, bestV);
+        x[k] = lo[k] + static_cast<int>(bestV);
+    }
+    minf = opt_objective(x, oc, nIdx, cIdx, lfRow, rhRow);
+    const unsigned n0 = static_cast<unsigned>(up[0] - lo[0] + 1), n2 = static_cast<unsigned>(up[2] - lo[2] + 1),
+                   n4 = static_cast<unsigned>(up[4] - lo[4] + 1), n6 = static_cast<unsigned>(up[6] - lo[6] + 1);
+    const double points = static_cast<double>(n0) * static_cast<double>(n2) * static_cast<double>(n4) * static_cast<double>(n6);
+    if (points > static_cast<double>(kMaxLatticePoints)) return 3;
+    const unsigned total = n0 * n2 * n4 * n6;
+    double bestKey = inf, bestF = inf;
+    unsigned bestT = 0xFFFFFFFFu;
+    double y[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y[k] = x[k];
+    for (unsigned t = static_cast<unsigned>(lane); t < total; t += 64u) {
+        unsigned r = t;
+        const unsigned d = r % n6; r /= n6;
+        const unsigned c = r % n4; r /= n4;
+        const unsigned b = r % n2;
+        const unsigned a = r / n2;
+        y[0] = lo[0] + static_cast<int>(a);
+        y[2] = lo[2] + static_cast<int>(b);
+        y[4] = lo[4] + static_cast<int>(c);
+        y[6] = lo[6] + static_cast<int>(d);
+        const double key = oc.useConstraints ? opt_violation(y, oc, lfRow, rhRow) : 0.0;
+        const double f = opt_objective(y, oc, nIdx, cIdx, lfRow, rhRow);
+        if (key < bestKey || (key == bestKey && f < bestF)) {  // t grows per lane: the first of equals stays
+            bestKey = key;
+            bestF = f;
+            bestT = t;
+        }
+    }
+    opt_wave_min(bestKey, bestF, bestT);
+    {
+        unsigned r = bestT;
+        const unsigned d = r % n6; r /= n6;
+        const unsigned c = r % n4; r /= n4;
+        const unsigned b = r % n2;
+        const unsigned a = r / n2;
+        x[0] = lo[0] + static_cast<int>(a);
+        x[2] = lo[2] + static_cast<int>(b);
+        x[4] = lo[4] + static_cast<int>(c);
+        x[6] = lo[6] + static_cast<int>(d);
+    }
+    minf = bestF;
+    return bestKey > 0.0 ? 2 : 0;
+}
+
+struct OptShared {
+    double cur[4][3];  // RF,RH,LH,LF_optCurrentPosition_
+    double cenX[4], cenY[4];
+    double resX[4], resY[4];
+    int bandBegin[4], bandEnd[4];
+    int code[4];
+};
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void opt_track_kernel(DevMap m, PlanConsts pc, OptConsts oc, const fpe_pose* __restrict__ poses, int B,
+                                                       int nCycles, const uint8_t* __restrict__ cycleOk, fpe_opt_out out) {
+    __shared__ OptShared sh;
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int lane = static_cast<int>(threadIdx.x);
+    const Grp<16> g(lane);
+    const int leg = lane >> 4;  // RF, RH, LH, LF: 16 lanes each
+    const fpe_pose* pp = poses + b;
+    const double x0 = pp->position[0], y0 = pp->position[1], z0 = pp->position[2];
+    const int gait = pp->gait;
+    const float rOverride = pp->leg_search_radius[leg];
+    const float Rf = rOverride > 0.0f ? rOverride : pc.searchRadius;  // searchRadius_ (cpp:1616-1617)
+    const double lx = static_cast<double>(Rf * 2), ly = static_cast<double>(Rf);
+    const bool odd = (leg & 1) != 0, high = (leg & 2) != 0;
+    const double biasX = high ? (odd ? pc.biasX[3] : pc.biasX[2]) : (odd ? pc.biasX[1] : pc.biasX[0]);
+    const double biasY = high ? (odd ? pc.biasY[3] : pc.biasY[2]) : (odd ? pc.biasY[1] : pc.biasY[0]);
+    // stance (cpp:350-378) and setFirstGait (cpp:582-588, 2679-2699)
+    if (g.sub == 0) {
+        double sx = (leg == 0 || leg == 3) ? pc.LbHalf : -pc.LbHalf;
+        double sy = (leg <= 1) ? pc.WbHalfNeg : pc.WbHalfPos;
+        double sz = 0;
+        sx += x0;
+        sy += y0;
+        sz += z0;
+        sh.cur[leg][0] = sx - pc.stepHalf;
+        sh.cur[leg][1] = sy;
+        sh.cur[leg][2] = sz;
+    }
+    pose_sync<16>();
+    double adjY = 0.0;                                  // ajustedPose_[1], cpp:759
+    double lfRow = oc.lfRow0, rhRow = oc.rhRow0;        // cpp:36
+    int failCycle = 255;
+    bool stopped = gait != 0;  // the walk gait (build-defined) has no opt track: zero records
+
+    for (int cyc = 0; cyc < nCycles; ++cyc) {
+        const size_t oCyc = static_cast<size_t>(b) * nCycles + cyc;
+        fpe_opt_cycle rec;
+        __builtin_memset(&rec, 0, sizeof(rec));
+        fpe_opt_foothold fh;
+        __builtin_memset(&fh, 0, sizeof(fh));
+        fh.foot_id = static_cast<uint8_t>(leg);
+        fh.gait_cycle_id = static_cast<uint8_t>(cyc);
+        SubGeom gm;
+        gm.ok = false;
+        double nextX = 0.0, nextY = 0.0;
+        if (!stopped) {
+            // ---- STEP(1) getGaitCycleSearchGridMap, cpp:2307-2408 ----
+            nextX = polygon_center_x(sh.cur) + pc.step;  // cpp:2322-2327
+            nextY = y0 + adjY;                           // cpp:2329
+            if (centre_usable(nextX, nextY)) gm = opt_submap(m.g, nextX, nextY, pc.isosLen, pc.isosWid);  // cpp:2345
+            if (!gm.ok) {  // cpp:2347-2349 -> cpp:931-934: the service handler returns false here
+                stopped = true;
+                failCycle = cyc;
+                rec.gate_failed = 1;
+            }
+        }
+        if (!stopped) {
+            rec.lf_current_row = lfRow;
+            rec.rh_current_row = rhRow;
+            rec.gait_top_left[0] = gm.i0;
+            rec.gait_top_left[1] = gm.j0;
+            rec.gait_size[0] = gm.g.rows;
+            rec.gait_size[1] = gm.g.cols;
+            // the leg's next default position (getDefaultFootholdNext, cpp:2391-2397, 2411-2418) and its gaitMap_ index
+            // (getMapIndex, cpp:965-976)
+            const double nx = nextX + biasX, ny = nextY + biasY;
+            const int nomI = index_of(nx, gm.g.orgX, gm.g.posX, gm.g.res), nomJ = index_of(ny, gm.g.orgY, gm.g.posY, gm.g.res);
+            // ---- STEP(3) checkFootholdUseCentroidMethod(gaitMap_, next, result, beginRow, endRow), cpp:1010-1013 ----
+            int code = 6, beginRow = 0, endRow = 0;
+            double cenX = 0.0, cenY = 0.0;
+            Submap ss;
+            ss.ok = false;
+            if (centre_usable(nx, ny)) ss = submap_info(gm.g, nx, ny, lx, ly);  // cpp:1627 on gaitMap_
+            if (ss.ok) {
+                const int ni = ss.ni, nj = ss.nj;
+                const int bottomRow = ni - 1, rightCol = nj - 1;
+                // row scan (cpp:1649-1658 whole-region test, cpp:1717-1750 blocked rows): lane = row, 16 rows per round
+                unsigned long long blkLo = 0ull, blkHi = 0ull;
+                bool anyBelow = false;
+                for (int r0 = 0; r0 < ni; r0 += 16) {
+                    const int r = r0 + g.sub;
+                    int cnt = 0;
+                    if (r < ni) {
+                        const float* row = m.trav + static_cast<size_t>(gm.i0 + ss.i0 + r) * m.g.cols + (gm.j0 + ss.j0);
+                        for (int c = 0; c < nj; ++c) cnt += (row[c] < pc.thrDefault) ? 1 : 0;  // raw compare: NaN passes (cpp:1653, 1736)
+                    }
+                    anyBelow |= cnt > 0;
+                    const unsigned long long mk = g.ballot(r < ni && 2 * cnt > nj);  // cpp:1743
+                    if (r0 < 64) blkLo |= mk << r0;
+                    else if (r0 < 128) blkHi |= mk << (r0 - 64);
+                }
+                const bool whole = ni * nj > 0 && !g.any(anyBelow);
+                const int minRow = blkLo ? __builtin_ctzll(blkLo) : (blkHi ? 64 + __builtin_ctzll(blkHi) : 0);
+                const int maxRow = blkHi ? 127 - __builtin_clzll(blkHi) : (blkLo ? 63 - __builtin_clzll(blkLo) : 0);
+                int newRow = 0, newCol = 0, bandB = 0, bandE = 0;
+                bool hasCell = false;
+                if (whole) {  // cpp:1684-1693
+                    code = 0;
+                    bandB = 0;
+                    bandE = bottomRow;
+                } else if (minRow == 0 && maxRow != bottomRow) {  // case 1, cpp:1777-1795
+                    code = 1;
+                    newRow = (maxRow + bottomRow + 1) >> 1;
+                    newCol = (rightCol + 1) >> 1;
+                    bandB = maxRow + 1;
+                    bandE = bottomRow;
+                    hasCell = true;
+                } else if (minRow != 0 && maxRow != bottomRow) {  // case 2, cpp:1843-1890
+                    if (minRow >= (bottomRow - maxRow)) {
+                        code = 2;
+                        newRow = (minRow + 1) >> 1;
+                        bandB = 0;
+                        bandE = minRow - 1;
+                    } else {
+                        code = 3;
+                        newRow = (maxRow + bottomRow) >> 1;
+                        bandB = maxRow + 1;
+                        bandE = bottomRow;
+                    }
+                    newCol = rightCol >> 1;
+                    hasCell = true;
+                } else if (minRow != 0 && maxRow == bottomRow) {  // case 3, cpp:1944-1961
+                    code = 4;
+                    newRow = (minRow + 1) >> 1;
+                    newCol = rightCol >> 1;
+                    bandB = 0;
+                    bandE = minRow - 1;
+                    hasCell = true;
+                } else {
+                    code = 5;  // no branch taken: result and rows untouched
+                }
+                if (code <= 4) {
+                    // cpp:1696-1710: the band's rows as rows of gaitMap_, through the position of the rectangle's cell (row, 1);
+                    // ONE Position for both conversions (a failed getPosition keeps it; uninitialised before the first: (0,0))
+                    double qx = 0.0, qy = 0.0;
+                    if (in_range(bandB, 1, ni, nj)) {
+                        qx = cell_pos(ss.baseX, gm.g.res, bandB);
+                        qy = cell_pos(ss.baseY, gm.g.res, 1);
+                    }
+                    beginRow = index_of(qx, gm.g.orgX, gm.g.posX, gm.g.res);
+                    if (in_range(bandE, 1, ni, nj)) {
+                        qx = cell_pos(ss.baseX, gm.g.res, bandE);
+                        qy = cell_pos(ss.baseY, gm.g.res, 1);
+                    }
+                    endRow = index_of(qx, gm.g.orgX, gm.g.posX, gm.g.res);
+                    (void)qy;
+                    cenX = hasCell ? cell_pos(ss.baseX, gm.g.res, newRow) : nx;  // cpp:1816 / cpp:1688-1689
+                    cenY = hasCell ? cell_pos(ss.baseY, gm.g.res, newCol) : ny;
+                }
+            }
+            // centroidIndex (cpp:1030-1041): getMapIndex of the result — (0, 0) when it was left untouched
+            const int cenI = index_of(cenX, gm.g.orgX, gm.g.posX, gm.g.res), cenJ = index_of(cenY, gm.g.orgY, gm.g.posY, gm.g.res);
+            // gather the four legs (lane 16 * leg holds the leg's values); optimiser order LF, RH, RF, LH
+            int nIdx[8], cIdx[8], lo[8], up[8];
+            {
+                constexpr int order[4] = {3, 1, 0, 2};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int src = 16 * order[k];
+                    nIdx[2 * k] = __shfl(nomI, src);
+                    nIdx[2 * k + 1] = __shfl(nomJ, src);
+                    cIdx[2 * k] = __shfl(cenI, src);
+                    cIdx[2 * k + 1] = __shfl(cenJ, src);
+                    lo[2 * k] = __shfl(beginRow, src);  // xBounds rows, cpp:1067-1076
+                    up[2 * k] = __shfl(endRow, src);
+                }
+                lo[1] = lo[7] = oc.colLoA;  // cpp:1063-1066
+                up[1] = up[7] = oc.colUpA;
+                lo[3] = lo[5] = oc.colLoB;
+                up[3] = up[5] = oc.colUpB;
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
+                    rec.traversable_row[0][l] = __shfl(beginRow, 16 * l);
+                    rec.traversable_row[1][l] = __shfl(endRow, 16 * l);
+                    rec.centroid_code[l] = static_cast<uint8_t>(__shfl(code, 16 * l));
+                }
+            }
+            // ---- STEP(4) the optimiser (build-defined) ----
+            double x[8], minf;
+            const int status = opt_solve(oc, nIdx, cIdx, lo, up, lfRow, rhRow, lane, x, minf);
+            rec.solver_status = static_cast<uint8_t>(status);
+            rec.minf = minf;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                rec.nominal_index[k] = nIdx[k];
+                rec.centroid_index[k] = cIdx[k];
+                rec.x_lower[k] = lo[k];
+                rec.x_upper[k] = up[k];
+                rec.x[k] = static_cast<int>(x[k]);
+            }
+            // ---- STEP(6) positions on gaitMap_ (cpp:1283-1314): ONE Position through the four conversions, in the order
+            // LF, RH, RF, LH; a failed getPosition keeps the previous one ----
+            double ppx = 0.0, ppy = 0.0;
+            double myX = 0.0, myY = 0.0;
+            int myI = 0, myJ = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                constexpr int order[4] = {3, 1, 0, 2};
+                const int i = static_cast<int>(x[2 * k]), j = static_cast<int>(x[2 * k + 1]);
+                if (in_range(i, j, gm.g.rows, gm.g.cols)) {
+                    ppx = cell_pos(gm.g.baseX, gm.g.res, i);
+                    ppy = cell_pos(gm.g.baseY, gm.g.res, j);
+                }
+                if (leg == order[k]) {
+                    myX = ppx;
+                    myY = ppy;
+                    myI = i;
+                    myJ = j;
+                }
+            }
+            const bool commit = cycleOk[oCyc] != 0;  // footholdValidation_ of the NOMINAL track (cpp:1323-1332)
+            float z = 0.0f;
+            if (g.sub == 0) z = opt_mean_height(gm.g, m.elev, m.g.cols, gm.i0, gm.j0, myX, myY, pc.rf, pc.rf2, pc.h);  // on gaitMap_
+            fh.x = myX;
+            fh.y = myY;
+            fh.z = z;
+            fh.row = myI;
+            fh.col = myJ;
+            fh.committed = commit ? 1 : 0;
+            rec.committed = commit ? 1 : 0;
+            pose_sync<16>();
+            if (commit) {  // cpp:1553-1568
+                if (g.sub == 0) {
+                    sh.cur[leg][0] = myX;
+                    sh.cur[leg][1] = myY;
+                    sh.cur[leg][2] = static_cast<double>(z);
+                }
+                const int rowOnGait = index_of(myX, gm.g.orgX, gm.g.posX, gm.g.res);  // gaitMap_.getIndex(...).x()
+                lfRow = static_cast<double>(__shfl(rowOnGait, 16 * 3));
+                rhRow = static_cast<double>(__shfl(rowOnGait, 16 * 1));
+            }
+            pose_sync<16>();
+            adjY += pc.drift;  // cpp:1578
+        }
+        if (lane == 0 && out.cycles) out.cycles[oCyc] = rec;
+        if (g.sub == 0 && out.footholds) out.footholds[oCyc * 4 + leg] = fh;
+    }
+    if (lane == 0 && out.gate_fail_cycle) out.gate_fail_cycle[b] = static_cast<uint8_t>(failCycle);
+}
+
+hipError_t launch_opt_track(const DevMap& m, const PlanConsts& pc, const OptConsts& oc, const fpe_pose* d_poses, int B, int nCycles,
+                            const uint8_t* d_cycleOk, const fpe_opt_out& d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(opt_track_kernel, dim3(B), dim3(64), 0, stream, m, pc, oc, d_poses, B, nCycles, d_cycleOk, d_out);
+    return hipGetLastError();
+}

@@ -12,8 +12,9 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (CENTROID_DTYPE, FOOTHOLD_DTYPE, GLOBAL_FOOTHOLDS_DTYPE, POSE_DTYPE, PARAMS_DTYPE, QUERY_DTYPE,
-                    SELECTED_DTYPE, TRACK_REPORT_DTYPE, EngineUnavailable, MapDesc, PlanOut, ptr)
+from ._capi import (CENTROID_DTYPE, FOOTHOLD_DTYPE, GLOBAL_FOOTHOLDS_DTYPE, OPT_CYCLE_DTYPE, OPT_FOOTHOLD_DTYPE, OPT_PARAMS_DTYPE,
+                    POSE_DTYPE, PARAMS_DTYPE, QUERY_DTYPE, SELECTED_DTYPE, TRACK_REPORT_DTYPE, EngineUnavailable, MapDesc, OptOut,
+                    PlanOut, ptr)
 
 
 class FpeError(RuntimeError):
@@ -49,7 +50,9 @@ class FootholdPlanner:
                 raise EngineUnavailable(f"fpe_create failed: {msg} (the engine has no CPU fallback)")
             raise FpeError(rc, msg)
         self.params = _capi.params_yaml() if params is None else np.array(params, dtype=PARAMS_DTYPE).reshape(1)
+        self.opt_params = _capi.opt_params_yaml()  # nlopt/* of the yaml
         self.device_id = int(device_id)
+        self._tuning = {}  # last value set per knob (tuning() restores these, not zeros)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -141,15 +144,19 @@ class FootholdPlanner:
         """fpe_set_tuning: plan_group, literal_discs, no_mid_variant, no_bits (build-defined test / tuning knobs)."""
         for k, v in kw.items():
             self._check(self._lib.fpe_set_tuning(self._h, k.encode(), int(v)))
+            self._tuning[k] = int(v)
 
     @contextlib.contextmanager
     def tuning(self, **kw):
-        """Set knobs for the duration of a with-block, then restore the automatic defaults (0)."""
+        """Set knobs for the duration of a with-block, then restore the values they had through this object (a knob
+        this object never set goes back to 0, the automatic default; knobs seeded from the environment in fpe_create are
+        not visible here — set them through set_tuning instead when with-blocks are used)."""
+        before = {k: self._tuning.get(k, 0) for k in kw}
         self.set_tuning(**kw)
         try:
             yield self
         finally:
-            self.set_tuning(**{k: 0 for k in kw})
+            self.set_tuning(**before)
 
     # ---- chained plan, host buffers ------------------------------------------------------------------
     def plan(self, poses, n_cycles, products=("nominal", "centroid", "default", "cycle_ok", "stance", "selected", "pose_status"),
@@ -181,6 +188,25 @@ class FootholdPlanner:
                      d_stance_ptr or None, d_selected_ptr or None, d_pose_status_ptr or None)
         self._check(self._lib.fpe_plan_device(self._h, ptr(self.params), C.c_void_p(d_poses_ptr), int(B), int(n_cycles),
                                               C.byref(po), C.c_void_p(stream or 0)))
+
+    # ---- the opt track of a batch (cpp:913-1319, 1485-1568; build-defined optimiser) ---------------------------
+    def plan_opt(self, poses, n_cycles, cycle_ok=None):
+        """fpe_plan_opt with host buffers; cycle_ok: the nominal plan's flags [B, n_cycles] (None: the engine plans first).
+        Returns {"footholds" [B, n, 4], "cycles" [B, n], "gate_fail_cycle" [B]}."""
+        poses = np.ascontiguousarray(poses, dtype=POSE_DTYPE)
+        B = poses.shape[0]
+        out = {"footholds": np.zeros((B, n_cycles, 4), OPT_FOOTHOLD_DTYPE), "cycles": np.zeros((B, n_cycles), OPT_CYCLE_DTYPE),
+               "gate_fail_cycle": np.zeros(B, np.uint8)}
+        ok = None if cycle_ok is None else np.ascontiguousarray(cycle_ok, dtype=np.uint8).reshape(B, n_cycles)
+        oo = OptOut(ptr(out["footholds"]), ptr(out["cycles"]), ptr(out["gate_fail_cycle"]))
+        self._check(self._lib.fpe_plan_opt(self._h, ptr(self.params), ptr(self.opt_params), ptr(poses), B, int(n_cycles), ptr(ok),
+                                           C.byref(oo)))
+        return out
+
+    def plan_opt_device(self, d_poses_ptr, B, n_cycles, d_cycle_ok_ptr, d_footholds_ptr=0, d_cycles_ptr=0, d_gate_ptr=0, stream=0):
+        oo = OptOut(d_footholds_ptr or None, d_cycles_ptr or None, d_gate_ptr or None)
+        self._check(self._lib.fpe_plan_opt_device(self._h, ptr(self.params), ptr(self.opt_params), C.c_void_p(d_poses_ptr), int(B),
+                                                  int(n_cycles), C.c_void_p(d_cycle_ok_ptr), C.byref(oo), C.c_void_p(stream or 0)))
 
     # ---- open-loop per-leg search (checkFoothold, cpp:2001-2036) -----------------------------------------
     def checkFoothold(self, queries):
@@ -224,12 +250,14 @@ class FootholdPlanner:
             self._check(rc)
             return self._msg(msg[0])
         cen = np.zeros(1, dtype=GLOBAL_FOOTHOLDS_DTYPE)
+        optm = np.zeros(1, dtype=GLOBAL_FOOTHOLDS_DTYPE)
         dflt = np.zeros((1 + int(gait_cycles), 4, 3), dtype=np.float64)
         nrows = C.c_int32(0)
-        rep = np.zeros(2, dtype=TRACK_REPORT_DTYPE)
-        rc = self._lib.fpe_plan_service_report(self._h, ptr(self.params), ptr(pos), int(gait_cycles) & 0xFF, ptr(msg),
-                                               ptr(cen), ptr(dflt), C.cast(C.byref(nrows), C.c_void_p),
-                                               ptr(rep[0:1]), ptr(rep[1:2]))
+        rep = np.zeros(3, dtype=TRACK_REPORT_DTYPE)
+        cyc = np.zeros(max(int(gait_cycles), 1), dtype=OPT_CYCLE_DTYPE)
+        rc = self._lib.fpe_plan_service_opt(self._h, ptr(self.params), ptr(self.opt_params), ptr(pos), int(gait_cycles) & 0xFF,
+                                            ptr(msg), ptr(cen), ptr(dflt), C.cast(C.byref(nrows), C.c_void_p), ptr(rep[0:1]),
+                                            ptr(rep[1:2]), ptr(optm), ptr(rep[2:3]), ptr(cyc))
         if rc == _capi.FPE_E_SERVICE_FALSE:
             return False
         self._check(rc)
@@ -238,6 +266,9 @@ class FootholdPlanner:
         out["default_footholds"] = dflt[: nrows.value].copy()
         out["report"] = self._report(rep[0])
         out["centroid"]["report"] = self._report(rep[1])
+        out["opt"] = self._msg(optm[0])  # global_footholds_opt (cpp:221, 1510-1532)
+        out["opt"]["report"] = self._report(rep[2])
+        out["opt"]["cycles"] = cyc[: int(gait_cycles)].copy()
         return out
 
 

@@ -221,7 +221,9 @@ def test_service_returns_false_where_the_opt_track_gate_fails(planner):
     assert want.any() and not want.all()
     for k in range(xs.size):
         r = planner.globalFootholdPlan(3, poses["position"][k])
-        assert (r is False) == bool(want[k] & _capi.FPE_POSE_OPT_SUBMAP_FAILED)
+        gate = util.oracle_service_gate(omap, planner, poses["position"][k], 3)
+        assert (gate == 0) == bool(want[k] & _capi.FPE_POSE_OPT_SUBMAP_FAILED)  # the plan kernels' bit is the cycle-0 gate
+        assert (r is False) == (gate != 255)
         if r is not False:
             assert r["gait_cycles"] == 3
 

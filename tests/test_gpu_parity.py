@@ -287,11 +287,19 @@ def test_service_message(planner):
     omap = fpo.OracleMap(trav, elev, 0.02)
     rng = np.random.default_rng(91)
     seen_fail = False
-    for _ in range(24):
+    answered = 0
+    for _ in range(40):
         pos = [rng.uniform(-3.2, -2.0), rng.uniform(-3, 3), 0.25]
         msg = planner.globalFootholdPlan(8, pos)
         o = omap.plan(util.to_oracle_params(planner.params), util.to_oracle_poses(make_poses([pos])), 8)
         ok = o["cycle_ok"][0]
+        if util.oracle_service_gate(omap, planner, pos, 8, o) != 255:
+            # the opt track's getGaitCycleSearchGridMap fails in some cycle: the handler returns false (cpp:931-934).  On
+            # terrain this harsh the opt track derails often: an untouched centroid result (0,0,0) is far outside the
+            # optimiser's box, the optimiser call throws, the feet land on stale positions (cpp:1030-1041, 1224-1226, 1287)
+            assert msg is False
+            continue
+        answered += 1
         assert msg["gait_cycles"] == 8
         assert msg["success"] == bool(ok[-1])
         assert msg["gait_cycles_succeed"] == (int(np.nonzero(ok)[0][-1]) + 1 if ok.any() else 0)
@@ -309,6 +317,7 @@ def test_service_message(planner):
                     k += 1
         seen_fail |= not ok.all()
     assert seen_fail, "the harsh map should make some cycles fail (commit/skip path)"
+    assert answered >= 5, answered
 
 
 @pytest.mark.parametrize("group", ["4", "8"])
@@ -334,8 +343,16 @@ def test_maximum_gait_cycles_255(planner):
     util.assert_plan_equal(eng, ora)
     assert eng["nominal"]["gait_cycle_id"][:, 254, :].tolist() == [[254] * 4] * 8
     assert (eng["centroid"]["code"] == 6).any(), "late cycles run off the map: getSubmap must fail there"
-    msg = planner.globalFootholdPlan(255, poses["position"][0])
-    assert msg["gait_cycles"] == 255 and len(msg["footholds"]) == 4 + 4 * int(ora["cycle_ok"][0].sum())
+    omap = fpo.OracleMap(trav, elev, 0.02)
+    answered = 0
+    for b in range(8):
+        msg = planner.globalFootholdPlan(255, poses["position"][b])
+        if util.oracle_service_gate(omap, planner, poses["position"][b], 255) != 255:
+            assert msg is False
+            continue
+        answered += 1
+        assert msg["gait_cycles"] == 255 and len(msg["footholds"]) == 4 + 4 * int(ora["cycle_ok"][b].sum())
+    assert answered > 0
 
 
 def test_service_all_tracks(planner):
@@ -346,10 +363,13 @@ def test_service_all_tracks(planner):
     omap = fpo.OracleMap(trav, elev, 0.02)
     rng = np.random.default_rng(92)
     seen_split = False
-    for _ in range(24):
+    for _ in range(48):
         pos = [rng.uniform(-3.2, -2.0), rng.uniform(-3, 3), 0.0]
         r = planner.globalFootholdPlan(6, pos, all_tracks=True)
         o = omap.plan(util.to_oracle_params(planner.params), util.to_oracle_poses(make_poses([pos])), 6)
+        if util.oracle_service_gate(omap, planner, pos, 6, o) != 255:
+            assert r is False
+            continue
         ok = o["cycle_ok"][0].astype(bool)
         cf = r["centroid"]["footholds"]
         assert len(cf) == 4 + 4 * int(ok.sum())
@@ -382,18 +402,25 @@ def test_service_track_reports(planner, rf_first):
     omap = fpo.OracleMap(trav, elev, 0.02)
     rng = np.random.default_rng(93 + rf_first)
     committed = 0
-    for _ in range(8):
+    for _ in range(24):
         pos = [rng.uniform(-3.2, -2.0), rng.uniform(-3, 3), 0.0]
         r = planner.globalFootholdPlan(7, pos, all_tracks=True)
+        if util.oracle_service_gate(omap, planner, pos, 7) != 255:
+            assert r is False
+            continue
         want = omap.plan_products(util.to_oracle_params(planner.params), util.to_oracle_poses(make_poses([pos])), 7)
         for got, w in ((r["report"], want["nominal"]), (r["centroid"]["report"], want["centroid"])):
-            assert got["path"].shape == (7, 3) == w["path"].shape
-            assert np.array_equal(got["path"][:, :2], w["path"][:, :2])
-            assert np.all(np.abs(got["path"][:, 2] - w["path"][:, 2]) <= util.Z_TOL)
+            # centroidFeetCenterPath also receives the opt track's feet centre of every cycle (cpp:946): its entries
+            # alternate centroid, opt (tests/test_gpu_opt.py checks the odd ones against the oracle's opt track)
+            path = got["path"][0::2] if got is r["centroid"]["report"] else got["path"]
+            assert path.shape == (7, 3) == w["path"].shape
+            assert np.array_equal(path[:, :2], w["path"][:, :2])
+            assert np.all(np.abs(path[:, 2] - w["path"][:, 2]) <= util.Z_TOL)
             assert np.array_equal(got["feet_distance"], w["feet_distance"])
             assert np.array_equal(got["cog_speed"], w["cog_speed"])
+        assert r["centroid"]["report"]["path"].shape == (14, 3)
         committed += len(r["report"]["cog_speed"]) // 2
-    assert 0 < committed < 8 * 7, "want both committed and skipped cycles"
+    assert 0 < committed < 24 * 7, "want both committed and skipped cycles"
     set_params(planner)
 
 
@@ -426,10 +453,13 @@ def test_concurrent_uploads_and_plans_see_whole_snapshots(planner):
     set_params(planner)
     maps = [synth.rough_map(300, 300, 0.02, seed=61, bad_frac=0.1), synth.rough_map(300, 300, 0.02, seed=62, bad_frac=0.25)]
     poses = synth.poses_in_map(48, 6.0, 6.0, 6, 0.18, seed=63, margin=0.7)
-    want = []
+    want, gate = [], []
     for trav, elev in maps:
-        o = fpo.OracleMap(trav, elev, 0.02).plan(util.to_oracle_params(planner.params), util.to_oracle_poses(poses), 6, threads=4)
+        om = fpo.OracleMap(trav, elev, 0.02)
+        o = om.plan(util.to_oracle_params(planner.params), util.to_oracle_poses(poses), 6, threads=4)
         want.append(o)
+        gate.append(om.plan_opt(util.to_oracle_params(planner.params), util.to_oracle_opt_params(planner.opt_params),
+                                util.to_oracle_poses(poses), 6, o["cycle_ok"])["gate_fail_cycle"])
     assert not np.array_equal(want[0]["nominal"]["row"], want[1]["nominal"]["row"]), "the two maps must plan differently"
     planner.gridmapCallback(maps[0][0], maps[0][1], 0.02)
     stop = threading.Event()
@@ -452,6 +482,9 @@ def test_concurrent_uploads_and_plans_see_whole_snapshots(planner):
                     b = it % 48
                     hits = []
                     for m in (0, 1):
+                        if gate[m][b] != 255 or msg is False:  # the handler returns false on this map (cpp:931-934)
+                            hits.append(msg is False and gate[m][b] != 255)
+                            continue
                         ok = want[m]["cycle_ok"][b].astype(bool)
                         ref = want[m]["nominal"][b][ok].reshape(-1)
                         f = msg["footholds"][4:]

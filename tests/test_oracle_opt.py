@@ -1,0 +1,190 @@
+"""CPU checks of the oracle's opt track (oracle/fpo_opt.cpp): known answers evaluated by hand from
+the reference's expressions (cpp:2307-2408, 965-976, 1057-1076, 1156-1159), the centroid method's traversable rows on a
+submap (cpp:1608-1609, 1692-1710), and the build-defined lattice optimiser against an independent numpy evaluation of the
+rule it states."""
+import itertools
+
+import numpy as np
+
+from oracle import fpo
+from tests.conftest import oracle_poses, yaml_params
+
+
+def flat(rows, cols):
+    return np.ones((rows, cols), np.float32), np.zeros((rows, cols), np.float32)
+
+
+def test_kat_gait_cycle_submap_and_indices_on_the_flat_reference_case():
+    """cfg-1: 200 x 200 @ 2 cm centred at the origin (x in [-2, 2)), pose (-1, 0, 0), yaml parameters.  By hand:
+    stance x = -1 +- 0.21935, current = stance - 0.09 => feet centre x = -1.09, next centre (-0.91, 0).
+    isos_.length = 0.4387 + 2 * 0.04 + 2 * 0.1 = 0.7187, isos_.width = (0.175 + 0.074) + 0.1 = 0.349 (cpp:384-394).
+    Row of x: floor((2 - x) / 0.02).  Top-left x = -0.91 + 0.35935 = -0.55065 -> row 127; bottom-right x = -1.26935 -> row
+    163: 37 rows.  Columns: y = +-0.1745 -> floor((2 -+ 0.1745) / 0.02) = 91 .. 108: 18 columns.
+    Next default x (bias +-(0.21935 +- 0.04)): LF -0.65065 -> row 132 -> submap row 5; RH -1.08935 -> 154 -> 27;
+    RF -0.73065 -> 136 -> 9; LH -1.16935 -> 158 -> 31.  y = -+0.1245: LF / LH +0.1245 -> column 93 -> 2; RF / RH -0.1245 ->
+    106 -> 15.  Flat map: every rectangle is traversable (code 0), so centroidIndex = nominalIndex and the traversable
+    rows are the rectangles' own: 11 rows of 2 cm around each foot (x +- 0.1: e.g. LF rows 127..137 -> 0..10).
+    xBounds columns: footSearchRect_.col = 0.1 / 0.02 = 5.0000001 -> 5; isos_.width / 0.02 = 17.45 -> 17; 17.45 - 5.0000001 -> 12."""
+    t, e = flat(200, 200)
+    om = fpo.OracleMap(t, e, 0.02)
+    p = yaml_params()
+    poses = oracle_poses([(-1.0, 0.0, 0.0)])
+    plan = om.plan(p, poses, 8)
+    o = om.plan_opt(p, fpo.opt_params_yaml(), poses, 8, plan["cycle_ok"])
+    c = o["cycles"][0, 0]
+    assert tuple(c["gait_top_left"]) == (127, 91) and tuple(c["gait_size"]) == (37, 18)
+    assert c["nominal_index"].tolist() == [5, 2, 27, 15, 9, 15, 31, 2]  # LF, RH, RF, LH x (row, col)
+    assert c["centroid_index"].tolist() == [5, 2, 27, 15, 9, 15, 31, 2]
+    assert c["centroid_code"].tolist() == [0, 0, 0, 0]
+    assert c["traversable_row"].tolist() == [[4, 22, 26, 0], [14, 32, 36, 10]]  # RF, RH, LH, LF
+    assert c["x_lower"].tolist() == [0, 0, 22, 12, 4, 12, 26, 0] and c["x_upper"].tolist() == [10, 5, 32, 17, 14, 17, 36, 5]
+    assert c["lf_current_row"] == 0.0 and c["rh_current_row"] == 0.0 and o["gate_fail_cycle"][0] == 255
+    # second cycle: lfCurrentRow / rhCurrentRow are the committed LF / RH rows on the FIRST cycle's submap (cpp:1561-1568)
+    c1 = o["cycles"][0, 1]
+    assert c1["lf_current_row"] == c["x"][0] and c1["rh_current_row"] == c["x"][2]
+    # positions come from the submap's own geometry: cell (r, c) of the submap is cell (127 + r, 91 + c) of the map
+    f = o["footholds"][0, 0]
+    for leg, k in ((3, 0), (1, 1), (0, 2), (2, 3)):  # LF, RH, RF, LH
+        ok, x, y = om.get_position(127 + int(c["x"][2 * k]), 91 + int(c["x"][2 * k + 1]))
+        assert ok and abs(f[leg]["x"] - x) < 1e-12 and abs(f[leg]["y"] - y) < 1e-12
+        assert f[leg]["row"] == c["x"][2 * k] and f[leg]["col"] == c["x"][2 * k + 1] and f[leg]["committed"] == 1
+
+
+def test_kat_infeasible_constraint_set_picks_the_least_violation():
+    """With the yaml values the eight constraints have no common point: 1-4 want both hip distances in
+    [0.9, 1.1] * 0.4387 / 0.02 = [19.74, 24.13] rows, 5-6 want them (2 * 0.04 * [0.8, 1.2] / 0.02) * 2 = [6.4, 9.6] rows
+    apart.  First cycle of the flat case (lfCurrentRow = rhCurrentRow = 0): constraint 8 wants |x5 - x7| <= 9.6 + 0.02,
+    constraint 3 wants it >= 19.74 - 0.01; their largest value is smallest at |x5 - x7| = 17 (max(2.74, 3.70) = 3.70 against
+    max(3.74, 3.20) at 16 and max(1.74, 4.20) at 18); x5 in [4, 14], x7 in [26, 36] then leaves 9 / 26 after the objective's
+    tie-break (x5 stays on its nominal = centroid row 9)."""
+    t, e = flat(200, 200)
+    om = fpo.OracleMap(t, e, 0.02)
+    p = yaml_params()
+    poses = oracle_poses([(-1.0, 0.0, 0.0)])
+    plan = om.plan(p, poses, 8)
+    o = om.plan_opt(p, fpo.opt_params_yaml(), poses, 8, plan["cycle_ok"])
+    c = o["cycles"][0, 0]
+    assert c["solver_status"] == 2
+    assert c["x"].tolist() == [5, 2, 27, 15, 9, 15, 26, 2]
+
+
+def _numpy_rule(op, n_idx, c_idx, lo, up, length_base, skew, res, lf, rh):
+    """The rule of solveLattice restated with numpy over the whole box (columns first, then rows)."""
+    w1, w2, w3, w4, wr, wc = (float(op[k][0]) for k in ("w1", "w2", "w3", "w4", "wr", "wc"))
+
+    def obj(x):
+        x = [np.asarray(v, np.float64) for v in x]
+        a = (w1 * (wr * np.abs(x[0] - n_idx[0]) + wc * np.abs(x[1] - n_idx[1]) + wr * np.abs(x[2] - n_idx[2]) + wc * np.abs(x[3] - n_idx[3]) +
+                   wr * np.abs(x[4] - n_idx[4]) + wc * np.abs(x[5] - n_idx[5]) + wr * np.abs(x[6] - n_idx[6]) + wc * np.abs(x[7] - n_idx[7])) +
+             w2 * (wr * np.abs(x[0] - c_idx[0]) + wc * np.abs(x[1] - c_idx[1]) + wr * np.abs(x[2] - c_idx[2]) + wc * np.abs(x[3] - c_idx[3]) +
+                   wr * np.abs(x[4] - c_idx[4]) + wc * np.abs(x[5] - c_idx[5]) + wr * np.abs(x[6] - c_idx[6]) + wc * np.abs(x[7] - c_idx[7])) +
+             w3 * (np.abs(np.abs(x[0] - x[2]) - length_base / res) + np.abs(np.abs(x[4] - x[6]) - length_base / res)) +
+             w4 * (np.abs(np.abs(0.5 * np.abs(x[0] - x[2]) - 0.5 * np.abs(x[4] - x[6])) - 2 * skew / res) +
+                   np.abs(np.abs(0.5 * np.abs(x[4] - x[6]) - 0.5 * np.abs(lf - rh)) - 2 * skew / res)))
+        return a
+
+    x = [float(v) for v in c_idx]
+    if any(lo[k] > up[k] or x[k] < lo[k] or x[k] > up[k] for k in range(8)):
+        return 1, x
+    for k in (1, 3, 5, 7):
+        vs = np.arange(lo[k], up[k] + 1)
+        xs = list(x)
+        xs[k] = vs
+        x[k] = float(vs[int(np.argmin(obj(xs)))])  # argmin: first of equals
+    grids = np.meshgrid(*[np.arange(lo[k], up[k] + 1) for k in (0, 2, 4, 6)], indexing="ij")
+    xs = list(x)
+    for g, k in zip(grids, (0, 2, 4, 6)):
+        xs[k] = g.reshape(-1).astype(np.float64)
+    f = obj(xs)
+    key = np.zeros_like(f)
+    if int(op["useInequalityConstraits"][0]):
+        t1 = length_base * float(op["hipLowerScale"][0]) / res
+        t2 = length_base * float(op["hipUpperScale"][0]) / res
+        t3 = 2 * skew * float(op["skewLowerScale"][0]) / res
+        t4 = 2 * skew * float(op["skewUpperScale"][0]) / res
+        a, b, c0 = np.abs(xs[0] - xs[2]), np.abs(xs[4] - xs[6]), abs(lf - rh)
+        cons = np.stack([t1 - a, a - t2, t1 - b, b - t2, t3 - 0.5 * np.abs(a - b), 0.5 * np.abs(a - b) - t4,
+                         t3 - 0.5 * np.abs(b - c0), 0.5 * np.abs(b - c0) - t4])
+        feas = (cons <= float(op["ctol"][0])).all(axis=0)
+        key = np.where(feas, 0.0, np.maximum(cons.max(axis=0), 0.0))
+    order = np.lexsort((np.arange(f.size), f, key))  # key, then objective, then enumeration order
+    w = int(order[0])
+    for k in (0, 2, 4, 6):
+        x[k] = float(xs[k][w])
+    return (2 if key[w] > 0 else 0), x
+
+
+def test_lattice_optimiser_follows_its_stated_rule_on_random_problems():
+    rng = np.random.default_rng(5)
+    length_base, skew = float(np.float32(0.4387)), float(np.float32(0.04))
+    statuses = set()
+    for trial in range(60):
+        res = float(rng.choice([0.02, 0.01, 0.03, 0.0237]))
+        op = fpo.opt_params_yaml()
+        op["useInequalityConstraits"] = int(rng.integers(0, 2))
+        if trial % 3 == 0:
+            for k in ("w1", "w2", "w3", "w4", "wr", "wc"):
+                op[k] = float(rng.uniform(0.3, 2.0))
+        if trial % 5 == 0:  # a problem the constraints CAN satisfy: loosen 5-8
+            op["skewLowerScale"], op["skewUpperScale"] = 0.0, 40.0
+        rows = int(round(0.7187 / res))
+        n_idx, c_idx, lo, up = (np.zeros(8, np.int32) for _ in range(4))
+        for k in range(4):
+            centre = int(rng.integers(2, rows - 2))
+            half = int(rng.integers(1, 6))
+            lo[2 * k], up[2 * k] = max(centre - half, 0), min(centre + half, rows - 1)
+            n_idx[2 * k] = centre
+            c_idx[2 * k] = int(rng.integers(lo[2 * k], up[2 * k] + 1))
+            lo[2 * k + 1], up[2 * k + 1] = 0, int(rng.integers(2, 9))
+            n_idx[2 * k + 1] = int(rng.integers(0, up[2 * k + 1] + 1))
+            c_idx[2 * k + 1] = int(rng.integers(0, up[2 * k + 1] + 1))
+        if trial % 11 == 0:
+            c_idx[4] = up[4] + 3  # x0 outside the box: NLopt's precondition fails
+        lf, rh = float(rng.integers(0, rows)), float(rng.integers(0, rows))
+        st, x, minf = fpo.solve_lattice(op, n_idx, c_idx, lo, up, length_base, skew, res, lf, rh)
+        st2, x2 = _numpy_rule(op, n_idx, c_idx, lo, up, length_base, skew, res, lf, rh)
+        assert st == st2 and x.tolist() == x2, (trial, st, st2, x, x2)
+        statuses.add(st)
+    assert statuses == {0, 1, 2}
+
+
+def test_centroid_method_on_a_submap_reports_the_traversable_band_in_submap_rows():
+    """A 120 x 100 map @ 2 cm (x in [-1.2, 1.2): row of x = floor((1.2 - x) / 0.02)) whose rows 39..41 are blocked;
+    gait-cycle-like submap of 0.7187 x 0.349 m around (0.3, 0): rows floor((1.2 - 0.65935) / 0.02) = 27 ..
+    floor((1.2 + 0.05935) / 0.02) = 62, i.e. submap row = map row - 27.
+    Foot at x = 0.365: rectangle x in [0.265, 0.465] -> map rows floor(36.75) = 36 .. floor(46.75) = 46, 11 rows.  Blocked
+    rows 39..41 are rectangle rows 3..5: case 2 with minRow 3, maxRow 5, bottomRow 10; 3 >= 10 - 5 is false -> the LOWER band
+    (code 3): rectangle rows 6..10 = map rows 42..46 = submap rows 15..19; new row floor((5 + 10) / 2) = 7 -> map row 43."""
+    trav = np.ones((120, 100), np.float32)
+    trav[39:42, :] = 0.1
+    elev = np.zeros_like(trav)
+    om = fpo.OracleMap(trav, elev, 0.02)
+    p = yaml_params()
+    ok, cen, info = om.centroid_on_submap(p, (0.3, 0.0), (0.7187, 0.349), 0.365, 0.05, np.float32(0.1))
+    assert ok and info["code"] == 3
+    assert (info["begin_row"], info["end_row"]) == (15, 19)
+    okp, x, _ = om.get_position(43, 0)
+    assert abs(cen["x"] - x) < 1e-12
+    # a rectangle that hangs over the submap's far edge is clipped to it: foot at x = 0.005 -> map rows floor(54.75) = 54 ..
+    # floor(64.75) = 64, the submap ends at row 62 -> 9 rows, all traversable: the band is submap rows 27..35
+    ok, cen, info = om.centroid_on_submap(p, (0.3, 0.0), (0.7187, 0.349), 0.005, 0.05, np.float32(0.1))
+    assert ok and info["code"] == 0 and (info["begin_row"], info["end_row"]) == (54 - 27, 62 - 27)
+
+
+def test_opt_gate_stops_the_chain_where_the_submap_leaves_the_map():
+    """The next feet centre's y is initialPose_[1] + ajustedPose_[1] (cpp:2329) and ajustedPose_[1] drifts by -0.007 per
+    cycle whether or not the cycle commits (cpp:1578).  Map y in (-2, 2]; y0 = -1.98: the centre is at -1.98, -1.987,
+    -1.994 in cycles 0..2 and at -2.001 — outside the map, getSubmap fails — in cycle 3: the handler returns false there
+    (cpp:931-934)."""
+    t, e = flat(200, 200)
+    om = fpo.OracleMap(t, e, 0.02)
+    p = yaml_params()
+    poses = oracle_poses([(-1.0, -1.98, 0.0)])
+    plan = om.plan(p, poses, 6)
+    o = om.plan_opt(p, fpo.opt_params_yaml(), poses, 6, plan["cycle_ok"])
+    assert o["gate_fail_cycle"][0] == 3
+    assert o["cycles"][0]["gate_failed"].tolist() == [0, 0, 0, 1, 0, 0]
+    assert (o["cycles"][0]["gait_size"][:3, 0] == 37).all() and (o["cycles"][0]["gait_size"][3:] == 0).all()
+    assert (o["footholds"][0, 3:]["x"] == 0).all() and (o["footholds"][0, :3]["x"] != 0).all()
+    prod = om.plan_opt_products(p, fpo.opt_params_yaml(), poses[0], 6, plan["cycle_ok"][0])
+    assert prod["gate_fail_cycle"] == 3 and prod["path"].shape[0] == 3
