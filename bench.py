@@ -73,9 +73,26 @@ def spawn_ranks(n):
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", FPE_BENCH_SPAWNED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # poll every rank: the first one that fails takes the others down with it (a rank that died before the rendezvous
+    # would otherwise leave its peers waiting in init_process_group / barrier until the collective's timeout)
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = abs(code) or 1
+    for p in live:  # only reached with rc != 0: stop the exact children this process started
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
     sys.exit(rc)
 
 
@@ -186,10 +203,12 @@ def main():
     backend = "none"
     if world > 1:
         backend = "gloo" if share else "nccl"
+        import datetime
+        rendezvous = datetime.timedelta(seconds=int(os.environ.get("FPE_BENCH_RENDEZVOUS_S", "180")))
         if share:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=rendezvous)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=rendezvous)
 
     # ---- workload --------------------------------------------------------------------------------
     cfg = synth.CONFIGS[args.config]
@@ -327,13 +346,25 @@ def main():
     src = eng["nominal"]["source"].reshape(-1)
     codes = np.bincount(eng["centroid"]["code"].reshape(-1), minlength=7)[:7] / src.size
 
-    traffic = None
+    # roofline.traffic: PMC passes cannot run inside bench.py, so this is the counter-measured figure of the committed
+    # profile of this configuration — reported only while the kernel the engine launches NOW is the kernel that profile
+    # measured (same template instance), and always with its source
+    traffic, traffic_source = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
+    kernel_now = planner.describe_plan()
+    if os.path.exists(pmc_path) and not args.no_bits:
         try:
-            traffic = json.load(open(pmc_path)).get(args.config, {}).get("hbm_bytes_per_launch")
+            ent = json.load(open(pmc_path)).get(args.config, {})
+            inst = kernel_now.split(" (")[0]  # e.g. "plan_bits_kernel<2, true>"
+            if ent and inst in ent.get("kernel", ""):
+                traffic = ent.get("hbm_bytes_per_launch")
+                traffic_source = {"file": ent.get("file", "profiles/pmc_traffic.json"), "round": ent.get("round"),
+                                  "commit": ent.get("commit", "round-2 HEAD"), "kernel": ent.get("kernel"),
+                                  "note": "static: measured by rocprofv3 --pmc passes when that profile was taken, not by this run"}
+            elif ent:
+                traffic_source = {"omitted": f"the committed profile measured `{ent.get('kernel')}`, this run launches `{inst}`"}
         except Exception:
-            traffic = None
+            traffic, traffic_source = None, None
 
     line = {
         "metric": "footholds/sec (4 legs x N cycles x B poses) on 1k^2 @2cm map",
@@ -376,30 +407,111 @@ def main():
             "unit": "GB/s",
             "frac": achieved / peak,
             "traffic": traffic,
-            "kernel": planner.describe_plan(),
+            "traffic_source": traffic_source,
+            "kernel": kernel_now,
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_foothold": alg_bytes,
-            "note": "latency/ALU bound; map is L2/Infinity-Cache resident (DESIGN.md)",
+            "frac_by_counter_bytes": (traffic / (kernel_ms * 1e-3) / 1e9 / peak) if traffic else None,
+            "note": "`achieved` / `frac` charge SURVEY 8(d)'s ALGORITHMIC bytes (the yardstick north_star names); the kernel is bound by "
+                    "the SIMDs' instruction issue, not by HBM: its counter-measured traffic is `traffic` (frac_by_counter_bytes), the map "
+                    "and its bit planes are L2 / Infinity-Cache resident (DESIGN.md §4)",
         },
     }
     if not verified:
         line["config"]["verify_error"] = why
+    if world > 1:
+        # what the exchange moves, so that a scaling line can be read against the links: xGMI is point to point (every
+        # peer's block arrives over its own link; a ring would push all world - 1 blocks through one)
+        local_bytes = n_rec * sel
+        link_gbs = 64.0  # GB/s per xGMI link and direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s bidirectional per GPU)
+        line["config"]["exchange_bytes_per_rank"] = local_bytes
+        line["config"]["exchange_inbound_bytes_per_gpu"] = local_bytes * (world - 1)
+        line["config"]["exchange_floor_ms"] = {"direct_links": local_bytes / (link_gbs * 1e9) * 1e3,
+                                               "ring": local_bytes * (world - 1) / (link_gbs * 1e9) * 1e3,
+                                               "plan_kernel_ms": kernel_ms,
+                                               "note": "per-step all-gather time a step cannot go below at 64 GB/s per link and direction; when it "
+                                                       "exceeds plan_kernel_ms the step is exchange-bound however well the gather overlaps the next plan"}
     if alt:
         line["config"]["exchange_alt"] = alt
     extras = rank == 0 and world == 1 and not args.no_extras
     if extras:
-        # the §8(d) metric as defined: wall time of fpe_plan with HOST buffers — poses H2D, kernel, every result D2H
-        out_h = planner.plan(poses, n_cycles)
-        t0 = time.perf_counter()
-        reps_h = 10
-        for _ in range(reps_h):
-            planner.plan(poses, n_cycles, out=out_h)
-        dt = (time.perf_counter() - t0) / reps_h
+        # the §8(d) metric as defined: wall time of fpe_plan with HOST buffers — poses H2D, kernel, results D2H.
+        # Three forms: every product into ordinary (pageable) arrays; every product into pinned arrays (fpe_host_alloc:
+        # the device writes them by DMA, no copy-out); the 16-byte selected records only (what north_star's consumer reads)
+        def timed_host(out, reps_h=20):
+            planner.plan(poses, n_cycles, out=out)
+            t0 = time.perf_counter()
+            for _ in range(reps_h):
+                planner.plan(poses, n_cycles, out=out)
+            return (time.perf_counter() - t0) / reps_h
+
+        out_h = planner.plan_outputs(B, n_cycles)
+        dt = timed_host(out_h)
         res_bytes = sum(v.nbytes for v in out_h.values())
+        out_p = planner.plan_outputs(B, n_cycles, pinned=True)
+        dt_p = timed_host(out_p)
+        for k in out_h:  # same launch, same results whichever way they travel
+            assert out_h[k].tobytes() == out_p[k].tobytes(), k
+        out_s = planner.plan_outputs(B, n_cycles, products=("selected",), pinned=True)
+        dt_s = timed_host(out_s)
+        assert out_s["selected"].tobytes() == out_h["selected"].tobytes()
+        # the link itself: one plain device -> pinned-host copy of the same number of bytes (what no D2H path can beat)
+        d_raw = torch.empty(res_bytes, dtype=torch.uint8, device=dev)
+        h_raw = torch.empty(res_bytes, dtype=torch.uint8, pin_memory=True)
+        h_raw.copy_(d_raw, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            h_raw.copy_(d_raw, non_blocking=True)
+            torch.cuda.synchronize()
+        link_gbs = res_bytes / ((time.perf_counter() - t0) / 10) / 1e9
+        del d_raw, h_raw
         line["value_incl_d2h"] = {"value": 4 * n_cycles * B / dt, "unit": "footholds/s", "ms_per_call": dt * 1e3,
+                                  "plain_d2h_copy_GB/s_on_this_box": link_gbs,
                                   "result_bytes": res_bytes, "pose_bytes": poses.nbytes,
-                                  "note": "fpe_plan (host buffers): poses H2D + kernel + all seven products D2H through the "
-                                          "engine's pinned arena + copy-out into the caller's arrays; SURVEY 8(d) wall-time definition"}
+                                  "GB/s_results": res_bytes / dt / 1e9,
+                                  "note": "fpe_plan (host buffers, ordinary pageable arrays): poses H2D + kernel + all seven products D2H in chunks "
+                                          "through the engine's pinned arena, copied out by the engine's copy threads while later chunks are in "
+                                          "flight; SURVEY 8(d) wall-time definition"}
+        line["value_incl_d2h_pinned"] = {"value": 4 * n_cycles * B / dt_p, "unit": "footholds/s", "ms_per_call": dt_p * 1e3,
+                                         "result_bytes": res_bytes, "GB/s_results": res_bytes / dt_p / 1e9,
+                                         "note": "same call, result arrays from fpe_host_alloc (pinned): every product is written by DMA straight "
+                                                 "into the caller's array"}
+        line["value_selected_only"] = {"value": 4 * n_cycles * B / dt_s, "unit": "footholds/s", "ms_per_call": dt_s * 1e3,
+                                       "result_bytes": out_s["selected"].nbytes,
+                                       "note": "fpe_plan asking for the 16-byte selected records only (pinned destination)"}
+        # the actual drop-in call: plan_global_footholds for ONE pose x 8 cycles (fpe_plan_service: plan kernel + the opt
+        # track's chain for the handler's return value, zero-copy through the pinned arena), wall time per call through
+        # ctypes; on a steady map and as the first call after a fresh map message (bit planes pre-built by the upload)
+        def service_us(fresh_map, no_bits, reps_s=60, gate0=False):
+            svc = FootholdPlanner(local_rank)
+            svc.params = planner.params.copy()
+            if no_bits:
+                svc.set_tuning(no_bits=1)
+            if gate0:
+                svc.set_tuning(service_cycle0_gate_only=1)
+            svc.gridmapCallback(trav, elev, res)
+            pos = poses["position"][0].copy()
+            svc.globalFootholdPlan(8, pos)
+            ts = []
+            for _ in range(reps_s):
+                if fresh_map:
+                    svc.gridmapCallback(trav, elev, res)
+                t0 = time.perf_counter()
+                svc.globalFootholdPlan(8, pos)
+                ts.append(time.perf_counter() - t0)
+            svc.close()
+            return float(np.median(ts) * 1e6)
+
+        line["service_latency_us"] = {
+            "steady_map": {"bit_window": service_us(False, False), "direct": service_us(False, True)},
+            "first_call_after_a_map": {"bit_window": service_us(True, False, 12), "direct": service_us(True, True, 12)},
+            "steady_map_without_the_opt_track": {"bit_window": service_us(False, False, gate0=True), "direct": service_us(False, True, gate0=True)},
+            "note": "median wall time of fpe_plan_service (1 pose x 8 cycles, response assembled) per call, ctypes overhead included: the "
+                    "plan kernel AND the opt track's chain (cpp:913-1319: eight optimiser searches of 14 641 lattice points each, one "
+                    "after the other), which the handler's return value depends on from the second cycle on; "
+                    "steady_map_without_the_opt_track = fpe_set_tuning('service_cycle0_gate_only', 1), the round-2 scope of the call",
+        }
         # map ingest: grid_map message layout (column-major, circular-buffer start
         # index) -> canonical HBM layers, device-resident source; HBM-bound transpose, 2 layers
         ir, ic = 4000, 4000

@@ -18,6 +18,7 @@
 #ifndef FPE_H
 #define FPE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -232,7 +233,9 @@ int fpe_destroy(fpe_handle h);
  * environment variables FPE_PLAN_GROUP, FPE_LITERAL_DISCS, FPE_NO_MID_VARIANT, FPE_NO_BITS only seed the
  * defaults once, in fpe_create).  Keys: "plan_group" (0 automatic; 4/8/16/64 lanes per leg, 65 = one
  * wavefront per pose), "literal_discs" (1: force the literal CircleIterator walk), "no_mid_variant"
- * (1: never launch the 3x3-only kernel variants), "no_bits" (1: never launch the bit-window kernels).
+ * (1: never launch the 3x3-only kernel variants), "no_bits" (1: never launch the bit-window kernels),
+ * "service_cycle0_gate_only" (1: fpe_plan_service* calls that ask for no opt product skip the opt track's chain — about
+ * 160 us of a 210 us call for 8 cycles — and report the handler's `return false` for the first gait cycle only).
  * Thread-safe: every plan / search call copies the knobs once, under the engine's lock, so a concurrent call runs
  * entirely with the values before or entirely with the values after a change (one key per call: callers that change
  * several keys while other threads plan get each key's change at its own moment). */
@@ -300,6 +303,13 @@ int fpe_set_max_leg_search_radius(fpe_handle h, float radius);
  * these products; it is a launch of its own (fpe_plan_opt*). */
 int fpe_plan(fpe_handle h, const fpe_params* params, const fpe_pose* poses, int32_t B, int32_t n_cycles,
              const fpe_plan_out* out);
+/* Host arrays the GPU can write by DMA (pinned).  fpe_plan / fpe_plan_opt copy a product whose destination lies in such
+ * memory — allocated here, by hipHostMalloc or registered with hipHostRegister — from the device straight into it;
+ * other destinations are served through the engine's own pinned arena and a copy (overlapped, chunk by chunk).  A ROS
+ * adapter that keeps its result arrays across service calls allocates them once with fpe_host_alloc. */
+int fpe_host_alloc(fpe_handle h, size_t bytes, void** out);
+int fpe_host_free(fpe_handle h, void* p);
+
 /* Device-resident variant: d_poses and every non-NULL pointer of d_out are DEVICE pointers; the
  * launch is asynchronous on `stream` (a hipStream_t; NULL = default stream). */
 int fpe_plan_device(fpe_handle h, const fpe_params* params, const fpe_pose* d_poses, int32_t B,

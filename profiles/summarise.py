@@ -91,7 +91,13 @@ if "FETCH_SIZE" in allc and "WRITE_SIZE" in allc:
     }
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     tr = json.load(open(tp)) if os.path.exists(tp) else {}
-    tr[cfg] = {"hbm_bytes_per_launch": fetch_b + write_b, "round": rnd, "kernel": plan_row["Name"][:60]}
+    import subprocess
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        commit = "unknown"
+    tr[cfg] = {"hbm_bytes_per_launch": fetch_b + write_b, "round": rnd, "kernel": plan_row["Name"][:60], "commit": commit,
+               "file": f"profiles/{rnd}_{cfg}_counters.json"}
     json.dump(tr, open(tp, "w"), indent=1)
 waves = allc.get("SQ_WAVES")
 if waves:

@@ -159,6 +159,8 @@ EXPORTED_SYMBOLS = [
     "fpe_set_max_leg_search_radius",
     "fpe_set_tuning",
     "fpe_describe_plan",
+    "fpe_host_alloc",
+    "fpe_host_free",
     "fpe_plan",
     "fpe_plan_device",
     "fpe_search_legs",
@@ -222,6 +224,8 @@ def lib():
     L.fpe_set_max_leg_search_radius.argtypes = [vp, f32]
     L.fpe_set_tuning.argtypes = [vp, C.c_char_p, i32]
     L.fpe_describe_plan.argtypes = [vp, vp, C.c_char_p, i32]
+    L.fpe_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.fpe_host_free.argtypes = [vp, vp]
     L.fpe_plan.argtypes = [vp, vp, vp, i32, i32, C.POINTER(PlanOut)]
     L.fpe_plan_device.argtypes = [vp, vp, vp, i32, i32, C.POINTER(PlanOut), vp]
     L.fpe_search_legs.argtypes = [vp, vp, vp, i32, vp]

@@ -37,6 +37,7 @@ struct Tuning {
     int32_t literalDiscs = 0;
     int32_t noMidVariant = 0;
     int32_t noBits = 0;
+    int32_t serviceCycle0GateOnly = 0;  // fpe_plan_service*: skip the opt track's chain (its gate is then exact for cycle 0 only)
 };
 
 struct PlanConsts {
@@ -134,6 +135,7 @@ struct OptConsts {
     double ctol;
     double lengthBase, skew, mapResolution;  // cpp:497-498, 514
     double t1, t2, t3, t4;                   // cpp:1156-1159
+    double lbOverRes, skew2OverRes;          // lengthBase/mapResolution, 2*skew/mapResolution (cpp:69-72): loop invariants
     double lfRow0, rhRow0;                   // lfCurrentRow / rhCurrentRow at entry of the call (cpp:36)
     int32_t useConstraints;
     int32_t colLoA, colUpA;                  // xBounds of x2 = x8 (cpp:1063-1064)

@@ -7,6 +7,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -127,10 +130,22 @@ struct CallCtx {
     size_t devCap = 0;
     unsigned char* pinned = nullptr;
     size_t pinCap = 0;
+    std::vector<hipEvent_t> events;  // one per staged result chunk in flight (created on demand, kept)
     ~CallCtx() {
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
         if (dev) (void)hipFree(dev);
         if (pinned) (void)hipHostFree(pinned);
         if (stream) (void)hipStreamDestroy(stream);
+    }
+    hipError_t event(size_t k, hipEvent_t* out) {
+        while (events.size() <= k) {
+            hipEvent_t e = nullptr;
+            hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            if (rc != hipSuccess) return rc;
+            events.push_back(e);
+        }
+        *out = events[k];
+        return hipSuccess;
     }
     hipError_t reserve(size_t bytes) {
         if (!stream) {
@@ -180,6 +195,88 @@ struct CtxLease {  // returns the context to the pool on every exit path
     ~CtxLease() { pool.give(std::move(ctx)); }
 };
 inline size_t align256(size_t n) { return (n + 255) & ~static_cast<size_t>(255); }
+
+// Copy-out of large results from the pinned arena into the caller's (pageable) arrays: a few persistent host threads,
+// so that the copy of chunk k runs while chunk k+1 is still crossing PCIe (one thread moves ~25 GB/s, the link ~50).
+class CopyPool {
+  public:
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    struct Batch {
+        std::mutex mu;
+        std::condition_variable cv;
+        int pending = 0;
+    };
+    void submit(Batch& b, void* dst, const void* src, size_t len) {
+        {
+            std::lock_guard<std::mutex> lk(b.mu);
+            ++b.pending;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (threads_.empty()) start();
+            q_.push_back(Task{&b, dst, src, len});
+        }
+        cv_.notify_one();
+    }
+    static void wait(Batch& b) {
+        std::unique_lock<std::mutex> lk(b.mu);
+        b.cv.wait(lk, [&] { return b.pending == 0; });
+    }
+
+  private:
+    struct Task {
+        Batch* b;
+        void* dst;
+        const void* src;
+        size_t len;
+    };
+    void start() {  // under mu_
+        unsigned n = std::thread::hardware_concurrency();
+        n = n > 4 ? 3 : (n > 1 ? n - 1 : 1);
+        for (unsigned k = 0; k < n; ++k) threads_.emplace_back([this] { run(); });
+    }
+    void run() {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                t = q_.front();
+                q_.pop_front();
+            }
+            std::memcpy(t.dst, t.src, t.len);
+            {
+                std::lock_guard<std::mutex> lk(t.b->mu);
+                if (--t.b->pending == 0) t.b->cv.notify_all();
+            }
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Task> q_;
+    std::vector<std::thread> threads_;
+    bool stop_ = false;
+};
+
+// Is `p` host memory the GPU can write by DMA (hipHostMalloc / hipHostRegister / fpe_host_alloc)?  Then results are
+// copied from the device straight into it.
+bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t a;
+    std::memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // an ordinary malloc'ed pointer is reported as an error: not sticky
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
 
 // Bit planes of a snapshot for one (defaultFootholdThreshold, candidateFootholdThreshold) pair: built by the upload
 // for the pairs the previous snapshot was planned with (the upload already owns the pool's synchronisation), lazily by
@@ -256,6 +353,7 @@ struct fpe_engine {
     std::shared_ptr<MapSnapshot> map;
     std::shared_ptr<BufferPool> pool = std::make_shared<BufferPool>();
     CtxPool ctxPool;
+    CopyPool copyPool;
     int16_t* d_di = nullptr;
     int16_t* d_dj = nullptr;
     uint8_t* d_ring = nullptr;
@@ -546,6 +644,7 @@ int fpe_set_tuning(fpe_handle h, const char* key, int32_t value) {
     else if (k == "literal_discs") h->tuning.literalDiscs = value ? 1 : 0;
     else if (k == "no_mid_variant") h->tuning.noMidVariant = value ? 1 : 0;
     else if (k == "no_bits") h->tuning.noBits = value ? 1 : 0;
+    else if (k == "service_cycle0_gate_only") h->tuning.serviceCycle0GateOnly = value ? 1 : 0;
     else return fail(FPE_E_INVALID_ARG, "unknown tuning key: " + k);
     return FPE_OK;
 }
@@ -805,9 +904,9 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
     // arena — two copy-engine round trips (~10 us each) less on a call whose kernel runs ~25 us.
     const bool zeroCopy = total <= kZeroCopyBytes;
     if (zeroCopy) {
-        void* mapped = nullptr;
-        FPE_HIP(hipHostGetDevicePointer(&mapped, hp, 0));
-        dp = static_cast<unsigned char*>(mapped);
+        void* arena = nullptr;
+        FPE_HIP(hipHostGetDevicePointer(&arena, hp, 0));
+        dp = static_cast<unsigned char*>(arena);
     } else {
         FPE_HIP(hipMemcpyAsync(dp, hp, static_cast<size_t>(B) * sizeof(fpe_pose), hipMemcpyHostToDevice, cx.stream));
         if (oout && cycleOkIn) FPE_HIP(hipMemcpyAsync(dp + oOk, hp + oOk, nCyc, hipMemcpyHostToDevice, cx.stream));
@@ -836,22 +935,96 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
         FPE_HIP(fpe::launch_opt_track(dev_map(*cp.snap), cp.pc, oc, reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, dp + oOk, od,
                                       cx.stream));
     }
-    if (total > szPose && !zeroCopy)  // results: one D2H copy of the whole result arena into pinned memory
-        FPE_HIP(hipMemcpyAsync(hp + szPose, dp + szPose, total - szPose, hipMemcpyDeviceToHost, cx.stream));
-    FPE_HIP(hipStreamSynchronize(cx.stream));
-    if (po.nominal) std::memcpy(po.nominal, hp + oNom, nRec * sizeof(fpe_foothold));
-    if (po.centroid) std::memcpy(po.centroid, hp + oCen, nRec * sizeof(fpe_centroid_foothold));
-    if (po.default_next) std::memcpy(po.default_next, hp + oDef, nRec * 3 * sizeof(double));
-    if (po.cycle_ok) std::memcpy(po.cycle_ok, hp + oOk, nCyc);
-    if (po.stance) std::memcpy(po.stance, hp + oSt, static_cast<size_t>(B) * 12 * sizeof(double));
-    if (po.selected) std::memcpy(po.selected, hp + oSel, nRec * sizeof(fpe_selected_foothold));
-    if (po.pose_status) std::memcpy(po.pose_status, hp + oPs, static_cast<size_t>(B));
-    if (szOf) std::memcpy(oout->footholds, hp + oOf, nRec * sizeof(fpe_opt_foothold));
-    if (szOc) std::memcpy(oout->cycles, hp + oOc, nCyc * sizeof(fpe_opt_cycle));
-    if (szOg) std::memcpy(oout->gate_fail_cycle, hp + oOg, static_cast<size_t>(B));
+    // ---- results to the caller ----
+    struct Seg {
+        size_t off, len;
+        void* dst;
+    };
+    Seg segs[10];
+    int nSeg = 0;
+    auto add = [&](size_t o, size_t len, void* dst) {
+        if (dst && len) segs[nSeg++] = Seg{o, len, dst};
+    };
+    add(oNom, nRec * sizeof(fpe_foothold), po.nominal);
+    add(oCen, nRec * sizeof(fpe_centroid_foothold), po.centroid);
+    add(oDef, nRec * 3 * sizeof(double), po.default_next);
+    add(oOk, nCyc, po.cycle_ok);
+    add(oSt, static_cast<size_t>(B) * 12 * sizeof(double), po.stance);
+    add(oSel, nRec * sizeof(fpe_selected_foothold), po.selected);
+    add(oPs, static_cast<size_t>(B), po.pose_status);
+    if (szOf) add(oOf, nRec * sizeof(fpe_opt_foothold), oout->footholds);
+    if (szOc) add(oOc, nCyc * sizeof(fpe_opt_cycle), oout->cycles);
+    if (szOg) add(oOg, static_cast<size_t>(B), oout->gate_fail_cycle);
+    if (zeroCopy) {  // the kernels wrote into the pinned arena itself
+        FPE_HIP(hipStreamSynchronize(cx.stream));
+        for (int k = 0; k < nSeg; ++k) std::memcpy(segs[k].dst, hp + segs[k].off, segs[k].len);
+        return FPE_OK;
+    }
+    // Only what the caller asked for crosses PCIe.  A product whose destination is pinned / registered host memory
+    // (fpe_host_alloc) is written by DMA directly; the others go through the pinned arena in chunks, and the copy of a
+    // chunk into the caller's array runs on the copy pool while the next chunks are still in flight.
+    size_t staged = 0;
+    for (int k = 0; k < nSeg; ++k) {
+        if (is_pinned_host(segs[k].dst)) {
+            FPE_HIP(hipMemcpyAsync(segs[k].dst, dp + segs[k].off, segs[k].len, hipMemcpyDeviceToHost, cx.stream));
+            segs[k].dst = nullptr;
+        } else {
+            staged += segs[k].len;
+        }
+    }
+    constexpr size_t kMaxChunks = 48;
+    const size_t chunk = std::max<size_t>(1u << 20, (staged / kMaxChunks + 4095) & ~static_cast<size_t>(4095));
+    struct Piece {
+        size_t off, len;
+        void* dst;
+    };
+    std::vector<Piece> pieces;
+    for (int k = 0; k < nSeg; ++k) {
+        if (!segs[k].dst) continue;
+        for (size_t c = 0; c < segs[k].len; c += chunk) {
+            const size_t len = std::min(chunk, segs[k].len - c);
+            pieces.push_back(Piece{segs[k].off + c, len, static_cast<unsigned char*>(segs[k].dst) + c});
+        }
+    }
+    for (size_t k = 0; k < pieces.size(); ++k) {
+        hipEvent_t ev;
+        FPE_HIP(cx.event(k, &ev));
+        FPE_HIP(hipMemcpyAsync(hp + pieces[k].off, dp + pieces[k].off, pieces[k].len, hipMemcpyDeviceToHost, cx.stream));
+        FPE_HIP(hipEventRecord(ev, cx.stream));
+    }
+    CopyPool::Batch batch;
+    hipError_t evErr = hipSuccess;
+    for (size_t k = 0; k < pieces.size(); ++k) {
+        const hipError_t e = hipEventSynchronize(cx.events[k]);
+        if (e != hipSuccess) {
+            evErr = e;
+            break;
+        }
+        if (pieces[k].len >= (256u << 10)) h->copyPool.submit(batch, pieces[k].dst, hp + pieces[k].off, pieces[k].len);
+        else std::memcpy(pieces[k].dst, hp + pieces[k].off, pieces[k].len);
+    }
+    CopyPool::wait(batch);
+    if (evErr != hipSuccess) return fail_hip(evErr, "result copy");
+    FPE_HIP(hipStreamSynchronize(cx.stream));  // the direct (pinned-destination) copies
     return FPE_OK;
 }
 }  // namespace
+
+int fpe_host_alloc(fpe_handle h, size_t bytes, void** out) {
+    if (!h || !out || bytes == 0) return fail(FPE_E_INVALID_ARG, "null argument");
+    *out = nullptr;
+    FPE_HIP(hipSetDevice(h->device));
+    FPE_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return FPE_OK;
+}
+
+int fpe_host_free(fpe_handle h, void* p) {
+    if (!h) return fail(FPE_E_INVALID_ARG, "null handle");
+    if (!p) return FPE_OK;
+    FPE_HIP(hipSetDevice(h->device));
+    FPE_HIP(hipHostFree(p));
+    return FPE_OK;
+}
 
 int fpe_plan(fpe_handle h, const fpe_params* params, const fpe_pose* poses, int32_t B, int32_t n_cycles,
              const fpe_plan_out* out) {
@@ -996,8 +1169,18 @@ int fpe_plan_service_opt(fpe_handle h, const fpe_params* params, const fpe_opt_p
         oout.gate_fail_cycle = &gateFail;
         oout.footholds = optf.data();
         oout.cycles = opt_cycles;
-        int rc = plan_host(h, params, opt, &pose, 1, N, &out, nullptr, &oout);
+        // fpe_set_tuning("service_cycle0_gate_only", 1): a latency-critical caller that asks for none of the opt products
+        // may skip the opt track's chain; the handler's return value is then exact for the first cycle only (round-2 behaviour)
+        bool skipOpt = false;
+        if (h && !opt_msg && !opt_report && !opt_cycles && !centroid_report) {
+            std::lock_guard<std::mutex> lk(h->mu);
+            skipOpt = h->tuning.serviceCycle0GateOnly != 0;
+        }
+        uint8_t poseStatus = 0;
+        if (skipOpt) out.pose_status = &poseStatus;
+        int rc = plan_host(h, params, opt, &pose, 1, N, &out, nullptr, skipOpt ? nullptr : &oout);
         if (rc != FPE_OK) return rc;
+        if (skipOpt && (poseStatus & FPE_POSE_OPT_SUBMAP_FAILED)) gateFail = 0;
         if (gateFail != 255) {
             // getGaitCycleSearchGridMap fails in cycle gateFail: the reference's handler logs "Failed to get gait-cycle
             // search gridmap." and returns false (cpp:931-934); the ROS response is never assigned (cpp:1588 is not reached)

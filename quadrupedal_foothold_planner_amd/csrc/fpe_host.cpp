@@ -437,6 +437,8 @@ int derive_opt_constants(const fpe_params& p, const fpe_opt_params& op, const Ma
     oc.t2 = lengthBase * hip_upper_scale/mapResolution;   // cpp:1157
     oc.t3 = 2* skew * skew_lower_scale/mapResolution;     // cpp:1158
     oc.t4 = 2* skew * skew_upper_scale/mapResolution;     // cpp:1159
+    oc.lbOverRes = lengthBase/mapResolution;              // cpp:69-70
+    oc.skew2OverRes = 2*skew/mapResolution;               // cpp:71-72
     oc.lfRow0 = op.lf_current_row0;
     oc.rhRow0 = op.rh_current_row0;
     oc.useConstraints = op.use_inequality_constraints ? 1 : 0;

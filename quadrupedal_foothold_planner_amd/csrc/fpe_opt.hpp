@@ -2,7 +2,8 @@
 // fpe): the OPT TRACK of globalFootholdPlan.
 //
 // Reference: cpp:54-88 nloptFunc, cpp:92-148 nloptConstraint1..8, cpp:913-1319 the per-cycle driver, cpp:1485-1568 the
-// commit, cpp:2307-2408 getGaitCycleSearchGridMap, cpp:2557-2568 getMapIndex.  One wavefront per pose, gait cycles in
+// commit, cpp:2307-2408 getGaitCycleSearchGridMap, cpp:2557-2568 getMapIndex.  One workgroup per pose — one wavefront
+// for batches, eight (seven of them only helping the optimiser's search) for a handful of poses — gait cycles in
 // sequence (the track's feet chain like the other tracks'); inside a cycle
 //   * the gait-cycle submap gaitMap_ = gridmap_.getSubmap(next feet centre, isos_.length x isos_.width) as a MapGeom
 //     of its own plus its top-left index in the map (no copy: cells are read from the map's layers);
@@ -42,35 +43,70 @@ __device__ __forceinline__ SubGeom opt_submap(const MapGeom& g, double px, doubl
 }
 
 // getFootholdMeanHeight (cpp:2520-2554) on a map given by its geometry `g` whose cell (i, j) is cell (offI + i, offJ + j)
-// of the elevation layer: one lane, cells in CircleIterator order (row-major over the bounding box).
-__device__ float opt_mean_height(const MapGeom& g, const float* elev, int ld, int offI, int offJ, double cx, double cy, double rf,
-                                 double rf2, double h) {
+// of the elevation layer.  The 16 lanes of a leg fetch the bounding box's cells side by side (one memory round trip
+// instead of one per cell) and leave (value, visited) in the leg's LDS scratch; lane 0 then runs the reference's f32
+// sum over them in CircleIterator order (row-major over the bounding box).  Boxes beyond the scratch (kOptBoxCells
+// cells) are walked by lane 0 alone, cell by cell.  The result is valid on lane 0 of the group.
+constexpr int kOptBoxCells = 128;
+__device__ float opt_mean_height(const Grp<16>& g, float* vals, const MapGeom& mg, const float* elev, int ld, int offI, int offJ, double cx,
+                                 double cy, double rf, double rf2, double h) {
     float iHeight = 0.0f, meanHeight = 0.0f;
     int n = 0;
     if (!centre_usable(cx, cy)) return static_cast<float>(meanHeight + h);
-    const BBox bb = circle_bbox(g, cx, cy, rf);
-    for (int a = 0; a < bb.ni; ++a)
-        for (int b = 0; b < bb.nj; ++b) {
+    const BBox bb = circle_bbox(mg, cx, cy, rf);
+    const int nb = (bb.ni > 0 && bb.nj > 0) ? bb.ni * bb.nj : 0;
+    if (nb <= kOptBoxCells) {
+        const float njInv = rcp_small(max(bb.nj, 1));
+        for (int t = g.sub; t < nb; t += 16) {
+            int a, b;
+            divmod_small(t, bb.nj, njInv, a, b);
             const int i = bb.i0 + a, j = bb.j0 + b;
-            if (!in_range(i, j, g.rows, g.cols) || !cell_in_disc(g, i, j, cx, cy, rf2)) continue;
-            const float e = elev[static_cast<size_t>(offI + i) * ld + (offJ + j)];
-            iHeight = __builtin_isfinite(e) ? e : 0.0f;  // cpp:2532-2537
-            if (iHeight < 10) {                            // cpp:2539
-                n++;
-                meanHeight = meanHeight + iHeight;
+            const bool vis = in_range(i, j, mg.rows, mg.cols) && cell_in_disc(mg, i, j, cx, cy, rf2);
+            float e = 0.0f;
+            if (vis) e = elev[static_cast<size_t>(offI + i) * ld + (offJ + j)];
+            // (a visited value is stored finite-or-zero as the reference reads it, cpp:2532-2537; NaN marks "not visited")
+            vals[t] = vis ? (__builtin_isfinite(e) ? e : 0.0f) : __builtin_nanf("");
+        }
+        pose_sync<16>();
+        if (g.sub == 0) {
+            for (int t = 0; t < nb; ++t) {
+                const float v = vals[t];
+                if (v != v) continue;
+                iHeight = v;
+                if (iHeight < 10) {  // cpp:2539
+                    n++;
+                    meanHeight = meanHeight + iHeight;
+                }
             }
         }
+        pose_sync<16>();
+    } else if (g.sub == 0) {
+        for (int a = 0; a < bb.ni; ++a)
+            for (int b = 0; b < bb.nj; ++b) {
+                const int i = bb.i0 + a, j = bb.j0 + b;
+                if (!in_range(i, j, mg.rows, mg.cols) || !cell_in_disc(mg, i, j, cx, cy, rf2)) continue;
+                const float e = elev[static_cast<size_t>(offI + i) * ld + (offJ + j)];
+                iHeight = __builtin_isfinite(e) ? e : 0.0f;
+                if (iHeight < 10) {
+                    n++;
+                    meanHeight = meanHeight + iHeight;
+                }
+            }
+    }
     if (n != 0) meanHeight = meanHeight / n;
     else meanHeight = iHeight;
     return static_cast<float>(meanHeight + h);
 }
 
 // nloptFunc, cpp:54-88 — the reference's expression, term for term (abs = std::abs(double): fabs).
+// (the two quotients lengthBase/mapResolution and 2*skew/mapResolution are loop invariants of the search: evaluated once
+// per call by the host — same operands, same division, same f64 values — OptConsts::lbOverRes / skew2OverRes)
 __device__ __forceinline__ double opt_objective(const double (&x)[8], const OptConsts& oc, const int (&nominalIndex)[8],
                                                 const int (&centroidIndex)[8], double lfCurrentRow, double rhCurrentRow) {
     const double w1 = oc.w1, w2 = oc.w2, w3 = oc.w3, w4 = oc.w4, wr = oc.wr, wc = oc.wc;
-    const double lengthBase = oc.lengthBase, skew = oc.skew, mapResolution = oc.mapResolution;
 #define abs fabs
+#define FPE_LB_OVER_RES oc.lbOverRes       /* lengthBase/mapResolution */
+#define FPE_SKEW2_OVER_RES oc.skew2OverRes /* 2*skew/mapResolution */
     return (
             w1*( wr*(abs(x[0]-nominalIndex[0])) + wc*(abs(x[1]-nominalIndex[1])) +
                  wr*(abs(x[2]-nominalIndex[2])) + wc*(abs(x[3]-nominalIndex[3])) +
@@ -80,12 +116,14 @@ __device__ __forceinline__ double opt_objective(const double (&x)[8], const OptC
                  wr*(abs(x[2]-centroidIndex[2])) + wc*(abs(x[3]-centroidIndex[3])) +
                  wr*(abs(x[4]-centroidIndex[4])) + wc*(abs(x[5]-centroidIndex[5])) +
                  wr*(abs(x[6]-centroidIndex[6])) + wc*(abs(x[7]-centroidIndex[7])) ) +
-            w3*( abs(abs(x[0]-x[2]) - lengthBase/mapResolution) +
-                 abs(abs(x[4]-x[6]) - lengthBase/mapResolution) ) +
-            w4*( abs(abs(0.5*abs(x[0]-x[2]) - 0.5*abs(x[4]-x[6])) - 2*skew/mapResolution) +
-                 abs(abs(0.5*abs(x[4]-x[6]) - 0.5*abs(lfCurrentRow - rhCurrentRow)) - 2*skew/mapResolution) )
+            w3*( abs(abs(x[0]-x[2]) - FPE_LB_OVER_RES) +
+                 abs(abs(x[4]-x[6]) - FPE_LB_OVER_RES) ) +
+            w4*( abs(abs(0.5*abs(x[0]-x[2]) - 0.5*abs(x[4]-x[6])) - FPE_SKEW2_OVER_RES) +
+                 abs(abs(0.5*abs(x[4]-x[6]) - 0.5*abs(lfCurrentRow - rhCurrentRow)) - FPE_SKEW2_OVER_RES) )
             );
 #undef abs
+#undef FPE_LB_OVER_RES
+#undef FPE_SKEW2_OVER_RES
 }
 
 // nloptConstraint1..8, cpp:92-148, folded into (every value <= ctol, largest value) — solveLattice's key.
@@ -126,12 +164,27 @@ __device__ __forceinline__ void opt_wave_min(double& key, double& f, unsigned& t
     }
 }
 
-// oracle/fpo_opt.cpp::solveLattice on a wavefront (lane = lattice point).  All arguments are wave-uniform.
-__device__ int opt_solve(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8],
-                         double lfRow, double rhRow, int lane, double (&x)[8], double& minf) {
+// One candidate of the cross-wavefront minimum (W > 1: the waves of a pose's workgroup each search a slice of the box)
+struct OptBest {
+    double key, f;
+    unsigned t, pad;
+};
+// The optimiser's problem of one cycle as wavefront 0 publishes it to the helper wavefronts (W > 1).
+struct OptProblem {
+    int run;  // 1: search the rows; 0: nothing to search in this cycle; -1: the track has stopped for good
+    int pad;
+    int nIdx[8], cIdx[8], lo[8], up[8];
+    double x[8];  // start point with the columns already decided
+    double lfRow, rhRow;
+};
+
+// oracle/fpo_opt.cpp::solveLattice, first part (one wavefront): start x = x0 = centroidIndex (cpp:1180-1183), NLopt's
+// precondition (status 1), the four column variables.  Returns -1 when the row search is to run, else the final status.
+__device__ int opt_solve_begin(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8],
+                               double lfRow, double rhRow, int lane, double (&x)[8], double& minf) {
     const double inf = __builtin_huge_val();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) x[k] = cIdx[k];  // cpp:1180-1183
+    for (int k = 0; k < 8; ++k) x[k] = cIdx[k];
     minf = opt_objective(x, oc, nIdx, cIdx, lfRow, rhRow);
     bool bad = false;
 #pragma unroll
@@ -156,72 +209,128 @@ __device__ int opt_solve(const OptConsts& oc, const int (&nIdx)[8], const int (&
         x[k] = lo[k] + static_cast<int>(bestV);
     }
     minf = opt_objective(x, oc, nIdx, cIdx, lfRow, rhRow);
-    const unsigned n0 = static_cast<unsigned>(up[0] - lo[0] + 1), n2 = static_cast<unsigned>(up[2] - lo[2] + 1),
-                   n4 = static_cast<unsigned>(up[4] - lo[4] + 1), n6 = static_cast<unsigned>(up[6] - lo[6] + 1);
-    const double points = static_cast<double>(n0) * static_cast<double>(n2) * static_cast<double>(n4) * static_cast<double>(n6);
+    const double points = static_cast<double>(up[0] - lo[0] + 1) * static_cast<double>(up[2] - lo[2] + 1) *
+                          static_cast<double>(up[4] - lo[4] + 1) * static_cast<double>(up[6] - lo[6] + 1);
     if (points > static_cast<double>(kMaxLatticePoints)) return 3;
-    const unsigned total = n0 * n2 * n4 * n6;
+    return -1;
+}
+
+// Second part, on every wavefront of the workgroup: row points (x[0], x[2], x[4], x[6]) = lo + (a, b, c, d), enumeration
+// index t = ((a n2 + b) n4 + c) n6 + d.  Wavefront w takes the (a, b) pairs w, w + W, ..., its lanes the (c, d) pairs;
+// per lane t only grows, so "strictly better" keeps the first of equals, and the reduction orders by (violation,
+// objective, t): the lexicographically first minimum, as the oracle's nested loops find it.
+template <int W>
+__device__ OptBest opt_solve_rows(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8],
+                                  double lfRow, double rhRow, int lane, int wave, const double (&x)[8]) {
+    const double inf = __builtin_huge_val();
+    const int n0 = up[0] - lo[0] + 1, n2 = up[2] - lo[2] + 1, n4 = up[4] - lo[4] + 1, n6 = up[6] - lo[6] + 1;
+    const int nAB = n0 * n2, nCD = n4 * n6;
+    const float n2Inv = rcp_small(n2), n6Inv = rcp_small(n6);
     double bestKey = inf, bestF = inf;
     unsigned bestT = 0xFFFFFFFFu;
     double y[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) y[k] = x[k];
-    for (unsigned t = static_cast<unsigned>(lane); t < total; t += 64u) {
-        unsigned r = t;
-        const unsigned d = r % n6; r /= n6;
-        const unsigned c = r % n4; r /= n4;
-        const unsigned b = r % n2;
-        const unsigned a = r / n2;
-        y[0] = lo[0] + static_cast<int>(a);
-        y[2] = lo[2] + static_cast<int>(b);
-        y[4] = lo[4] + static_cast<int>(c);
-        y[6] = lo[6] + static_cast<int>(d);
-        const double key = oc.useConstraints ? opt_violation(y, oc, lfRow, rhRow) : 0.0;
-        const double f = opt_objective(y, oc, nIdx, cIdx, lfRow, rhRow);
-        if (key < bestKey || (key == bestKey && f < bestF)) {  // t grows per lane: the first of equals stays
-            bestKey = key;
-            bestF = f;
-            bestT = t;
+    for (int ab = wave; ab < nAB; ab += W) {
+        int a, b;
+        divmod_small(ab, n2, n2Inv, a, b);
+        y[0] = lo[0] + a;
+        y[2] = lo[2] + b;
+        const unsigned tAB = static_cast<unsigned>(ab) * static_cast<unsigned>(nCD);
+        for (int cd = lane; cd < nCD; cd += 64) {
+            int c, d;
+            divmod_small(cd, n6, n6Inv, c, d);
+            y[4] = lo[4] + c;
+            y[6] = lo[6] + d;
+            const double key = oc.useConstraints ? opt_violation(y, oc, lfRow, rhRow) : 0.0;
+            const double f = opt_objective(y, oc, nIdx, cIdx, lfRow, rhRow);
+            if (key < bestKey || (key == bestKey && f < bestF)) {
+                bestKey = key;
+                bestF = f;
+                bestT = tAB + static_cast<unsigned>(cd);
+            }
         }
     }
     opt_wave_min(bestKey, bestF, bestT);
-    {
-        unsigned r = bestT;
-        const unsigned d = r % n6; r /= n6;
-        const unsigned c = r % n4; r /= n4;
-        const unsigned b = r % n2;
-        const unsigned a = r / n2;
-        x[0] = lo[0] + static_cast<int>(a);
-        x[2] = lo[2] + static_cast<int>(b);
-        x[4] = lo[4] + static_cast<int>(c);
-        x[6] = lo[6] + static_cast<int>(d);
-    }
-    minf = bestF;
-    return bestKey > 0.0 ? 2 : 0;
+    return OptBest{bestKey, bestF, bestT, 0u};
+}
+
+// Third part (wavefront 0): the winner's point.
+__device__ int opt_solve_end(const OptBest& best, const int (&lo)[8], const int (&up)[8], double (&x)[8], double& minf) {
+    const int n2 = up[2] - lo[2] + 1, n4 = up[4] - lo[4] + 1, n6 = up[6] - lo[6] + 1;
+    const int nCD = n4 * n6;
+    int ab, cd, a, b, c, d;
+    divmod_small(static_cast<int>(best.t), nCD, rcp_small(nCD), ab, cd);
+    divmod_small(ab, n2, rcp_small(n2), a, b);
+    divmod_small(cd, n6, rcp_small(n6), c, d);
+    x[0] = lo[0] + a;
+    x[2] = lo[2] + b;
+    x[4] = lo[4] + c;
+    x[6] = lo[6] + d;
+    minf = best.f;
+    return best.key > 0.0 ? 2 : 0;
 }
 
 struct OptShared {
     double cur[4][3];  // RF,RH,LH,LF_optCurrentPosition_
-    double cenX[4], cenY[4];
-    double resX[4], resY[4];
-    int bandBegin[4], bandEnd[4];
-    int code[4];
+    float vals[4][kOptBoxCells];  // per-leg scratch of the mean heights
 };
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void opt_track_kernel(DevMap m, PlanConsts pc, OptConsts oc, const fpe_pose* __restrict__ poses, int B,
-                                                       int nCycles, const uint8_t* __restrict__ cycleOk, fpe_opt_out out) {
+// W wavefronts per pose: 1 for batches (throughput: a pose per wavefront), 8 for a handful of poses (512 threads keep the 256-register budget: 1024 halve it and spill) — the service call
+// plans ONE pose, and the optimiser's box (14 641 row points per cycle at 2 cm) would otherwise be walked by one
+// wavefront, cycle after cycle.  Wavefront 0 runs the track; the others wait at the workgroup barrier (they consume no
+// issue slots there), take their slice of the row search when wavefront 0 publishes a problem, and hand back their best.
+template <int W>
+__global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts pc, OptConsts oc, const fpe_pose* __restrict__ poses, int B,
+                                                           int nCycles, const uint8_t* __restrict__ cycleOk, fpe_opt_out out) {
     __shared__ OptShared sh;
+    __shared__ OptBest slots[W];
+    __shared__ OptProblem probs[2];  // by cycle parity: wavefront 0 may publish cycle g + 1 while a helper still reads cycle g
     const int b = blockIdx.x;
     if (b >= B) return;
-    const int lane = static_cast<int>(threadIdx.x);
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    const int wave = static_cast<int>(threadIdx.x) >> 6;
+    if constexpr (W > 1) {
+        if (wave > 0) {  // helper wavefronts: the row search only
+            for (int cyc = 0; cyc < nCycles; ++cyc) {
+                __syncthreads();  // (A) the cycle's problem is published
+                const OptProblem& prob = probs[cyc & 1];
+                const int run = prob.run;
+                if (run < 0) return;
+                if (run == 0) continue;
+                int nIdx[8], cIdx[8], lo[8], up[8];
+                double x[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    nIdx[k] = prob.nIdx[k];
+                    cIdx[k] = prob.cIdx[k];
+                    lo[k] = prob.lo[k];
+                    up[k] = prob.up[k];
+                    x[k] = prob.x[k];
+                }
+                const OptBest mine = opt_solve_rows<W>(oc, nIdx, cIdx, lo, up, prob.lfRow, prob.rhRow, lane, wave, x);
+                if (lane == 0) slots[wave] = mine;
+                __syncthreads();  // (B) every slice's best is in place
+            }
+            return;
+        }
+    }
     const Grp<16> g(lane);
     const int leg = lane >> 4;  // RF, RH, LH, LF: 16 lanes each
     const fpe_pose* pp = poses + b;
     const double x0 = pp->position[0], y0 = pp->position[1], z0 = pp->position[2];
     const int gait = pp->gait;
     const float rOverride = pp->leg_search_radius[leg];
+    // the nominal track's cycle flags of this pose, fetched once (device-mapped host memory for small calls: a PCIe round
+    // trip each): lane l holds cycles l, l + 64, l + 128, l + 192
+    unsigned long long okMask[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + 64 * q;
+        okMask[q] = __ballot(c < nCycles && cycleOk[static_cast<size_t>(b) * nCycles + c] != 0);
+    }
     const float Rf = rOverride > 0.0f ? rOverride : pc.searchRadius;  // searchRadius_ (cpp:1616-1617)
     const double lx = static_cast<double>(Rf * 2), ly = static_cast<double>(Rf);
     const bool odd = (leg & 1) != 0, high = (leg & 2) != 0;
@@ -244,6 +353,7 @@ __global__ __launch_bounds__(64) void opt_track_kernel(DevMap m, PlanConsts pc, 
     double lfRow = oc.lfRow0, rhRow = oc.rhRow0;        // cpp:36
     int failCycle = 255;
     bool stopped = gait != 0;  // the walk gait (build-defined) has no opt track: zero records
+    bool helpersGone = false;  // (W > 1) the helper wavefronts have been told to leave
 
     for (int cyc = 0; cyc < nCycles; ++cyc) {
         const size_t oCyc = static_cast<size_t>(b) * nCycles + cyc;
@@ -265,6 +375,13 @@ __global__ __launch_bounds__(64) void opt_track_kernel(DevMap m, PlanConsts pc, 
                 stopped = true;
                 failCycle = cyc;
                 rec.gate_failed = 1;
+            }
+        }
+        if constexpr (W > 1) {
+            if (stopped && !helpersGone) {
+                if (lane == 0) probs[cyc & 1].run = -1;
+                __syncthreads();  // (A) of this cycle: the helpers read run = -1 and return
+                helpersGone = true;
             }
         }
         if (!stopped) {
@@ -295,7 +412,13 @@ __global__ __launch_bounds__(64) void opt_track_kernel(DevMap m, PlanConsts pc, 
                     int cnt = 0;
                     if (r < ni) {
                         const float* row = m.trav + static_cast<size_t>(gm.i0 + ss.i0 + r) * m.g.cols + (gm.j0 + ss.j0);
-                        for (int c = 0; c < nj; ++c) cnt += (row[c] < pc.thrDefault) ? 1 : 0;  // raw compare: NaN passes (cpp:1653, 1736)
+                        for (int c0 = 0; c0 < nj; c0 += 8) {  // eight loads in flight (a plain loop waits for each)
+                            float v[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) v[u] = row[min(c0 + u, nj - 1)];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) cnt += (c0 + u < nj && v[u] < pc.thrDefault) ? 1 : 0;  // raw compare: NaN passes (cpp:1653, 1736)
+                        }
                     }
                     anyBelow |= cnt > 0;
                     const unsigned long long mk = g.ballot(r < ni && 2 * cnt > nj);  // cpp:1743
@@ -345,18 +468,11 @@ __global__ __launch_bounds__(64) void opt_track_kernel(DevMap m, PlanConsts pc, 
                 if (code <= 4) {
                     // cpp:1696-1710: the band's rows as rows of gaitMap_, through the position of the rectangle's cell (row, 1);
                     // ONE Position for both conversions (a failed getPosition keeps it; uninitialised before the first: (0,0))
-                    double qx = 0.0, qy = 0.0;
-                    if (in_range(bandB, 1, ni, nj)) {
-                        qx = cell_pos(ss.baseX, gm.g.res, bandB);
-                        qy = cell_pos(ss.baseY, gm.g.res, 1);
-                    }
+                    double qx = 0.0;
+                    if (in_range(bandB, 1, ni, nj)) qx = cell_pos(ss.baseX, gm.g.res, bandB);
                     beginRow = index_of(qx, gm.g.orgX, gm.g.posX, gm.g.res);
-                    if (in_range(bandE, 1, ni, nj)) {
-                        qx = cell_pos(ss.baseX, gm.g.res, bandE);
-                        qy = cell_pos(ss.baseY, gm.g.res, 1);
-                    }
+                    if (in_range(bandE, 1, ni, nj)) qx = cell_pos(ss.baseX, gm.g.res, bandE);
                     endRow = index_of(qx, gm.g.orgX, gm.g.posX, gm.g.res);
-                    (void)qy;
                     cenX = hasCell ? cell_pos(ss.baseX, gm.g.res, newRow) : nx;  // cpp:1816 / cpp:1688-1689
                     cenY = hasCell ? cell_pos(ss.baseY, gm.g.res, newCol) : ny;
                 }
@@ -390,7 +506,38 @@ __global__ __launch_bounds__(64) void opt_track_kernel(DevMap m, PlanConsts pc, 
             }
             // ---- STEP(4) the optimiser (build-defined) ----
             double x[8], minf;
-            const int status = opt_solve(oc, nIdx, cIdx, lo, up, lfRow, rhRow, lane, x, minf);
+            int status = opt_solve_begin(oc, nIdx, cIdx, lo, up, lfRow, rhRow, lane, x, minf);
+            if constexpr (W > 1) {
+                OptProblem& prob = probs[cyc & 1];
+                if (lane == 0) {
+                    prob.run = status < 0 ? 1 : 0;
+                    prob.lfRow = lfRow;
+                    prob.rhRow = rhRow;
+                }
+                if (status < 0 && lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        prob.nIdx[k] = nIdx[k];
+                        prob.cIdx[k] = cIdx[k];
+                        prob.lo[k] = lo[k];
+                        prob.up[k] = up[k];
+                        prob.x[k] = x[k];
+                    }
+                }
+                __syncthreads();  // (A)
+            }
+            if (status < 0) {
+                OptBest best = opt_solve_rows<W>(oc, nIdx, cIdx, lo, up, lfRow, rhRow, lane, 0, x);
+                if constexpr (W > 1) {
+                    if (lane == 0) slots[0] = best;
+                    __syncthreads();  // (B)
+                    OptBest o{__builtin_huge_val(), __builtin_huge_val(), 0xFFFFFFFFu, 0u};
+                    if (lane < W) o = slots[lane];
+                    opt_wave_min(o.key, o.f, o.t);
+                    best = o;
+                }
+                status = opt_solve_end(best, lo, up, x, minf);
+            }
             rec.solver_status = static_cast<uint8_t>(status);
             rec.minf = minf;
 #pragma unroll
@@ -421,9 +568,9 @@ __global__ __launch_bounds__(64) void opt_track_kernel(DevMap m, PlanConsts pc, 
                     myJ = j;
                 }
             }
-            const bool commit = cycleOk[oCyc] != 0;  // footholdValidation_ of the NOMINAL track (cpp:1323-1332)
-            float z = 0.0f;
-            if (g.sub == 0) z = opt_mean_height(gm.g, m.elev, m.g.cols, gm.i0, gm.j0, myX, myY, pc.rf, pc.rf2, pc.h);  // on gaitMap_
+            const bool commit = ((okMask[(cyc >> 6) & 3] >> (cyc & 63)) & 1ull) != 0ull;  // footholdValidation_ of the NOMINAL track (cpp:1323-1332)
+            const float zLane = opt_mean_height(g, sh.vals[leg], gm.g, m.elev, m.g.cols, gm.i0, gm.j0, myX, myY, pc.rf, pc.rf2, pc.h);  // on gaitMap_
+            const float z = __shfl(zLane, 16 * leg);
             fh.x = myX;
             fh.y = myY;
             fh.z = z;
@@ -453,6 +600,7 @@ __global__ __launch_bounds__(64) void opt_track_kernel(DevMap m, PlanConsts pc, 
 
 hipError_t launch_opt_track(const DevMap& m, const PlanConsts& pc, const OptConsts& oc, const fpe_pose* d_poses, int B, int nCycles,
                             const uint8_t* d_cycleOk, const fpe_opt_out& d_out, hipStream_t stream) {
-    hipLaunchKernelGGL(opt_track_kernel, dim3(B), dim3(64), 0, stream, m, pc, oc, d_poses, B, nCycles, d_cycleOk, d_out);
+    if (B <= 64) hipLaunchKernelGGL(opt_track_kernel<8>, dim3(B), dim3(64 * 8), 0, stream, m, pc, oc, d_poses, B, nCycles, d_cycleOk, d_out);
+    else hipLaunchKernelGGL(opt_track_kernel<1>, dim3(B), dim3(64), 0, stream, m, pc, oc, d_poses, B, nCycles, d_cycleOk, d_out);
     return hipGetLastError();
 }

@@ -56,6 +56,9 @@ class FootholdPlanner:
 
     def close(self):
         if getattr(self, "_h", None):
+            for p in getattr(self, "_pinned", []):  # arrays from host_array() must not be used after close()
+                self._lib.fpe_host_free(self._h, p)
+            self._pinned = []
             self._lib.fpe_destroy(self._h)
             self._h = None
 
@@ -158,6 +161,30 @@ class FootholdPlanner:
         finally:
             self.set_tuning(**before)
 
+    # ---- pinned host arrays (fpe_host_alloc): results are written into them by DMA, no copy-out ----------
+    def host_array(self, shape, dtype):
+        """A numpy array over pinned host memory of the engine (kept alive by the planner until close())."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        self._check(self._lib.fpe_host_alloc(self._h, max(n, 1), C.byref(p)))
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        buf = (C.c_ubyte * max(n, 1)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=np.uint8, count=n).view(dtype).reshape(shape)
+        a[...] = np.zeros((), dtype)
+        return a
+
+    def plan_outputs(self, B, n_cycles, products=("nominal", "centroid", "default", "cycle_ok", "stance", "selected", "pose_status"),
+                     pinned=False):
+        shapes = {
+            "nominal": ((B, n_cycles, 4), FOOTHOLD_DTYPE), "centroid": ((B, n_cycles, 4), CENTROID_DTYPE),
+            "default": ((B, n_cycles, 4, 3), np.float64), "cycle_ok": ((B, n_cycles), np.uint8),
+            "stance": ((B, 4, 3), np.float64), "selected": ((B, n_cycles, 4), SELECTED_DTYPE), "pose_status": ((B,), np.uint8),
+        }
+        make = self.host_array if pinned else (lambda shape, dt: np.zeros(shape, dtype=dt))
+        return {k: make(*shapes[k]) for k in products}
+
     # ---- chained plan, host buffers ------------------------------------------------------------------
     def plan(self, poses, n_cycles, products=("nominal", "centroid", "default", "cycle_ok", "stance", "selected", "pose_status"),
              out=None):
@@ -174,6 +201,8 @@ class FootholdPlanner:
                   "stance": "stance", "selected": "selected", "pose_status": "pose_status"}
         if out is None:
             out = {k: np.zeros(shapes[k][0], dtype=shapes[k][1]) for k in products}
+        else:
+            products = tuple(k for k in products if k in out)
         po = PlanOut()
         for k in products:
             assert out[k].shape == shapes[k][0] and out[k].dtype == shapes[k][1]

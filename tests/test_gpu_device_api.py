@@ -267,3 +267,32 @@ def test_multi_device_group_shards_a_batch_through_the_c_abi(n_engines, B):
     ora["pose_status"] = omap.pose_status(op, opo)
     util.assert_plan_equal(eng, ora)
     mp.close()
+
+
+@pytest.mark.parametrize("config,batch", [("headline", 512), ("cfg4", 1024)])
+def test_bench_two_ranks_on_one_gpu(config, batch):
+    """The N > 1 path of bench.py on the 1-GPU box: `python bench.py --gpus 2` starts its two rank processes itself
+    (fresh children of a child that never touches the GPU; FPE_BENCH_SHARE_GPU=1 puts both on cuda:0 with gloo
+    collectives — RCCL refuses two ranks on one device).  The JSON must name the 2-rank exchange, carry the exchange
+    accounting, and every rank's shard must equal the oracle (`verified`)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FPE_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", config, "--batch", str(batch),
+                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--gather-every", "2"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert "2 ranks in the process group" in line["config"]["exchange"] and "gloo" in line["config"]["exchange"]
+    assert line["config"]["verified"] is True
+    assert line["config"]["footholds_per_step"] == 2 * batch * line["config"]["n_cycles"] * 4
+    assert line["config"]["exchange_bytes_per_rank"] == batch * line["config"]["n_cycles"] * 4 * 16
+    assert line["config"]["exchange_alt"]["gather_every"] == 2
+    assert line["value"] > 0 and "roofline" in line
