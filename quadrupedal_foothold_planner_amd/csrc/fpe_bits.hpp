@@ -53,6 +53,21 @@ __global__ __launch_bounds__(256) void build_bitmap_kernel(const float* __restri
 
 // (bit_group_index: fpe_device.hpp — the tiled plane layout, shared with win_issue)
 
+// Synchronisation of the lanes of a pose in the bit-window kernels.  A pose never spans more than ONE wavefront here
+// (8 lanes per leg: half a wavefront; one wavefront per pose), and the LDS operations of a wavefront execute in order:
+// the compiler must not reorder across the point, nothing has to be waited for.  (pose_sync<64> of the direct kernels is
+// a workgroup barrier — a pose owns four wavefronts there — which also waits for every outstanding global load and
+// store of the wavefront: in the one-wavefront-per-pose kernels that serialised the leg's loads with its LDS hand-offs.)
+template <int G>
+__device__ __forceinline__ void bits_sync() {
+#ifdef FPE_BITS_BARRIER_SYNC
+    pose_sync<G>();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+
 // 64-lane kernels: upper bound of a CircleIterator bounding box (cells) whose elevations are compacted into LDS
 constexpr int kBitsMaxBoxCells = 128;
 
@@ -495,7 +510,7 @@ __device__ __forceinline__ void heights3_finish(const Grp<G>& g, float* hs, cons
         if (kB < padEnd) hs[kBitsMaxBoxCells + kB] = -0.0f;
         if (kC < padEnd) hs[2 * kBitsMaxBoxCells + kC] = -0.0f;
     }
-    pose_sync<G>();
+    bits_sync<G>();
     const int d = min(g.sub >> 4, 2);
     const float* p = hs + d * kBitsMaxBoxCells;
     float sum = 0.0f;
@@ -687,7 +702,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             // masks by ballots over the columns, one window row at a time
             folded = window_column_rows<G, KW>(m.g, c, g, jw0, lb.colRows);
             if (folded) {
-                pose_sync<G>();
+                bits_sync<G>();
                 // Column intervals -> row masks without a ballot per row.  Column c is inside for the rows [lo_c, hi_c): it
                 // ENTERS at row lo_c and LEAVES at row hi_c.  Each column sets its bit in the "enters" word of its first
                 // row and in the "leaves" word of its end row (LDS atomic OR; two scratch row arrays that are free here);
@@ -701,7 +716,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                     entersAt[idx] = 0u;
                     leavesAt[idx] = 0u;
                 }
-                pose_sync<G>();
+                bits_sync<G>();
 #pragma unroll
                 for (int u = 0; u < (32 * KW + G - 1) / G; ++u) {
                     const int col = g.sub + G * u;
@@ -715,7 +730,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                         }
                     }
                 }
-                pose_sync<G>();
+                bits_sync<G>();
                 unsigned inside[NRL][KW];
                 // rows a candidate's foot disc can touch: within nRings + footReach rows of the centre row (winH)
                 const int reachRows = min(c.nRings + pc.footReach, pc.winH);
@@ -759,7 +774,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             }
         }
     }
-    pose_sync<G>();
+    bits_sync<G>();
     // (2) erosion with the foot-disc offset table: E bit (row, col) = AND_k P(row + da_k, col + db_k)
     const uint32_t* E = lb.a;
     if (!kOneCellFoot && pc.nFoot > 1 && pc.nHW > 0) {
@@ -801,7 +816,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                     if (ri < NR) lb.h0[hw * lb.hStride + ri * KW + q] = T[q];
             }
         }
-        pose_sync<G>();
+        bits_sync<G>();
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
             const int ri = g.sub + G * k;
@@ -820,7 +835,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             for (int q = 0; q < KW; ++q)
                 if (ri < NR) lb.a[ri * KW + q] = e[q];  // the P rows are dead: E takes their place
         }
-        pose_sync<G>();
+        bits_sync<G>();
     } else if (!kOneCellFoot && pc.nFoot > 1) {
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
@@ -845,7 +860,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             for (int q = 0; q < KW; ++q)
                 if (ri < NR) lb.h0[ri * KW + q] = e[q];
         }
-        pose_sync<G>();
+        bits_sync<G>();
         E = lb.h0;
     }
     // Two forms of the candidate scan, chosen per kernel shape by measurement (A/B on the BASELINE configurations):
@@ -1081,7 +1096,7 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
         vx[4] = nx2 - hx;  vy[4] = ny + hy;
         vx[5] = nx2 + hx;  vy[5] = ny + hy;
     }
-    if (G == 64 && polyKind != 0) pose_sync<G>();  // the vertices are read by the other lanes of the wavefront
+    if (G == 64 && polyKind != 0) bits_sync<G>();  // the vertices are read by the other lanes of the wavefront
     LegCtx c;
     c.cyc = cyc;
     c.cx = nx1;  // centre from the CENTROID track (cpp:861-862)
@@ -1150,10 +1165,10 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
             for (int q = 0; q < KW; ++q)
                 if (g.sub + G * k < lb.rows) lb.a[(g.sub + G * k) * KW + q] = w.Df[k][q];
         const CentroidScan sc = rows_from_bits<G, NRL, KW>(sm, w, g, iw0, jw0);
-        pose_sync<G>();
+        bits_sync<G>();
         stamp(pc, cyc, 4);
         const bool defaultOk = default_ok_bits<G, KW, kMid>(m, pc, c.cx, c.cy, bb, dc, lb.a, lb.rows, iw0, jw0, g);  // cpp:2012
-        pose_sync<G>();  // lb doubles as scratch below
+        bits_sync<G>();  // lb doubles as scratch below
         bool unused;
         float zCentre = 0.0f;
         TermSum osA{nullptr, 0, 0, 0.0f}, osB{nullptr, 0, 0, 0.0f}, osC{nullptr, 0, 0, 0.0f};
@@ -1187,7 +1202,7 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
         } else {
             nominal_invalid(no, c.cx, c.cy, 2);
             int wi = 0, wj = 0;
-            pose_sync<G>();
+            bits_sync<G>();
 #ifdef FPE_TRACE
             const long long tSp0 = __builtin_readcyclecounter();
 #endif
@@ -1207,7 +1222,7 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
                 no.x = cell_pos(m.g.baseX, m.g.res, wi);  // cpp:2105-2107
                 no.y = cell_pos(m.g.baseY, m.g.res, wj);
             }
-            pose_sync<G>();
+            bits_sync<G>();
         }
         stamp(pc, cyc, 8);
         if constexpr (G == 64) {
@@ -1664,10 +1679,10 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
 #pragma unroll
         for (int k = 0; k < NRL; ++k) lb.a[g.sub + G * k] = w.Df[k][0];
         const CentroidScan sc = rows_from_bits<G, NRL, KW>(sm, w, g, iw0, jw0);
-        pose_sync<G>();
+        bits_sync<G>();
         stamp(pc, cyc, 4);
         const bool defaultOk = default_ok_bits<G, KW, kMid>(m, pc, c.cx, c.cy, bb, dc, lb.a, lb.rows, iw0, jw0, g);  // cpp:2012
-        pose_sync<G>();  // lb doubles as scratch below
+        bits_sync<G>();  // lb doubles as scratch below
         bool unused;
         float zCentre = 0.0f;
         if constexpr (kDefer) {
@@ -1701,7 +1716,7 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
         } else {
             nominal_invalid(no, c.cx, c.cy, 2);
             int wi = 0, wj = 0;
-            pose_sync<G>();
+            bits_sync<G>();
             if (spiral_bits<G, NRL, KW, kMid>(m, pc, lut, head, c, w, lb, g, iw0, jw0, wi, wj, &ye)) {  // cpp:2022
                 no.valid = 1;
                 no.source = 1;
@@ -1711,7 +1726,7 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
                 no.y = cell_pos(m.g.baseY, m.g.res, wj);
                 no.z = zCentre;  // z at the DEFAULT centre even for a candidate (cpp:2029)
             }
-            pose_sync<G>();
+            bits_sync<G>();
         }
         stamp(pc, cyc, 8);
         if constexpr (kDefer) {
@@ -2001,7 +2016,7 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
                 const unsigned inside = (i >= iA && i <= iB) ? ye.pmask : 0u;
                 if (ri < NR) lb.a[ri] = ~w.F[k][0] | (~w.C[k][0] & inside);
             }
-            pose_sync<G>();
+            bits_sync<G>();
             const int rowW = ici - iw0, colW = icj - jw0;  // the centre inside the window (winH, winH)
             static_assert(kLutHeadRounds == 2, "both register rounds are evaluated side by side");
             // both rounds' pass bits in flight together, one broadcast of the winning entry
@@ -2019,7 +2034,7 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
             wi = ici + static_cast<int16_t>(eWin & 0xFFFF);
             wj = icj + (eWin >> 16);
             searched = lk.nCand <= G * kLutHeadRounds;  // nothing beyond the two rounds
-            pose_sync<G>();
+            bits_sync<G>();
         }
         if (!found && !searched) {  // other polygons, larger foot discs, small search radii, or no hit in the first two rounds
             LegCtx c;
@@ -2055,10 +2070,10 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
                     vx[4] = nx2 - hx;  vy[4] = ny + hy;
                     vx[5] = nx2 + hx;  vy[5] = ny + hy;
                 }
-                pose_sync<G>();
+                bits_sync<G>();
             }
             found = spiral_bits<G, NRL, KW, true>(m, pc, lut, head, c, w, lb, g, iw0, jw0, wi, wj, &yeIn);  // cpp:2022
-            pose_sync<G>();
+            bits_sync<G>();
         }
         if (found) {
             no.valid = 1;
@@ -2216,7 +2231,7 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
             sh.cur[t][leg][2] = sz;
         }
     }
-    pose_sync<G>();
+    bits_sync<G>();
     stamp(pc, 1, 12);
     if (out.pose_status) {
         // getGaitCycleSearchGridMap's getSubmap in the first cycle (opt_gate_cycle0), its four corners on four lanes
@@ -2280,7 +2295,7 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
                 if (g.sub == k) mine = a;
             }
             fill_yentry(m.g, pc, ls, (y0 + mine) + ls.biasY, ytab[g.sub]);  // cpp:2201, 2414
-            pose_sync<G>();
+            bits_sync<G>();
             stamp(pc, 1, 14);
         }
         const YEntry& ye = ytab[cyc & 7];
@@ -2318,7 +2333,7 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
                     sh.cur[t][leg][1] = lc.v[t][1];
                 }
             }
-            pose_sync<G>();
+            bits_sync<G>();
             cycleOk = cycleOk && phaseOk;
             stamp(pc, cyc, 10);
         }
@@ -2332,7 +2347,7 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
                 stamp(pc, 2, 11);
                 if (live && c0 + g.sub <= cyc) flush_unit(m, pc, units[g.sub], ytab[g.sub], b, c0 + g.sub, leg, nCycles, okBits, out);
                 okBits = 0u;
-                pose_sync<G>();  // the units and the y entries are rewritten next
+                bits_sync<G>();  // the units and the y entries are rewritten next
                 stamp(pc, 2, 12);
             }
         } else {

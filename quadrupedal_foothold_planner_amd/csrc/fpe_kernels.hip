@@ -33,6 +33,19 @@ __device__ __forceinline__ void stamp(const PlanConsts& pc, int cyc, int point) 
 #ifdef FPE_TRACE
     if (pc.trace && blockIdx.x < 256 && cyc < 8 && threadIdx.x == 0)
         pc.trace[(static_cast<size_t>(blockIdx.x) * 8 + cyc) * 16 + point] = __builtin_readcyclecounter();
+#ifdef FPE_TRACE_ALL_BLOCKS  // (start, end, hardware id) of EVERY block behind the 256 x 8 x 16 stage table: residency studies
+    if (pc.trace && cyc == 6 && point >= 14 && threadIdx.x == 0 && blockIdx.x < 65536) {
+        pc.trace[256 * 8 * 16 + static_cast<size_t>(blockIdx.x) * 4 + (point - 14)] = __builtin_readcyclecounter();
+        if (point == 14) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            pc.trace[256 * 8 * 16 + static_cast<size_t>(blockIdx.x) * 4 + 2] = hw;
+            pc.trace[256 * 8 * 16 + static_cast<size_t>(blockIdx.x) * 4 + 3] = xcc;
+        }
+    }
+#endif
 #else
     (void)pc;
     (void)cyc;
