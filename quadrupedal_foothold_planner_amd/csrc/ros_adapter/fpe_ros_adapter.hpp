@@ -106,6 +106,40 @@ public:
         return true;
     }
 
+    // The same call with the opt track's products as well: global_footholds_opt (cpp:221, 1510-1532;
+    // like the centroid message never cleared between calls: appended) and footholdsKPI_.feetDistance_opt / cogSpeed_opt
+    // (cpp:1488-1499).  `optParams` are the node's nlopt/* parameters (cpp:297-307); lfCurrentRow / rhCurrentRow are
+    // file-scope globals in the reference (cpp:36) that survive from one service call to the next: the CALLER keeps them
+    // (`lfRhCurrentRow`, zero at node start) and this function hands back the values the call left.  The optimiser behind
+    // it is build-defined (include/fpe.h): the node's NLopt dependency is not needed for this call.
+    bool planWithOptTrack(const fpe_params& params, fpe_opt_params optParams, double lfRhCurrentRow[2], const double initialPose[3],
+                          uint8_t gaitCycles, foothold_planner_msgs::GlobalFootholds& msg,
+                          foothold_planner_msgs::GlobalFootholds& optMsg, std::vector<double>& cogSpeedOpt,
+                          std::vector<double>& feetDistanceOpt) {
+        optParams.lf_current_row0 = lfRhCurrentRow[0];
+        optParams.rh_current_row0 = lfRhCurrentRow[1];
+        std::unique_ptr<fpe_global_footholds> resp(new fpe_global_footholds), opt(new fpe_global_footholds);
+        std::unique_ptr<fpe_track_report> repOpt(new fpe_track_report);
+        std::vector<fpe_opt_cycle> cycles(std::max<size_t>(gaitCycles, 1));
+        if (fpe_plan_service_opt(h_, &params, &optParams, initialPose, gaitCycles, resp.get(), nullptr, nullptr, nullptr, nullptr, nullptr,
+                                 opt.get(), repOpt.get(), cycles.data()) != FPE_OK)
+            return false;  // FPE_E_SERVICE_FALSE: getGaitCycleSearchGridMap failed in some cycle (cpp:931-934)
+        fill(*resp, msg, true);
+        const uint8_t keepGaitCycles = optMsg.gait_cycles;  // never written by the reference (cpp:743)
+        fill(*opt, optMsg, false);
+        optMsg.gait_cycles = keepGaitCycles;
+        const fpe_track_report& rep = *repOpt;
+        cogSpeedOpt.assign(rep.cog_speed, rep.cog_speed + rep.n_kpi);
+        feetDistanceOpt.assign(rep.feet_distance, rep.feet_distance + rep.n_kpi);
+        // cpp:1561-1568: the rows of the last COMMITTED cycle's LF / RH feet on that cycle's gait-cycle submap
+        for (int g = 0; g < gaitCycles; ++g)
+            if (cycles[static_cast<size_t>(g)].committed) {
+                lfRhCurrentRow[0] = cycles[static_cast<size_t>(g)].x[0];
+                lfRhCurrentRow[1] = cycles[static_cast<size_t>(g)].x[2];
+            }
+        return true;
+    }
+
     const char* lastError() const { return fpe_last_error(h_); }
     fpe_handle handle() const { return h_; }
 
