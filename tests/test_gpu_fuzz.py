@@ -70,6 +70,8 @@ def test_random_differential_campaign():
     seed0 = int(os.environ.get("FPE_FUZZ_SEED", "20000"))
     src = np.zeros(4, np.int64)
     codes = np.zeros(7, np.int64)
+    opt_status = np.zeros(4, np.int64)
+    opt_gates = 0
     kernels = {}
     for k in range(n_cases):
         c = make_case(seed0 + k)
@@ -89,8 +91,40 @@ def test_random_differential_campaign():
             raise AssertionError(f"case seed {seed0 + k} (res {c['res']}, group {c['group']}, literal {c['literal']}): {e}")
         src += np.bincount(eng["nominal"]["source"].ravel(), minlength=4)[:4]
         codes += np.bincount(eng["centroid"]["code"].ravel(), minlength=7)[:7]
+        # the opt track of the first poses of the case: random optimiser parameters; the oracle's exhaustive
+        # search bounds the size ((2R / res + 1)^4 lattice points per pose and cycle)
+        rng = np.random.default_rng(seed0 + k + 7_000_000)
+        if 2.0 * float(c["params"]["searchRadius"][0]) / c["res"] <= 26.0:
+            nb = 6
+            planner.opt_params = _capi.opt_params_yaml()
+            planner.opt_params["use_inequality_constraints"] = int(rng.integers(0, 2))
+            if rng.random() < 0.5:
+                for key in ("w1", "w2", "w3", "w4", "wr", "wc"):
+                    planner.opt_params[key] = float(rng.uniform(0.2, 2.5))
+            if rng.random() < 0.3:
+                planner.opt_params["skew_lower_scale"], planner.opt_params["skew_upper_scale"] = 0.0, 60.0  # a feasible problem
+            if rng.random() < 0.3:
+                planner.opt_params["lf_current_row0"], planner.opt_params["rh_current_row0"] = float(rng.integers(0, 40)), float(rng.integers(0, 40))
+            try:
+                oeng = planner.plan_opt(c["poses"][:nb], c["n"], eng["cycle_ok"][:nb])
+            except FpeError as e:
+                assert e.code == _capi.FPE_E_UNSUPPORTED, e
+                oeng = None
+            if oeng is not None:
+                from oracle import fpo
+                omap = fpo.OracleMap(c["trav"], c["elev"], c["res"], c["pos"])
+                oora = omap.plan_opt(util.to_oracle_params(planner.params), util.to_oracle_opt_params(planner.opt_params),
+                                     util.to_oracle_poses(c["poses"][:nb]), c["n"], ora["cycle_ok"][:nb])
+                try:
+                    util.assert_opt_equal(oeng, oora)
+                except AssertionError as e:
+                    raise AssertionError(f"opt track, case seed {seed0 + k} (res {c['res']}): {e}")
+                opt_status += np.bincount(oeng["cycles"]["solver_status"].ravel(), minlength=4)[:4]
+                opt_gates += int((oeng["gate_fail_cycle"] != 255).sum())
     planner.close()
+    print("opt track: solver statuses", opt_status.tolist(), "poses with a failed gate", opt_gates)
     print("kernels exercised:", kernels)
     assert (src[:3] > 0).all() and (codes > 0).all(), (src, codes)
     if n_cases >= 100:
+        assert (opt_status[:3] > 0).all() and opt_gates > 0, (opt_status, opt_gates)
         assert any(k.startswith("plan_bits_kernel") for k in kernels) and any(k.startswith("plan_bits_seq_kernel") for k in kernels), kernels
