@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the ingest / open-loop / D2H side measurements (profiling runs)")
     ap.add_argument("--no-bits", action="store_true", help="run the direct kernels (fpe_set_tuning no_bits=1) instead of the bit-window kernels")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target seconds of oracle work per baseline leg")
-    ap.add_argument("--gather-every", type=int, default=8, help="N>1: secondary measurement with one all-gather every K steps")
+    ap.add_argument("--gather-every", type=int, default=8, help="N>1: one all-gather per K steps, carrying all K steps' records (1: a collective per step; measured as config.exchange_alt)")
     return ap.parse_args()
 
 
@@ -244,29 +244,33 @@ def main():
     d_sel = torch.zeros(n_rec * sel, dtype=torch.uint8, device=dev)
 
     stream = torch.cuda.current_stream()
-    # N>1: the all-gather of step k (RCCL, its own stream) overlaps the plan kernel of step k+1; two
-    # selected-record blocks are cycled (quadrupedal_foothold_planner_amd.dist.FootholdExchange) and the plan kernel
-    # writes the 16-byte records of step k straight into block k % 2.  Every gathered step's footholds reach every
-    # rank; the timed region ends after the last gather has completed.
-    ex = fdist.FootholdExchange(n_rec * sel, dev) if world > 1 else None
-    step_no = [0]
+    # N>1: every step's 16-byte selected records are exchanged (RCCL all-gather, its own stream).  The plan kernel of step k
+    # writes them straight into sub-block k % K of a staging buffer and every K-th step ONE all-gather moves the whole
+    # buffer, overlapping the plans of the next batch (quadrupedal_foothold_planner_amd.dist.BatchedFootholdExchange; two
+    # staging buffers).  K = --gather-every (default 8: "fewer, larger collectives" — a collective has a fixed cost of tens
+    # of microseconds against a 29 us headline step); K = 1 is measured as well (config.exchange_alt).  Every gathered step's
+    # footholds reach every rank; the timed region ends after the last all-gather has completed.
+    def run(batch):
+        ex_ = fdist.BatchedFootholdExchange(n_rec * sel, dev, batch=batch) if world > 1 else None
+        k_ = [0]
 
-    def step(gather_every=1):
-        k = step_no[0]
-        step_no[0] += 1
-        sel_buf = ex.acquire(k) if ex else d_sel  # waits (stream-ordered) until the gather that last read this block is done
-        planner.plan_device(d_poses.data_ptr(), B, n_cycles, d_nom.data_ptr(), d_cen.data_ptr(), d_def.data_ptr(),
-                            d_ok.data_ptr(), d_st.data_ptr(), stream=stream.cuda_stream, d_selected_ptr=sel_buf.data_ptr(),
-                            d_pose_status_ptr=d_ps.data_ptr())
-        if ex and k % gather_every == gather_every - 1:
-            ex.gather(k)
+        def step():
+            k = k_[0]
+            k_[0] += 1
+            sel_buf = ex_.acquire(k) if ex_ else d_sel  # waits (stream-ordered) until the gather that last read this buffer is done
+            planner.plan_device(d_poses.data_ptr(), B, n_cycles, d_nom.data_ptr(), d_cen.data_ptr(), d_def.data_ptr(),
+                                d_ok.data_ptr(), d_st.data_ptr(), stream=stream.cuda_stream, d_selected_ptr=sel_buf.data_ptr(),
+                                d_pose_status_ptr=d_ps.data_ptr())
+            if ex_:
+                ex_.gather(k)
 
-    def timed(gather_every):
-        """W warmup steps, then exactly K steps between barrier + synchronize pairs; MAX over ranks."""
+        # W warmup steps, then exactly K steps between barrier + synchronize pairs; MAX over ranks
         for _ in range(args.warmup):
-            step(gather_every)
-        if ex:
-            ex.drain()
+            step()
+        if ex_:
+            ex_.flush(k_[0] - 1)
+            ex_.drain()
+            k_[0] = ((k_[0] + batch - 1) // batch) * batch  # the timed region starts on a batch boundary
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if world > 1:
             dist.barrier()
@@ -274,9 +278,10 @@ def main():
         t0 = time.perf_counter()
         ev0.record(stream)
         for _ in range(args.steps):
-            step(gather_every)
-        if ex:
-            ex.drain()  # the stream waits for the in-flight all-gathers
+            step()
+        if ex_:
+            ex_.flush(k_[0] - 1)
+            ex_.drain()  # the stream waits for the in-flight all-gathers
         ev1.record(stream)
         torch.cuda.synchronize()
         if world > 1:
@@ -285,22 +290,24 @@ def main():
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item()), ev0.elapsed_time(ev1) / args.steps
+        return float(t.item()), ev0.elapsed_time(ev1) / args.steps, ex_, k_[0] - 1
 
     # HIP events on the launch stream bracket the K launches of the timed region; at N=1 the region
     # holds nothing but the K plan kernels, so elapsed/K is the mean launch duration (an upper bound
     # of the kernel time: it includes the ~2 us dispatch gap between back-to-back launches).  At N>1
     # the all-gather shares the stream, so a second, kernel-only pass measures the launch duration.
-    elapsed, kernel_ms = timed(1)
-    last_step = step_no[0] - 1
+    gather_batch = max(1, args.gather_every) if world > 1 else 1
+    elapsed, kernel_ms, ex, last_step = run(gather_batch)
     alt = None
     if world > 1:
         g = ex.result(last_step)[rank * n_rec * sel:(rank + 1) * n_rec * sel]
         mine = np.frombuffer(g.cpu().numpy().tobytes(), dtype=_capi.SELECTED_DTYPE)
-        if args.gather_every > 1:
-            el2, _ = timed(args.gather_every)
-            alt = {"gather_every": args.gather_every, "value": 4 * n_cycles * B * world * args.steps / el2,
-                   "ms_per_step": el2 / args.steps * 1e3}
+        sel_last = ex.local_block(last_step).clone()
+        if gather_batch > 1:
+            el1, _, ex1, _ = run(1)
+            alt = {"gather_every": 1, "value": 4 * n_cycles * B * world * args.steps / el1, "ms_per_step": el1 / args.steps * 1e3,
+                   "note": "one all-gather per step (2 x the collectives' fixed cost per 29 us headline step)"}
+            del ex1
         k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         k0.record(stream)
         for _ in range(args.steps):
@@ -326,11 +333,9 @@ def main():
         "default": d_def.cpu().numpy().reshape(B, n_cycles, 4, 3),
         "cycle_ok": d_ok.cpu().numpy().reshape(B, n_cycles),
         "stance": d_st.cpu().numpy().reshape(B, 4, 3),
-        "selected": (ex.local[last_step % ex.depth] if ex else d_sel).cpu().numpy().view(_capi.SELECTED_DTYPE).reshape(B, n_cycles, 4),
+        "selected": (sel_last if world > 1 else d_sel).cpu().numpy().view(_capi.SELECTED_DTYPE).reshape(B, n_cycles, 4),
         "pose_status": d_ps.cpu().numpy(),
     }
-    if ex and alt:  # the alternate run overwrote the exchange blocks; the kernel-only pass refreshed d_sel
-        eng["selected"] = d_sel.cpu().numpy().view(_capi.SELECTED_DTYPE).reshape(B, n_cycles, 4)
     verified, why = verify_plan(eng, trav, elev, res, params, poses, n_cycles)
     if world > 1:
         nom_host = eng["nominal"].reshape(-1)
@@ -397,7 +402,8 @@ def main():
             "default_hit_fraction": float((src == 0).mean()),
             "centroid_code_fractions": [float(c) for c in codes],
             "exchange": (f"all_gather_into_tensor of the selected footholds (16 B records written by the plan kernel: grid index, z, "
-                         f"flags), every step, overlapped with the next step's plan kernel; backend {backend}, "
+                         f"flags): EVERY step's records, one collective per {gather_batch} steps ({gather_batch} x the bytes), overlapped "
+                         f"with the plan kernels of the next batch; backend {backend}, "
                          f"{dist.get_world_size()} ranks in the process group") if world > 1 else "none",
         },
         "roofline": {

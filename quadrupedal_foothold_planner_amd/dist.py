@@ -118,6 +118,86 @@ class FootholdExchange:
                 self.work[slot] = None
 
 
+class BatchedFootholdExchange:
+    """The exchange of a stream of plans in collectives of `batch` steps: step k writes its selected records into
+    sub-block k % batch of a staging buffer, and every `batch`-th step ONE all-gather moves the whole buffer — every
+    step's footholds still reach every rank, in 1 / batch as many collectives of batch times the size.  xGMI is point
+    to point and a collective has a fixed cost of tens of microseconds: the headline step is a 29 us kernel with 2 MB of
+    records per rank, so per-step gathers are launch-bound long before they are link-bound ("fewer, larger
+    collectives").  `depth` staging buffers are cycled so that the gather of one batch overlaps the plans of the next; a
+    buffer is handed out again only after the all-gather that read it has completed (stream-ordered wait).
+
+        ex = BatchedFootholdExchange(local_bytes, device, batch=8)
+        for k in range(steps):
+            buf = ex.acquire(k)          # device block the plan of step k writes its selected records into
+            plan(..., d_selected_ptr=buf.data_ptr())
+            ex.gather(k)                 # launches the batch's all-gather after its last step (asynchronous)
+        ex.flush(steps - 1)              # a trailing partial batch
+        all_footholds = ex.result(steps - 1)   # [world * local_bytes] of that step, rank order
+        ex.drain()
+    """
+
+    def __init__(self, local_bytes, device, batch=8, depth=2):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.batch = max(1, int(batch))
+        self.depth = depth
+        self.local_bytes = int(local_bytes)
+        n = self.local_bytes * self.batch
+        self.stage = [torch.zeros(n, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.out = [torch.empty(n * self.world, dtype=torch.uint8, device=device) if self.world > 1 else None for _ in range(depth)]
+        self.work = [None] * depth
+        self.launched = [-1] * depth  # last step whose batch was gathered from this buffer
+
+    def _slot(self, k):
+        return (k // self.batch) % self.depth
+
+    def _wait(self, slot):
+        if self.work[slot] is not None:
+            self.work[slot].wait()
+            self.work[slot] = None
+
+    def acquire(self, k):
+        slot = self._slot(k)
+        if k % self.batch == 0:
+            self._wait(slot)  # the gather that last read this buffer
+        lb = self.local_bytes
+        return self.stage[slot][(k % self.batch) * lb:(k % self.batch + 1) * lb]
+
+    def local_block(self, k):
+        lb = self.local_bytes
+        return self.stage[self._slot(k)][(k % self.batch) * lb:(k % self.batch + 1) * lb]
+
+    def gather(self, k):
+        if k % self.batch == self.batch - 1:
+            self._launch(k)
+
+    def flush(self, k_last):
+        """After the last step: the trailing batch, if it was not complete."""
+        if k_last >= 0 and k_last % self.batch != self.batch - 1:
+            self._launch(k_last)
+
+    def _launch(self, k):
+        slot = self._slot(k)
+        self.launched[slot] = k
+        if self.world > 1:
+            self.work[slot] = dist.all_gather_into_tensor(self.out[slot], self.stage[slot], async_op=True)
+
+    def result(self, k):
+        """Records of step k from every rank, rank order (waits for that batch's all-gather)."""
+        slot = self._slot(k)
+        lb = self.local_bytes
+        sub = k % self.batch
+        if self.world == 1:
+            return self.stage[slot][sub * lb:(sub + 1) * lb]
+        self._wait(slot)
+        n = lb * self.batch
+        return torch.cat([self.out[slot][r * n + sub * lb: r * n + (sub + 1) * lb] for r in range(self.world)])
+
+    def drain(self):
+        for slot in range(self.depth):
+            self._wait(slot)
+
+
 def records_to_numpy(t, n_cycles, dtype=FOOTHOLD_DTYPE):
     a = t.detach().cpu().numpy().view(dtype)
     return a.reshape(-1, n_cycles, 4)
