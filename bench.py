@@ -613,7 +613,9 @@ def main():
         line["filters"] = {"map": f"{rows}x{cols} @ {res} m elevation layer of this workload", "ms": f_ms, "cells_per_s": rows * cols / (f_ms * 1e-3),
                            "GB/s_by_layers": (1 + 8) * rows * cols * 4 / (f_ms * 1e-3) / 1e9, "verified": f_ok,
                            "note": "fpe_traversability_device: 1 layer read + 8 layers written per cell (36 B) against ~10^3 f64 operations per "
-                                   "cell (published filters gather f64 points and a 3x3 covariance per cell): f64-VALU-bound, not HBM-bound; "
+                                   "cell (published filters gather f64 points and a 3x3 covariance per cell): bound by the SIMDs' instruction issue (per 64 cells at "
+                                   "1 cm: 6.8 k VALU + 3.1 k SALU + 0.6 k LDS instructions, VALU-active 16 % of a wavefront's lifetime at 7 wavefronts per "
+                                   "SIMD, profiles/round3_filters.txt) — loop control and LDS reads as much as f64 arithmetic — not by HBM; "
                                    "`verified`: engine against oracle on a 96 x 96 corner of the layer taken as a map of its own"}
         del d_fe, d_ft, d_fl
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -569,7 +569,7 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
 
 extern "C" {
 
-const char* fpe_version(void) { return "fpe 0.2.0 (gfx950, wave64; 8 lanes per leg and two poses per wavefront, one wavefront per pose for large windows)"; }
+const char* fpe_version(void) { return "fpe 0.3.0 (gfx950, wave64; bit-window plan kernels on tiled planes: 8 lanes per leg and two poses per wavefront, one wavefront per pose for large windows; opt track with a build-defined optimiser)"; }
 
 const char* fpe_last_error(fpe_handle) { return g_err.c_str(); }
 

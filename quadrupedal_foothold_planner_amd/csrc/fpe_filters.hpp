@@ -13,7 +13,8 @@
 // per-axis quantities — the bounding rows / columns of findSubmapParameters and the squared centre distances of
 // isInside — depend on (cell row, row offset) and (cell column, column offset) only and are tabulated in LDS by the
 // workgroup, so a visit costs one LDS read, one f64 add and one compare before the filter's own arithmetic.
-// Bound: f64 VALU (the published filters gather f64 points and a 3 x 3 covariance per cell), not HBM: 4 B read and
+// Bound: instruction issue (loop control, LDS reads and the f64 arithmetic of the published filters — points and a
+// 3 x 3 covariance per cell; profiles/round3_filters.txt), not HBM: 4 B read and
 // 4 B written per cell and layer against some thousand f64 operations per cell.
 // (included inside namespace fpe of fpe_kernels.hip, like fpe_bits.hpp)
 #pragma once

@@ -82,5 +82,38 @@ def main():
         print(name, "sources(default,candidate,none)", src, "centroid codes", codes, "cycle_ok", int(out["cycle_ok"].sum()), "/", out["cycle_ok"].size)
 
 
+# Opt track on the same maps / poses / cycle flags: tests/golden/opt/<name>_<variant>.npz hold only the
+# optimiser parameters and the opt products (the map and the plan come from the base file).
+OPT_VARIANTS = {
+    "yaml": {},                                           # constraints on: the reference's infeasible set -> least violation
+    "code": {"useInequalityConstraits": 0},               # readParameters' defaults: unconstrained
+    "weights": {"w1": 0.7, "w2": 1.3, "w3": 0.45, "w4": 2.1, "wr": 0.9, "wc": 1.15, "skewLowerScale": 0.0, "skewUpperScale": 40.0,
+                "lfCurrentRow0": 5.0, "rhCurrentRow0": 27.0},
+}
+
+
+def main_opt():
+    os.makedirs(os.path.join(OUT, "opt"), exist_ok=True)
+    for name in ("trot_2cm", "trot_1cm_r015", "harsh_2cm", "code_defaults_3cm"):
+        z = np.load(os.path.join(OUT, name + ".npz"))
+        m = fpo.OracleMap(z["trav"], z["elev"], float(z["res"]))
+        p, poses, n = z["params"].view(fpo.PARAMS_DTYPE), z["poses"].view(fpo.POSE_DTYPE), int(z["n_cycles"])
+        for vname, ov in OPT_VARIANTS.items():
+            if name == "trot_1cm_r015" and vname != "yaml":
+                continue  # 31^4 lattice points per problem: one variant is enough for a CPU test
+            op = fpo.opt_params_yaml()
+            for k, v in ov.items():
+                op[k] = v
+            o = m.plan_opt(p, op, poses, n, z["cycle_ok"])
+            np.savez_compressed(os.path.join(OUT, "opt", f"{name}_{vname}.npz"), base=name, opt_params=op, footholds=o["footholds"],
+                                cycles=o["cycles"], gate_fail_cycle=o["gate_fail_cycle"])
+            print("opt", name, vname, "status", np.bincount(o["cycles"]["solver_status"].ravel(), minlength=4).tolist(), "gate", o["gate_fail_cycle"].tolist(),
+                  "codes", np.bincount(o["cycles"]["centroid_code"].ravel(), minlength=7).tolist())
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "opt":
+        main_opt()  # (the base vectors stay as committed in round 1)
+    else:
+        main()
+        main_opt()
