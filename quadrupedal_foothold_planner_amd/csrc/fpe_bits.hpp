@@ -68,7 +68,7 @@ __device__ __forceinline__ void bits_sync() {
 #endif
 }
 
-// 64-lane kernels: upper bound of a CircleIterator bounding box (cells) whose elevations are compacted into LDS
+// 64-lane kernels: upper bound of a CircleIterator bounding box (cells): two rounds of 64 membership tests
 constexpr int kBitsMaxBoxCells = 128;
 
 // ---- window rows ------------------------------------------------------------------------------------------
@@ -81,8 +81,7 @@ struct WinRows {
 // Per-leg LDS: row masks shared between the lanes of the leg's group — a: Df rows, later P rows, then E rows (row-
 // interval erosion); f: F rows for polygons that are not folded into P; h[k]: horizontally eroded P rows, one array
 // per distinct row half-width of the disc (h[0] doubles as the E rows of the offset-by-offset erosion); colRows: the
-// polygon's row interval per window column (64-lane kernels); hs: the visited elevations of the three discs (64-lane
-// kernels).  Arrays hold `rows` window rows of KW words (the 64-lane kernels allocate 2 winH + 1 rows, not 64 * NRL:
+// polygon's row interval per window column (64-lane kernels).  Arrays hold `rows` window rows of KW words (the 64-lane kernels allocate 2 winH + 1 rows, not 64 * NRL:
 // LDS, not registers, bounds their occupancy).  The row arrays double as float scratch of a direct disc pass.
 struct LegBits {
     uint32_t* a;
@@ -90,13 +89,13 @@ struct LegBits {
     uint32_t* h0;  // array k of the eroded rows at h0 + k * hStride (a pointer array indexed at run time would live in scratch)
     int hStride;
     int* colRows;
-    float* hs;
+    float* hs;  // 96-bit-row kernels only: the visited elevations of a leg's three discs (in-chain heights, heights3_finish)
     int rows;
 };
 // words (4 bytes) of one leg's LDS: (2 + max(nHW, 1)) row arrays, then colRows and hs for the 64-lane kernels
 __host__ __device__ __forceinline__ int legbits_words(int rows, int kw, int nHW, bool wide) {
     const int arrays = 2 + (nHW > 0 ? nHW : 1);
-    return ((arrays * rows * kw + 3) & ~3) + (wide ? 2 * 32 * kw + 3 * kBitsMaxBoxCells : 0);
+    return ((arrays * rows * kw + 3) & ~3) + (wide ? 2 * 32 * kw + (kw >= 3 ? 3 * kBitsMaxBoxCells : 0) : 0);
 }
 __device__ __forceinline__ LegBits make_legbits(unsigned char* base, int rows, int kw, int nHW, bool wide) {
     LegBits lb;
@@ -333,7 +332,7 @@ struct CentroidPendingBits {
 };
 // yA / yB (optional): the two possible result ordinates cell_pos(s.baseY, res, (rightCol + 1) >> 1) and
 // cell_pos(s.baseY, res, rightCol >> 1), precomputed with the y side of the leg's geometry (YEntry).
-template <int G, bool kOneCell, bool kHaveY = false>
+template <int G, bool kOneCell, bool kHaveY = false, bool kLoad = true>
 __device__ __forceinline__ void centroid_begin_bits_impl(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const Submap& s,
                                                          const CentroidScan& sc, float zCentre, const Grp<G>& g, CentroidPendingBits& cp,
                                                          double yA, double yB) {
@@ -393,7 +392,9 @@ __device__ __forceinline__ void centroid_begin_bits_impl(const DevMap& m, const 
     else o.y = cell_pos(s.baseY, m.g.res, newCol);
     o.row = s.i0 + newRow;
     o.col = s.j0 + newCol;
-    if constexpr (kOneCell) {
+    if constexpr (!kLoad) {
+        // (the caller defers the result's height: flush_seqrec walks the offset table itself)
+    } else if constexpr (kOneCell) {
         cp.e0 = m.elev[static_cast<size_t>(o.row) * m.g.cols + o.col];  // a cell of the submap: inside the map
     } else {
         constexpr int kRounds = G >= 64 ? 1 : kDiscRounds;  // nFoot <= 64 fits one 64-lane round (bits_supported)
@@ -411,10 +412,10 @@ __device__ __forceinline__ void centroid_begin_bits_impl(const DevMap& m, const 
     }
     cp.needDisc = 1;
 }
-template <int G, bool kOneCell>
+template <int G, bool kOneCell, bool kLoad = true>
 __device__ __forceinline__ void centroid_begin_bits(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const Submap& s,
                                                     const CentroidScan& sc, float zCentre, const Grp<G>& g, CentroidPendingBits& cp) {
-    centroid_begin_bits_impl<G, kOneCell, false>(m, pc, c, s, sc, zCentre, g, cp, 0.0, 0.0);
+    centroid_begin_bits_impl<G, kOneCell, false, kLoad>(m, pc, c, s, sc, zCentre, g, cp, 0.0, 0.0);
 }
 template <int G, bool kOneCell>
 __device__ __forceinline__ void centroid_begin_bits(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const Submap& s,
@@ -1054,15 +1055,32 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
 }
 
 // One-wavefront-per-pose kernels: what a leg's four output records are made of, staged in LDS by the leg's lane 0 and
-// written out for a few cycles at a time by one lane per (cycle, leg) — full records side by side instead of eight
-// single-lane store instructions per leg (8 % of a leg's clocks on cfg-3).
-struct SeqRec {
+// finished for a few cycles at a time by one lane per (cycle, leg): full records side by side instead of eight
+// single-lane store instructions per leg — and, since round 3, the MEAN HEIGHTS leave the chain as well.  Nothing a later
+// phase reads depends on a height (the feet-polygon centre uses x and y, cpp:2421-2463; records are write-only), so the
+// chain only deposits which cells of each CircleIterator bounding box were visited (two 64-bit ballots per disc) and
+// where the box lies; flush_seqrec reads those elevations itself and runs the reference's ordered f32 sums
+// (cpp:2520-2554), up to 32 units side by side instead of one leg at a time (compaction into LDS, three serial sums,
+// three divisions per leg-phase: 15-19 % of a leg's clocks on cfg-3 / cfg-5).
+struct SeqRecBase {
     double nomX, nomY, cenX, cenY, defX, defY;
-    float nomZ, cenZ, defZ;
+    float nomZ, cenZ, defZ;  // final values of the heights that were NOT deferred (see flags)
     int32_t nomRow, nomCol, cenRow, cenCol;
-    uint32_t flags;  // nominal valid | source << 8 | centroid code << 16
+    uint32_t flags;  // nominal valid | source << 8 | centroid code << 16 | kSeqDefer* << 24
 };
-static_assert(sizeof(SeqRec) == 80 && sizeof(SeqRec) % 16 == 0, "SeqRec layout");
+struct SeqRec : SeqRecBase {  // kernels that defer the heights (64-bit rows)
+    int32_t aI0, aJ0, aNj;  // centre disc: bounding box origin and width (cells in row-major order t = a * nj + b)
+    int32_t bI0, bJ0, bNj;  // default-track disc
+    uint32_t pad[2];
+    unsigned long long visA[2], visB[2];  // bit t of word t / 64: cell t of the box is a member inside the map
+};
+static_assert(sizeof(SeqRecBase) == 80 && sizeof(SeqRec) == 144 && sizeof(SeqRec) % 16 == 0, "SeqRec layout");
+template <int KW>
+using SeqRecOf = typename std::conditional<(KW <= 2), SeqRec, SeqRecBase>::type;
+constexpr uint32_t kSeqDeferA = 1u << 24;  // zA = mean height of the centre disc, to be computed by flush_seqrec
+constexpr uint32_t kSeqDeferB = 1u << 25;  // zB (default track)
+constexpr uint32_t kSeqDeferC = 1u << 26;  // zC = mean height of the cell-centred disc of (cenRow, cenCol) (offset table)
+constexpr uint32_t kSeqCIsA = 1u << 27;    // zC = zA (whole region valid: the height at the centre, cpp:1687)
 
 // One swing leg of one phase on the bit window: the three tracks' next positions, the centroid method
 // (cpp:1605-1997) and checkFoothold (cpp:2001-2036) around the centroid track's position, the mean heights.
@@ -1072,7 +1090,7 @@ template <int G, int NRL, int KW, bool kMid, bool kDirect>
 __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut,
                                                const LutHead& head, PoseShared& sh, const LegBits& lb, const Grp<G>& g, int leg,
                                                const LegStatic& ls, double y0, double adjY, double advance, int cyc, int nCycles,
-                                               int b, bool live, const fpe_plan_out& out, LegCommit* lc, SeqRec* recs = nullptr) {
+                                               int b, bool live, const fpe_plan_out& out, LegCommit* lc, SeqRecOf<KW>* recs = nullptr) {
     const float Rf = ls.Rf;
     const int polyKind = ls.polyKind;
     const LegConst& lk = ls.lk;
@@ -1126,6 +1144,14 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
     float zDefault = static_cast<float>(static_cast<double>(0.0f) + pc.h);  // value when no cell is visited
     float* scratch = reinterpret_cast<float*>(lb.a);
     const bool wantDefault = out.default_next != nullptr;
+    // one wavefront per pose: the mean heights are deferred to flush_seqrec (SeqRec); what the chain deposits for them
+    // (64-bit-row kernels: 1 cm maps, boxes of <= 25 cells, layers that stay in the L2s.  The 96-bit-row kernels keep the
+    // heights in the chain: their boxes hold up to 81 cells of a layer that does not fit the L2s, and a flush that waits for
+    // eleven dependent load batches per disc costs more than the chain's overlapped loads — measured on cfg-5: +8 %)
+    constexpr bool kDeferH = (G == 64) && !kDirect && KW <= 2;
+    uint32_t deferFlags = 0u;
+    unsigned long long visA0 = 0ull, visA1 = 0ull, visB0 = 0ull, visB1 = 0ull;
+    int aI0 = 0, aJ0 = 0, aNj = 1, bI0 = 0, bJ0 = 0, bNj = 1;
     if (!ls.radiusOk || !centre_usable(c.cx, c.cy)) {
         nominal_invalid(no, c.cx, c.cy, ls.radiusOk ? 2 : 3);
         co.x = co.y = 0.0; co.z = 0.0f; co.row = co.col = -1; co.code = 6;
@@ -1153,9 +1179,9 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
         uint4 grp[NRL][KW + 1];
         win_issue<G, NRL, KW>(bm, m.g, g, iw0, jw0, grp);
         DiscLoads dc, dd;
-        disc_issue<G, false, kMid>(m, pc, c.cx, c.cy, bb, g, dc);
+        disc_issue<G, false, kMid, !kDeferH>(m, pc, c.cx, c.cy, bb, g, dc);
         const bool dfltUsable = wantDefault && centre_usable(nx0, ny);
-        if (dfltUsable) disc_issue<G, false, kMid>(m, pc, nx0, ny, dbox, g, dd);
+        if (dfltUsable) disc_issue<G, false, kMid, !kDeferH>(m, pc, nx0, ny, dbox, g, dd);
         stamp(pc, cyc, 3);
         WinRows<NRL, KW> w;
         win_finish<NRL, KW>(jw0, grp, w);
@@ -1172,7 +1198,29 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
         bool unused;
         float zCentre = 0.0f;
         TermSum osA{nullptr, 0, 0, 0.0f}, osB{nullptr, 0, 0, 0.0f}, osC{nullptr, 0, 0, 0.0f};
-        if constexpr (G == 64) {
+        if constexpr (kDeferH) {
+            // membership of the two discs around known centres as ballots over the bounding boxes' cells (t = round * 64 +
+            // lane, row-major: CircleIterator order); a box beyond the two rounds (never with bits_supported's bound on
+            // the foot radius) is walked here
+            if (dc.pipelined) {
+                visA0 = g.ballot(dc.vis[0] != 0);
+                visA1 = g.ballot(dc.vis[1] != 0);
+                aI0 = bb.i0; aJ0 = bb.j0; aNj = max(bb.nj, 1);
+                deferFlags |= kSeqDeferA;
+            } else {
+                zCentre = disc_pass_direct<G, false>(m, pc, c.cx, c.cy, bb, g, unused, scratch);
+            }
+            if (dfltUsable) {
+                if (dd.pipelined) {
+                    visB0 = g.ballot(dd.vis[0] != 0);
+                    visB1 = g.ballot(dd.vis[1] != 0);
+                    bI0 = dbox.i0; bJ0 = dbox.j0; bNj = max(dbox.nj, 1);
+                    deferFlags |= kSeqDeferB;
+                } else {
+                    zDefault = disc_pass_direct<G, false>(m, pc, nx0, ny, dbox, g, unused, scratch);
+                }
+            }
+        } else if constexpr (G == 64) {
             // the three ordered height sums run side by side at the end of the leg (heights3_finish): here the visited
             // elevations of the two discs around known centres are only compacted into LDS
             osA.terms = lb.hs;
@@ -1186,7 +1234,7 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
         stamp(pc, cyc, 5);
         constexpr bool kOneCell = kMid;  // the 3x3-only variants are launched for one-cell foot discs
         CentroidPendingBits cp;
-        centroid_begin_bits<G, kOneCell>(m, pc, c, sm, sc, zCentre, g, cp);                                 // cpp:818-821
+        centroid_begin_bits<G, kOneCell, !kDeferH>(m, pc, c, sm, sc, zCentre, g, cp);                        // cpp:818-821
         stamp(pc, cyc, 6);
         if constexpr (G != 64) {
             if (dfltUsable) zDefault = disc_consume<G, false, kMid>(m, pc, nx0, ny, dbox, g, dd, unused, scratch);  // cpp:2289-2301
@@ -1225,7 +1273,15 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
             bits_sync<G>();
         }
         stamp(pc, cyc, 8);
-        if constexpr (G == 64) {
+        if constexpr (kDeferH) {
+            if (cp.needDisc != 0) deferFlags |= kSeqDeferC;          // the result's own cell-centred disc (offset table)
+            else if (cp.o.code == 0) {                               // whole region valid: the height at the centre (cpp:1687)
+                if (deferFlags & kSeqDeferA) deferFlags |= kSeqCIsA;
+                else cp.o.z = zCentre;
+            }
+            stamp(pc, cyc, 11);
+            stamp(pc, cyc, 12);
+        } else if constexpr (G == 64) {
             if (cp.needDisc != 0) {
                 const float v = __builtin_isfinite(cp.e[0]) ? cp.e[0] : 0.0f;
                 term_push(g, osC, cp.vis[0] != 0, v);
@@ -1258,11 +1314,18 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
         }
         stamp(pc, cyc, 13);
         if (live && recs) {  // staged: flush_seqrec writes the records of a few cycles at a time
-            SeqRec r;
+            SeqRecOf<KW> r;
             r.nomX = no.x; r.nomY = no.y; r.cenX = co.x; r.cenY = co.y; r.defX = nx0; r.defY = ny;
             r.nomZ = no.z; r.cenZ = co.z; r.defZ = zDefault;
             r.nomRow = no.row; r.nomCol = no.col; r.cenRow = co.row; r.cenCol = co.col;
-            r.flags = static_cast<uint32_t>(no.valid) | (static_cast<uint32_t>(no.source) << 8) | (static_cast<uint32_t>(co.code) << 16);
+            r.flags = static_cast<uint32_t>(no.valid) | (static_cast<uint32_t>(no.source) << 8) | (static_cast<uint32_t>(co.code) << 16) | deferFlags;
+            if constexpr (kDeferH) {
+                r.aI0 = aI0; r.aJ0 = aJ0; r.aNj = aNj;
+                r.bI0 = bI0; r.bJ0 = bJ0; r.bNj = bNj;
+                r.pad[0] = r.pad[1] = 0u;
+                r.visA[0] = visA0; r.visA[1] = visA1;
+                r.visB[0] = visB0; r.visB[1] = visB1;
+            }
             recs[leg] = r;
         } else if (live) {
             const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
@@ -1319,35 +1382,107 @@ struct Unit {
 };
 static_assert(sizeof(Unit) == 144 && sizeof(Unit) % 16 == 0, "Unit layout");
 
-__device__ __forceinline__ void flush_seqrec(const SeqRec& rLds, int b, int cyc, int leg, int nCycles, const fpe_plan_out& out) {
-    SeqRec r;
-    __builtin_memcpy(&r, &rLds, sizeof(SeqRec));
+// getFootholdMeanHeight (cpp:2520-2554) over the visited cells of a bounding box, cell t = a * nj + b in row-major order
+// (CircleIterator order), one lane, the loads eight at a time (unvisited cells read the layer's first cell and are
+// dropped: no branch around a load).
+__device__ __forceinline__ float seq_mean_box(const float* __restrict__ elev, int cols, int i0, int j0, int nj, unsigned long long v0,
+                                              unsigned long long v1, double h) {
+    float sum = 0.0f, last = 0.0f;
+    int cnt = 0;
+    const float njInv = rcp_small(nj);
+    const int nMax = v1 ? 128 - __builtin_clzll(v1) : (v0 ? 64 - __builtin_clzll(v0) : 0);  // one past the last visited cell
+    for (int t0 = 0; t0 < nMax; t0 += 8) {
+        const unsigned bits = static_cast<unsigned>(((t0 < 64 ? v0 : v1) >> (t0 & 63)) & 0xFFull);
+        float e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int a, b;
+            divmod_small(t0 + u, nj, njInv, a, b);
+            const bool vis = ((bits >> u) & 1u) != 0u;
+            const unsigned cell = vis ? __umul24(static_cast<unsigned>(i0 + a), static_cast<unsigned>(cols)) + static_cast<unsigned>(j0 + b) : 0u;
+            e[u] = load_cell(elev, cell);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool vis = ((bits >> u) & 1u) != 0u;
+            const float v = __builtin_isfinite(e[u]) ? e[u] : 0.0f;  // cpp:2532-2537
+            const bool inc = vis && v < 10;                           // cpp:2539
+            last = vis ? v : last;
+            cnt += inc ? 1 : 0;
+            sum = sum + (inc ? v : -0.0f);  // s + (-0.0f) == s for every s
+        }
+    }
+    return finish_mean(sum, last, cnt, h);
+}
+// The same over the host-proved offset table of a CELL-CENTRED disc (the centroid result's, CircleIterator order).
+__device__ __forceinline__ float seq_mean_table(const float* __restrict__ elev, int rows, int cols, int row, int col, const int8_t* da,
+                                                const int8_t* db, int nFoot, double h) {
+    float sum = 0.0f, last = 0.0f;
+    int cnt = 0;
+    for (int k0 = 0; k0 < nFoot; k0 += 8) {
+        float e[8];
+        bool vis[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = min(k0 + u, nFoot - 1);
+            const int qi = row + da[k], qj = col + db[k];
+            vis[u] = k0 + u < nFoot && in_range(qi, qj, rows, cols);
+            const unsigned cell = vis[u] ? __umul24(static_cast<unsigned>(qi), static_cast<unsigned>(cols)) + static_cast<unsigned>(qj) : 0u;
+            e[u] = load_cell(elev, cell);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float v = __builtin_isfinite(e[u]) ? e[u] : 0.0f;
+            const bool inc = vis[u] && v < 10;
+            last = vis[u] ? v : last;
+            cnt += inc ? 1 : 0;
+            sum = sum + (inc ? v : -0.0f);
+        }
+    }
+    return finish_mean(sum, last, cnt, h);
+}
+
+template <class Rec>
+__device__ __forceinline__ void flush_seqrec(const DevMap& m, const PlanConsts& pc, const int8_t* footDa, const int8_t* footDb, const Rec& rLds,
+                                             int b, int cyc, int leg, int nCycles, const fpe_plan_out& out) {
+    Rec r;
+    __builtin_memcpy(&r, &rLds, sizeof(Rec));
     const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
     const uint8_t valid = static_cast<uint8_t>(r.flags & 0xFFu), source = static_cast<uint8_t>((r.flags >> 8) & 0xFFu);
+    // the deferred mean heights of this (cycle, leg) unit (one lane per unit: up to 32 units side by side; a split by
+    // (unit, disc) pairs over the lanes was measured slower on 25-cell boxes)
+    float zA = r.nomZ, zB = r.defZ, zC = r.cenZ;
+    if constexpr (std::is_same<Rec, SeqRec>::value) {
+        if (r.flags & kSeqDeferA) zA = seq_mean_box(m.elev, m.g.cols, r.aI0, r.aJ0, r.aNj, r.visA[0], r.visA[1], pc.h);
+        if ((r.flags & kSeqDeferB) && out.default_next) zB = seq_mean_box(m.elev, m.g.cols, r.bI0, r.bJ0, r.bNj, r.visB[0], r.visB[1], pc.h);
+        if ((r.flags & kSeqDeferC) && out.centroid) zC = seq_mean_table(m.elev, m.g.rows, m.g.cols, r.cenRow, r.cenCol, footDa, footDb, pc.nFoot, pc.h);
+        else if (r.flags & kSeqCIsA) zC = zA;
+    }
+    const float zN = (r.flags & kSeqDeferA) ? (valid ? zA : 0.0f) : r.nomZ;  // z at the DEFAULT centre, for a spiral candidate too (cpp:2029)
     if (out.nominal) {
         fpe_foothold f;
-        f.row = r.nomRow; f.col = r.nomCol; f.x = r.nomX; f.y = r.nomY; f.z = r.nomZ;
+        f.row = r.nomRow; f.col = r.nomCol; f.x = r.nomX; f.y = r.nomY; f.z = zN;
         f.valid = valid; f.source = source;
         f.foot_id = static_cast<uint8_t>(leg); f.gait_cycle_id = static_cast<uint8_t>(cyc);
         store_record<true>(out.nominal + o, f);
     }
     if (out.selected) {
         fpe_selected_foothold sf;
-        sf.row = r.nomRow; sf.col = r.nomCol; sf.z = r.nomZ;
+        sf.row = r.nomRow; sf.col = r.nomCol; sf.z = zN;
         sf.valid = valid; sf.source = source;
         sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
         store_record<true>(out.selected + o, sf);
     }
     if (out.centroid) {
         fpe_centroid_foothold cf;
-        cf.x = r.cenX; cf.y = r.cenY; cf.z = r.cenZ; cf.row = r.cenRow; cf.col = r.cenCol;
+        cf.x = r.cenX; cf.y = r.cenY; cf.z = zC; cf.row = r.cenRow; cf.col = r.cenCol;
         cf.code = static_cast<uint8_t>((r.flags >> 16) & 0xFFu); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
         store_record<true>(out.centroid + o, cf);
     }
     if (out.default_next) {
         store_record<true>(out.default_next + o * 3 + 0, r.defX);
         store_record<true>(out.default_next + o * 3 + 1, r.defY);
-        store_record<true>(out.default_next + o * 3 + 2, static_cast<double>(r.defZ));
+        store_record<true>(out.default_next + o * 3 + 2, static_cast<double>(zB));
     }
 }
 
@@ -2379,7 +2514,8 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
     const LegBits lb = make_legbits(smem + sizeof(PoseShared) + kLsBytes, min(2 * pc.winH + 1, NR), KW, pc.nHW, true);
     // staged output records: recSlots (a power of two, sized by the launch to keep the LDS within the occupancy budget)
     // cycles of four legs behind the row arrays
-    SeqRec* recBase = reinterpret_cast<SeqRec*>(
+    using Rec = SeqRecOf<KW>;
+    Rec* recBase = reinterpret_cast<Rec*>(
         smem + ((sizeof(PoseShared) + kLsBytes + 4 * static_cast<size_t>(legbits_words(min(2 * pc.winH + 1, NR), KW, pc.nHW, true)) + 15) & ~static_cast<size_t>(15)));
     const int b = blockIdx.x;
     if (b >= B) return;
@@ -2462,7 +2598,7 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
             if (slot == recSlots - 1 || cyc == nCycles - 1) {
                 pose_sync<16>();
                 const int s = tid >> 2, c = (cyc - slot) + s;
-                if (tid < 4 * recSlots && c <= cyc) flush_seqrec(recBase[tid], b, c, tid & 3, nCycles, out);
+                if (tid < 4 * recSlots && c <= cyc) flush_seqrec(m, pc, sh.footDa, sh.footDb, recBase[tid], b, c, tid & 3, nCycles, out);
                 pose_sync<16>();  // the slots are rewritten next
             }
         }
@@ -2528,7 +2664,7 @@ bool bits_supported(const PlanConsts& pc, const MapGeom& g) {
     // the per-leg LDS (3 row arrays) doubles as float scratch of a direct disc pass over a CircleIterator
     // bounding box of up to (2 ceil(rf / res) + 2)^2 cells
     const double side = 2.0 * ceil(pc.rf / g.res) + 2.0;
-    if (sp.lanes == 64) return side * side <= kBitsMaxBoxCells;  // 64-lane kernels: pipelined in two rounds, compacted into LegBits::hs
+    if (sp.lanes == 64) return side * side <= kBitsMaxBoxCells;  // 64-lane kernels: membership in two rounds of 64 cells (SeqRec::visA / visB)
     return side * side <= legbits_words(8 * sp.nrl, 1, pc.nHW, false);
 }
 
@@ -2565,8 +2701,8 @@ hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts&
                              4 * legbits_words(2 * pc.winH + 1 < 64 * NRL ? 2 * pc.winH + 1 : 64 * NRL, KW, pc.nHW, true) + 15) &        \
                             ~static_cast<size_t>(15);                                                                                 \
         int recSlots = 8; /* cycles of staged records: as many as keep sixteen blocks per CU (10 KiB each) */                      \
-        while (recSlots > 1 && base + recSlots * 4 * sizeof(SeqRec) > 10240) recSlots >>= 1;                                         \
-        hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW>), dim3(B), block, base + recSlots * 4 * sizeof(SeqRec), stream, m, bm, pc, \
+        while (recSlots > 1 && base + recSlots * 4 * sizeof(SeqRecOf<KW>) > 10240) recSlots >>= 1;                                   \
+        hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW>), dim3(B), block, base + recSlots * 4 * sizeof(SeqRecOf<KW>), stream, m, bm, pc, \
                            lut, d_poses, B, nCycles, d_out, recSlots);                                                                \
     } while (0)
     if (sp.lanes == 8) {

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <type_traits>
 
 #include "fpe_device.hpp"
 
@@ -777,7 +778,9 @@ struct DiscLoads {
 // join and stalls the 3x3 form on the row loads issued just before it (measured: 56.2 -> 53.7 us per launch).
 // dy2tab (optional, 3x3 form only): (cell_pos(baseY, res, bb.j0 + k) - cy)^2 for k = 0..2, precomputed by the caller —
 // the y side of a leg's geometry does not depend on the chain (fpe_bits.hpp, YEntry).
-template <int G, bool kCheck, bool kMid = false>
+// kLoad = false: membership only (DiscLoads::vis / pipelined) — the caller defers the heights and reads the elevations
+// itself later (one-wavefront-per-pose bit-window kernels, fpe_bits.hpp::flush_seqrec).
+template <int G, bool kCheck, bool kMid = false, bool kLoad = true>
 __device__ __forceinline__ void disc_issue(const DevMap& m, const PlanConsts& pc, double cx, double cy, const BBox& bb,
                                            const Grp<G>& g, DiscLoads& d, const double* dy2tab = nullptr) {
     const int nb = bb.ni * bb.nj;
@@ -851,10 +854,12 @@ __device__ __forceinline__ void disc_issue(const DevMap& m, const PlanConsts& pc
         const bool inMap = in_range(i, j, m.g.rows, m.g.cols), inDisc = cell_in_disc(m.g, i, j, cx, cy, pc.rf2);
         const bool vis = (t < nb) & inMap & inDisc;
         d.vis[r] = vis;
-        if (vis) {
-            const size_t off = static_cast<size_t>(i) * m.g.cols + j;
-            d.e[r] = m.elev[off];
-            if (kCheck) d.t[r] = m.trav[off];
+        if constexpr (kLoad) {
+            if (vis) {
+                const size_t off = static_cast<size_t>(i) * m.g.cols + j;
+                d.e[r] = m.elev[off];
+                if (kCheck) d.t[r] = m.trav[off];
+            }
         }
     }
 }
