@@ -417,11 +417,11 @@ __device__ __forceinline__ void centroid_begin_bits(const DevMap& m, const PlanC
                                                     const CentroidScan& sc, float zCentre, const Grp<G>& g, CentroidPendingBits& cp) {
     centroid_begin_bits_impl<G, kOneCell, false, kLoad>(m, pc, c, s, sc, zCentre, g, cp, 0.0, 0.0);
 }
-template <int G, bool kOneCell>
+template <int G, bool kOneCell, bool kLoad = true>
 __device__ __forceinline__ void centroid_begin_bits(const DevMap& m, const PlanConsts& pc, const LegCtx& c, const Submap& s,
                                                     const CentroidScan& sc, float zCentre, const Grp<G>& g, CentroidPendingBits& cp,
                                                     double yA, double yB) {
-    centroid_begin_bits_impl<G, kOneCell, true>(m, pc, c, s, sc, zCentre, g, cp, yA, yB);
+    centroid_begin_bits_impl<G, kOneCell, true, kLoad>(m, pc, c, s, sc, zCentre, g, cp, yA, yB);
 }
 // getFootholdMeanHeight (cpp:2520-2554) of the centroid result from the loads centroid_begin_bits issued.
 template <int G, bool kOneCell>
@@ -1583,6 +1583,100 @@ __device__ __forceinline__ void flush_unit(const DevMap& m, const PlanConsts& pc
     }
 }
 
+// ---- generic 8-lane kernels (boxes of up to 32 cells, foot-disc tables): the same deferral --------------------------
+// The chain deposits, per (leg, cycle), the MEMBERSHIP of the two discs around known centres (a 32-bit mask over the
+// bounding box's cells in CircleIterator order, with the box's origin) and the words that identify the results; it
+// issues no elevation load at all.  Every fourth cycle (the LDS of twelve workgroups per CU holds four cycles of units
+// and y entries, not eight) lane (leg, s < 4) of a pose takes the unit of cycle base + s, reads the elevations itself
+// (seq_mean_box / seq_mean_table: eight independent loads per batch) and runs the three ordered sums (cpp:2520-2554).
+constexpr uint32_t kUgValid = 1u << 8, kUgSrcShift = 9, kUgPreA = 1u << 12, kUgPreB = 1u << 13, kUgCTable = 1u << 14, kUgCIsA = 1u << 15;
+struct UnitG {
+    double cx;    // search centre x (nominal x of a default hit / invalid leg; centroid x of code 0)
+    double cenX;  // centroid result x (codes 1-4)
+    double defX;  // default track x
+    int aI0, aJ0;
+    uint32_t visA;  // centre disc (cpp:2029): bit t = cell t of the box visited; kUgPreA: the f32 height itself (direct pass)
+    int bI0, bJ0;
+    uint32_t visB;  // default-track disc (cpp:2289-2301), kUgPreB likewise
+    int nomRow, nomCol, cenRow, cenCol;
+    uint32_t flags;  // centroid code | kUgValid | source << 9 | kUg* | aNj << 16 | bNj << 24
+    uint32_t pad[3];
+};
+static_assert(sizeof(UnitG) == 80 && sizeof(UnitG) % 16 == 0, "UnitG layout");
+
+__device__ __forceinline__ void unitg_put_disc(const DevMap& m, const PlanConsts& pc, double cx, double cy, const BBox& bb, const Grp<8>& g,
+                                               const DiscLoads& d, uint32_t& vis, bool& pre, float* scratch) {
+    if (d.pipelined) {  // wave-uniform
+        if (d.mid) {    // 3x3 form: lane s holds cell s + (s >= 4), the middle cell is always visited
+            const unsigned mk = static_cast<unsigned>(g.ballot(d.vis[0] != 0));
+            vis = (mk & 0xFu) | 0x10u | ((mk & 0xF0u) << 1);
+        } else {
+            vis = 0u;
+#pragma unroll
+            for (int r = 0; r < kDiscRounds; ++r) vis |= (static_cast<uint32_t>(g.ballot(d.vis[r] != 0)) & 0xFFu) << (8 * r);
+        }
+        pre = false;
+    } else {
+        bool unused;
+        vis = __float_as_uint(disc_pass_direct<8, false>(m, pc, cx, cy, bb, g, unused, scratch));
+        pre = true;
+    }
+}
+// One (leg, cycle) unit per lane: heights and the four output records of that unit.
+__device__ __forceinline__ void flush_unit_g(const DevMap& m, const PlanConsts& pc, const int8_t* footDa, const int8_t* footDb,
+                                             const UnitG& uLds, const YEntry& yeLds, int b, int cyc, int leg, int nCycles, uint32_t okBits,
+                                             const fpe_plan_out& out) {
+    const MapGeom& mg = m.g;
+    UnitG u;
+    __builtin_memcpy(&u, &uLds, sizeof(UnitG));
+    const double ny = yeLds.ny, yA = yeLds.yA, yB = yeLds.yB;
+    if (leg == 0 && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = static_cast<uint8_t>((okBits >> (cyc & 7)) & 1u);
+    const int aNj = static_cast<int>((u.flags >> 16) & 0xFFu), bNj = static_cast<int>(u.flags >> 24);
+    const float zA = (u.flags & kUgPreA) ? __uint_as_float(u.visA) : seq_mean_box(m.elev, mg.cols, u.aI0, u.aJ0, aNj, u.visA, 0ull, pc.h);
+    float zB = 0.0f;
+    if (out.default_next) zB = (u.flags & kUgPreB) ? __uint_as_float(u.visB) : seq_mean_box(m.elev, mg.cols, u.bI0, u.bJ0, bNj, u.visB, 0ull, pc.h);
+    const int code = static_cast<int>(u.flags & 0xFFu);
+    float zC = 0.0f;
+    if ((u.flags & kUgCTable) && out.centroid) zC = seq_mean_table(m.elev, mg.rows, mg.cols, u.cenRow, u.cenCol, footDa, footDb, pc.nFoot, pc.h);
+    else if (u.flags & kUgCIsA) zC = zA;  // whole region valid: the height at the centre (cpp:1687)
+    const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
+    const int valid = (u.flags & kUgValid) ? 1 : 0, source = static_cast<int>((u.flags >> kUgSrcShift) & 3u);
+    const float zN = valid ? zA : 0.0f;  // z at the DEFAULT centre, for a spiral candidate too (cpp:2029)
+    if (out.nominal) {
+        fpe_foothold f;
+        f.row = u.nomRow;
+        f.col = u.nomCol;
+        f.x = source == 1 ? cell_pos(mg.baseX, mg.res, u.nomRow) : u.cx;  // cpp:2105-2107 / cpp:2016-2017
+        f.y = source == 1 ? cell_pos(mg.baseY, mg.res, u.nomCol) : ny;
+        f.z = zN;
+        f.valid = static_cast<uint8_t>(valid);
+        f.source = static_cast<uint8_t>(source);
+        f.foot_id = static_cast<uint8_t>(leg);
+        f.gait_cycle_id = static_cast<uint8_t>(cyc);
+        store_record<true>(out.nominal + o, f);
+    }
+    if (out.selected) {
+        fpe_selected_foothold sf;
+        sf.row = u.nomRow; sf.col = u.nomCol; sf.z = zN;
+        sf.valid = static_cast<uint8_t>(valid); sf.source = static_cast<uint8_t>(source);
+        sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
+        store_record<true>(out.selected + o, sf);
+    }
+    if (out.centroid) {
+        fpe_centroid_foothold cf;
+        cf.x = code == 0 ? u.cx : (code <= 4 ? u.cenX : 0.0);
+        cf.y = code == 0 ? ny : (code == 1 ? yA : (code <= 4 ? yB : 0.0));
+        cf.z = zC; cf.row = u.cenRow; cf.col = u.cenCol;
+        cf.code = static_cast<uint8_t>(code); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
+        store_record<true>(out.centroid + o, cf);
+    }
+    if (out.default_next) {
+        store_record<true>(out.default_next + o * 3 + 0, u.defX);
+        store_record<true>(out.default_next + o * 3 + 1, ny);
+        store_record<true>(out.default_next + o * 3 + 2, static_cast<double>(zB));
+    }
+}
+
 __device__ __forceinline__ void fill_yentry(const MapGeom& mg, const PlanConsts& pc, const LegStatic& ls, double ny, YEntry& e) {
     const double ly = ls.lk.ly;  // centroid rectangle width (cpp:1617)
     const double r = static_cast<double>(ls.Rf);
@@ -1670,9 +1764,13 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
                                                 const LutHead& head, PoseShared& sh, const LegBits& lb, const Grp<8>& g, int leg,
                                                 const LegStatic& ls, const YEntry& ye, double ctr0, double ctr1, double ctr2,
                                                 double advance, int cyc, int nCycles, int b, bool live, const fpe_plan_out& out,
-                                                LegCommit* lc, Unit* unit) {
+                                                LegCommit* lc, typename std::conditional<kMid, Unit, UnitG>::type* unit) {
     constexpr int G = 8, KW = 1;
-    constexpr bool kDefer = kMid;  // heights and records deposited in `unit`, finished by flush_unit every eighth cycle
+    // heights and records are deposited in `unit` and finished by flush_unit (3x3-only kernels, every eighth cycle) /
+    // flush_unit_g (generic kernels, every fourth cycle)
+    constexpr bool kDefer = true;
+    uint32_t ugFlags = 0u, ugVisA = 0u, ugVisB = 0u;  // generic kernels: UnitG fields in the making
+    int ugAI0 = 0, ugAJ0 = 0, ugANj = 1, ugBI0 = 0, ugBJ0 = 0, ugBNj = 1;
     const float Rf = ls.Rf;
     const int polyKind = ls.polyKind;
     const LegConst& lk = ls.lk;
@@ -1733,7 +1831,7 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
             bool unused;
             zDefault = disc_pass_direct<G, false>(m, pc, nx0, ny, dbox, g, unused, scratch);
         }
-        if constexpr (kDefer) {
+        if constexpr (kMid) {
             if (g.sub == 0) {
                 unit->visA = 0x80000000u;  // the nominal leg is invalid: its height is never used
                 unit->eA[0] = 0.0f;
@@ -1741,6 +1839,10 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
                 unit->eB[0] = zDefault;
                 unit->eC = 0.0f;
             }
+        } else {
+            ugFlags = kUgPreA | kUgPreB;
+            ugVisA = __float_as_uint(0.0f);
+            ugVisB = __float_as_uint(zDefault);
         }
     } else {
         // ---- x side: one corner quantity per lane ----
@@ -1805,9 +1907,9 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
         uint4 grp[NRL][KW + 1];
         win_issue<G, NRL, KW>(bm, m.g, g, iw0, jw0, grp);
         DiscLoads dc, dd;
-        disc_issue<G, false, kMid>(m, pc, c.cx, c.cy, bb, g, dc, ye.dy2);
+        disc_issue<G, false, kMid, kMid>(m, pc, c.cx, c.cy, bb, g, dc, ye.dy2);
         const bool dfltUsable = wantDefault && fabs(nx0) <= 1e6;
-        if (dfltUsable) disc_issue<G, false, kMid>(m, pc, nx0, ny, dbox, g, dd, ye.dy2);
+        if (dfltUsable) disc_issue<G, false, kMid, kMid>(m, pc, nx0, ny, dbox, g, dd, ye.dy2);
         stamp(pc, cyc, 3);
         WinRows<NRL, KW> w;
         win_finish<NRL, KW>(jw0, grp, w);
@@ -1820,7 +1922,7 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
         bits_sync<G>();  // lb doubles as scratch below
         bool unused;
         float zCentre = 0.0f;
-        if constexpr (kDefer) {
+        if constexpr (kMid) {
             uint32_t visA = 0u, visB = 0u;
             unit_put_disc<true>(m, pc, c.cx, c.cy, bb, g, dc, unit->eA, visA, scratch);
             if (dfltUsable) unit_put_disc<true>(m, pc, nx0, ny, dbox, g, dd, unit->eB, visB, scratch);
@@ -1829,16 +1931,25 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
                 unit->visB = visB;
             }
         } else {
-            zCentre = disc_consume<G, false, kMid>(m, pc, c.cx, c.cy, bb, g, dc, unused, scratch);  // cpp:2029
+            bool pre;
+            unitg_put_disc(m, pc, c.cx, c.cy, bb, g, dc, ugVisA, pre, scratch);
+            if (pre) ugFlags |= kUgPreA;
+            ugAI0 = bb.i0; ugAJ0 = bb.j0; ugANj = max(bb.nj, 1);
+            if (dfltUsable) {
+                unitg_put_disc(m, pc, nx0, ny, dbox, g, dd, ugVisB, pre, scratch);
+                if (pre) ugFlags |= kUgPreB;
+                ugBI0 = dbox.i0; ugBJ0 = dbox.j0; ugBNj = max(dbox.nj, 1);
+            } else {
+                ugFlags |= kUgPreB;
+                ugVisB = __float_as_uint(zDefault);
+            }
         }
+        (void)unused;
         stamp(pc, cyc, 5);
         constexpr bool kOneCell = kMid;  // the 3x3-only variants are launched for one-cell foot discs
         CentroidPendingBits cp;
-        centroid_begin_bits<G, kOneCell>(m, pc, c, sm, sc, zCentre, g, cp, ye.yA, ye.yB);                  // cpp:818-821
+        centroid_begin_bits<G, kOneCell, kMid>(m, pc, c, sm, sc, zCentre, g, cp, ye.yA, ye.yB);          // cpp:818-821
         stamp(pc, cyc, 6);
-        if constexpr (!kDefer) {
-            if (dfltUsable) zDefault = disc_consume<G, false, kMid>(m, pc, nx0, ny, dbox, g, dd, unused, scratch);  // cpp:2289-2301
-        }
         stamp(pc, cyc, 7);
         if (defaultOk) {
             no.valid = 1;
@@ -1864,12 +1975,14 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
             bits_sync<G>();
         }
         stamp(pc, cyc, 8);
-        if constexpr (kDefer) {
+        if constexpr (kMid) {
             if (g.sub == 0) unit->eC = cp.e0;
             cp.o.z = 0.0f;
             if (g.sub == 0) unit->cenCode = static_cast<uint32_t>(cp.o.code) | (cp.needDisc != 0 ? 0x100u : 0u);
         } else {
-            if (cp.needDisc != 0) cp.o.z = centroid_height_bits<G, kOneCell>(pc, g, cp, scratch);
+            cp.o.z = 0.0f;
+            if (cp.needDisc != 0) ugFlags |= kUgCTable;   // the result's own cell-centred disc (offset table)
+            else if (cp.o.code == 0) ugFlags |= kUgCIsA;  // whole region valid: the height at the centre (cpp:1687)
         }
         co = cp.o;
     }
@@ -1877,7 +1990,20 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
     lc->v[0][0] = nx0;   lc->v[0][1] = ny;    lc->v[0][2] = static_cast<double>(zDefault);
     lc->v[1][0] = co.x;  lc->v[1][1] = co.y;  lc->v[1][2] = static_cast<double>(co.z);
     lc->v[2][0] = no.x;  lc->v[2][1] = no.y;  lc->v[2][2] = static_cast<double>(no.z);
-    if constexpr (kDefer) {
+    if constexpr (!kMid) {
+        if (g.sub == 0) {  // what flush_unit_g needs to rebuild this leg's four records
+            UnitG u;
+            u.cx = c.cx; u.cenX = co.x; u.defX = nx0;
+            u.aI0 = ugAI0; u.aJ0 = ugAJ0; u.visA = ugVisA;
+            u.bI0 = ugBI0; u.bJ0 = ugBJ0; u.visB = ugVisB;
+            u.nomRow = no.row; u.nomCol = no.col; u.cenRow = co.row; u.cenCol = co.col;
+            u.flags = static_cast<uint32_t>(co.code) | (no.valid ? kUgValid : 0u) | (static_cast<uint32_t>(no.source) << kUgSrcShift) | ugFlags |
+                      (static_cast<uint32_t>(ugANj) << 16) | (static_cast<uint32_t>(ugBNj) << 24);
+            u.pad[0] = u.pad[1] = u.pad[2] = 0u;
+            *unit = u;
+        }
+        return;
+    } else if constexpr (kDefer) {
         if (g.sub == 0) {  // what flush_unit needs to rebuild this leg's four records
             unit->nomRow = no.row;
             unit->nomCol = no.col;
@@ -2288,12 +2414,15 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Grp<G> g(tid);
     const size_t legBytes = 4 * static_cast<size_t>(legbits_words(NR, 1, pc.nHW, false));
-    const size_t poseBytes = sizeof(PoseShared) + 4 * legBytes + sizeof(YEntry) * 4 * 8 + (kMid ? sizeof(Unit) * 4 * 8 : 0);
+    // cycles between two flushes (units and y entries staged in LDS): eight for the 3x3-only kernels, four for the generic ones
+    constexpr int kBatch = kMid ? 8 : 4;
+    using UnitT = typename std::conditional<kMid, Unit, UnitG>::type;
+    const size_t poseBytes = sizeof(PoseShared) + 4 * legBytes + (sizeof(YEntry) + sizeof(UnitT)) * 4 * kBatch;
     unsigned char* base = smem + static_cast<size_t>(slot) * poseBytes;
     PoseShared& sh = *reinterpret_cast<PoseShared*>(base);
     const LegBits lb = make_legbits(base + sizeof(PoseShared) + static_cast<size_t>(leg) * legBytes, NR, 1, pc.nHW, false);
-    YEntry* ytab = reinterpret_cast<YEntry*>(base + sizeof(PoseShared) + 4 * legBytes) + leg * 8;  // [cycle & 7] of this leg
-    Unit* units = reinterpret_cast<Unit*>(base + sizeof(PoseShared) + 4 * legBytes + sizeof(YEntry) * 4 * 8) + leg * 8;
+    YEntry* ytab = reinterpret_cast<YEntry*>(base + sizeof(PoseShared) + 4 * legBytes) + leg * kBatch;  // [cycle % kBatch] of this leg
+    UnitT* units = reinterpret_cast<UnitT*>(base + sizeof(PoseShared) + 4 * legBytes + sizeof(YEntry) * 4 * kBatch) + leg * kBatch;
 
     const LutHead head = load_lut_head(lut, g);
 #ifdef FPE_TRACE
@@ -2420,20 +2549,20 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
     uint32_t okBits = 0u;  // cycleOk of the cycles since the last flush (3x3-only kernels: stored by flush_unit)
 
     for (int cyc = 0; cyc < nCycles; ++cyc) {
-        if ((cyc & 7) == 0) {
-            // y side of the next eight cycles: lane (leg, s) fills the entry of cycle cyc + s.  ajustedPose_[1] is the
+        if ((cyc & (kBatch - 1)) == 0) {
+            // y side of the next kBatch cycles: lane (leg, s) fills the entry of cycle cyc + s.  ajustedPose_[1] is the
             // reference's running sum (cpp:1578): cycle cyc + s has seen s more additions of the drift
             double a = adjY, mine = adjY;
 #pragma unroll
-            for (int k = 1; k < 8; ++k) {
+            for (int k = 1; k < kBatch; ++k) {
                 a += hc.drift;
                 if (g.sub == k) mine = a;
             }
-            fill_yentry(m.g, pc, ls, (y0 + mine) + ls.biasY, ytab[g.sub]);  // cpp:2201, 2414
+            if (kBatch == 8 || g.sub < kBatch) fill_yentry(m.g, pc, ls, (y0 + mine) + ls.biasY, ytab[g.sub]);  // cpp:2201, 2414
             bits_sync<G>();
             stamp(pc, 1, 14);
         }
-        const YEntry& ye = ytab[cyc & 7];
+        const YEntry& ye = ytab[cyc & (kBatch - 1)];
         bool cycleOk = true;
         for (int ph = 0; ph < nPhases; ++ph) {
             const unsigned mask = (gait == 1) ? (1u << ((walkOrder >> (2 * ph)) & 3)) : 0xFu;
@@ -2450,13 +2579,13 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
             if (active) {
                 if constexpr (kMid) {
                     leg_fast8m<NRL>(m, bm, pc, hc, role, lut, head, sh, lb, g, leg, ls, ye, myCtr, advance, cyc, nCycles, b, live, out, &lc,
-                                    units + (cyc & 7));
+                                    units + (cyc & (kBatch - 1)));
                 } else {
                     constexpr int kKeep = (~(G - 1)) & 0x1F;
                     const double ctr0 = swizzle_f64<kKeep | (0 << 5)>(myCtr), ctr1 = swizzle_f64<kKeep | (1 << 5)>(myCtr),
                                  ctr2 = swizzle_f64<kKeep | (2 << 5)>(myCtr);
                     leg_phase_bits8<NRL, false>(m, bm, pc, lut, head, sh, lb, g, leg, ls, ye, ctr0, ctr1, ctr2, advance, cyc, nCycles, b, live,
-                                                out, &lc, nullptr);
+                                                out, &lc, units + (cyc & (kBatch - 1)));
                 }
             }
             stamp(pc, cyc, 9);
@@ -2473,20 +2602,21 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
             stamp(pc, cyc, 10);
         }
         adjY += hc.drift;  // cpp:1578
-        if constexpr (kMid) {
-            okBits |= (cycleOk ? 1u : 0u) << (cyc & 7);
-            if ((cyc & 7) == 7 || cyc == nCycles - 1) {
-                // heights, output records and cycle validity of the last (up to) eight cycles: lane (leg, s) takes the
-                // unit of cycle base + s
-                const int c0 = cyc & ~7;
-                stamp(pc, 2, 11);
+        okBits |= (cycleOk ? 1u : 0u) << (cyc & 7);
+        if ((cyc & (kBatch - 1)) == kBatch - 1 || cyc == nCycles - 1) {
+            // heights, output records and cycle validity of the last (up to) kBatch cycles: lane (leg, s) takes the
+            // unit of cycle base + s
+            const int c0 = cyc & ~(kBatch - 1);
+            stamp(pc, 2, 11);
+            if constexpr (kMid) {
                 if (live && c0 + g.sub <= cyc) flush_unit(m, pc, units[g.sub], ytab[g.sub], b, c0 + g.sub, leg, nCycles, okBits, out);
-                okBits = 0u;
-                bits_sync<G>();  // the units and the y entries are rewritten next
-                stamp(pc, 2, 12);
+            } else {
+                if (live && g.sub < kBatch && c0 + g.sub <= cyc)
+                    flush_unit_g(m, pc, sh.footDa, sh.footDb, units[g.sub], ytab[g.sub], b, c0 + g.sub, leg, nCycles, okBits, out);
             }
-        } else {
-            if (leg == 0 && g.sub == 0 && live && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = cycleOk ? 1 : 0;
+            okBits = 0u;
+            bits_sync<G>();  // the units and the y entries are rewritten next
+            stamp(pc, 2, 12);
         }
     }
 }
@@ -2693,8 +2823,9 @@ hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts&
     const dim3 block(64);
 #define FPE_LAUNCH_BITS(NRL, MID)                                                                                            \
     hipLaunchKernelGGL((plan_bits_kernel<NRL, MID>), dim3((B + 1) / 2), block,                                              \
-                       2 * (sizeof(PoseShared) + 16 * legbits_words(8 * NRL, 1, pc.nHW, false) + sizeof(YEntry) * 32 +                \
-                            (MID ? sizeof(Unit) * 32 : 0)), stream, d_poses, B, nCycles, m, bm, pc, lut, d_out)
+                       2 * (sizeof(PoseShared) + 16 * legbits_words(8 * NRL, 1, pc.nHW, false) +                                      \
+                            (MID ? (sizeof(YEntry) + sizeof(Unit)) * 32 : (sizeof(YEntry) + sizeof(UnitG)) * 16)), stream, d_poses, B,  \
+                       nCycles, m, bm, pc, lut, d_out)
 #define FPE_LAUNCH_BITS_SEQ(NRL, KW)                                                                                         \
     do {                                                                                                                     \
         const size_t base = (sizeof(PoseShared) + ((4 * sizeof(LegStatic) + 15) & ~static_cast<size_t>(15)) +                            \

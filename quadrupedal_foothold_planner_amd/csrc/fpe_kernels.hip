@@ -812,13 +812,15 @@ __device__ __forceinline__ void disc_issue(const DevMap& m, const PlanConsts& pc
             } else {
                 d.vis[0] = cell_in_disc(m.g, i, j, cx, cy, pc.rf2) ? 1 : 0;  // the unclamped box lies inside the map
             }
-            const size_t offM = static_cast<size_t>(bb.i0 + 1) * m.g.cols + (bb.j0 + 1);
-            d.eMid = m.elev[offM];
-            if (kCheck) d.tMid = m.trav[offM];
-            if (d.vis[0]) {
-                const size_t off = static_cast<size_t>(i) * m.g.cols + j;
-                d.e[0] = m.elev[off];
-                if (kCheck) d.t[0] = m.trav[off];
+            if constexpr (kLoad) {
+                const size_t offM = static_cast<size_t>(bb.i0 + 1) * m.g.cols + (bb.j0 + 1);
+                d.eMid = m.elev[offM];
+                if (kCheck) d.tMid = m.trav[offM];
+                if (d.vis[0]) {
+                    const size_t off = static_cast<size_t>(i) * m.g.cols + j;
+                    d.e[0] = m.elev[off];
+                    if (kCheck) d.t[0] = m.trav[off];
+                }
             }
             return;
         }
