@@ -93,9 +93,14 @@ struct LegBits {
     int rows;
 };
 // words (4 bytes) of one leg's LDS: (2 + max(nHW, 1)) row arrays, then colRows and hs for the 64-lane kernels
+// widest row (in 32-bit words) of the one-wavefront-per-pose kernels whose mean heights leave the chain (flush_seqrec2)
+#ifndef FPE_SEQ_DEFER_KW
+#define FPE_SEQ_DEFER_KW 2
+#endif
+constexpr int kSeqDeferMaxKW = FPE_SEQ_DEFER_KW;
 __host__ __device__ __forceinline__ int legbits_words(int rows, int kw, int nHW, bool wide) {
     const int arrays = 2 + (nHW > 0 ? nHW : 1);
-    return ((arrays * rows * kw + 3) & ~3) + (wide ? 2 * 32 * kw + (kw >= 3 ? 3 * kBitsMaxBoxCells : 0) : 0);
+    return ((arrays * rows * kw + 3) & ~3) + (wide ? 2 * 32 * kw + (kw > kSeqDeferMaxKW ? 3 * kBitsMaxBoxCells : 0) : 0);
 }
 __device__ __forceinline__ LegBits make_legbits(unsigned char* base, int rows, int kw, int nHW, bool wide) {
     LegBits lb;
@@ -1076,7 +1081,7 @@ struct SeqRec : SeqRecBase {  // kernels that defer the heights (64-bit rows)
 };
 static_assert(sizeof(SeqRecBase) == 80 && sizeof(SeqRec) == 144 && sizeof(SeqRec) % 16 == 0, "SeqRec layout");
 template <int KW>
-using SeqRecOf = typename std::conditional<(KW <= 2), SeqRec, SeqRecBase>::type;
+using SeqRecOf = typename std::conditional<(KW <= kSeqDeferMaxKW), SeqRec, SeqRecBase>::type;
 constexpr uint32_t kSeqDeferA = 1u << 24;  // zA = mean height of the centre disc, to be computed by flush_seqrec
 constexpr uint32_t kSeqDeferB = 1u << 25;  // zB (default track)
 constexpr uint32_t kSeqDeferC = 1u << 26;  // zC = mean height of the cell-centred disc of (cenRow, cenCol) (offset table)
@@ -1148,7 +1153,7 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
     // (64-bit-row kernels: 1 cm maps, boxes of <= 25 cells, layers that stay in the L2s.  The 96-bit-row kernels keep the
     // heights in the chain: their boxes hold up to 81 cells of a layer that does not fit the L2s, and a flush that waits for
     // eleven dependent load batches per disc costs more than the chain's overlapped loads — measured on cfg-5: +8 %)
-    constexpr bool kDeferH = (G == 64) && !kDirect && KW <= 2;
+    constexpr bool kDeferH = (G == 64) && !kDirect && KW <= kSeqDeferMaxKW;
     uint32_t deferFlags = 0u;
     unsigned long long visA0 = 0ull, visA1 = 0ull, visB0 = 0ull, visB1 = 0ull;
     int aI0 = 0, aJ0 = 0, aNj = 1, bI0 = 0, bJ0 = 0, bNj = 1;
@@ -1442,6 +1447,54 @@ __device__ __forceinline__ float seq_mean_table(const float* __restrict__ elev, 
     return finish_mean(sum, last, cnt, h);
 }
 
+// Two mean heights side by side — a disc around a known centre (bounding box + membership mask) and, optionally, a
+// cell-centred disc (offset table) — with the loads of both in ONE batch per eight cells.  Each sum is the ordered f32 sum
+// of getFootholdMeanHeight (cpp:2520-2554), exactly as in seq_mean_box / seq_mean_table.
+struct MeanAcc {
+    float sum, last;
+    int cnt;
+};
+__device__ __forceinline__ void mean_acc(MeanAcc& a, bool vis, float e) {
+    const float v = __builtin_isfinite(e) ? e : 0.0f;  // cpp:2532-2537
+    const bool inc = vis && v < 10;                     // cpp:2539
+    a.last = vis ? v : a.last;
+    a.cnt += inc ? 1 : 0;
+    a.sum = a.sum + (inc ? v : -0.0f);  // s + (-0.0f) == s for every s
+}
+__device__ __forceinline__ void seq_mean2(const float* __restrict__ elev, int rows, int cols, int i0, int j0, int nj, unsigned long long v0,
+                                          unsigned long long v1, bool wantC, int cRow, int cCol, const int8_t* da, const int8_t* db, int nFoot,
+                                          double h, float& zBox, float& zC) {
+    MeanAcc A{0.0f, 0.0f, 0}, C{0.0f, 0.0f, 0};
+    const float njInv = rcp_small(nj);
+    const int nC = wantC ? nFoot : 0;
+    const int nMax = max(v1 ? 128 - __builtin_clzll(v1) : (v0 ? 64 - __builtin_clzll(v0) : 0), nC);  // one past the last cell of either
+    for (int t0 = 0; t0 < nMax; t0 += 8) {
+        const unsigned ba = static_cast<unsigned>(((t0 < 64 ? v0 : v1) >> (t0 & 63)) & 0xFFull);
+        unsigned bc = 0u;
+        float eA[8], eC[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int r, q;
+            divmod_small(t0 + u, nj, njInv, r, q);
+            const unsigned cellA = ((ba >> u) & 1u) ? __umul24(static_cast<unsigned>(i0 + r), static_cast<unsigned>(cols)) + static_cast<unsigned>(j0 + q) : 0u;
+            eA[u] = load_cell(elev, cellA);
+            const int k = min(t0 + u, max(nC - 1, 0));
+            const int qi = cRow + da[k], qj = cCol + db[k];
+            const bool visC = t0 + u < nC && in_range(qi, qj, rows, cols);
+            bc |= visC ? (1u << u) : 0u;
+            const unsigned cellC = visC ? __umul24(static_cast<unsigned>(qi), static_cast<unsigned>(cols)) + static_cast<unsigned>(qj) : 0u;
+            eC[u] = load_cell(elev, cellC);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            mean_acc(A, ((ba >> u) & 1u) != 0u, eA[u]);
+            mean_acc(C, ((bc >> u) & 1u) != 0u, eC[u]);
+        }
+    }
+    zBox = finish_mean(A.sum, A.last, A.cnt, h);
+    zC = finish_mean(C.sum, C.last, C.cnt, h);
+}
+
 template <class Rec>
 __device__ __forceinline__ void flush_seqrec(const DevMap& m, const PlanConsts& pc, const int8_t* footDa, const int8_t* footDb, const Rec& rLds,
                                              int b, int cyc, int leg, int nCycles, const fpe_plan_out& out) {
@@ -1483,6 +1536,54 @@ __device__ __forceinline__ void flush_seqrec(const DevMap& m, const PlanConsts& 
         store_record<true>(out.default_next + o * 3 + 0, r.defX);
         store_record<true>(out.default_next + o * 3 + 1, r.defY);
         store_record<true>(out.default_next + o * 3 + 2, static_cast<double>(zB));
+    }
+}
+
+// The same with two lanes per unit (64-bit-row kernels, deferred heights): lane half 0 takes the centre disc and the
+// centroid result's disc and writes the nominal / selected / centroid records, half 1 the default-track disc and the
+// default_next record.  One instruction stream for both halves (the arguments differ per lane, not the code).
+__device__ __forceinline__ void flush_seqrec2(const DevMap& m, const PlanConsts& pc, const int8_t* footDa, const int8_t* footDb, const SeqRec& rLds,
+                                              int b, int cyc, int leg, int half, int nCycles, const fpe_plan_out& out) {
+    SeqRec r;
+    __builtin_memcpy(&r, &rLds, sizeof(SeqRec));
+    const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
+    const bool h1 = half != 0;
+    const bool defer = (r.flags & (h1 ? kSeqDeferB : kSeqDeferA)) != 0u && (h1 ? out.default_next != nullptr : true);
+    const bool wantC = !h1 && (r.flags & kSeqDeferC) != 0u && out.centroid != nullptr;
+    float sBox, sC;
+    seq_mean2(m.elev, m.g.rows, m.g.cols, h1 ? r.bI0 : r.aI0, h1 ? r.bJ0 : r.aJ0, max(h1 ? r.bNj : r.aNj, 1), defer ? (h1 ? r.visB[0] : r.visA[0]) : 0ull,
+              defer ? (h1 ? r.visB[1] : r.visA[1]) : 0ull, wantC, r.cenRow, r.cenCol, footDa, footDb, pc.nFoot, pc.h, sBox, sC);
+    if (h1) {
+        if (out.default_next) {
+            store_record<true>(out.default_next + o * 3 + 0, r.defX);
+            store_record<true>(out.default_next + o * 3 + 1, r.defY);
+            store_record<true>(out.default_next + o * 3 + 2, static_cast<double>(defer ? sBox : r.defZ));
+        }
+        return;
+    }
+    const uint8_t valid = static_cast<uint8_t>(r.flags & 0xFFu), source = static_cast<uint8_t>((r.flags >> 8) & 0xFFu);
+    const float zA = defer ? sBox : r.nomZ;
+    const float zC = wantC ? sC : ((r.flags & kSeqCIsA) ? zA : r.cenZ);
+    const float zN = defer ? (valid ? zA : 0.0f) : r.nomZ;  // z at the DEFAULT centre, for a spiral candidate too (cpp:2029)
+    if (out.nominal) {
+        fpe_foothold f;
+        f.row = r.nomRow; f.col = r.nomCol; f.x = r.nomX; f.y = r.nomY; f.z = zN;
+        f.valid = valid; f.source = source;
+        f.foot_id = static_cast<uint8_t>(leg); f.gait_cycle_id = static_cast<uint8_t>(cyc);
+        store_record<true>(out.nominal + o, f);
+    }
+    if (out.selected) {
+        fpe_selected_foothold sf;
+        sf.row = r.nomRow; sf.col = r.nomCol; sf.z = zN;
+        sf.valid = valid; sf.source = source;
+        sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
+        store_record<true>(out.selected + o, sf);
+    }
+    if (out.centroid) {
+        fpe_centroid_foothold cf;
+        cf.x = r.cenX; cf.y = r.cenY; cf.z = zC; cf.row = r.cenRow; cf.col = r.cenCol;
+        cf.code = static_cast<uint8_t>((r.flags >> 16) & 0xFFu); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
+        store_record<true>(out.centroid + o, cf);
     }
 }
 
@@ -1622,24 +1723,39 @@ __device__ __forceinline__ void unitg_put_disc(const DevMap& m, const PlanConsts
         pre = true;
     }
 }
-// One (leg, cycle) unit per lane: heights and the four output records of that unit.
+// Two lanes per (leg, cycle) unit: lane half 0 takes the centre disc and the centroid result's disc and writes the
+// nominal / selected / centroid records, half 1 the default-track disc, the default_next record and the cycle's
+// validity.  One instruction stream for both (the arguments differ per lane, not the code).
 __device__ __forceinline__ void flush_unit_g(const DevMap& m, const PlanConsts& pc, const int8_t* footDa, const int8_t* footDb,
-                                             const UnitG& uLds, const YEntry& yeLds, int b, int cyc, int leg, int nCycles, uint32_t okBits,
-                                             const fpe_plan_out& out) {
+                                             const UnitG& uLds, const YEntry& yeLds, int b, int cyc, int leg, int half, int nCycles,
+                                             uint32_t okBits, const fpe_plan_out& out) {
     const MapGeom& mg = m.g;
     UnitG u;
     __builtin_memcpy(&u, &uLds, sizeof(UnitG));
     const double ny = yeLds.ny, yA = yeLds.yA, yB = yeLds.yB;
-    if (leg == 0 && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = static_cast<uint8_t>((okBits >> (cyc & 7)) & 1u);
-    const int aNj = static_cast<int>((u.flags >> 16) & 0xFFu), bNj = static_cast<int>(u.flags >> 24);
-    const float zA = (u.flags & kUgPreA) ? __uint_as_float(u.visA) : seq_mean_box(m.elev, mg.cols, u.aI0, u.aJ0, aNj, u.visA, 0ull, pc.h);
-    float zB = 0.0f;
-    if (out.default_next) zB = (u.flags & kUgPreB) ? __uint_as_float(u.visB) : seq_mean_box(m.elev, mg.cols, u.bI0, u.bJ0, bNj, u.visB, 0ull, pc.h);
-    const int code = static_cast<int>(u.flags & 0xFFu);
-    float zC = 0.0f;
-    if ((u.flags & kUgCTable) && out.centroid) zC = seq_mean_table(m.elev, mg.rows, mg.cols, u.cenRow, u.cenCol, footDa, footDb, pc.nFoot, pc.h);
-    else if (u.flags & kUgCIsA) zC = zA;  // whole region valid: the height at the centre (cpp:1687)
+    const bool h1 = half != 0;
+    const bool pre = (u.flags & (h1 ? kUgPreB : kUgPreA)) != 0u;
+    const uint32_t visW = h1 ? u.visB : u.visA;
+    const bool wantBox = !pre && (h1 ? out.default_next != nullptr : true);
+    const bool wantC = !h1 && (u.flags & kUgCTable) != 0u && out.centroid != nullptr;
+    const int nj = max(static_cast<int>(h1 ? (u.flags >> 24) : ((u.flags >> 16) & 0xFFu)), 1);
+    float sBox, sC;
+    seq_mean2(m.elev, mg.rows, mg.cols, h1 ? u.bI0 : u.aI0, h1 ? u.bJ0 : u.aJ0, nj, wantBox ? static_cast<unsigned long long>(visW) : 0ull, 0ull,
+              wantC, u.cenRow, u.cenCol, footDa, footDb, pc.nFoot, pc.h, sBox, sC);
+    const float zBox = pre ? __uint_as_float(visW) : sBox;
     const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
+    if (h1) {
+        if (leg == 0 && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = static_cast<uint8_t>((okBits >> (cyc & 7)) & 1u);
+        if (out.default_next) {
+            store_record<true>(out.default_next + o * 3 + 0, u.defX);
+            store_record<true>(out.default_next + o * 3 + 1, ny);
+            store_record<true>(out.default_next + o * 3 + 2, static_cast<double>(zBox));
+        }
+        return;
+    }
+    const float zA = zBox;
+    const float zC = wantC ? sC : ((u.flags & kUgCIsA) ? zA : 0.0f);  // code 0, whole region valid: the height at the centre (cpp:1687)
+    const int code = static_cast<int>(u.flags & 0xFFu);
     const int valid = (u.flags & kUgValid) ? 1 : 0, source = static_cast<int>((u.flags >> kUgSrcShift) & 3u);
     const float zN = valid ? zA : 0.0f;  // z at the DEFAULT centre, for a spiral candidate too (cpp:2029)
     if (out.nominal) {
@@ -1669,11 +1785,6 @@ __device__ __forceinline__ void flush_unit_g(const DevMap& m, const PlanConsts& 
         cf.z = zC; cf.row = u.cenRow; cf.col = u.cenCol;
         cf.code = static_cast<uint8_t>(code); cf.pad[0] = cf.pad[1] = cf.pad[2] = 0;
         store_record<true>(out.centroid + o, cf);
-    }
-    if (out.default_next) {
-        store_record<true>(out.default_next + o * 3 + 0, u.defX);
-        store_record<true>(out.default_next + o * 3 + 1, ny);
-        store_record<true>(out.default_next + o * 3 + 2, static_cast<double>(zB));
     }
 }
 
@@ -2611,8 +2722,9 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
             if constexpr (kMid) {
                 if (live && c0 + g.sub <= cyc) flush_unit(m, pc, units[g.sub], ytab[g.sub], b, c0 + g.sub, leg, nCycles, okBits, out);
             } else {
-                if (live && g.sub < kBatch && c0 + g.sub <= cyc)
-                    flush_unit_g(m, pc, sh.footDa, sh.footDb, units[g.sub], ytab[g.sub], b, c0 + g.sub, leg, nCycles, okBits, out);
+                const int us = g.sub >> 1;  // two lanes per unit (kBatch * 2 == G)
+                if (live && c0 + us <= cyc)
+                    flush_unit_g(m, pc, sh.footDa, sh.footDb, units[us], ytab[us], b, c0 + us, leg, g.sub & 1, nCycles, okBits, out);
             }
             okBits = 0u;
             bits_sync<G>();  // the units and the y entries are rewritten next
@@ -2727,8 +2839,13 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
             const int slot = cyc & (recSlots - 1);
             if (slot == recSlots - 1 || cyc == nCycles - 1) {
                 pose_sync<16>();
-                const int s = tid >> 2, c = (cyc - slot) + s;
-                if (tid < 4 * recSlots && c <= cyc) flush_seqrec(m, pc, sh.footDa, sh.footDb, recBase[tid], b, c, tid & 3, nCycles, out);
+                if constexpr (KW <= kSeqDeferMaxKW) {  // deferred heights: two lanes per (cycle, leg) unit
+                    const int un = tid >> 1, c = (cyc - slot) + (un >> 2);
+                    if (un < 4 * recSlots && c <= cyc) flush_seqrec2(m, pc, sh.footDa, sh.footDb, recBase[un], b, c, un & 3, tid & 1, nCycles, out);
+                } else {
+                    const int s = tid >> 2, c = (cyc - slot) + s;
+                    if (tid < 4 * recSlots && c <= cyc) flush_seqrec(m, pc, sh.footDa, sh.footDb, recBase[tid], b, c, tid & 3, nCycles, out);
+                }
                 pose_sync<16>();  // the slots are rewritten next
             }
         }
