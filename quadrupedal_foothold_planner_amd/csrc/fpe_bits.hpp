@@ -1705,6 +1705,49 @@ struct UnitG {
 };
 static_assert(sizeof(UnitG) == 80 && sizeof(UnitG) % 16 == 0, "UnitG layout");
 
+// Membership of a leg's two foot discs — the centre disc around (cxA, cy) and the default-track disc around (cxB, cy):
+// same columns, the y side is shared — with lane = BOX ROW: bit q of the lane's word = cell (i0 + sub, j0 + q) is visited
+// (inside the box, the map and the disc; CircleIterator::isInside, the expression of cell_in_disc).  Boxes of up to 8 x 8
+// cells; one pass over the columns instead of four rounds of eight cells per disc with a division each.
+__device__ __forceinline__ void disc_rows8(const MapGeom& mg, double rf2, double cxA, double cxB, double cy, const BBox& ba, const BBox& bbx,
+                                           const Grp<8>& g, uint32_t& rowA, uint32_t& rowB) {
+    const int iA = ba.i0 + g.sub, iB = bbx.i0 + g.sub;
+    const double dxA = cell_pos(mg.baseX, mg.res, iA) - cxA, dxB = cell_pos(mg.baseX, mg.res, iB) - cxB;
+    const double dxA2 = dxA * dxA, dxB2 = dxB * dxB;
+    const int j0 = ba.j0, nj = ba.nj;  // (both boxes: YEntry::j0d / njd)
+    uint32_t a = 0u, b = 0u;
+    for (int q = 0; __ballot(q < nj) != 0ull; ++q) {  // wave-uniform trip count
+        const double dy = cell_pos(mg.baseY, mg.res, j0 + q) - cy;
+        const double dy2 = dy * dy;
+        a |= ((dxA2 + dy2) <= rf2) ? (1u << q) : 0u;
+        b |= ((dxB2 + dy2) <= rf2) ? (1u << q) : 0u;
+    }
+    const int lo = max(0, -j0), hi = min(nj - 1, mg.cols - 1 - j0);  // columns inside the box and the map
+    const uint32_t colMask = hi >= lo ? ((2u << hi) - (1u << lo)) : 0u;
+    rowA = (g.sub < ba.ni && static_cast<unsigned>(iA) < static_cast<unsigned>(mg.rows)) ? (a & colMask) : 0u;
+    rowB = (g.sub < bbx.ni && static_cast<unsigned>(iB) < static_cast<unsigned>(mg.rows)) ? (b & colMask) : 0u;
+}
+// OR over the eight lanes of a group (DPP: two quad permutations and the half-row mirror)
+__device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
+    int x = static_cast<int>(v);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    return static_cast<uint32_t>(x);
+}
+// The box's 32-bit membership mask in CircleIterator order (cell t = a * nj + b) from the row words
+__device__ __forceinline__ uint32_t box_mask_from_rows8(uint32_t row, int nj, const Grp<8>& g) {
+    return or_reduce8(row << min(g.sub * nj, 31));  // (rows beyond the box hold 0)
+}
+// checkFoothold's default test (cpp:2012) on the row words: no visited cell of the centre disc has its Df bit set
+__device__ __forceinline__ bool default_ok_rows8(uint32_t rowA, const BBox& bb, const uint32_t* rowsDf, int nRows, int iw0, int jw0, const Grp<8>& g) {
+    const int ri = bb.i0 - iw0 + g.sub, cj0 = bb.j0 - jw0;
+    const uint32_t df = rowsDf[min(max(ri, 0), nRows - 1)];
+    // bit q of `sh` = window column cj0 + q of the row (columns outside the 32-bit window: 0, as win_bit)
+    const uint32_t sh = (cj0 >= 32 || cj0 <= -32) ? 0u : (cj0 >= 0 ? df >> cj0 : df << -cj0);
+    const bool fail = static_cast<unsigned>(ri) < static_cast<unsigned>(nRows) && (rowA & sh) != 0u;
+    return g.any(rowA != 0u) && !g.any(fail);
+}
 __device__ __forceinline__ void unitg_put_disc(const DevMap& m, const PlanConsts& pc, double cx, double cy, const BBox& bb, const Grp<8>& g,
                                                const DiscLoads& d, uint32_t& vis, bool& pre, float* scratch) {
     if (d.pipelined) {  // wave-uniform
@@ -2018,9 +2061,21 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
         uint4 grp[NRL][KW + 1];
         win_issue<G, NRL, KW>(bm, m.g, g, iw0, jw0, grp);
         DiscLoads dc, dd;
-        disc_issue<G, false, kMid, kMid>(m, pc, c.cx, c.cy, bb, g, dc, ye.dy2);
         const bool dfltUsable = wantDefault && fabs(nx0) <= 1e6;
-        if (dfltUsable) disc_issue<G, false, kMid, kMid>(m, pc, nx0, ny, dbox, g, dd, ye.dy2);
+        uint32_t rowA = 0u, rowB = 0u;     // generic kernels: membership of the two discs, lane = box row
+        bool rowsA = false, rowsB = false;  // ... when every box of the wavefront has at most 8 x 8 = 32 cells
+        if constexpr (kMid) {
+            disc_issue<G, false, kMid, kMid>(m, pc, c.cx, c.cy, bb, g, dc, ye.dy2);
+            if (dfltUsable) disc_issue<G, false, kMid, kMid>(m, pc, nx0, ny, dbox, g, dd, ye.dy2);
+        } else {
+            dc.pipelined = dd.pipelined = false;
+            dc.mid = dd.mid = false;
+            const bool fitA = bb.ni <= 8 && bb.nj <= 8 && bb.ni * bb.nj <= 32;
+            const bool fitB = !dfltUsable || (dbox.ni <= 8 && dbox.nj <= 8 && dbox.ni * dbox.nj <= 32);
+            rowsA = __ballot(!fitA) == 0ull;
+            rowsB = __ballot(!fitB) == 0ull;
+            if (rowsA || rowsB) disc_rows8(m.g, pc.rf2, c.cx, nx0, c.cy, bb, dbox, g, rowA, rowB);
+        }
         stamp(pc, cyc, 3);
         WinRows<NRL, KW> w;
         win_finish<NRL, KW>(jw0, grp, w);
@@ -2029,7 +2084,13 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
         const CentroidScan sc = rows_from_bits<G, NRL, KW>(sm, w, g, iw0, jw0);
         bits_sync<G>();
         stamp(pc, cyc, 4);
-        const bool defaultOk = default_ok_bits<G, KW, kMid>(m, pc, c.cx, c.cy, bb, dc, lb.a, lb.rows, iw0, jw0, g);  // cpp:2012
+        bool defaultOk;
+        if constexpr (kMid) {
+            defaultOk = default_ok_bits<G, KW, kMid>(m, pc, c.cx, c.cy, bb, dc, lb.a, lb.rows, iw0, jw0, g);  // cpp:2012
+        } else {
+            defaultOk = rowsA ? default_ok_rows8(rowA, bb, lb.a, lb.rows, iw0, jw0, g)
+                              : default_ok_bits<G, KW, kMid>(m, pc, c.cx, c.cy, bb, dc, lb.a, lb.rows, iw0, jw0, g);
+        }
         bits_sync<G>();  // lb doubles as scratch below
         bool unused;
         float zCentre = 0.0f;
@@ -2043,12 +2104,20 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
             }
         } else {
             bool pre;
-            unitg_put_disc(m, pc, c.cx, c.cy, bb, g, dc, ugVisA, pre, scratch);
-            if (pre) ugFlags |= kUgPreA;
+            if (rowsA) {
+                ugVisA = box_mask_from_rows8(rowA, bb.nj, g);
+            } else {
+                unitg_put_disc(m, pc, c.cx, c.cy, bb, g, dc, ugVisA, pre, scratch);  // (not pipelined: the direct pass)
+                if (pre) ugFlags |= kUgPreA;
+            }
             ugAI0 = bb.i0; ugAJ0 = bb.j0; ugANj = max(bb.nj, 1);
             if (dfltUsable) {
-                unitg_put_disc(m, pc, nx0, ny, dbox, g, dd, ugVisB, pre, scratch);
-                if (pre) ugFlags |= kUgPreB;
+                if (rowsB) {
+                    ugVisB = box_mask_from_rows8(rowB, dbox.nj, g);
+                } else {
+                    unitg_put_disc(m, pc, nx0, ny, dbox, g, dd, ugVisB, pre, scratch);
+                    if (pre) ugFlags |= kUgPreB;
+                }
                 ugBI0 = dbox.i0; ugBJ0 = dbox.j0; ugBNj = max(dbox.nj, 1);
             } else {
                 ugFlags |= kUgPreB;
