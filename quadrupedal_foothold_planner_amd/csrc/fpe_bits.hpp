@@ -681,7 +681,14 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
     // candidate; without this test such a leg scans every round with in_range false, in every phase of every remaining
     // cycle (cfg-3: 122 of a pose's 128 searches, 1.3 of its 2.5 M clocks, and the kernel waits for its slowest pose).
     if (c.ici + c.nRings < 0 || c.ici - c.nRings >= m.g.rows || c.icj + c.nRings < 0 || c.icj - c.nRings >= m.g.cols) return false;
+    if (G == 8) stamp_any(pc, c.cyc, 11);
+    // generic 8-lane kernels: the first round's table entries are requested here, ahead of the P rows and the erosion
+    uint4 tabFirst = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (G == 8 && KW == 1 && !kOneCellFoot) tabFirst = reinterpret_cast<const uint4*>(lut.packed)[g.sub];
     bool polyFolded = true;  // the polygon test is part of P (rectangle: always; other polygons: see below)
+    unsigned Preg[NRL];      // single-word rows: this lane's P rows stay in registers for the erosion
+#pragma unroll
+    for (int k = 0; k < NRL; ++k) Preg[k] = 0u;
     // (1) per row: P = cells that do NOT fail checkCirclePolygonFoothold's per-cell test (cpp:2132-2138)
     if (c.rect) {
         IndexRect ir = rectangle_index_bounds(m.g, c.xlo, c.xhi, c.ylo, c.yhi, g);
@@ -698,6 +705,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             for (int q = 0; q < KW; ++q) {
                 const unsigned inside = rowIn ? ((ye && KW == 1) ? ye->pmask : range_word(ir.jA - jw0, ir.jB - jw0, q)) : 0u;
                 if (ri < NR) lb.a[ri * KW + q] = ~w.F[k][q] | (~w.C[k][q] & inside);
+                if constexpr (KW == 1) Preg[k] = ~w.F[k][0] | (~w.C[k][0] & inside);
             }
         }
     } else {
@@ -776,11 +784,13 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                     if (ri >= NR) continue;
                     lb.a[ri * KW + q] = ~w.C[k][q];  // threshold only (C implies F); the polygon is tested per candidate below
                     lb.f[ri * KW + q] = w.F[k][q];
+                    if constexpr (KW == 1) Preg[k] = ~w.C[k][0];
                 }
             }
         }
     }
     bits_sync<G>();
+    if (G == 8) stamp_any(pc, c.cyc, 12);
     // (2) erosion with the foot-disc offset table: E bit (row, col) = AND_k P(row + da_k, col + db_k)
     const uint32_t* E = lb.a;
     if (!kOneCellFoot && pc.nFoot > 1 && pc.nHW > 0) {
@@ -795,6 +805,23 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
         //   E(row) = AND_a H_w(a)(P(row + a)) & H_w(a)(P(row - a)),   H_w(x) bit j = AND_{|t| <= w} x bit j + t,
         // and H_w is built by doubling (x & x>>1, & >>2, ...) — a handful of shifts per distinct width instead of one
         // shift per offset (45 offsets on a 0.5 cm map)
+        if constexpr (KW == 1) {
+            // single-word rows: H_w of this lane's rows straight from the registers (no LDS read, no doubling loop):
+            // H_w(x) = AND_{|t| <= w} x shifted by t
+            for (int hw = 0; hw < pc.nHW; ++hw) {
+                const int wdt = static_cast<int>((hwListW >> (8 * hw)) & 0xFFu);
+                unsigned acc[NRL];
+#pragma unroll
+                for (int k = 0; k < NRL; ++k) acc[k] = Preg[k];
+                for (int t = 1; t <= wdt; ++t) {
+#pragma unroll
+                    for (int k = 0; k < NRL; ++k) acc[k] &= (Preg[k] >> t) & (Preg[k] << t);
+                }
+#pragma unroll
+                for (int k = 0; k < NRL; ++k)
+                    if (g.sub + G * k < NR) lb.h0[hw * lb.hStride + g.sub + G * k] = acc[k];
+            }
+        } else
         for (int hw = 0; hw < pc.nHW; ++hw) {
             const int wdt = static_cast<int>((hwListW >> (8 * hw)) & 0xFFu);
             const int L = 2 * wdt + 1;
@@ -823,6 +850,24 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             }
         }
         bits_sync<G>();
+        if constexpr (KW == 1) {
+            // (row offset a outermost: the reads of all of this lane's rows are in flight together)
+            unsigned e[NRL];
+#pragma unroll
+            for (int k = 0; k < NRL; ++k) e[k] = ~0u;
+            for (int a = 0; a <= pc.footReach; ++a) {
+                const int hwOfRow = static_cast<int>(((a < 8 ? hwIdxLo : hwIdxHi) >> (8 * (a & 7))) & 0xFFu);
+                const uint32_t* hrow = lb.h0 + hwOfRow * lb.hStride;
+#pragma unroll
+                for (int k = 0; k < NRL; ++k) {
+                    const int ri = g.sub + G * k;
+                    e[k] &= hrow[min(max(ri - a, 0), NR - 1)] & hrow[min(max(ri + a, 0), NR - 1)];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NRL; ++k)
+                if (g.sub + G * k < NR) lb.a[g.sub + G * k] = e[k];  // the P rows are dead: E takes their place
+        } else
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
             const int ri = g.sub + G * k;
@@ -869,6 +914,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
         bits_sync<G>();
         E = lb.h0;
     }
+    if (G == 8) stamp_any(pc, c.cyc, 13);
     // Two forms of the candidate scan, chosen per kernel shape by measurement (A/B on the BASELINE configurations):
     // 96-bit windows (0.5 cm maps: thousands of candidates, searches that run for tens of rounds) take the straight-line
     // rounds with the ring skip (cfg-5: 0.98 -> 0.76 ms); the 8-lane kernels take the straight-line rounds without it
@@ -881,7 +927,80 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
     constexpr bool kFlatRounds = true;
     constexpr bool kRingSkip = KW >= 2;
 #endif
-    if constexpr (kFlatRounds) {
+    if constexpr (G == 8 && KW == 1 && !kOneCellFoot) {
+        // (3) generic 8-lane kernels (the 3x3-only ones evaluate ranks 0-15 in leg_fast8m and come here for the rest; the
+        // scan below cost them registers: measured +3 % on the headline): FOUR candidates per lane and round (rank k = 32 * round + 4 * lane + u, one uint4 of packed
+        // table entries per lane), so the first valid cell in spiral order is the lowest (lane, u) with a pass bit.  A
+        // candidate lies within nRings <= winH rows and columns of the window's centre: its E bit is read without range
+        // tests; cells outside the map are cleared from E first (wave-uniform, windows at the map's border only).
+        const int M = c.nCand;
+        const int rowW = c.ici - iw0, colW = c.icj - jw0;  // the centre inside the window: (winH, winH)
+        uint32_t* Ew = const_cast<uint32_t*>(E);
+        const bool border = iw0 < 0 || jw0 < 0 || iw0 + NR > m.g.rows || jw0 + 32 > m.g.cols;
+        if (__ballot(border) != 0ull) {
+            const uint32_t colIn = range_word(-jw0, m.g.cols - 1 - jw0, 0);
+#pragma unroll
+            for (int k = 0; k < NRL; ++k) {
+                const int ri = g.sub + G * k;
+                if (ri < NR) Ew[ri] = static_cast<unsigned>(iw0 + ri) < static_cast<unsigned>(m.g.rows) ? (Ew[ri] & colIn) : 0u;
+            }
+            bits_sync<G>();
+        }
+        const uint4* tab = reinterpret_cast<const uint4*>(lut.packed);
+        const int nRounds = (M + 31) >> 5;
+        uint4 nxt = tabFirst;
+        for (int round = 0; round < nRounds; ++round) {
+            const uint4 cur = nxt;
+            nxt = tab[(round + 1) * G + g.sub];  // (the table is padded by one round)
+            const uint32_t wds[4] = {cur.x, cur.y, cur.z, cur.w};
+            const int k0 = round * 32 + 4 * g.sub;
+            bool ok[4], outer[4];
+            bool anyOuterOk = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool liveU = k0 + u < M;
+                const int di = static_cast<int8_t>(wds[u] & 0xFFu), dj = static_cast<int8_t>((wds[u] >> 8) & 0xFFu);
+                const int r = static_cast<int>((wds[u] >> 16) & 0xFFu);
+                const uint32_t row = Ew[liveU ? rowW + di : 0];  // (entries beyond this leg's radius may point outside the window)
+                ok[u] = liveU & (((row >> ((colW + dj) & 31)) & 1u) != 0u);
+                // SpiralIterator::generateRing filters rings nRings-1 and nRings by isInside; the centre cell (ring 0) is
+                // pushed unfiltered by the constructor
+                outer[u] = (r >= 1) & (r + 1 >= c.nRings);
+                anyOuterOk |= ok[u] & outer[u];
+            }
+            if (__ballot(anyOuterOk) != 0ull) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int di = static_cast<int8_t>(wds[u] & 0xFFu), dj = static_cast<int8_t>((wds[u] >> 8) & 0xFFu);
+                    if (ok[u] & outer[u]) ok[u] = cell_in_disc(m.g, c.ici + di, c.icj + dj, c.cx, c.cy, c.R2);
+                }
+            }
+            if (!polyFolded && __ballot(ok[0] | ok[1] | ok[2] | ok[3]) != 0ull) {
+                // arbitrary polygon not folded into P: every FINITE cell of the foot disc must lie inside it (cpp:2138)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (!ok[u]) continue;
+                    const int i = c.ici + static_cast<int8_t>(wds[u] & 0xFFu), j = c.icj + static_cast<int8_t>((wds[u] >> 8) & 0xFFu);
+                    for (int f = 0; f < pc.nFoot; ++f) {
+                        const int qi = i + c.footDa[f], qj = j + c.footDb[f];
+                        if (win_bit<KW>(lb.f, NR, qi - iw0, qj - jw0) == 0u) continue;
+                        if (!polygon_inside_fast(c.vx, c.vy, c.nv, cell_pos(m.g.baseX, m.g.res, qi), cell_pos(m.g.baseY, m.g.res, qj))) {
+                            ok[u] = false;
+                            break;
+                        }
+                    }
+                }
+            }
+            const unsigned mask = static_cast<unsigned>(g.ballot(ok[0] | ok[1] | ok[2] | ok[3]));
+            if (mask) {
+                const uint32_t mine = ok[0] ? wds[0] : (ok[1] ? wds[1] : (ok[2] ? wds[2] : wds[3]));
+                const uint32_t win = g.bcast(mine, __builtin_ctz(mask));
+                wi = c.ici + static_cast<int8_t>(win & 0xFFu);
+                wj = c.icj + static_cast<int8_t>((win >> 8) & 0xFFu);
+                return true;
+            }
+        }
+    } else if constexpr (kFlatRounds) {
         // (3) candidates in rank order, lane = rank; lowest set ballot bit = argmin of rank.  Straight-line per round
         // (per-lane `if` chains are compiled into exec-mask branches): lanes beyond the table and cells outside the map carry
         // ok = false through unconditional, clamped evaluations; the disc filter of the outer rings and the per-candidate

@@ -25,6 +25,9 @@ struct SpiralLut {
     const int32_t* ringStart;  // [maxRing + 2]
     int32_t maxRing;
     int32_t total;             // ringStart[maxRing + 1]: entries of the whole table (spares the kernels a dependent load)
+    // entry k as one word, (di & 0xFF) | (dj & 0xFF) << 8 | ring << 16, padded with (0, 0, 255) to a multiple of 32 entries
+    // plus one more group of 32: the 8-lane bit-window kernels read four consecutive entries per lane and round (uint4)
+    const uint32_t* packed;
 };
 
 constexpr int kMaxFootOffsets = 128;

@@ -358,13 +358,14 @@ struct fpe_engine {
     int16_t* d_dj = nullptr;
     uint8_t* d_ring = nullptr;
     int32_t* d_ringStart = nullptr;
+    uint32_t* d_packed = nullptr;
     int maxRing = 0;
     std::vector<int32_t> ringStart;   // host copy of the rank table's ring offsets
     float maxLegSearchRadius = 0.0f;  // fpe_set_max_leg_search_radius
     fpe::Tuning tuning;               // fpe_set_tuning; seeded from the environment once, in fpe_create
 
     fpe::SpiralLut lut() const {
-        return fpe::SpiralLut{d_di, d_dj, d_ring, d_ringStart, maxRing, ringStart.empty() ? 0 : ringStart[static_cast<size_t>(maxRing) + 1]};
+        return fpe::SpiralLut{d_di, d_dj, d_ring, d_ringStart, maxRing, ringStart.empty() ? 0 : ringStart[static_cast<size_t>(maxRing) + 1], d_packed};
     }
 };
 
@@ -615,6 +616,13 @@ int fpe_create(int device_id, fpe_handle* out) {
     FPE_HIP_C(hipMemcpy(h->d_dj, t.dj.data(), n * sizeof(int16_t), hipMemcpyHostToDevice));
     FPE_HIP_C(hipMemcpy(h->d_ring, t.ring.data(), n * sizeof(uint8_t), hipMemcpyHostToDevice));
     FPE_HIP_C(hipMemcpy(h->d_ringStart, t.ringStart.data(), t.ringStart.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    {
+        std::vector<uint32_t> packed(((n + 31) / 32 + 1) * 32, 255u << 16);  // SpiralLut::packed
+        for (size_t k = 0; k < n; ++k)
+            packed[k] = (static_cast<uint32_t>(t.di[k]) & 0xFFu) | ((static_cast<uint32_t>(t.dj[k]) & 0xFFu) << 8) | (static_cast<uint32_t>(t.ring[k]) << 16);
+        FPE_HIP_C(hipMalloc(reinterpret_cast<void**>(&h->d_packed), packed.size() * sizeof(uint32_t)));
+        FPE_HIP_C(hipMemcpy(h->d_packed, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     // every kernel may use the whole 160 KiB of LDS: set once per process and device, never lowered again (a
     // second engine on the same device sets the same value)
     FPE_HIP_C(fpe::set_max_lds(kMaxLdsBytes, kMaxLdsBytes));
@@ -631,6 +639,7 @@ int fpe_destroy(fpe_handle h) {
     if (h->d_dj) (void)hipFree(h->d_dj);
     if (h->d_ring) (void)hipFree(h->d_ring);
     if (h->d_ringStart) (void)hipFree(h->d_ringStart);
+    if (h->d_packed) (void)hipFree(h->d_packed);
     h->map.reset();
     delete h;
     return FPE_OK;

@@ -54,6 +54,19 @@ __device__ __forceinline__ void stamp(const PlanConsts& pc, int cyc, int point) 
 #endif
 }
 
+// the same from whichever lane is the first active one (inside lane-divergent regions)
+__device__ __forceinline__ void stamp_any(const PlanConsts& pc, int cyc, int point) {
+#ifdef FPE_TRACE
+    const int first = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x));
+    if (pc.trace && blockIdx.x < 256 && cyc < 8 && static_cast<int>(threadIdx.x) == first)
+        pc.trace[(static_cast<size_t>(blockIdx.x) * 8 + cyc) * 16 + point] = __builtin_readcyclecounter();
+#else
+    (void)pc;
+    (void)cyc;
+    (void)point;
+#endif
+}
+
 __device__ __forceinline__ void stamp_value(const PlanConsts& pc, int cyc, int point, long long v) {
 #ifdef FPE_TRACE
     if (pc.trace && blockIdx.x < 256 && cyc < 8 && threadIdx.x == 0)
