@@ -682,9 +682,15 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
     // cycle (cfg-3: 122 of a pose's 128 searches, 1.3 of its 2.5 M clocks, and the kernel waits for its slowest pose).
     if (c.ici + c.nRings < 0 || c.ici - c.nRings >= m.g.rows || c.icj + c.nRings < 0 || c.icj - c.nRings >= m.g.cols) return false;
     if (G == 8) stamp_any(pc, c.cyc, 11);
+    if (G == 64) stamp_any(pc, 0, 14);  // (profiling builds: the LAST search of the pose wins; see scratch/trace_seq.py)
     // generic 8-lane kernels: the first round's table entries are requested here, ahead of the P rows and the erosion
     uint4 tabFirst = make_uint4(0u, 0u, 0u, 0u);
     if constexpr (G == 8 && KW == 1 && !kOneCellFoot) tabFirst = reinterpret_cast<const uint4*>(lut.packed)[g.sub];
+    // Window rows sized for the largest search radius a pose may ask for (fpe_set_max_leg_search_radius) are beyond the reach
+    // of a leg with the usual radius: when every row such a leg's candidates and their foot discs can touch is held in the
+    // lanes' FIRST row (one-wavefront-per-pose kernels with two rows per lane), the second row's share of the P rows, the
+    // erosion and the ring skip is not computed at all (cfg-5: half of those stages)
+    const int kLim = (G == 64 && NRL > 1 && pc.winH + c.nRings + pc.footReach < G) ? 1 : NRL;
     bool polyFolded = true;  // the polygon test is part of P (rectangle: always; other polygons: see below)
     unsigned Preg[NRL];      // single-word rows: this lane's P rows stay in registers for the erosion
 #pragma unroll
@@ -698,6 +704,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
         }
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
+            if (k >= kLim) continue;  // (rows no candidate of this leg can touch)
             const int ri = g.sub + G * k;
             const int i = iw0 + ri;
             const bool rowIn = i >= ir.iA && i <= ir.iB;
@@ -754,6 +761,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                 for (int q = 0; q < KW; ++q) carryIn[q] = carryOut[q] = 0u;
 #pragma unroll
                 for (int k = 0; k < NRL; ++k) {
+                    if (k >= kLim) continue;  // (rows no candidate of this leg can touch)
                     const int ri = g.sub + G * k;
 #pragma unroll
                     for (int q = 0; q < KW; ++q) {
@@ -767,6 +775,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                 }
 #pragma unroll
                 for (int k = 0; k < NRL; ++k) {
+                    if (k >= kLim) continue;  // (rows no candidate of this leg can touch)
                     const int ri = g.sub + G * k;
 #pragma unroll
                     for (int q = 0; q < KW; ++q)
@@ -778,6 +787,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
         if (!folded) {
 #pragma unroll
             for (int k = 0; k < NRL; ++k) {
+                if (k >= kLim) continue;  // (rows no candidate of this leg can touch)
                 const int ri = g.sub + G * k;
 #pragma unroll
                 for (int q = 0; q < KW; ++q) {
@@ -791,6 +801,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
     }
     bits_sync<G>();
     if (G == 8) stamp_any(pc, c.cyc, 12);
+    if (G == 64) stamp_any(pc, 0, 15);
     // (2) erosion with the foot-disc offset table: E bit (row, col) = AND_k P(row + da_k, col + db_k)
     const uint32_t* E = lb.a;
     if (!kOneCellFoot && pc.nFoot > 1 && pc.nHW > 0) {
@@ -827,6 +838,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             const int L = 2 * wdt + 1;
 #pragma unroll
             for (int k = 0; k < NRL; ++k) {
+                if (k >= kLim) continue;  // (rows no candidate of this leg can touch)
                 const int ri = g.sub + G * k;
                 unsigned A[KW], T[KW];
 #pragma unroll
@@ -860,6 +872,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                 const uint32_t* hrow = lb.h0 + hwOfRow * lb.hStride;
 #pragma unroll
                 for (int k = 0; k < NRL; ++k) {
+                    if (k >= kLim) continue;  // (rows no candidate of this leg can touch)
                     const int ri = g.sub + G * k;
                     e[k] &= hrow[min(max(ri - a, 0), NR - 1)] & hrow[min(max(ri + a, 0), NR - 1)];
                 }
@@ -870,6 +883,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
         } else
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
+            if (k >= kLim) continue;  // (rows no candidate of this leg can touch)
             const int ri = g.sub + G * k;
             unsigned e[KW];
 #pragma unroll
@@ -890,6 +904,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
     } else if (!kOneCellFoot && pc.nFoot > 1) {
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
+            if (k >= kLim) continue;  // (rows no candidate of this leg can touch)
             const int ri = g.sub + G * k;
             unsigned e[KW];
 #pragma unroll
@@ -915,6 +930,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
         E = lb.h0;
     }
     if (G == 8) stamp_any(pc, c.cyc, 13);
+    if (G == 64) stamp_any(pc, 2, 14);
     // Two forms of the candidate scan, chosen per kernel shape by measurement (A/B on the BASELINE configurations):
     // 96-bit windows (0.5 cm maps: thousands of candidates, searches that run for tens of rounds) take the straight-line
     // rounds with the ring skip (cfg-5: 0.98 -> 0.76 ms); the 8-lane kernels take the straight-line rounds without it
@@ -941,6 +957,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             const uint32_t colIn = range_word(-jw0, m.g.cols - 1 - jw0, 0);
 #pragma unroll
             for (int k = 0; k < NRL; ++k) {
+                if (k >= kLim) continue;  // (rows no candidate of this leg can touch)
                 const int ri = g.sub + G * k;
                 if (ri < NR) Ew[ri] = static_cast<unsigned>(iw0 + ri) < static_cast<unsigned>(m.g.rows) ? (Ew[ri] & colIn) : 0u;
             }
@@ -1020,6 +1037,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             bool near = false;
 #pragma unroll
             for (int k = 0; k < NRL; ++k) {
+                if (k >= kLim) continue;  // (rows no candidate of this leg can touch)
                 const int ri = g.sub + G * k;
                 const int cj = c.icj - jw0;
                 uint32_t bits = 0u;
@@ -1034,6 +1052,7 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             int ringRow = 1 << 20;
 #pragma unroll
             for (int k = 0; k < NRL; ++k) {
+                if (k >= kLim) continue;  // (rows no candidate of this leg can touch)
                 const int ri = g.sub + G * k;
                 const int a = abs(ri - (c.ici - iw0));
                 uint32_t rowIn[KW];  // the row's E bits on columns inside the map (cells outside it pass every test but are no candidates)
@@ -1055,6 +1074,8 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             }
         }
         int round = startBase / G;
+        if (G == 64) stamp_any(pc, 2, 15);
+        if (G == 64) stamp_value(pc, 4, 14, round);
         int nDi = 0, nDj = 0, nR = c.nRings;
         if (__ballot(round >= kLutHeadRounds) != 0ull) {  // uniform: a late start reads its first round's entries here
             const int kn = min(startBase + g.sub, M - 1);
@@ -1112,6 +1133,8 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                 const int l = __builtin_ctzll(mask);
                 wi = g.bcast(i, l);
                 wj = g.bcast(j, l);
+                if (G == 64) stamp_any(pc, 3, 14);
+                if (G == 64) stamp_value(pc, 4, 15, round);
                 return true;
             }
         }
