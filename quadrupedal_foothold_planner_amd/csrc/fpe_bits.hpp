@@ -668,6 +668,29 @@ __device__ __forceinline__ int group_min7(const Grp<G>& g, int v) {
     return r;
 }
 
+// H_d(x): bit j = AND_{|t| <= d} x bit j + t (zeros beyond the row's words), by doubling: x & x>>1, & >>2, ... then centred
+template <int KW>
+__device__ __forceinline__ void erode_h(unsigned (&A)[KW], int d) {
+    if (d <= 0) return;
+    const int L = 2 * d + 1;
+    unsigned T[KW];
+    int span = 1;
+    while (2 * span <= L) {  // A covers columns [j, j + span)
+        row_shr<KW>(A, static_cast<unsigned>(span), T);
+#pragma unroll
+        for (int q = 0; q < KW; ++q) A[q] &= T[q];
+        span *= 2;
+    }
+    if (span < L) {
+        row_shr<KW>(A, static_cast<unsigned>(L - span), T);
+#pragma unroll
+        for (int q = 0; q < KW; ++q) A[q] &= T[q];
+    }
+    row_shl<KW>(A, static_cast<unsigned>(d), T);  // centre the interval: [j - d, j + d]
+#pragma unroll
+    for (int q = 0; q < KW; ++q) A[q] = T[q];
+}
+
 // checkCandidateFoothold (cpp:2085-2114) on the window's bit rows: first valid cell in SpiralIterator order.
 // kOneCellFoot: the caller is a 3x3-only kernel, launched for one-cell foot discs only (launch_plan_bits): the erosion
 // is compiled out (its code and live scalars cost the chain of those kernels 1 us of register allocation otherwise).
@@ -813,12 +836,11 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
         __builtin_memcpy(&hwIdxLo, pc.hwIdx, 8);
         __builtin_memcpy(&hwIdxHi, pc.hwIdx + 8, 8);
         // row-interval form: the disc's row +-a holds the columns [-w(a), w(a)], so
-        //   E(row) = AND_a H_w(a)(P(row + a)) & H_w(a)(P(row - a)),   H_w(x) bit j = AND_{|t| <= w} x bit j + t,
-        // and H_w is built by doubling (x & x>>1, & >>2, ...) — a handful of shifts per distinct width instead of one
-        // shift per offset (45 offsets on a 0.5 cm map)
+        //   E(row) = AND_a H_w(a)(P(row + a)) & H_w(a)(P(row - a)),   H_w(x) bit j = AND_{|t| <= w} x bit j + t
+        // — a handful of shifts per distinct width instead of one shift per offset (45 offsets on a 0.5 cm map)
         if constexpr (KW == 1) {
-            // single-word rows: H_w of this lane's rows straight from the registers (no LDS read, no doubling loop):
-            // H_w(x) = AND_{|t| <= w} x shifted by t
+            // single-word rows (8-lane kernels; measured against the nested form below: cfg-4 -2.5 %): H_w of this lane's
+            // rows straight from the registers, H_w(x) = AND_{|t| <= w} x shifted by t, one array per distinct width ...
             for (int hw = 0; hw < pc.nHW; ++hw) {
                 const int wdt = static_cast<int>((hwListW >> (8 * hw)) & 0xFFu);
                 unsigned acc[NRL];
@@ -832,38 +854,8 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                 for (int k = 0; k < NRL; ++k)
                     if (g.sub + G * k < NR) lb.h0[hw * lb.hStride + g.sub + G * k] = acc[k];
             }
-        } else
-        for (int hw = 0; hw < pc.nHW; ++hw) {
-            const int wdt = static_cast<int>((hwListW >> (8 * hw)) & 0xFFu);
-            const int L = 2 * wdt + 1;
-#pragma unroll
-            for (int k = 0; k < NRL; ++k) {
-                if (k >= kLim) continue;  // (rows no candidate of this leg can touch)
-                const int ri = g.sub + G * k;
-                unsigned A[KW], T[KW];
-#pragma unroll
-                for (int q = 0; q < KW; ++q) A[q] = lb.a[min(ri, NR - 1) * KW + q];
-                int span = 1;
-                while (2 * span <= L) {  // A covers columns [j, j + span)
-                    row_shr<KW>(A, static_cast<unsigned>(span), T);
-#pragma unroll
-                    for (int q = 0; q < KW; ++q) A[q] &= T[q];
-                    span *= 2;
-                }
-                if (span < L) {
-                    row_shr<KW>(A, static_cast<unsigned>(L - span), T);
-#pragma unroll
-                    for (int q = 0; q < KW; ++q) A[q] &= T[q];
-                }
-                row_shl<KW>(A, static_cast<unsigned>(wdt), T);  // centre the interval: [j - w, j + w]
-#pragma unroll
-                for (int q = 0; q < KW; ++q)
-                    if (ri < NR) lb.h0[hw * lb.hStride + ri * KW + q] = T[q];
-            }
-        }
-        bits_sync<G>();
-        if constexpr (KW == 1) {
-            // (row offset a outermost: the reads of all of this lane's rows are in flight together)
+            bits_sync<G>();
+            // ... then the rows +-a of the array of w(a) (a outermost: the reads of all of this lane's rows are in flight together)
             unsigned e[NRL];
 #pragma unroll
             for (int k = 0; k < NRL; ++k) e[k] = ~0u;
@@ -872,7 +864,6 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                 const uint32_t* hrow = lb.h0 + hwOfRow * lb.hStride;
 #pragma unroll
                 for (int k = 0; k < NRL; ++k) {
-                    if (k >= kLim) continue;  // (rows no candidate of this leg can touch)
                     const int ri = g.sub + G * k;
                     e[k] &= hrow[min(max(ri - a, 0), NR - 1)] & hrow[min(max(ri + a, 0), NR - 1)];
                 }
@@ -880,25 +871,50 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
 #pragma unroll
             for (int k = 0; k < NRL; ++k)
                 if (g.sub + G * k < NR) lb.a[g.sub + G * k] = e[k];  // the P rows are dead: E takes their place
-        } else
+        } else {
+            // Multi-word rows, vertical first: H_w distributes over AND and H_a(H_b(x)) = H_(a + b)(x) (zero fill included),
+            // and a disc's widths do not grow with |a| (derive_foot_offsets checks it), so with V_q = AND of the rows
+            // P(row +- a) whose width is the q-th distinct one, w_0 > w_1 > ...:
+            //   E = H_w0(V_0) & H_w1(V_1) & ... = H_w(n-1)( ... H_(w1 - w2)( H_(w0 - w1)(V_0) & V_1 ) & V_2 ... )
+            // — the rows are ANDed as they are read (no intermediate arrays, no second pass), and the horizontal work is
+            // w_0 single steps per row in total instead of one full H_w per distinct width (cfg-5: -5 %).
+            unsigned acc[NRL][KW];
 #pragma unroll
-        for (int k = 0; k < NRL; ++k) {
-            if (k >= kLim) continue;  // (rows no candidate of this leg can touch)
-            const int ri = g.sub + G * k;
-            unsigned e[KW];
+            for (int k = 0; k < NRL; ++k)
 #pragma unroll
-            for (int q = 0; q < KW; ++q) e[q] = ~0u;
+                for (int q = 0; q < KW; ++q) acc[k][q] = ~0u;
+            int curW = static_cast<int>(hwListW & 0xFFu);  // w(0): hwIdx[0] == 0 by construction
             for (int a = 0; a <= pc.footReach; ++a) {
                 const int hwOfRow = static_cast<int>(((a < 8 ? hwIdxLo : hwIdxHi) >> (8 * (a & 7))) & 0xFFu);
-                const uint32_t* hrow = lb.h0 + hwOfRow * lb.hStride;
-                const uint32_t* up = hrow + min(max(ri - a, 0), NR - 1) * KW;
-                const uint32_t* dn = hrow + min(max(ri + a, 0), NR - 1) * KW;
+                const int wa = static_cast<int>((hwListW >> (8 * hwOfRow)) & 0xFFu);
+                if (wa != curW) {  // uniform: the next (narrower) group of rows
 #pragma unroll
-                for (int q = 0; q < KW; ++q) e[q] &= up[q] & dn[q];
+                    for (int k = 0; k < NRL; ++k) {
+                        if (k >= kLim) continue;  // (rows no candidate of this leg can touch)
+                        erode_h<KW>(acc[k], curW - wa);
+                    }
+                    curW = wa;
+                }
+#pragma unroll
+                for (int k = 0; k < NRL; ++k) {
+                    if (k >= kLim) continue;
+                    const int ri = g.sub + G * k;
+                    const uint32_t* up = lb.a + min(max(ri - a, 0), NR - 1) * KW;
+                    const uint32_t* dn = lb.a + min(max(ri + a, 0), NR - 1) * KW;
+#pragma unroll
+                    for (int q = 0; q < KW; ++q) acc[k][q] &= up[q] & dn[q];
+                }
             }
 #pragma unroll
-            for (int q = 0; q < KW; ++q)
-                if (ri < NR) lb.a[ri * KW + q] = e[q];  // the P rows are dead: E takes their place
+            for (int k = 0; k < NRL; ++k) {
+                if (k >= kLim) continue;
+                const int ri = g.sub + G * k;
+                erode_h<KW>(acc[k], curW);
+#pragma unroll
+                for (int q = 0; q < KW; ++q)
+                    if (ri < NR) lb.h0[ri * KW + q] = acc[k][q];
+            }
+            E = lb.h0;
         }
         bits_sync<G>();
     } else if (!kOneCellFoot && pc.nFoot > 1) {

@@ -186,6 +186,7 @@ void derive_foot_offsets(float footRadius, const MapGeom& g, PlanConsts& c) {
         for (int a = 0; a <= mx; ++a) {
             if (w[a] < 0) ok = false;
             else expect += (a == 0 ? 1 : 2) * (2 * w[a] + 1);
+            if (a > 0 && w[a] > w[a - 1]) ok = false;  // (the kernels' nested erosion takes the widths in non-increasing order)
         }
         if (ok && expect == c.nFoot) {  // |set| matches and every entry lies inside its row interval: the forms are equal
             int n = 0;
