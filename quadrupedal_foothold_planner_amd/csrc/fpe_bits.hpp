@@ -565,7 +565,7 @@ __device__ __forceinline__ IndexRect rectangle_index_bounds(const MapGeom& mg, d
     const double x = cell_pos(base, mg.res, t);
     const bool pred = isLo ? (x >= lim) : (x < lim);
     const unsigned b = static_cast<unsigned>(g.ballot(pred && g.sub < 8));
-    const int eXhi = g.bcast(e, 0), eXlo = g.bcast(e, 2), eYhi = g.bcast(e, 4), eYlo = g.bcast(e, 6);
+    const int eXhi = g.template bcast_c<0>(e), eXlo = g.template bcast_c<2>(e), eYhi = g.template bcast_c<4>(e), eYlo = g.template bcast_c<6>(e);
     IndexRect r;
     r.iA = (b & 1u) ? eXhi : ((b & 2u) ? eXhi + 1 : eXhi + 2);
     r.iB = (b & 4u) ? eXlo + 1 : ((b & 8u) ? eXlo : eXlo - 1);

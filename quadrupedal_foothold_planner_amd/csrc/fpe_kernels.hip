@@ -106,6 +106,13 @@ struct Grp {
     __device__ __forceinline__ bool any(bool p) const { return ballot(p) != 0ull; }
     // Value of lane l of the group.  Every caller derives l from a group ballot (or passes a constant), so l is uniform
     // over the group; with one group per wavefront that is a v_readlane (no LDS round trip) instead of a ds_bpermute.
+    // Value of lane L (a compile-time constant) of the group: v_readlane with one group per wavefront, else a ds_swizzle in
+    // bit mode (no address register, no index arithmetic: a ds_bpermute needs both)
+    template <int L>
+    __device__ __forceinline__ int bcast_c(int v) const {
+        if constexpr (G == 64) return __builtin_amdgcn_readlane(v, L);
+        else return __builtin_amdgcn_ds_swizzle(v, ((~(G - 1)) & 0x1F) | (L << 5));
+    }
     template <class T>
     __device__ __forceinline__ T bcast(T v, int l) const {
         if constexpr (G == 64 && sizeof(T) == 4) {
