@@ -1253,7 +1253,8 @@ template <int G, int NRL, int KW, bool kMid, bool kDirect>
 __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut,
                                                const LutHead& head, PoseShared& sh, const LegBits& lb, const Grp<G>& g, int leg,
                                                const LegStatic& ls, double y0, double adjY, double advance, int cyc, int nCycles,
-                                               int b, bool live, const fpe_plan_out& out, LegCommit* lc, SeqRecOf<KW>* recs = nullptr) {
+                                               int b, bool live, const fpe_plan_out& out, LegCommit* lc, SeqRecOf<KW>* recs = nullptr,
+                                               int* validOut = nullptr) {
     const float Rf = ls.Rf;
     const int polyKind = ls.polyKind;
     const LegConst& lk = ls.lk;
@@ -1468,12 +1469,15 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
         lc->v[1][0] = co.x;  lc->v[1][1] = co.y;  lc->v[1][2] = static_cast<double>(co.z);
         lc->v[2][0] = no.x;  lc->v[2][1] = no.y;  lc->v[2][2] = static_cast<double>(no.z);
     }
+    if (validOut) *validOut = no.valid;  // (one wavefront per pose: the flag is uniform, the vote stays in registers)
     if (g.sub == 0) {
         if constexpr (!kDirect) {
-            sh.valid[leg] = no.valid;
-            sh.nxt[0][leg][0] = nx0;   sh.nxt[0][leg][1] = ny;    sh.nxt[0][leg][2] = static_cast<double>(zDefault);
-            sh.nxt[1][leg][0] = co.x;  sh.nxt[1][leg][1] = co.y;  sh.nxt[1][leg][2] = static_cast<double>(co.z);
-            sh.nxt[2][leg][0] = no.x;  sh.nxt[2][leg][1] = no.y;  sh.nxt[2][leg][2] = static_cast<double>(no.z);
+            if (!validOut) sh.valid[leg] = no.valid;
+            if (!recs) {  // (with staged records the commit reads the next positions from the record itself)
+                sh.nxt[0][leg][0] = nx0;   sh.nxt[0][leg][1] = ny;    sh.nxt[0][leg][2] = static_cast<double>(zDefault);
+                sh.nxt[1][leg][0] = co.x;  sh.nxt[1][leg][1] = co.y;  sh.nxt[1][leg][2] = static_cast<double>(co.z);
+                sh.nxt[2][leg][0] = no.x;  sh.nxt[2][leg][1] = no.y;  sh.nxt[2][leg][2] = static_cast<double>(no.z);
+            }
         }
         stamp(pc, cyc, 13);
         if (live && recs) {  // staged: flush_seqrec writes the records of a few cycles at a time
@@ -3036,24 +3040,28 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
             stamp(pc, cyc, 0);
             // feet-polygon centres: lane t computes track t (getPolygonCenter, cpp:2191, 2265)
             if (tid < 3) sh.ctr[tid] = polygon_center_x(sh.cur[tid]);
-            if (tid < 4) sh.valid[tid] = 1;  // non-swing legs do not vote
             pose_sync<16>();
+            int allValid = 1;  // non-swing legs do not vote
             for (int leg = 0; leg < 4; ++leg) {
                 if (!((mask >> leg) & 1u)) continue;
                 const LegStatic ls = lsTab[leg];
                 stamp(pc, cyc, 1);
+                int legValid = 1;
                 leg_phase_bits<G, NRL, KW, false, false>(m, bm, pc, lut, head, sh, lb, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out, nullptr,
-                                                         recBase + 4 * (cyc & (recSlots - 1)));
+                                                         recBase + 4 * (cyc & (recSlots - 1)), &legValid);
+                allValid &= legValid;
                 stamp(pc, cyc, 9);
             }
             pose_sync<16>();
             // footholdValidation_ = AND of the swing legs' flags (cpp:1323); commit or skip (cpp:1332-1576)
-            const bool phaseOk = (sh.valid[0] & sh.valid[1] & sh.valid[2] & sh.valid[3]) != 0;
-            if (phaseOk && tid < 36) {
-                const int leg = tid / 9, e = tid - leg * 9;
+            const bool phaseOk = allValid != 0;
+            if (phaseOk && tid < 24) {
+                // x and y of the three tracks' next positions, straight from the staged record (its first six doubles: nominal,
+                // centroid, default track); no later cycle reads a committed z (getPolygonCenter, cpp:2421-2463)
+                const int leg = tid / 6, e = tid - leg * 6;
                 if ((mask >> leg) & 1u) {
-                    const int t = e / 3, k = e - t * 3;
-                    sh.cur[t][leg][k] = sh.nxt[t][leg][k];
+                    const double* rd = reinterpret_cast<const double*>(recBase + 4 * (cyc & (recSlots - 1)) + leg);
+                    sh.cur[2 - (e >> 1)][leg][e & 1] = rd[e];
                 }
             }
             pose_sync<16>();
