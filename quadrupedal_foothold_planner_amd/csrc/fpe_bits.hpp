@@ -79,28 +79,29 @@ struct WinRows {
     uint32_t D[NRL][KW], Df[NRL][KW], C[NRL][KW], F[NRL][KW];
 };
 // Per-leg LDS: row masks shared between the lanes of the leg's group — a: Df rows, later P rows, then E rows (row-
-// interval erosion); f: F rows for polygons that are not folded into P; h[k]: horizontally eroded P rows, one array
-// per distinct row half-width of the disc (h[0] doubles as the E rows of the offset-by-offset erosion); colRows: the
-// polygon's row interval per window column (64-lane kernels).  Arrays hold `rows` window rows of KW words (the 64-lane kernels allocate 2 winH + 1 rows, not 64 * NRL:
+// interval erosion); f: F rows for polygons that are not folded into P; h[k]: single-word rows: horizontally eroded P rows,
+// one array per distinct row half-width of the disc; multi-word rows: ONE array, the E rows of the nested erosion (h[0]
+// is also the E rows of the offset-by-offset erosion, and f / h[0] the scratch of the polygon's row masks).  Arrays hold `rows` window rows of KW words (the 64-lane kernels allocate 2 winH + 1 rows, not 64 * NRL:
 // LDS, not registers, bounds their occupancy).  The row arrays double as float scratch of a direct disc pass.
 struct LegBits {
     uint32_t* a;
     uint32_t* f;
     uint32_t* h0;  // array k of the eroded rows at h0 + k * hStride (a pointer array indexed at run time would live in scratch)
     int hStride;
-    int* colRows;
     float* hs;  // 96-bit-row kernels only: the visited elevations of a leg's three discs (in-chain heights, heights3_finish)
     int rows;
 };
-// words (4 bytes) of one leg's LDS: (2 + max(nHW, 1)) row arrays, then colRows and hs for the 64-lane kernels
+// words (4 bytes) of one leg's LDS: the row arrays, then hs for the 96-bit-row kernels
 // widest row (in 32-bit words) of the one-wavefront-per-pose kernels whose mean heights leave the chain (flush_seqrec2)
 #ifndef FPE_SEQ_DEFER_KW
 #define FPE_SEQ_DEFER_KW 2
 #endif
 constexpr int kSeqDeferMaxKW = FPE_SEQ_DEFER_KW;
 __host__ __device__ __forceinline__ int legbits_words(int rows, int kw, int nHW, bool wide) {
+    // (multi-word rows use three of the arrays only since the nested erosion; the others stay: shrinking the allocation
+    // to three arrays was measured 1.5 % SLOWER on cfg-3, neutral on cfg-5 — kept as measured)
     const int arrays = 2 + (nHW > 0 ? nHW : 1);
-    return ((arrays * rows * kw + 3) & ~3) + (wide ? 2 * 32 * kw + (kw > kSeqDeferMaxKW ? 3 * kBitsMaxBoxCells : 0) : 0);
+    return ((arrays * rows * kw + 3) & ~3) + ((wide && kw > kSeqDeferMaxKW) ? 3 * kBitsMaxBoxCells : 0);
 }
 __device__ __forceinline__ LegBits make_legbits(unsigned char* base, int rows, int kw, int nHW, bool wide) {
     LegBits lb;
@@ -112,9 +113,8 @@ __device__ __forceinline__ LegBits make_legbits(unsigned char* base, int rows, i
     lb.h0 = p + 2 * n;
     lb.hStride = n;
     const int arrays = 2 + (nHW > 0 ? nHW : 1);
-    uint32_t* tail = p + ((arrays * n + 3) & ~3);
-    lb.colRows = reinterpret_cast<int*>(tail);
-    lb.hs = reinterpret_cast<float*>(tail + (wide ? 2 * 32 * kw : 0));
+    lb.hs = reinterpret_cast<float*>(p + ((arrays * n + 3) & ~3));
+    (void)wide;
     return lb;
 }
 
@@ -581,11 +581,14 @@ __device__ __forceinline__ IndexRect rectangle_index_bounds(const MapGeom& mg, d
 // comparison is a row threshold t(X) = min{i : px_i < X} (found exactly, as in rectangle_index_bounds): column c is
 // inside for the rows [min(t0, t1), max(t0, t1)).  Lane = column; writes (lo, hi) per column.  Returns false when
 // some column has more than two crossings (non-convex polygon): the per-cell PNPOLY loop is then used.
+// The columns [colLo, colHi] only (those a candidate's foot disc can touch), and each column sets its bits in the
+// "enters" / "leaves" row arrays itself (see the caller): the interval stays in the lane's registers.
 template <int G, int KW>
-__device__ __forceinline__ bool window_column_rows(const MapGeom& mg, const LegCtx& c, const Grp<G>& g, int jw0, int* colRows) {
+__device__ __forceinline__ bool window_column_rows(const MapGeom& mg, const LegCtx& c, const Grp<G>& g, int iw0, int jw0, int colLo, int colHi,
+                                                   int NR, uint32_t* entersAt, uint32_t* leavesAt) {
     const double ninf = -__builtin_huge_val();
     bool over = false;
-    for (int b = g.sub; b < 32 * KW; b += G) {
+    for (int b = colLo + g.sub; b <= colHi; b += G) {
         const double py = cell_pos(mg.baseY, mg.res, jw0 + b);
         double X[2] = {ninf, ninf};
         // the (at most two) edges that straddle py, found with comparisons only; their abscissae afterwards — two division
@@ -620,8 +623,13 @@ __device__ __forceinline__ bool window_column_rows(const MapGeom& mg, const LegC
             const bool p0 = cell_pos(mg.baseX, mg.res, e) < X[u], p1 = cell_pos(mg.baseX, mg.res, e + 1) < X[u];
             t[u] = p0 ? e : (p1 ? e + 1 : e + 2);
         }
-        colRows[2 * b] = min(t[0], t[1]);
-        colRows[2 * b + 1] = max(t[0], t[1]);
+        const int rl = min(t[0], t[1]) - iw0, rh = max(t[0], t[1]) - iw0;  // window rows [rl, rh)
+        const uint32_t bit = 1u << (b & 31);
+        const int wq = b >> 5;
+        if (rl < rh && rh > 0 && rl < NR) {
+            atomicOr(&entersAt[max(rl, 0) * KW + wq], bit);
+            if (rh < NR) atomicOr(&leavesAt[rh * KW + wq], bit);
+        }
     }
     return !g.any(over);
 }
@@ -744,9 +752,19 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
             static_assert(G == 64, "the column -> row transposition runs on whole wavefronts");
             // the polygon's row interval per window column (lane = column), then transposed into per-row column
             // masks by ballots over the columns, one window row at a time
-            folded = window_column_rows<G, KW>(m.g, c, g, jw0, lb.colRows);
+            uint32_t* entersAt = lb.f;
+            uint32_t* leavesAt = lb.h0;
+            for (int idx = g.sub; idx < NR * KW; idx += G) {
+                entersAt[idx] = 0u;
+                leavesAt[idx] = 0u;
+            }
+            bits_sync<G>();
+            // columns a candidate's foot disc can touch: within nRings + footReach of the centre column (winH) — one pass of
+            // the wavefront instead of two for the usual radius on a 96-bit window
+            const int reachCols = min(c.nRings + pc.footReach, pc.winH);
+            folded = window_column_rows<G, KW>(m.g, c, g, iw0, jw0, max(pc.winH - reachCols, 0), min(pc.winH + reachCols, 32 * KW - 1), NR,
+                                               entersAt, leavesAt);
             if (folded) {
-                bits_sync<G>();
                 // Column intervals -> row masks without a ballot per row.  Column c is inside for the rows [lo_c, hi_c): it
                 // ENTERS at row lo_c and LEAVES at row hi_c.  Each column sets its bit in the "enters" word of its first
                 // row and in the "leaves" word of its end row (LDS atomic OR; two scratch row arrays that are free here);
@@ -754,26 +772,6 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
                 // gives, for every row, the columns that have entered and the columns that have left:
                 //     inside(row) = entered(row) & ~left(row)
                 // — the same set as the per-row comparison i >= lo_c && i < hi_c, by construction.
-                uint32_t* entersAt = lb.f;
-                uint32_t* leavesAt = lb.h0;
-                for (int idx = g.sub; idx < NR * KW; idx += G) {
-                    entersAt[idx] = 0u;
-                    leavesAt[idx] = 0u;
-                }
-                bits_sync<G>();
-#pragma unroll
-                for (int u = 0; u < (32 * KW + G - 1) / G; ++u) {
-                    const int col = g.sub + G * u;
-                    if (col < 32 * KW) {
-                        const int rl = lb.colRows[2 * col] - iw0, rh = lb.colRows[2 * col + 1] - iw0;  // window rows [rl, rh)
-                        const uint32_t bit = 1u << (col & 31);
-                        const int wq = col >> 5;
-                        if (rl < rh && rh > 0 && rl < NR) {
-                            atomicOr(&entersAt[max(rl, 0) * KW + wq], bit);
-                            if (rh < NR) atomicOr(&leavesAt[rh * KW + wq], bit);
-                        }
-                    }
-                }
                 bits_sync<G>();
                 unsigned inside[NRL][KW];
                 // rows a candidate's foot disc can touch: within nRings + footReach rows of the centre row (winH)
