@@ -299,6 +299,8 @@ __device__ __forceinline__ bool default_ok_bits(const DevMap& m, const PlanConst
             const float njInv = rcp_small(bb.nj);
 #pragma unroll
             for (int r = 0; r < disc_rounds<G>(); ++r) {
+                // wave-uniform: a round past every box of the wavefront (64-bit rows: boxes of <= 64 cells; not worth a test on the 96-bit ones)
+                if (KW <= 2 && r > 0 && __ballot(d.vis[r] != 0) == 0ull) continue;
                 int a, bq;
                 divmod_small(min(r * G + g.sub, 4095), max(bb.nj, 1), njInv, a, bq);
                 const bool v = d.vis[r] != 0;
