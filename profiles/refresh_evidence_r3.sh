@@ -8,6 +8,7 @@ cp gpurun_out/r3p_bench_full.json profiles/round3_bench_line_full.json
 cp gpurun_out/r3p_pytest.log profiles/round3_gpu_pytest_durations.log
 [ -f gpurun_out/r3p_batch_scaling.txt ] && cp gpurun_out/r3p_batch_scaling.txt profiles/round3_batch_scaling.txt
 [ -f gpurun_out/r3p_residency.txt ] && grep -v "Warn\|amdgpu.ids" gpurun_out/r3p_residency.txt > profiles/round3_residency.txt
+[ -f gpurun_out/r3p_stage_traces.txt ] && cp gpurun_out/r3p_stage_traces.txt profiles/round3_stage_traces.txt
 [ -f gpurun_out/r3p_service_latency.txt ] && grep -v "Warn\|amdgpu.ids" gpurun_out/r3p_service_latency.txt > profiles/round3_service_latency.txt
 [ -f gpurun_out/r3p_bench_2rank.json ] && cp gpurun_out/r3p_bench_2rank.json profiles/round3_bench_line_2rank_one_gpu.json
 [ -d gpurun_out/prof_filters ] && python3 profiles/summarise_filters.py > profiles/round3_filters.txt

@@ -24,13 +24,20 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $d -o f -- python3 profiles/probe_filters.py > /dev/null 2>&1
 done
 # residency / arbitration study of the one-wavefront-per-pose kernels (profiling build scratch/libfpe_trace.so:
-# -DFPE_TRACE -DFPE_TRACE_ALL_BLOCKS, built by scratch/build_trace.sh before the push)
+# -DFPE_TRACE -DFPE_TRACE_ALL_BLOCKS, built by `EXTRA_DEFS=-DFPE_TRACE_ALL_BLOCKS bash profiles/build_trace.sh` before the push)
 if [ -f scratch/libfpe_trace.so ]; then
   for c in cfg3 cfg5; do FPE_LIB=scratch/libfpe_trace.so python3 profiles/probe_residency.py $c 4096; done > gpurun_out/r3p_residency.txt 2>&1
   for b in 1024 2048 3072 4096; do for c in cfg3 cfg5; do
     python3 bench.py --config $c --batch $b --steps 10 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "
 import json,sys
 l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$c poses $b (= %d wavefronts per SIMD) kernel_ms %.4f' % ($b // 1024, l['roofline']['kernel_ms']))"; done; done >> gpurun_out/r3p_residency.txt 2>&1
+fi
+# stage traces (s_memtime stamps, profiling build): where a gait cycle / a leg search goes, per kernel family
+if [ -f scratch/libfpe_trace.so ]; then
+  { echo "== headline (plan_bits_kernel<2,true>)"; FPE_LIB=scratch/libfpe_trace.so python3 profiles/trace_stages.py headline 4096 2>&1 | grep -v "Warn\|amdgpu.ids" | head -24;
+    echo "== cfg4 (plan_bits_kernel<3,false>)"; FPE_LIB=scratch/libfpe_trace.so python3 profiles/trace_stages_generic.py cfg4 32768 2>&1 | grep -v "Warn\|amdgpu.ids";
+    echo "== cfg3 (plan_bits_seq_kernel<1,2>)"; FPE_LIB=scratch/libfpe_trace.so python3 profiles/trace_stages_seq.py cfg3 4096 2>&1 | grep -v "Warn\|amdgpu.ids\|RuntimeWarning\|ret = \|_methods";
+    echo "== cfg5 (plan_bits_seq_kernel<2,3>)"; FPE_LIB=scratch/libfpe_trace.so python3 profiles/trace_stages_seq.py cfg5 4096 2>&1 | grep -v "Warn\|amdgpu.ids\|RuntimeWarning\|ret = \|_methods"; } > gpurun_out/r3p_stage_traces.txt
 fi
 # service-shaped calls: latency split (plan kernel / opt track)
 python3 profiles/probe_service_latency.py > gpurun_out/r3p_service_latency.txt 2>&1
