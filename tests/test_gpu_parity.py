@@ -601,3 +601,45 @@ def test_open_loop_ragged_query_counts(planner, n):
     eng = planner.checkFoothold(q)
     ora = fpo.OracleMap(trav, elev, 0.02).search_legs(util.to_oracle_params(planner.params), util.to_oracle_queries(q))
     util.assert_nominal_equal(eng, ora, "checkFoothold")
+
+
+@pytest.mark.parametrize("n_cycles", [3, 11])
+def test_round3_kernel_paths_at_the_map_border(planner, n_cycles):
+    """The round-3 forms of the three bit-window kernel families on maps whose borders lie inside the pose range, with a
+    cycle count that leaves the last flush batch partial: generic 8-lane kernels at 1 cm (5x5 disc boxes by box rows, 32-bit
+    membership masks finished by flush_unit_g every fourth cycle, four table entries per lane in the scan, E cleared outside
+    the map), 64-bit rows at 1 cm / R 0.15 (two lanes per staged record), 96-bit rows at 0.5 cm with per-leg radii on both
+    sides of the one-row-slot limit and both polygon kinds (nested erosion, polygon columns within reach only)."""
+    rng = np.random.default_rng(900 + n_cycles)
+    # generic 8-lane kernel
+    set_params(planner)
+    trav, elev = synth.rough_map(260, 300, 0.01, seed=91, bad_frac=0.15, nan_frac=0.01)
+    xs, ys = rng.uniform(-1.6, 1.4, 160), rng.uniform(-1.7, 1.7, 160)
+    xs[:30], ys[:30] = np.round(xs[:30] / 0.01) * 0.01, np.round(ys[:30] / 0.01) * 0.01
+    poses = make_poses(np.column_stack([xs, ys, np.zeros(160)]))
+    poses["gait"] = rng.integers(0, 2, 160)
+    eng, ora = util.run_both(planner, trav, elev, 0.01, poses, n_cycles, threads=8)
+    assert planner.describe_plan().startswith("plan_bits_kernel<3, false>"), planner.describe_plan()
+    util.assert_plan_equal(eng, ora)
+    assert (eng["centroid"]["code"] == 6).any() and (eng["nominal"]["source"] == 1).any()
+    # 64-bit rows
+    set_params(planner, searchRadius=np.float32(0.15))
+    eng, ora = util.run_both(planner, trav, elev, 0.01, poses[:96], n_cycles, threads=8)
+    assert planner.describe_plan().startswith("plan_bits_seq_kernel<1, 2>"), planner.describe_plan()
+    util.assert_plan_equal(eng, ora)
+    # 96-bit rows, mixed radii and polygons
+    set_params(planner)
+    trav5, elev5 = synth.rough_map(420, 380, 0.005, seed=92, bad_frac=0.2, nan_frac=0.01)
+    p5 = make_poses(np.column_stack([rng.uniform(-1.2, 1.0, 64), rng.uniform(-1.1, 1.1, 64), np.zeros(64)]))
+    p5["gait"] = rng.integers(0, 2, 64)
+    p5["leg_search_radius"] = rng.uniform(0.05, 0.15, (64, 4)).astype(np.float32)
+    p5["leg_polygon_kind"] = rng.integers(0, 2, (64, 4))
+    planner.set_max_leg_search_radius(0.15)
+    try:
+        eng, ora = util.run_both(planner, trav5, elev5, 0.005, p5, n_cycles, threads=8)
+        assert planner.describe_plan().startswith("plan_bits_seq_kernel<2, 3>"), planner.describe_plan()
+        util.assert_plan_equal(eng, ora)
+        assert (eng["nominal"]["source"] == 1).any()
+    finally:
+        planner.set_max_leg_search_radius(0.0)
+        set_params(planner)
