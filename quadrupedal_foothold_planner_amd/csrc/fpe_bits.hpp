@@ -1623,35 +1623,47 @@ __device__ __forceinline__ void mean_acc(MeanAcc& a, bool vis, float e) {
     a.cnt += inc ? 1 : 0;
     a.sum = a.sum + (inc ? v : -0.0f);  // s + (-0.0f) == s for every s
 }
+#ifndef FPE_FLUSH_NA
+#define FPE_FLUSH_NA 8
+#endif
+#ifndef FPE_FLUSH_NC
+#define FPE_FLUSH_NC 8
+#endif
+// NA box cells and NC table entries per batch (one dependent round trip per batch)
+template <int NA = FPE_FLUSH_NA, int NC = FPE_FLUSH_NC>
 __device__ __forceinline__ void seq_mean2(const float* __restrict__ elev, int rows, int cols, int i0, int j0, int nj, unsigned long long v0,
                                           unsigned long long v1, bool wantC, int cRow, int cCol, const int8_t* da, const int8_t* db, int nFoot,
                                           double h, float& zBox, float& zC) {
     MeanAcc A{0.0f, 0.0f, 0}, C{0.0f, 0.0f, 0};
     const float njInv = rcp_small(nj);
     const int nC = wantC ? nFoot : 0;
-    const int nMax = max(v1 ? 128 - __builtin_clzll(v1) : (v0 ? 64 - __builtin_clzll(v0) : 0), nC);  // one past the last cell of either
-    for (int t0 = 0; t0 < nMax; t0 += 8) {
-        const unsigned ba = static_cast<unsigned>(((t0 < 64 ? v0 : v1) >> (t0 & 63)) & 0xFFull);
+    const int nA = v1 ? 128 - __builtin_clzll(v1) : (v0 ? 64 - __builtin_clzll(v0) : 0);  // one past the last visited cell
+    for (int t0 = 0, c0 = 0; t0 < nA || c0 < nC; t0 += NA, c0 += NC) {
+        // bits t0 .. t0 + NA - 1 of the 128-bit membership mask
+        const unsigned long long lo = t0 < 64 ? (v0 >> t0) | (t0 ? v1 << (64 - t0) : 0ull) : (t0 < 128 ? v1 >> (t0 - 64) : 0ull);
+        const unsigned ba = static_cast<unsigned>(lo) & ((1u << NA) - 1u);
         unsigned bc = 0u;
-        float eA[8], eC[8];
+        float eA[NA], eC[NC];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NA; ++u) {
             int r, q;
             divmod_small(t0 + u, nj, njInv, r, q);
             const unsigned cellA = ((ba >> u) & 1u) ? __umul24(static_cast<unsigned>(i0 + r), static_cast<unsigned>(cols)) + static_cast<unsigned>(j0 + q) : 0u;
             eA[u] = load_cell(elev, cellA);
-            const int k = min(t0 + u, max(nC - 1, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+            const int k = min(c0 + u, max(nC - 1, 0));
             const int qi = cRow + da[k], qj = cCol + db[k];
-            const bool visC = t0 + u < nC && in_range(qi, qj, rows, cols);
+            const bool visC = c0 + u < nC && in_range(qi, qj, rows, cols);
             bc |= visC ? (1u << u) : 0u;
             const unsigned cellC = visC ? __umul24(static_cast<unsigned>(qi), static_cast<unsigned>(cols)) + static_cast<unsigned>(qj) : 0u;
             eC[u] = load_cell(elev, cellC);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            mean_acc(A, ((ba >> u) & 1u) != 0u, eA[u]);
-            mean_acc(C, ((bc >> u) & 1u) != 0u, eC[u]);
-        }
+        for (int u = 0; u < NA; ++u) mean_acc(A, ((ba >> u) & 1u) != 0u, eA[u]);
+#pragma unroll
+        for (int u = 0; u < NC; ++u) mean_acc(C, ((bc >> u) & 1u) != 0u, eC[u]);
     }
     zBox = finish_mean(A.sum, A.last, A.cnt, h);
     zC = finish_mean(C.sum, C.last, C.cnt, h);
