@@ -93,8 +93,10 @@ struct LegBits {
 };
 // words (4 bytes) of one leg's LDS: the row arrays, then hs for the 96-bit-row kernels
 // widest row (in 32-bit words) of the one-wavefront-per-pose kernels whose mean heights leave the chain (flush_seqrec2)
+// (2: the 96-bit-row kernels keep their in-chain sums — TermSum / heights3_finish — as they did until the flush read its
+// boxes without divisions and in two load groups per batch; measured then: cfg-5 0.402 ms in-chain, 0.379 ms deferred)
 #ifndef FPE_SEQ_DEFER_KW
-#define FPE_SEQ_DEFER_KW 2
+#define FPE_SEQ_DEFER_KW 3
 #endif
 constexpr int kSeqDeferMaxKW = FPE_SEQ_DEFER_KW;
 __host__ __device__ __forceinline__ int legbits_words(int rows, int kw, int nHW, bool wide) {
@@ -1634,10 +1636,14 @@ template <int NA = FPE_FLUSH_NA, int NC = FPE_FLUSH_NC>
 __device__ __forceinline__ void seq_mean2(const float* __restrict__ elev, int rows, int cols, int i0, int j0, int nj, unsigned long long v0,
                                           unsigned long long v1, bool wantC, int cRow, int cCol, const int8_t* da, const int8_t* db, int nFoot,
                                           double h, float& zBox, float& zC) {
+    static_assert(NC == 8, "the offset table is read eight entries (two 64-bit LDS words) at a time");
     MeanAcc A{0.0f, 0.0f, 0}, C{0.0f, 0.0f, 0};
-    const float njInv = rcp_small(nj);
     const int nC = wantC ? nFoot : 0;
     const int nA = v1 ? 128 - __builtin_clzll(v1) : (v0 ? 64 - __builtin_clzll(v0) : 0);  // one past the last visited cell
+    // the box is walked row-major (cell t = a * nj + b): column counter and cell offset advance together, no division
+    int qcol = 0;
+    unsigned cell = __umul24(static_cast<unsigned>(i0), static_cast<unsigned>(cols)) + static_cast<unsigned>(j0);
+    const unsigned rowStep = static_cast<unsigned>(cols - nj + 1);
     for (int t0 = 0, c0 = 0; t0 < nA || c0 < nC; t0 += NA, c0 += NC) {
         // bits t0 .. t0 + NA - 1 of the 128-bit membership mask
         const unsigned long long lo = t0 < 64 ? (v0 >> t0) | (t0 ? v1 << (64 - t0) : 0ull) : (t0 < 128 ? v1 >> (t0 - 64) : 0ull);
@@ -1646,15 +1652,19 @@ __device__ __forceinline__ void seq_mean2(const float* __restrict__ elev, int ro
         float eA[NA], eC[NC];
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
-            int r, q;
-            divmod_small(t0 + u, nj, njInv, r, q);
-            const unsigned cellA = ((ba >> u) & 1u) ? __umul24(static_cast<unsigned>(i0 + r), static_cast<unsigned>(cols)) + static_cast<unsigned>(j0 + q) : 0u;
-            eA[u] = load_cell(elev, cellA);
+            eA[u] = load_cell(elev, ((ba >> u) & 1u) ? cell : 0u);
+            const bool wrap = ++qcol == nj;
+            qcol = wrap ? 0 : qcol;
+            cell += wrap ? rowStep : 1u;
         }
+        // eight table entries as two 64-bit words each (the arrays are 16-byte aligned and hold kMaxFootOffsets entries:
+        // c0 is a multiple of 8 below nFoot, or 0; entries past nFoot are masked)
+        unsigned long long daW, dbW;
+        __builtin_memcpy(&daW, da + (c0 < nC ? c0 : 0), 8);
+        __builtin_memcpy(&dbW, db + (c0 < nC ? c0 : 0), 8);
 #pragma unroll
         for (int u = 0; u < NC; ++u) {
-            const int k = min(c0 + u, max(nC - 1, 0));
-            const int qi = cRow + da[k], qj = cCol + db[k];
+            const int qi = cRow + static_cast<int8_t>((daW >> (8 * u)) & 0xFFull), qj = cCol + static_cast<int8_t>((dbW >> (8 * u)) & 0xFFull);
             const bool visC = c0 + u < nC && in_range(qi, qj, rows, cols);
             bc |= visC ? (1u << u) : 0u;
             const unsigned cellC = visC ? __umul24(static_cast<unsigned>(qi), static_cast<unsigned>(cols)) + static_cast<unsigned>(qj) : 0u;
