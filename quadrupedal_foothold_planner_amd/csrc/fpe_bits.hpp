@@ -1735,7 +1735,10 @@ __device__ __forceinline__ void flush_seqrec2(const DevMap& m, const PlanConsts&
     const bool defer = (r.flags & (h1 ? kSeqDeferB : kSeqDeferA)) != 0u && (h1 ? out.default_next != nullptr : true);
     const bool wantC = !h1 && (r.flags & kSeqDeferC) != 0u && out.centroid != nullptr;
     float sBox, sC;
-    seq_mean2(m.elev, m.g.rows, m.g.cols, h1 ? r.bI0 : r.aI0, h1 ? r.bJ0 : r.aJ0, max(h1 ? r.bNj : r.aNj, 1), defer ? (h1 ? r.visB[0] : r.visA[0]) : 0ull,
+#ifndef FPE_FLUSH_NA_SEQ
+#define FPE_FLUSH_NA_SEQ 12  // box cells per batch here (measured: 8 -> 12: cfg-3 -1.3 %, cfg-5 -1.5 %; 13, 14 the same; 16 worse on cfg-3)
+#endif
+    seq_mean2<FPE_FLUSH_NA_SEQ, 8>(m.elev, m.g.rows, m.g.cols, h1 ? r.bI0 : r.aI0, h1 ? r.bJ0 : r.aJ0, max(h1 ? r.bNj : r.aNj, 1), defer ? (h1 ? r.visB[0] : r.visA[0]) : 0ull,
               defer ? (h1 ? r.visB[1] : r.visA[1]) : 0ull, wantC, r.cenRow, r.cenCol, footDa, footDb, pc.nFoot, pc.h, sBox, sC);
     if (h1) {
         if (out.default_next) {
