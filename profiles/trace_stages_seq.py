@@ -2,7 +2,7 @@
 usage on the GPU box: FPE_LIB=scratch/libfpe_trace.so python3 profiles/trace_stages_seq.py cfg3 4096"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, '.')
-buf = torch.zeros(256*8*16, dtype=torch.int64, device='cuda')
+buf = torch.zeros(256*8*16 + 65536*4, dtype=torch.int64, device='cuda')  # (+ the per-block area of -DFPE_TRACE_ALL_BLOCKS builds)
 os.environ["FPE_TRACE_PTR"] = str(buf.data_ptr())
 from quadrupedal_foothold_planner_amd import _capi, synth
 from quadrupedal_foothold_planner_amd.planner import FootholdPlanner
@@ -22,7 +22,7 @@ for it in range(3):
     buf.zero_()
     pl.plan_device(d_poses.data_ptr(), B, n, d_nom.data_ptr(), d_cen.data_ptr(), d_def.data_ptr(), d_ok.data_ptr(), d_st.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, d_selected_ptr=d_sel.data_ptr(), d_pose_status_ptr=d_ps.data_ptr())
     torch.cuda.synchronize()
-t = buf.cpu().numpy().reshape(256, 8, 16).astype(np.float64)
+t = buf.cpu().numpy()[:256*8*16].reshape(256, 8, 16).astype(np.float64)
 names = {1:"leg start",2:"corners+submap",3:"loads issued",4:"rows arrived+scan",5:"default chk+zCentre",6:"centroid begin",7:"zDefault",8:"spiral",9:"centroid z+stores",10:"commit"}
 pts = sorted(names)
 prev = 1
