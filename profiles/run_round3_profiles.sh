@@ -18,7 +18,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r3p_ol_stats 
 # the producer's filter chain (N3): per-kernel split by resolution
 rm -rf gpurun_out/prof_filters
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_filters -o f -- python3 profiles/probe_filters.py > gpurun_out/probe_filters.txt 2>&1
-for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
+for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64" "SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32"; do
   d=gpurun_out/prof_filters_pmc_$(echo $grp | tr ' ' '_')
   rm -rf $d
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $d -o f -- python3 profiles/probe_filters.py > /dev/null 2>&1

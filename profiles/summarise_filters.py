@@ -30,7 +30,7 @@ for f in glob.glob("gpurun_out/prof_filters_pmc_*/**/*counter_collection.csv", r
         n = len(v) // 3
         cnt[k][c] = [x for _, x in v[n:2 * n]]
 if cnt:
-    cal = json.load(open("profiles/round2_headline_counters.json"))["calibration"]
+    cal = json.load(open("profiles/round3_headline_counters.json"))["calibration"]
     print("\ncounters per launch, 2000x2000 @ 0.01 m (mean over the map's launches):")
     for k, c in cnt.items():
         m = {name: sum(v) / len(v) for name, v in c.items() if v}
@@ -39,5 +39,10 @@ if cnt:
         if w and "SQ_INSTS_VALU" in m: line += f", VALU instructions per wavefront {m['SQ_INSTS_VALU'] / w:.0f}, SALU {m.get('SQ_INSTS_SALU', 0) / w:.0f}, LDS {m.get('SQ_INSTS_LDS', 0) / w:.0f}"
         if w and "SQ_WAVE_CYCLES" in m and "SQ_ACTIVE_INST_VALU" in m:
             line += f"; wavefront lifetime {4 * m['SQ_WAVE_CYCLES'] / w:.0f} clk, VALU-active {4 * m['SQ_ACTIVE_INST_VALU'] / w:.0f} clk per wavefront"
+        if w and "SQ_INSTS_VALU_ADD_F64" in m and "SQ_INSTS_VALU" in m:
+            f64 = m["SQ_INSTS_VALU_ADD_F64"] + m.get("SQ_INSTS_VALU_MUL_F64", 0) + m.get("SQ_INSTS_VALU_FMA_F64", 0) + m.get("SQ_INSTS_VALU_TRANS_F64", 0)
+            line += (f"; f64 arithmetic {f64 / w:.0f} per wavefront = {f64 / m['SQ_INSTS_VALU']:.0%} of the VALU instructions "
+                     f"(add {m['SQ_INSTS_VALU_ADD_F64'] / w:.0f}, mul {m.get('SQ_INSTS_VALU_MUL_F64', 0) / w:.0f}, fma {m.get('SQ_INSTS_VALU_FMA_F64', 0) / w:.0f}, "
+                     f"division / sqrt steps {m.get('SQ_INSTS_VALU_TRANS_F64', 0) / w:.0f}), conversions {m.get('SQ_INSTS_VALU_CVT', 0) / w:.0f}, integer arithmetic {m.get('SQ_INSTS_VALU_INT32', 0) / w:.0f}")
         if "FETCH_SIZE" in m: line += f"; fabric read {m['FETCH_SIZE'] * 1024 * cal['fetch_factor'] / 1e6:.1f} MB, written {m.get('WRITE_SIZE', 0) * 1024 * cal['write_factor'] / 1e6:.1f} MB (algorithmic: 16 MB per layer)"
         print(line)
