@@ -2760,18 +2760,22 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
     const int polyKindIn = pp->leg_polygon_kind[leg];
     __builtin_amdgcn_sched_barrier(0);  // (the loads above stay ahead of the kernel-argument fetches below)
     stamp(pc, 1, 11);
-    // the map geometry doubles are operands of vector f64 arithmetic only: parked in VGPRs (see plan_chained_kernel)
+    // the map geometry doubles are operands of vector f64 arithmetic only: parked in VGPRs (see plan_chained_kernel) — in
+    // the 3x3-only variants; the generic ones run at their register cap (168 VGPRs at three wavefronts per SIMD), where the
+    // twenty registers cost more in spills than the scalar operands do in moves (measured: cfg-4 0.713 -> 0.664 ms without)
     DevMap m = mArg;
-    m.g.res = in_vgpr(m.g.res);
-    m.g.rinv = in_vgpr(m.g.rinv);
-    m.g.lenX = in_vgpr(m.g.lenX);
-    m.g.lenY = in_vgpr(m.g.lenY);
-    m.g.posX = in_vgpr(m.g.posX);
-    m.g.posY = in_vgpr(m.g.posY);
-    m.g.orgX = in_vgpr(m.g.orgX);
-    m.g.orgY = in_vgpr(m.g.orgY);
-    m.g.baseX = in_vgpr(m.g.baseX);
-    m.g.baseY = in_vgpr(m.g.baseY);
+    if constexpr (kMid) {
+        m.g.res = in_vgpr(m.g.res);
+        m.g.rinv = in_vgpr(m.g.rinv);
+        m.g.lenX = in_vgpr(m.g.lenX);
+        m.g.lenY = in_vgpr(m.g.lenY);
+        m.g.posX = in_vgpr(m.g.posX);
+        m.g.posY = in_vgpr(m.g.posY);
+        m.g.orgX = in_vgpr(m.g.orgX);
+        m.g.orgY = in_vgpr(m.g.orgY);
+        m.g.baseX = in_vgpr(m.g.baseX);
+        m.g.baseY = in_vgpr(m.g.baseY);
+    }
     HotConsts hc;
     hc.rf = in_vgpr(pc.rf);
     hc.rf2 = in_vgpr(pc.rf2);
