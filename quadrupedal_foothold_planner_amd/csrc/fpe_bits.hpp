@@ -3063,6 +3063,20 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
     const int walkOrder = pc.RF_FIRST ? ((0) | (2 << 2) | (3 << 4) | (1 << 6)) : ((3) | (1 << 2) | (0 << 4) | (2 << 6));
 
     for (int cyc = 0; cyc < nCycles; ++cyc) {
+        {
+            // Issue priority by PROGRESS (s_setprio, four levels): the SIMD's arbiter serves the oldest wavefront first, so the
+            // four poses of a SIMD finish one after the other and the last one runs alone at a third of the four-wavefront issue
+            // rate (profiles/round3_residency.txt: lifetimes 1.2 / 1.4 / 1.6 / 1.9 M clocks by launch order).  A wavefront that
+            // is behind gets the higher priority: the four advance together and finish together.  Measured: cfg-3 0.727 -> 0.640 ms,
+            // cfg-5 0.375 -> 0.325 ms; the reverse mapping reproduces the default.  (The 8-lane kernels: headline neutral — its two
+            // wavefronts per SIMD start and advance together anyway —, cfg-4 +3 %: new workgroups would starve the ones about to
+            // finish; not used there.)
+            const int q = (cyc * 4) / nCycles;
+            if (q == 0) __builtin_amdgcn_s_setprio(3);
+            else if (q == 1) __builtin_amdgcn_s_setprio(2);
+            else if (q == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         bool cycleOk = true;
         for (int ph = 0; ph < nPhases; ++ph) {
             const unsigned mask = (gait == 1) ? (1u << ((walkOrder >> (2 * ph)) & 3)) : 0xFu;
