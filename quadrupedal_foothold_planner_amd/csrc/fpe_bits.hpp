@@ -3071,7 +3071,13 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
             // cfg-5 0.375 -> 0.325 ms; the reverse mapping reproduces the default.  (The 8-lane kernels: headline neutral — its two
             // wavefronts per SIMD start and advance together anyway —, cfg-4 +3 %: new workgroups would starve the ones about to
             // finish; not used there.)
-            const int q = (cyc * 4) / nCycles;
+            // The levels change where a half, a quarter and an eighth of the cycles remain: wavefronts re-synchronise at every
+            // boundary (the one ahead waits at the lower level), and the free run after the last boundary — oldest first again —
+            // is the last eighth only.  Measured against four equal quarters: cfg-3 0.644 -> 0.625 ms, cfg-5 0.328 -> 0.325 ms;
+            // boundaries per leg search instead of per cycle, later boundaries (1/4, 1/8, 1/16) and a rotating offset that
+            // emulates sixteen levels were all slower.
+            const int rem8 = ((nCycles - cyc) * 8 + nCycles - 1) / nCycles;  // remaining cycles in eighths, rounded up: 8 .. 1
+            const int q = rem8 > 4 ? 0 : (rem8 > 2 ? 1 : (rem8 > 1 ? 2 : 3));
             if (q == 0) __builtin_amdgcn_s_setprio(3);
             else if (q == 1) __builtin_amdgcn_s_setprio(2);
             else if (q == 2) __builtin_amdgcn_s_setprio(1);
