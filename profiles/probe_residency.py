@@ -24,7 +24,8 @@ for it in range(3):
     pl.plan_device(d_poses.data_ptr(), B, n, d_nom.data_ptr(), d_cen.data_ptr(), d_def.data_ptr(), d_ok.data_ptr(), d_st.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, d_selected_ptr=d_sel.data_ptr(), d_pose_status_ptr=d_ps.data_ptr())
     e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
-t = buf.cpu().numpy()[256*8*16:].reshape(NB, 4)[:B].astype(np.float64)
+nblk = B if 'seq_kernel' in pl.describe_plan() else (B + 1) // 2  # (8-lane kernels: two poses per workgroup)
+t = buf.cpu().numpy()[256*8*16:].reshape(NB, 4)[:nblk].astype(np.float64)
 start, end = t[:,0], t[:,1]
 hw = t[:,2].astype(np.int64); xcc = t[:,3].astype(np.int64)
 t0 = start.min()
@@ -33,7 +34,7 @@ print("span clk", end.max()-t0, "=> implied clock GHz", (end.max()-t0)/(ms*1e-3)
 print("start offsets clk: min %.0f median %.0f p90 %.0f max %.0f" % tuple(np.percentile(start-t0,[0,50,90,100])))
 print("lifetime clk: median %.0f p90 %.0f max %.0f" % tuple(np.percentile(end-start,[50,90,100])))
 late = (start - t0) > 0.1*(end.max()-t0)
-print("blocks starting later than 10%% of the span: %d of %d" % (late.sum(), B))
+print("blocks starting later than 10%% of the span: %d of %d" % (late.sum(), nblk))
 # hw id: wave_id[3:0], simd_id[5:4], pipe[7:6], cu_id[11:8], sh_id[12], se_id[15:13]
 cu = (hw>>8)&0xF; sh=(hw>>12)&1; se=(hw>>13)&7; simd=(hw>>4)&3
 key = ((xcc&0xF)*8+se)*2*16+sh*16+cu
@@ -52,10 +53,10 @@ for x in sorted(set(xcc.tolist())):
     print("xcc", x, "blocks", m.sum(), "start offs p50 %.0f max %.0f" % (np.median(so), so.max()), "life p10 %.0f p50 %.0f p90 %.0f max %.0f" % tuple(np.percentile(life[m],[10,50,90,100])), "span %.0f" % (end[m].max()-s0),
           "CUs", len(set(key[m].tolist())))
 # lifetime by position within launch order
-idx = np.arange(B)
-for lo in range(0, B, 512):
-    sl = slice(lo, lo+512)
-    print("blocks %4d-%4d life p50 %.0f max %.0f  xcc set %s" % (lo, lo+511, np.median(life[sl]), life[sl].max(), sorted(set(xcc[sl].tolist()))[:8]))
+idx = np.arange(nblk)
+for lo in range(0, nblk, 512 if nblk > 2048 else 256):
+    sl = slice(lo, lo + (512 if nblk > 2048 else 256))
+    print("blocks %4d-%4d life p50 %.0f max %.0f  xcc set %s" % (lo, sl.stop - 1, np.median(life[sl]), life[sl].max(), sorted(set(xcc[sl].tolist()))[:8]))
 # per-SIMD: sum of lifetimes vs max
 sk = key*4+simd
 import collections

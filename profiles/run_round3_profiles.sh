@@ -27,7 +27,7 @@ done
 # residency / arbitration study of the one-wavefront-per-pose kernels (profiling build scratch/libfpe_trace.so:
 # -DFPE_TRACE -DFPE_TRACE_ALL_BLOCKS, built by `EXTRA_DEFS=-DFPE_TRACE_ALL_BLOCKS bash profiles/build_trace.sh` before the push)
 if [ -f scratch/libfpe_trace.so ]; then
-  for c in cfg3 cfg5; do FPE_LIB=scratch/libfpe_trace.so python3 profiles/probe_residency.py $c 4096; done > gpurun_out/r3p_residency.txt 2>&1
+  for c in cfg3 cfg5 headline; do FPE_LIB=scratch/libfpe_trace.so python3 profiles/probe_residency.py $c 4096; done > gpurun_out/r3p_residency.txt 2>&1
   for b in 1024 2048 3072 4096; do for c in cfg3 cfg5; do
     python3 bench.py --config $c --batch $b --steps 10 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "
 import json,sys

@@ -2760,6 +2760,7 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
     const int polyKindIn = pp->leg_polygon_kind[leg];
     __builtin_amdgcn_sched_barrier(0);  // (the loads above stay ahead of the kernel-argument fetches below)
     stamp(pc, 1, 11);
+    stamp(pc, 6, 14);  // (-DFPE_TRACE_ALL_BLOCKS builds: start / end / hardware id of every workgroup, with the stamp after the cycle loop)
     // the map geometry doubles are operands of vector f64 arithmetic only: parked in VGPRs (see plan_chained_kernel) — in
     // the 3x3-only variants; the generic ones run at their register cap (168 VGPRs at three wavefronts per SIMD), where the
     // twenty registers cost more in spills than the scalar operands do in moves (measured: cfg-4 0.713 -> 0.664 ms without)
@@ -2991,6 +2992,7 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
             stamp(pc, 2, 12);
         }
     }
+    stamp(pc, 6, 15);
 }
 
 // ---- chained plan on the bit window, sequential-legs form (large windows): one wavefront per pose, lane = window
