@@ -64,3 +64,7 @@ d = collections.defaultdict(list)
 for k_, l_ in zip(sk.tolist(), life.tolist()): d[k_].append(l_)
 mx = np.array([max(v) for v in d.values()]); sm = np.array([sum(v) for v in d.values()]); nn = np.array([len(v) for v in d.values()])
 print("SIMDs", len(d), "waves per SIMD min/max", nn.min(), nn.max(), "max-life per SIMD p50 %.0f max %.0f; corr(sum of lifetimes on the SIMD, max) %.2f" % (np.median(mx), mx.max(), np.corrcoef(sm, mx)[0,1]))
+# hardware wave slot (HW_ID.WAVE_ID) by launch order: do the slots of a SIMD fill in order?
+wid = hw & 0xF
+step = 512 if nblk > 2048 else 256
+print("wave slot by launch order:", "  ".join("%d-%d: %s" % (lo, lo + step - 1, dict(sorted(collections.Counter(wid[lo:lo + step].tolist()).items()))) for lo in range(0, nblk, step)))
