@@ -949,11 +949,11 @@ __device__ bool spiral_bits(const DevMap& m, const PlanConsts& pc, const SpiralL
     }
     if (G == 8) stamp_any(pc, c.cyc, 13);
     if (G == 64) stamp_any(pc, 2, 14);
-    // Two forms of the candidate scan, chosen per kernel shape by measurement (A/B on the BASELINE configurations):
-    // 96-bit windows (0.5 cm maps: thousands of candidates, searches that run for tens of rounds) take the straight-line
-    // rounds with the ring skip (cfg-5: 0.98 -> 0.76 ms); the 8-lane kernels take the straight-line rounds without it
-    // (cfg-4: -1.5 %; the skip costs registers the generic variant does not have: +12 %); the 64-bit windows keep the
-    // branchy rounds (cfg-3 loses 6 % / 14 % with the other two: its searches are rare and short).
+    // Forms of the candidate scan, chosen per kernel shape by measurement (A/B on the BASELINE configurations): the
+    // one-wavefront-per-pose kernels (64- and 96-bit rows) take straight-line rounds of 64 candidates with the ring skip
+    // (cfg-5: 0.98 -> 0.76 ms in round 2); the generic 8-lane kernels four packed table entries per lane and round (below); the
+    // 3x3-only 8-lane kernels, which come here only for ranks beyond their own first sixteen, the straight-line rounds
+    // without the skip.  (The branchy rounds at the end of this function are the round-1 form, kept for A/B builds.)
 #ifdef FPE_SKIP_ALL
     constexpr bool kFlatRounds = true;
     constexpr bool kRingSkip = true;
@@ -1551,69 +1551,10 @@ struct Unit {
 };
 static_assert(sizeof(Unit) == 144 && sizeof(Unit) % 16 == 0, "Unit layout");
 
-// getFootholdMeanHeight (cpp:2520-2554) over the visited cells of a bounding box, cell t = a * nj + b in row-major order
-// (CircleIterator order), one lane, the loads eight at a time (unvisited cells read the layer's first cell and are
-// dropped: no branch around a load).
-__device__ __forceinline__ float seq_mean_box(const float* __restrict__ elev, int cols, int i0, int j0, int nj, unsigned long long v0,
-                                              unsigned long long v1, double h) {
-    float sum = 0.0f, last = 0.0f;
-    int cnt = 0;
-    const float njInv = rcp_small(nj);
-    const int nMax = v1 ? 128 - __builtin_clzll(v1) : (v0 ? 64 - __builtin_clzll(v0) : 0);  // one past the last visited cell
-    for (int t0 = 0; t0 < nMax; t0 += 8) {
-        const unsigned bits = static_cast<unsigned>(((t0 < 64 ? v0 : v1) >> (t0 & 63)) & 0xFFull);
-        float e[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            int a, b;
-            divmod_small(t0 + u, nj, njInv, a, b);
-            const bool vis = ((bits >> u) & 1u) != 0u;
-            const unsigned cell = vis ? __umul24(static_cast<unsigned>(i0 + a), static_cast<unsigned>(cols)) + static_cast<unsigned>(j0 + b) : 0u;
-            e[u] = load_cell(elev, cell);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool vis = ((bits >> u) & 1u) != 0u;
-            const float v = __builtin_isfinite(e[u]) ? e[u] : 0.0f;  // cpp:2532-2537
-            const bool inc = vis && v < 10;                           // cpp:2539
-            last = vis ? v : last;
-            cnt += inc ? 1 : 0;
-            sum = sum + (inc ? v : -0.0f);  // s + (-0.0f) == s for every s
-        }
-    }
-    return finish_mean(sum, last, cnt, h);
-}
-// The same over the host-proved offset table of a CELL-CENTRED disc (the centroid result's, CircleIterator order).
-__device__ __forceinline__ float seq_mean_table(const float* __restrict__ elev, int rows, int cols, int row, int col, const int8_t* da,
-                                                const int8_t* db, int nFoot, double h) {
-    float sum = 0.0f, last = 0.0f;
-    int cnt = 0;
-    for (int k0 = 0; k0 < nFoot; k0 += 8) {
-        float e[8];
-        bool vis[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = min(k0 + u, nFoot - 1);
-            const int qi = row + da[k], qj = col + db[k];
-            vis[u] = k0 + u < nFoot && in_range(qi, qj, rows, cols);
-            const unsigned cell = vis[u] ? __umul24(static_cast<unsigned>(qi), static_cast<unsigned>(cols)) + static_cast<unsigned>(qj) : 0u;
-            e[u] = load_cell(elev, cell);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float v = __builtin_isfinite(e[u]) ? e[u] : 0.0f;
-            const bool inc = vis[u] && v < 10;
-            last = vis[u] ? v : last;
-            cnt += inc ? 1 : 0;
-            sum = sum + (inc ? v : -0.0f);
-        }
-    }
-    return finish_mean(sum, last, cnt, h);
-}
-
 // Two mean heights side by side — a disc around a known centre (bounding box + membership mask) and, optionally, a
 // cell-centred disc (offset table) — with the loads of both in ONE batch per eight cells.  Each sum is the ordered f32 sum
-// of getFootholdMeanHeight (cpp:2520-2554), exactly as in seq_mean_box / seq_mean_table.
+// of getFootholdMeanHeight (cpp:2520-2554): visited cells in CircleIterator (row-major) order, non-finite values count as 0,
+// values >= 10 are skipped, finish_mean divides (or falls back on the last visited value).
 struct MeanAcc {
     float sum, last;
     int cnt;
@@ -1686,16 +1627,13 @@ __device__ __forceinline__ void flush_seqrec(const DevMap& m, const PlanConsts& 
     __builtin_memcpy(&r, &rLds, sizeof(Rec));
     const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
     const uint8_t valid = static_cast<uint8_t>(r.flags & 0xFFu), source = static_cast<uint8_t>((r.flags >> 8) & 0xFFu);
-    // the deferred mean heights of this (cycle, leg) unit (one lane per unit: up to 32 units side by side; a split by
-    // (unit, disc) pairs over the lanes was measured slower on 25-cell boxes)
-    float zA = r.nomZ, zB = r.defZ, zC = r.cenZ;
-    if constexpr (std::is_same<Rec, SeqRec>::value) {
-        if (r.flags & kSeqDeferA) zA = seq_mean_box(m.elev, m.g.cols, r.aI0, r.aJ0, r.aNj, r.visA[0], r.visA[1], pc.h);
-        if ((r.flags & kSeqDeferB) && out.default_next) zB = seq_mean_box(m.elev, m.g.cols, r.bI0, r.bJ0, r.bNj, r.visB[0], r.visB[1], pc.h);
-        if ((r.flags & kSeqDeferC) && out.centroid) zC = seq_mean_table(m.elev, m.g.rows, m.g.cols, r.cenRow, r.cenCol, footDa, footDb, pc.nFoot, pc.h);
-        else if (r.flags & kSeqCIsA) zC = zA;
-    }
-    const float zN = (r.flags & kSeqDeferA) ? (valid ? zA : 0.0f) : r.nomZ;  // z at the DEFAULT centre, for a spiral candidate too (cpp:2029)
+    // (records whose heights are deferred go through flush_seqrec2; the ones that arrive here — -DFPE_SEQ_DEFER_KW=2 builds of
+    // the 96-bit-row kernel — carry final values)
+    const float zN = r.nomZ, zB = r.defZ, zC = r.cenZ;
+    (void)footDa;
+    (void)footDb;
+    (void)m;
+    (void)pc;
     if (out.nominal) {
         fpe_foothold f;
         f.row = r.nomRow; f.col = r.nomCol; f.x = r.nomX; f.y = r.nomY; f.z = zN;
@@ -1876,7 +1814,7 @@ __device__ __forceinline__ void flush_unit(const DevMap& m, const PlanConsts& pc
 // bounding box's cells in CircleIterator order, with the box's origin) and the words that identify the results; it
 // issues no elevation load at all.  Every fourth cycle (the LDS of twelve workgroups per CU holds four cycles of units
 // and y entries, not eight) lane (leg, s < 4) of a pose takes the unit of cycle base + s, reads the elevations itself
-// (seq_mean_box / seq_mean_table: eight independent loads per batch) and runs the three ordered sums (cpp:2520-2554).
+// (seq_mean2: two groups of eight independent loads per batch) and runs the ordered sums (cpp:2520-2554).
 constexpr uint32_t kUgValid = 1u << 8, kUgSrcShift = 9, kUgPreA = 1u << 12, kUgPreB = 1u << 13, kUgCTable = 1u << 14, kUgCIsA = 1u << 15;
 struct UnitG {
     double cx;    // search centre x (nominal x of a default hit / invalid leg; centroid x of code 0)
