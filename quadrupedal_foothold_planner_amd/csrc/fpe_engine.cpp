@@ -912,12 +912,21 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
     // poses from, and write their few KB of results straight into, the pinned (coherent, device-mapped) host
     // arena — two copy-engine round trips (~10 us each) less on a call whose kernel runs ~25 us.
     const bool zeroCopy = total <= kZeroCopyBytes;
+    const fpe_pose* dPoses = nullptr;  // where the kernels read the poses (null: the head of the device arena)
     if (zeroCopy) {
         void* arena = nullptr;
         FPE_HIP(hipHostGetDevicePointer(&arena, hp, 0));
         dp = static_cast<unsigned char*>(arena);
     } else {
+#ifndef FPE_POSES_BY_DMA
+        // the poses are read by the kernels straight from the pinned arena (device-mapped): 64 bytes per pose, once, at the start
+        // of its workgroup — a DMA transfer ahead of the launch costs its fixed fifteen microseconds before anything runs
+        void* mapped = nullptr;
+        FPE_HIP(hipHostGetDevicePointer(&mapped, hp, 0));
+        dPoses = static_cast<const fpe_pose*>(mapped);
+#else
         FPE_HIP(hipMemcpyAsync(dp, hp, static_cast<size_t>(B) * sizeof(fpe_pose), hipMemcpyHostToDevice, cx.stream));
+#endif
         if (oout && cycleOkIn) FPE_HIP(hipMemcpyAsync(dp + oOk, hp + oOk, nCyc, hipMemcpyHostToDevice, cx.stream));
     }
     if (runPlan) {
@@ -932,7 +941,7 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
         if (po.pose_status) d.pose_status = dp + oPs;
         // every (pose, cycle, leg) record is written by the kernel (trot: all legs each cycle; walk: each
         // leg in its phase), so the buffers need no clearing
-        rc = launch_plan(h, cp, reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, d, cx.stream);
+        rc = launch_plan(h, cp, dPoses ? dPoses : reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, d, cx.stream);
         if (rc != FPE_OK) return rc;
     }
     if (oout) {
@@ -941,8 +950,8 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
         if (oout->footholds) od.footholds = reinterpret_cast<fpe_opt_foothold*>(dp + oOf);
         if (oout->cycles) od.cycles = reinterpret_cast<fpe_opt_cycle*>(dp + oOc);
         if (oout->gate_fail_cycle) od.gate_fail_cycle = dp + oOg;
-        FPE_HIP(fpe::launch_opt_track(dev_map(*cp.snap), cp.pc, oc, reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, dp + oOk, od,
-                                      cx.stream));
+        FPE_HIP(fpe::launch_opt_track(dev_map(*cp.snap), cp.pc, oc, dPoses ? dPoses : reinterpret_cast<const fpe_pose*>(dp), B, n_cycles,
+                                      dp + oOk, od, cx.stream));
     }
     // ---- results to the caller ----
     struct Seg {
@@ -972,14 +981,27 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
     // Only what the caller asked for crosses PCIe.  A product whose destination is pinned / registered host memory
     // (fpe_host_alloc) is written by DMA directly; the others go through the pinned arena in chunks, and the copy of a
     // chunk into the caller's array runs on the copy pool while the next chunks are still in flight.
+    // Pinned destinations that lie behind one another exactly as the products do in the device arena (no padding in between:
+    // FootholdPlanner.plan_outputs(pinned=True) carves them out of ONE fpe_host_alloc block in this order) leave in ONE copy:
+    // a DMA transfer has a fixed cost of some ten microseconds, and seven of them in a row are a third of a 4 096-pose call.
     size_t staged = 0;
+    bool pinnedSeg[10];
+    for (int k = 0; k < nSeg; ++k) pinnedSeg[k] = is_pinned_host(segs[k].dst);
     for (int k = 0; k < nSeg; ++k) {
-        if (is_pinned_host(segs[k].dst)) {
-            FPE_HIP(hipMemcpyAsync(segs[k].dst, dp + segs[k].off, segs[k].len, hipMemcpyDeviceToHost, cx.stream));
-            segs[k].dst = nullptr;
-        } else {
+        if (!pinnedSeg[k]) {
             staged += segs[k].len;
+            continue;
         }
+        size_t len = segs[k].len;
+        int last = k;
+        while (last + 1 < nSeg && pinnedSeg[last + 1] && segs[last + 1].off == segs[last].off + segs[last].len &&
+               static_cast<unsigned char*>(segs[last + 1].dst) == static_cast<unsigned char*>(segs[last].dst) + segs[last].len) {
+            ++last;
+            len += segs[last].len;
+        }
+        FPE_HIP(hipMemcpyAsync(segs[k].dst, dp + segs[k].off, len, hipMemcpyDeviceToHost, cx.stream));
+        for (int q = k; q <= last; ++q) segs[q].dst = nullptr;
+        k = last;
     }
     constexpr size_t kMaxChunks = 48;
     const size_t chunk = std::max<size_t>(1u << 20, (staged / kMaxChunks + 4095) & ~static_cast<size_t>(4095));

@@ -182,8 +182,18 @@ class FootholdPlanner:
             "default": ((B, n_cycles, 4, 3), np.float64), "cycle_ok": ((B, n_cycles), np.uint8),
             "stance": ((B, 4, 3), np.float64), "selected": ((B, n_cycles, 4), SELECTED_DTYPE), "pose_status": ((B,), np.uint8),
         }
-        make = self.host_array if pinned else (lambda shape, dt: np.zeros(shape, dtype=dt))
-        return {k: make(*shapes[k]) for k in products}
+        if not pinned:
+            return {k: np.zeros(shapes[k][0], dtype=shapes[k][1]) for k in products}
+        # ONE pinned block, the products behind one another in the order of the engine's device arena (each rounded up to
+        # 256 bytes as there): fpe_plan then moves neighbours without padding in between in one DMA transfer
+        order = [k for k in ("nominal", "centroid", "default", "cycle_ok", "stance", "selected", "pose_status") if k in products]
+        sizes = [int(np.prod(shapes[k][0])) * np.dtype(shapes[k][1]).itemsize for k in order]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 255) & ~255
+        arena = self.host_array((max(total, 1),), np.uint8)
+        return {k: arena[o:o + n].view(shapes[k][1]).reshape(shapes[k][0]) for k, o, n in zip(order, offs, sizes)}
 
     # ---- chained plan, host buffers ------------------------------------------------------------------
     def plan(self, poses, n_cycles, products=("nominal", "centroid", "default", "cycle_ok", "stance", "selected", "pose_status"),

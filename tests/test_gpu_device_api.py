@@ -297,3 +297,31 @@ def test_bench_two_ranks_on_one_gpu(config, batch):
     assert line["config"]["exchange_bytes_per_rank"] == batch * line["config"]["n_cycles"] * 4 * 16
     assert line["config"]["exchange_alt"]["gather_every"] == 1
     assert line["value"] > 0 and "roofline" in line
+
+
+@pytest.mark.parametrize("B", [4096, 1000, 37])
+def test_host_plan_into_pinned_arrays_equals_the_pageable_path(planner, B):
+    """fpe_plan with pinned destinations (fpe_host_alloc, FootholdPlanner.plan_outputs(pinned=True): one block, the products
+    behind one another as in the engine's device arena): neighbours without padding in between leave in ONE DMA transfer
+    (B = 4096: all seven), products with padding (B = 1000, 37: sizes that are no multiples of 256) or with a product left
+    out in between in separate ones; mixed pinned / pageable destinations as well.  Same bytes as the staged path."""
+    planner.params = _capi.params_yaml()
+    trav, elev = synth.rough_map(300, 300, 0.02, seed=77)
+    rng = np.random.default_rng(B)
+    poses = make_poses(np.column_stack([rng.uniform(-2.0, 0.5, B), rng.uniform(-2.0, 2.0, B), np.zeros(B)]))
+    poses["gait"] = rng.integers(0, 2, B)
+    n = 5
+    planner.gridmapCallback(trav, elev, 0.02)
+    ref = planner.plan(poses, n)
+    out = planner.plan(poses, n, out=planner.plan_outputs(B, n, pinned=True))
+    for k in ref:
+        assert out[k].tobytes() == ref[k].tobytes(), k
+    some = ("nominal", "default", "selected", "pose_status")  # centroid, cycle_ok and stance left out: gaps in the arena order
+    out2 = planner.plan(poses, n, products=some, out=planner.plan_outputs(B, n, products=some, pinned=True))
+    for k in some:
+        assert out2[k].tobytes() == ref[k].tobytes(), k
+    mixed = planner.plan_outputs(B, n, pinned=True)
+    mixed["centroid"] = np.zeros_like(ref["centroid"])  # a pageable array between pinned neighbours
+    out3 = planner.plan(poses, n, out=mixed)
+    for k in ref:
+        assert out3[k].tobytes() == ref[k].tobytes(), k
