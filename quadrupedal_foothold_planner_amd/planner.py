@@ -213,10 +213,18 @@ class FootholdPlanner:
             out = {k: np.zeros(shapes[k][0], dtype=shapes[k][1]) for k in products}
         else:
             products = tuple(k for k in products if k in out)
-        po = PlanOut()
-        for k in products:
-            assert out[k].shape == shapes[k][0] and out[k].dtype == shapes[k][1]
-            setattr(po, fields[k], ptr(out[k]))
+        # the checked argument block of an `out` dict is kept for its next use (timing loops call with the same arrays: comparing
+        # seven structured dtypes and taking seven pointers costs more Python time than the engine needs for its launches)
+        key = (id(out), B, int(n_cycles), products) + tuple(out[k].ctypes.data for k in products)
+        cached = getattr(self, "_plan_out_cache", None)
+        if cached is not None and cached[0] == key:
+            po = cached[1]
+        else:
+            po = PlanOut()
+            for k in products:
+                assert out[k].shape == shapes[k][0] and out[k].dtype == shapes[k][1]
+                setattr(po, fields[k], ptr(out[k]))
+            self._plan_out_cache = (key, po, out)
         self._check(self._lib.fpe_plan(self._h, ptr(self.params), ptr(poses), B, int(n_cycles), C.byref(po)))
         return out
 
