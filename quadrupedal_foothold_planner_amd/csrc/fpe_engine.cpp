@@ -229,6 +229,10 @@ class CopyPool {
         std::unique_lock<std::mutex> lk(b.mu);
         b.cv.wait(lk, [&] { return b.pending == 0; });
     }
+    static size_t width() {  // threads of the pool (start())
+        const unsigned n = std::thread::hardware_concurrency();
+        return n > 4 ? 3 : (n > 1 ? n - 1 : 1);
+    }
 
   private:
     struct Task {
@@ -238,9 +242,8 @@ class CopyPool {
         size_t len;
     };
     void start() {  // under mu_
-        unsigned n = std::thread::hardware_concurrency();
-        n = n > 4 ? 3 : (n > 1 ? n - 1 : 1);
-        for (unsigned k = 0; k < n; ++k) threads_.emplace_back([this] { run(); });
+        const size_t n = width();
+        for (size_t k = 0; k < n; ++k) threads_.emplace_back([this] { run(); });
     }
     void run() {
         for (;;) {
@@ -1003,19 +1006,24 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
         for (int q = k; q <= last; ++q) segs[q].dst = nullptr;
         k = last;
     }
-    constexpr size_t kMaxChunks = 48;
-    const size_t chunk = std::max<size_t>(1u << 20, (staged / kMaxChunks + 4095) & ~static_cast<size_t>(4095));
+    // A DMA transfer has a fixed cost of some ten microseconds: few, large pieces (a quarter of what is staged, at least
+    // 1 MB), and the copy of a piece into the caller's array split over the pool's threads so that the last piece's copy — the
+    // only one that is not hidden behind a later transfer — is short.
+    constexpr size_t kTargetChunks = 4;
+    const size_t chunk = std::max<size_t>(1u << 20, (staged / kTargetChunks + 4095) & ~static_cast<size_t>(4095));
+    // DMA pieces are cut from RUNS of staged products that are neighbours in the arena (alignment padding rides along: both
+    // arenas are the engine's own), not from single products: four transfers for seven products, not nine.
     struct Piece {
         size_t off, len;
-        void* dst;
     };
     std::vector<Piece> pieces;
     for (int k = 0; k < nSeg; ++k) {
         if (!segs[k].dst) continue;
-        for (size_t c = 0; c < segs[k].len; c += chunk) {
-            const size_t len = std::min(chunk, segs[k].len - c);
-            pieces.push_back(Piece{segs[k].off + c, len, static_cast<unsigned char*>(segs[k].dst) + c});
-        }
+        int last = k;
+        while (last + 1 < nSeg && segs[last + 1].dst && segs[last + 1].off == align256(segs[last].off + segs[last].len)) ++last;
+        const size_t end = segs[last].off + segs[last].len;
+        for (size_t c = segs[k].off; c < end; c += chunk) pieces.push_back(Piece{c, std::min(chunk, end - c)});
+        k = last;
     }
     for (size_t k = 0; k < pieces.size(); ++k) {
         hipEvent_t ev;
@@ -1031,8 +1039,22 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
             evErr = e;
             break;
         }
-        if (pieces[k].len >= (256u << 10)) h->copyPool.submit(batch, pieces[k].dst, hp + pieces[k].off, pieces[k].len);
-        else std::memcpy(pieces[k].dst, hp + pieces[k].off, pieces[k].len);
+        // what the piece holds of each staged product, into the caller's array
+        const size_t p0 = pieces[k].off, p1 = p0 + pieces[k].len;
+        for (int q = 0; q < nSeg; ++q) {
+            if (!segs[q].dst) continue;
+            const size_t a0 = std::max(p0, segs[q].off), a1 = std::min(p1, segs[q].off + segs[q].len);
+            if (a0 >= a1) continue;
+            unsigned char* dst = static_cast<unsigned char*>(segs[q].dst) + (a0 - segs[q].off);
+            const size_t len = a1 - a0;
+            if (len >= (256u << 10)) {
+                const size_t parts = std::min<size_t>(h->copyPool.width(), (len + (256u << 10) - 1) / (256u << 10));
+                const size_t step = ((len + parts - 1) / parts + 63) & ~static_cast<size_t>(63);
+                for (size_t c = 0; c < len; c += step) h->copyPool.submit(batch, dst + c, hp + a0 + c, std::min(step, len - c));
+            } else {
+                std::memcpy(dst, hp + a0, len);
+            }
+        }
     }
     CopyPool::wait(batch);
     if (evErr != hipSuccess) return fail_hip(evErr, "result copy");
