@@ -306,7 +306,10 @@ int fpe_plan(fpe_handle h, const fpe_params* params, const fpe_pose* poses, int3
 /* Host arrays the GPU can write by DMA (pinned).  fpe_plan / fpe_plan_opt copy a product whose destination lies in such
  * memory — allocated here, by hipHostMalloc or registered with hipHostRegister — from the device straight into it;
  * other destinations are served through the engine's own pinned arena and a copy (overlapped, chunk by chunk).  A ROS
- * adapter that keeps its result arrays across service calls allocates them once with fpe_host_alloc. */
+ * adapter that keeps its result arrays across service calls allocates them once with fpe_host_alloc.  Products whose
+ * pinned destinations lie directly behind one another in the order of fpe_plan_out's fields (nominal, centroid, default_next,
+ * cycle_ok, stance, selected, pose_status; no gap, sizes that are multiples of 256 bytes) leave in ONE transfer: carve them
+ * out of one block in that order (a transfer has a fixed cost of some ten microseconds). */
 int fpe_host_alloc(fpe_handle h, size_t bytes, void** out);
 int fpe_host_free(fpe_handle h, void* p);
 
