@@ -114,6 +114,21 @@ typedef struct fpe_selected_foothold {
     uint8_t valid, source, foot_id, gait_cycle_id;
 } fpe_selected_foothold;
 
+/* The same record in 8 bytes (build-defined; the exchange of a multi-GPU step moves HALF the bytes): one word holding
+ * the grid index and the two flags, and the height.  foot_id / gait_cycle_id are positional (record (b, g, leg) sits at
+ * ((b * n_cycles) + g) * 4 + leg on every rank).  Maps of up to 16383 x 16383 cells (fpe_plan* fail with
+ * FPE_E_UNSUPPORTED when the product is requested on a larger map). */
+typedef struct fpe_selected_packed {
+    uint32_t cell; /* bits 0-13 row, 14-27 col (0x3FFF = -1: no foothold), bit 28 valid, bits 29-30 source, bit 31 zero */
+    float z;
+} fpe_selected_packed;
+#define FPE_PACKED_NONE 0x3FFFu
+#define FPE_PACKED_MAX_CELLS 16383
+#define FPE_PACKED_ROW(c) ((int32_t)((c) & 0x3FFFu) == 0x3FFF ? -1 : (int32_t)((c) & 0x3FFFu))
+#define FPE_PACKED_COL(c) ((int32_t)(((c) >> 14) & 0x3FFFu) == 0x3FFF ? -1 : (int32_t)(((c) >> 14) & 0x3FFFu))
+#define FPE_PACKED_VALID(c) (((c) >> 28) & 1u)
+#define FPE_PACKED_SOURCE(c) (((c) >> 29) & 3u)
+
 /* fpe_plan_out.pose_status bits */
 #define FPE_POSE_OPT_SUBMAP_FAILED 1u /* getGaitCycleSearchGridMap (cpp:2307-2349) fails in the FIRST gait cycle:
                                          getSubmap(next feet centre, isos_.length x isos_.width) — the reference's
@@ -131,6 +146,7 @@ typedef struct fpe_plan_out {
     double* stance;                  /* [B * 4 * 3] RF/RH/LH/LF_initialPosition_ (cpp:350-378) */
     fpe_selected_foothold* selected; /* [B * n_cycles * 4] 16-byte form of `nominal` (multi-GPU exchange record) */
     uint8_t* pose_status;            /* [B] FPE_POSE_* bits */
+    fpe_selected_packed* selected_packed; /* [B * n_cycles * 4] 8-byte form of `selected` (halves the exchange) */
 } fpe_plan_out;
 
 /* ---- the "opt" track: cpp:54-148 objective + constraints, cpp:913-1319 per-cycle driver,
@@ -153,7 +169,7 @@ typedef struct fpe_opt_params {
     double skew_lower_scale, skew_upper_scale; /* cpp:49: 0.8, 1.2 */
     double lf_current_row0, rh_current_row0;   /* file-scope lfCurrentRow / rhCurrentRow (cpp:36) at entry of the call:
                                                   0 at node start, afterwards whatever the previous call left — the
-                                                  adapter carries fpe_opt_cycle.lf/rh_current_row of the last cycle */
+                                                  adapter carries fpe_opt_out.rows_after / fpe_service_gate.lf/rh_current_row */
 } fpe_opt_params;
 int fpe_opt_params_yaml(fpe_opt_params* out);          /* yaml:53-63 + cpp:28-51 */
 int fpe_opt_params_code_defaults(fpe_opt_params* out); /* cpp:297-307 (constraints off) */
@@ -196,6 +212,9 @@ typedef struct fpe_opt_out {
     fpe_opt_cycle* cycles;       /* [B * n_cycles] */
     uint8_t* gate_fail_cycle;    /* [B] first cycle whose getGaitCycleSearchGridMap failed — the cycle in which the
                                     reference's service handler returns false (cpp:931-934); 255 = none */
+    double* rows_after;          /* [B * 2] lfCurrentRow, rhCurrentRow as the call leaves them (cpp:1561-1568: gaitMap_.getIndex
+                                    of the committed LF / RH positions; unchanged by cycles that do not commit): what the
+                                    NEXT call's fpe_opt_params.lf/rh_current_row0 must be (file-scope globals, cpp:36) */
 } fpe_opt_out;
 
 /* One open-loop checkFoothold call (hpp:94-100) with an arbitrary polygon (grid_map::Polygon). */
@@ -234,8 +253,13 @@ int fpe_destroy(fpe_handle h);
  * defaults once, in fpe_create).  Keys: "plan_group" (0 automatic; 4/8/16/64 lanes per leg, 65 = one
  * wavefront per pose), "literal_discs" (1: force the literal CircleIterator walk), "no_mid_variant"
  * (1: never launch the 3x3-only kernel variants), "no_bits" (1: never launch the bit-window kernels),
- * "service_cycle0_gate_only" (1: fpe_plan_service* calls that ask for no opt product skip the opt track's chain — about
- * 160 us of a 210 us call for 8 cycles — and report the handler's `return false` for the first gait cycle only).
+ * "service_opt_gate" — what the fpe_plan_service* calls do about the gate of gait cycles >= 1, whose x side follows the
+ * opt track's feet, i.e. the BUILD-DEFINED optimiser (see fpe_service_gate below): 0 (default) the opt track's chain is
+ * not run for the gate (it still runs when an opt product is asked for) and the call returns FPE_E_SERVICE_FALSE only on
+ * the optimiser-independent failures; 1 advisory: the chain runs next to the plan (its own stream), its verdict is
+ * reported by fpe_last_service_gate, the return value stays optimiser-independent; 2 enforce: as 1, and the call returns
+ * FPE_E_SERVICE_FALSE on the build-defined verdict too (round 3's behaviour).  "service_cycle0_gate_only" (older name):
+ * 1 = service_opt_gate 0, 0 = service_opt_gate 2.
  * Thread-safe: every plan / search call copies the knobs once, under the engine's lock, so a concurrent call runs
  * entirely with the values before or entirely with the values after a change (one key per call: callers that change
  * several keys while other threads plan get each key's change at its own moment). */
@@ -334,10 +358,31 @@ int fpe_search_legs_device(fpe_handle h, const fpe_params* params, const fpe_leg
                            fpe_foothold* d_out, void* stream);
 
 /* ---- service-shaped call: one pose, response content of plan_global_footholds (cpp:539-1602) --
- * Returns FPE_E_SERVICE_FALSE (response zeroed) where the reference's handler returns false because
- * getGaitCycleSearchGridMap fails (cpp:920-934) — in ANY gait cycle: the service calls run the opt track's chain
- * (yaml optimiser parameters unless fpe_plan_service_opt passes others) next to the plan.  From the second cycle on
- * the gate follows the opt track's feet, i.e. the build-defined optimiser (see fpe_opt_params). */
+ * The reference's handler returns false when getGaitCycleSearchGridMap's getSubmap fails (cpp:920-934, 2345-2349) — in
+ * ANY gait cycle.  That submap is centred at (x of the opt track's next feet centre, initialPose_[1] + ajustedPose_[1]):
+ *   * in gait cycle 0 the feet are the stance: exact, decided by the plan kernels (FPE_POSE_OPT_SUBMAP_FAILED);
+ *   * its y side depends on the cycle number only (the lateral drift, cpp:1578): exact in EVERY cycle, decided on the
+ *     host with the same grid arithmetic — a request whose y side fails in some cycle g < gait_cycles is refused by the
+ *     reference in cycle g at the latest, whatever its optimiser does;
+ *   * its x side in cycles >= 1 follows the opt track's feet, i.e. NLopt's COBYLA iterates (cpp:1116-1211), which this
+ *     build cannot reproduce (fpe_opt_params): BUILD-DEFINED, advisory by default.
+ * These calls return FPE_E_SERVICE_FALSE (response zeroed) on the first two kinds; on the third only under
+ * fpe_set_tuning("service_opt_gate", 2).  fpe_last_service_gate tells the kinds apart. */
+typedef struct fpe_service_gate {
+    uint8_t fail_cycle;  /* gait cycle in which the handler's gate fails; 255 = it never does */
+    uint8_t fail_kind;   /* FPE_GATE_* */
+    uint8_t chain_ran;   /* the opt track's chain was run for this call (its verdict is known) */
+    uint8_t returned_false; /* the call returned FPE_E_SERVICE_FALSE */
+    uint8_t pad[4];
+    double lf_current_row, rh_current_row; /* chain_ran: lfCurrentRow / rhCurrentRow as the call leaves them
+                                              (fpe_opt_out.rows_after): the adapter carries them into the next call */
+} fpe_service_gate;
+#define FPE_GATE_NONE 0          /* no failing cycle (x side of cycles >= 1 unknown when chain_ran = 0) */
+#define FPE_GATE_CYCLE0 1        /* exact: first gait cycle, stance feet */
+#define FPE_GATE_LATERAL 2       /* exact: y side of cycle fail_cycle (lateral drift), optimiser-independent */
+#define FPE_GATE_BUILD_DEFINED 3 /* x side of a cycle >= 1: follows the build-defined optimiser's feet */
+/* Gate verdict of the last fpe_plan_service* call made on THIS thread with engine h. */
+int fpe_last_service_gate(fpe_handle h, fpe_service_gate* out);
 int fpe_plan_service(fpe_handle h, const fpe_params* params, const double initial_position[3],
                      uint8_t gait_cycles, fpe_global_footholds* response);
 
@@ -410,6 +455,31 @@ int fpe_multi_upload_map(fpe_multi_handle h, const fpe_map_desc* desc, const flo
 int fpe_multi_set_tuning(fpe_multi_handle h, const char* key, int32_t value);
 int fpe_multi_plan(fpe_multi_handle h, const fpe_params* params, const fpe_pose* poses, int32_t B, int32_t n_cycles,
                    const fpe_plan_out* out);
+/* Block of device k of a batch of B poses split over n_devices: poses [*first, *first + *count). */
+int fpe_multi_shard_range(int32_t B, int32_t k, int32_t n_devices, int32_t* first, int32_t* count);
+
+/* Device-resident form with the xGMI all-gather north_star names, for the C++ host that owns every GPU of the node
+ * (replaces the 4 std::thread + join of cpp:863-909 for every pose of the batch, on all devices at once).  io[k]
+ * describes device k: its block's poses and products in ITS memory (block = fpe_multi_shard_range(B, k, n)), its
+ * stream (NULL: the group's own stream of that device, fpe_multi_stream), and — when record_kind is not
+ * FPE_EXCHANGE_NONE — d_gathered: room for the records of the WHOLE batch in pose order, [B * n_cycles * 4] records of
+ * the chosen kind.  The call queues, per device, the plan of its block and then ONE fused RCCL collective
+ * (ncclGroupStart / ncclAllGather per device / ncclGroupEnd; grouped ncclBroadcasts when B % n != 0) on the same
+ * streams: d_gathered on every device holds every block's records once its stream has passed the call.  Nothing
+ * synchronises the host.  RCCL is loaded at the first gathering call (librccl.so.1); FPE_E_UNSUPPORTED without it. */
+#define FPE_EXCHANGE_NONE 0
+#define FPE_EXCHANGE_SELECTED 1 /* fpe_selected_foothold, 16 bytes: d_out.selected is the block's contribution */
+#define FPE_EXCHANGE_PACKED 2   /* fpe_selected_packed, 8 bytes: d_out.selected_packed */
+typedef struct fpe_multi_device_io {
+    const fpe_pose* d_poses; /* device k's block of poses */
+    fpe_plan_out d_out;      /* device k's products of its block (device pointers; any may be NULL) */
+    void* d_gathered;        /* device k: records of the whole batch, or NULL with FPE_EXCHANGE_NONE */
+    void* stream;            /* hipStream_t of device k, or NULL */
+} fpe_multi_device_io;
+int fpe_multi_plan_device(fpe_multi_handle h, const fpe_params* params, const fpe_multi_device_io* io, int32_t B, int32_t n_cycles,
+                          int32_t record_kind);
+void* fpe_multi_stream(fpe_multi_handle h, int32_t k); /* the group's own stream of device k (a hipStream_t) */
+int fpe_multi_synchronize(fpe_multi_handle h);          /* waits for the group's own streams */
 
 /* ---- host-side helpers (no GPU needed) -------------------------------------------------------- */
 /* SpiralIterator visiting order as index offsets (di,dj) for rings 0..n_rings (generateRing walk,

@@ -137,6 +137,7 @@ def lib():
         L.fpo_plan.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
         L.fpo_search_legs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.fpo_pose_status.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.fpo_gate_lateral.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.fpo_plan_as_written.restype = C.c_ulonglong
         L.fpo_plan_as_written.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.fpo_plan_products.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7
@@ -221,6 +222,15 @@ class OracleMap:
         poses = np.ascontiguousarray(poses, dtype=POSE_DTYPE)
         out = np.zeros(poses.shape[0], dtype=np.uint8)
         lib().fpo_pose_status(self._h, _ptr(params), _ptr(poses), poses.shape[0], _ptr(out))
+        return out
+
+    def gate_lateral(self, params, poses, n_cycles):
+        """First gait cycle whose getGaitCycleSearchGridMap fails on its LATERAL (y) side, per pose; 255 = none: the
+        optimiser-independent part of the handler's gate in every cycle (fpo_capi.cpp::fpo_gate_lateral)."""
+        params = np.ascontiguousarray(params, dtype=PARAMS_DTYPE).reshape(1)
+        poses = np.ascontiguousarray(poses, dtype=POSE_DTYPE)
+        out = np.zeros(poses.shape[0], dtype=np.uint8)
+        lib().fpo_gate_lateral(self._h, _ptr(params), _ptr(poses), poses.shape[0], int(n_cycles), _ptr(out))
         return out
 
     def plan_as_written(self, params, poses, n_cycles):

@@ -149,6 +149,38 @@ int fpo_pose_status(const void* mapHandle, const Params* params, const PoseSpec*
     return 0;
 }
 
+// The LATERAL side of the handler's gate (cpp:2307-2349, 931-934): getGaitCycleSearchGridMap's getSubmap is centred at
+// (x of the opt track's next feet centre, initialPose_[1] + ajustedPose_[1]); every condition of getSubmap is a
+// conjunction of an x-only and a y-only condition, and the y of cycle g depends on g only (the drift, cpp:1578).  With x
+// at the map's centre (where the x conditions hold) the call fails iff the y side fails: fail[b] = first such cycle of
+// pose b, 255 = none.  A request whose y side fails in cycle g is refused by the reference in cycle g at the latest,
+// whatever its optimiser does (include/fpe.h, fpe_service_gate).
+int fpo_gate_lateral(const void* mapHandle, const Params* params, const PoseSpec* poses, int B, int nCycles, uint8_t* fail) {
+    const GridMap& map = *static_cast<const GridMap*>(mapHandle);
+    for (int b = 0; b < B; ++b) {
+        fail[b] = 255;
+        double ajustedPoseY = 0.0;  // cpp:759
+        for (int g = 0; g < nCycles; ++g) {
+            // four feet whose polygon centre has x = map centre - stepLength, so that getGaitCycleSearchGridMap's
+            // p.x = feetCenter.x + stepLength lands near the map's centre (any x whose x side passes serves)
+            const double cx = map.position.x - static_cast<double>(params->stepLength);
+            Point3 cur[4];
+            const double dx[4] = {0.2, -0.2, -0.2, 0.2}, dy[4] = {-0.1, -0.1, 0.1, 0.1};
+            for (int l = 0; l < 4; ++l) {
+                cur[l].x = cx + dx[l];
+                cur[l].y = dy[l];
+                cur[l].z = 0.0;
+            }
+            if (!getGaitCycleSearchGridMap(map, *params, cur, poses[b].pose[1], ajustedPoseY)) {
+                fail[b] = static_cast<uint8_t>(g);
+                break;
+            }
+            ajustedPoseY += params->lateralDrift;  // cpp:1578
+        }
+    }
+    return 0;
+}
+
 // Evaluation products of ONE trot plan: per track k (0 centroid, 1 nominal)
 //   path[k]: up to nCycles x 3 doubles, dist[k] / speed[k]: up to 2*nCycles doubles; counts[k] = {nPath, nKpi}.
 int fpo_plan_products(const void* mapHandle, const Params* params, const PoseSpec* pose, int nCycles, double* path0,

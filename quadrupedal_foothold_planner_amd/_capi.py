@@ -54,6 +54,29 @@ SELECTED_DTYPE = np.dtype(
     [("row", "<i4"), ("col", "<i4"), ("z", "<f4"), ("valid", "u1"), ("source", "u1"), ("foot_id", "u1"), ("gait_cycle_id", "u1")],
     align=True,
 )
+# fpe_selected_packed: the 8-byte exchange record (row | col << 14 | valid << 28 | source << 29, z); -1 indices are 0x3FFF
+PACKED_DTYPE = np.dtype([("cell", "<u4"), ("z", "<f4")], align=True)
+PACKED_NONE = 0x3FFF
+PACKED_MAX_CELLS = 16383
+
+
+def unpack_selected(packed):
+    """fpe_selected_packed records -> SELECTED_DTYPE records (foot_id / gait_cycle_id from the positions [..., n_cycles, 4])."""
+    c = packed["cell"]
+    out = np.zeros(packed.shape, dtype=SELECTED_DTYPE)
+    row = (c & 0x3FFF).astype(np.int32)
+    col = ((c >> 14) & 0x3FFF).astype(np.int32)
+    out["row"] = np.where(row == PACKED_NONE, -1, row)
+    out["col"] = np.where(col == PACKED_NONE, -1, col)
+    out["z"] = packed["z"]
+    out["valid"] = (c >> 28) & 1
+    out["source"] = (c >> 29) & 3
+    if packed.ndim >= 2:
+        out["foot_id"] = np.arange(packed.shape[-1], dtype=np.uint8)
+        out["gait_cycle_id"] = np.arange(packed.shape[-2], dtype=np.uint8)[:, None]
+    return out
+
+
 QUERY_DTYPE = np.dtype(
     [("cx", "<f8"), ("cy", "<f8"), ("search_radius", "<f4"), ("n_vertices", "<i4"),
      ("vx", "<f8", (MAX_POLYGON_VERTICES,)), ("vy", "<f8", (MAX_POLYGON_VERTICES,))],
@@ -118,11 +141,27 @@ class PlanOut(C.Structure):
         ("stance", C.c_void_p),
         ("selected", C.c_void_p),
         ("pose_status", C.c_void_p),
+        ("selected_packed", C.c_void_p),
     ]
 
 
+class MultiDeviceIO(C.Structure):
+    """fpe_multi_device_io: one device's block of a device-resident multi-GPU plan."""
+    _fields_ = [("d_poses", C.c_void_p), ("d_out", PlanOut), ("d_gathered", C.c_void_p), ("stream", C.c_void_p)]
+
+
+class ServiceGate(C.Structure):
+    """fpe_service_gate: verdict of the handler's gate for the last service call of this thread."""
+    _fields_ = [("fail_cycle", C.c_uint8), ("fail_kind", C.c_uint8), ("chain_ran", C.c_uint8), ("returned_false", C.c_uint8),
+                ("pad", C.c_uint8 * 4), ("lf_current_row", C.c_double), ("rh_current_row", C.c_double)]
+
+
+GATE_NONE, GATE_CYCLE0, GATE_LATERAL, GATE_BUILD_DEFINED = 0, 1, 2, 3
+EXCHANGE_NONE, EXCHANGE_SELECTED, EXCHANGE_PACKED = 0, 1, 2
+
+
 class OptOut(C.Structure):
-    _fields_ = [("footholds", C.c_void_p), ("cycles", C.c_void_p), ("gate_fail_cycle", C.c_void_p)]
+    _fields_ = [("footholds", C.c_void_p), ("cycles", C.c_void_p), ("gate_fail_cycle", C.c_void_p), ("rows_after", C.c_void_p)]
 
 
 class FilterParams(C.Structure):
@@ -169,6 +208,7 @@ EXPORTED_SYMBOLS = [
     "fpe_plan_service_ex",
     "fpe_plan_service_report",
     "fpe_plan_service_opt",
+    "fpe_last_service_gate",
     "fpe_opt_params_yaml",
     "fpe_opt_params_code_defaults",
     "fpe_plan_opt",
@@ -181,6 +221,10 @@ EXPORTED_SYMBOLS = [
     "fpe_multi_upload_map",
     "fpe_multi_set_tuning",
     "fpe_multi_plan",
+    "fpe_multi_shard_range",
+    "fpe_multi_plan_device",
+    "fpe_multi_stream",
+    "fpe_multi_synchronize",
     "fpe_spiral_offsets",
     "fpe_tile_halfwidth",
     "fpe_algorithmic_bytes_per_foothold",
@@ -234,6 +278,7 @@ def lib():
     L.fpe_plan_service_ex.argtypes = [vp, vp, vp, C.c_uint8, vp, vp, vp, vp]
     L.fpe_plan_service_report.argtypes = [vp, vp, vp, C.c_uint8, vp, vp, vp, vp, vp, vp]
     L.fpe_plan_service_opt.argtypes = [vp, vp, vp, vp, C.c_uint8] + [vp] * 9
+    L.fpe_last_service_gate.argtypes = [vp, C.POINTER(ServiceGate)]
     L.fpe_opt_params_yaml.argtypes = [vp]
     L.fpe_opt_params_code_defaults.argtypes = [vp]
     L.fpe_plan_opt.argtypes = [vp, vp, vp, vp, i32, i32, vp, C.POINTER(OptOut)]
@@ -248,6 +293,11 @@ def lib():
     L.fpe_multi_upload_map.argtypes = [vp, C.POINTER(MapDesc), vp, vp]
     L.fpe_multi_set_tuning.argtypes = [vp, C.c_char_p, i32]
     L.fpe_multi_plan.argtypes = [vp, vp, vp, i32, i32, C.POINTER(PlanOut)]
+    L.fpe_multi_shard_range.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.fpe_multi_plan_device.argtypes = [vp, vp, C.POINTER(MultiDeviceIO), i32, i32, i32]
+    L.fpe_multi_stream.restype = vp
+    L.fpe_multi_stream.argtypes = [vp, i32]
+    L.fpe_multi_synchronize.argtypes = [vp]
     L.fpe_spiral_offsets.argtypes = [i32, vp, i32]
     L.fpe_tile_halfwidth.argtypes = [f32, f32, f64]
     L.fpe_algorithmic_bytes_per_foothold.restype = f64

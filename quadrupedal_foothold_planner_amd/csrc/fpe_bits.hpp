@@ -1499,13 +1499,7 @@ __device__ __forceinline__ void leg_phase_bits(const DevMap& m, const BitMap& bm
         } else if (live) {
             const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
             if (out.nominal) store_foothold(out.nominal + o, no, leg, cyc);
-            if (out.selected) {
-                fpe_selected_foothold sf;
-                sf.row = no.row; sf.col = no.col; sf.z = no.z;
-                sf.valid = static_cast<uint8_t>(no.valid); sf.source = static_cast<uint8_t>(no.source);
-                sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
-                store_record<false>(out.selected + o, sf);
-            }
+            store_selected<false>(out, o, no.row, no.col, no.z, no.valid, no.source, leg, cyc);
             if (out.centroid) {
                 fpe_centroid_foothold cf;
                 cf.x = co.x; cf.y = co.y; cf.z = co.z; cf.row = co.row; cf.col = co.col;
@@ -1641,13 +1635,7 @@ __device__ __forceinline__ void flush_seqrec(const DevMap& m, const PlanConsts& 
         f.foot_id = static_cast<uint8_t>(leg); f.gait_cycle_id = static_cast<uint8_t>(cyc);
         store_record<true>(out.nominal + o, f);
     }
-    if (out.selected) {
-        fpe_selected_foothold sf;
-        sf.row = r.nomRow; sf.col = r.nomCol; sf.z = zN;
-        sf.valid = valid; sf.source = source;
-        sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
-        store_record<true>(out.selected + o, sf);
-    }
+    store_selected<true>(out, o, r.nomRow, r.nomCol, zN, valid, source, leg, cyc);
     if (out.centroid) {
         fpe_centroid_foothold cf;
         cf.x = r.cenX; cf.y = r.cenY; cf.z = zC; cf.row = r.cenRow; cf.col = r.cenCol;
@@ -1697,13 +1685,7 @@ __device__ __forceinline__ void flush_seqrec2(const DevMap& m, const PlanConsts&
         f.foot_id = static_cast<uint8_t>(leg); f.gait_cycle_id = static_cast<uint8_t>(cyc);
         store_record<true>(out.nominal + o, f);
     }
-    if (out.selected) {
-        fpe_selected_foothold sf;
-        sf.row = r.nomRow; sf.col = r.nomCol; sf.z = zN;
-        sf.valid = valid; sf.source = source;
-        sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
-        store_record<true>(out.selected + o, sf);
-    }
+    store_selected<true>(out, o, r.nomRow, r.nomCol, zN, valid, source, leg, cyc);
     if (out.centroid) {
         fpe_centroid_foothold cf;
         cf.x = r.cenX; cf.y = r.cenY; cf.z = zC; cf.row = r.cenRow; cf.col = r.cenCol;
@@ -1787,13 +1769,7 @@ __device__ __forceinline__ void flush_unit(const DevMap& m, const PlanConsts& pc
         f.gait_cycle_id = static_cast<uint8_t>(cyc);
         store_record<true>(out.nominal + o, f);
     }
-    if (out.selected) {
-        fpe_selected_foothold sf;
-        sf.row = u.nomRow; sf.col = u.nomCol; sf.z = zN;
-        sf.valid = static_cast<uint8_t>(valid); sf.source = static_cast<uint8_t>(source);
-        sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
-        store_record<true>(out.selected + o, sf);
-    }
+    store_selected<true>(out, o, u.nomRow, u.nomCol, zN, valid, source, leg, cyc);
     if (out.centroid) {
         fpe_centroid_foothold cf;
         cf.x = code == 0 ? u.cx : (code <= 4 ? u.cenX : 0.0);
@@ -1939,13 +1915,7 @@ __device__ __forceinline__ void flush_unit_g(const DevMap& m, const PlanConsts& 
         f.gait_cycle_id = static_cast<uint8_t>(cyc);
         store_record<true>(out.nominal + o, f);
     }
-    if (out.selected) {
-        fpe_selected_foothold sf;
-        sf.row = u.nomRow; sf.col = u.nomCol; sf.z = zN;
-        sf.valid = static_cast<uint8_t>(valid); sf.source = static_cast<uint8_t>(source);
-        sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
-        store_record<true>(out.selected + o, sf);
-    }
+    store_selected<true>(out, o, u.nomRow, u.nomCol, zN, valid, source, leg, cyc);
     if (out.centroid) {
         fpe_centroid_foothold cf;
         cf.x = code == 0 ? u.cx : (code <= 4 ? u.cenX : 0.0);
@@ -2329,13 +2299,7 @@ __device__ __forceinline__ void leg_phase_bits8(const DevMap& m, const BitMap& b
     if (g.sub == 0 && live) {
         const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
         if (out.nominal) store_foothold<true>(out.nominal + o, no, leg, cyc);
-        if (out.selected) {
-            fpe_selected_foothold sf;
-            sf.row = no.row; sf.col = no.col; sf.z = no.z;
-            sf.valid = static_cast<uint8_t>(no.valid); sf.source = static_cast<uint8_t>(no.source);
-            sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
-            store_record<true>(out.selected + o, sf);
-        }
+        store_selected<true>(out, o, no.row, no.col, no.z, no.valid, no.source, leg, cyc);
         if (out.centroid) {
             fpe_centroid_foothold cf;
             cf.x = co.x; cf.y = co.y; cf.z = co.z; cf.row = co.row; cf.col = co.col;

@@ -40,7 +40,7 @@ struct Tuning {
     int32_t literalDiscs = 0;
     int32_t noMidVariant = 0;
     int32_t noBits = 0;
-    int32_t serviceCycle0GateOnly = 0;  // fpe_plan_service*: skip the opt track's chain (its gate is then exact for cycle 0 only)
+    int32_t serviceOptGate = 0;  // fpe_plan_service*: 0 exact gates only (no opt chain), 1 advisory (chain runs, reported), 2 enforce (include/fpe.h)
 };
 
 struct PlanConsts {

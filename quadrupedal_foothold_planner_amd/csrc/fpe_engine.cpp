@@ -51,6 +51,8 @@ hipError_t launch_opt_track(const DevMap& m, const PlanConsts& pc, const OptCons
 namespace {
 
 thread_local std::string g_err;
+thread_local fpe_service_gate g_gate = {255, FPE_GATE_NONE, 0, 0, {0, 0, 0, 0}, 0.0, 0.0};  // verdict of this thread's last fpe_plan_service* call
+thread_local const void* g_gateEngine = nullptr;
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -131,6 +133,11 @@ struct CallCtx {
     unsigned char* pinned = nullptr;
     size_t pinCap = 0;
     std::vector<hipEvent_t> events;  // one per staged result chunk in flight (created on demand, kept)
+    // work may be queued on `stream` that reads / writes the arenas (and the caller's pinned arrays): set before the first
+    // enqueue of a call, cleared once the call has synchronised.  A call that leaves early (a failed HIP call after its
+    // kernels were queued) hands the context back with the flag set, and the lease waits for the stream before the next
+    // call's memcpy can touch the arena the kernels are still reading.
+    bool inFlight = false;
     ~CallCtx() {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         if (dev) (void)hipFree(dev);
@@ -192,7 +199,13 @@ struct CtxLease {  // returns the context to the pool on every exit path
     CtxPool& pool;
     std::unique_ptr<CallCtx> ctx;
     explicit CtxLease(CtxPool& p) : pool(p), ctx(p.take()) {}
-    ~CtxLease() { pool.give(std::move(ctx)); }
+    ~CtxLease() {
+        if (ctx && ctx->inFlight && ctx->stream) {
+            (void)hipStreamSynchronize(ctx->stream);  // best effort: an early exit after work was queued
+            ctx->inFlight = false;
+        }
+        pool.give(std::move(ctx));
+    }
 };
 inline size_t align256(size_t n) { return (n + 255) & ~static_cast<size_t>(255); }
 
@@ -573,7 +586,7 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
 
 extern "C" {
 
-const char* fpe_version(void) { return "fpe 0.3.0 (gfx950, wave64; bit-window plan kernels on tiled planes: 8 lanes per leg and two poses per wavefront, one wavefront per pose for large windows; opt track with a build-defined optimiser)"; }
+const char* fpe_version(void) { return "fpe 0.4.0 (gfx950, wave64; bit-window plan kernels on tiled planes: 8 lanes per leg and two poses per wavefront, one wavefront per pose for large windows; opt track with a build-defined optimiser)"; }
 
 const char* fpe_last_error(fpe_handle) { return g_err.c_str(); }
 
@@ -656,7 +669,10 @@ int fpe_set_tuning(fpe_handle h, const char* key, int32_t value) {
     else if (k == "literal_discs") h->tuning.literalDiscs = value ? 1 : 0;
     else if (k == "no_mid_variant") h->tuning.noMidVariant = value ? 1 : 0;
     else if (k == "no_bits") h->tuning.noBits = value ? 1 : 0;
-    else if (k == "service_cycle0_gate_only") h->tuning.serviceCycle0GateOnly = value ? 1 : 0;
+    else if (k == "service_opt_gate") {
+        if (value < 0 || value > 2) return fail(FPE_E_INVALID_ARG, "service_opt_gate is 0 (exact gates only), 1 (advisory) or 2 (enforce)");
+        h->tuning.serviceOptGate = value;
+    } else if (k == "service_cycle0_gate_only") h->tuning.serviceOptGate = value ? 0 : 2;  // (older name)
     else return fail(FPE_E_INVALID_ARG, "unknown tuning key: " + k);
     return FPE_OK;
 }
@@ -805,6 +821,8 @@ int fpe_map_info(fpe_handle h, fpe_map_desc* out) {
 // One chained-plan launch on `stream`: the bit-window kernels when the snapshot's bit planes apply, else the direct ones.
 static int launch_plan(fpe_engine* h, const CallPlan& cp, const fpe_pose* d_poses, int32_t B, int32_t n_cycles,
                        const fpe_plan_out& d_out, hipStream_t stream) {
+    if (d_out.selected_packed && (cp.snap->g.rows > FPE_PACKED_MAX_CELLS || cp.snap->g.cols > FPE_PACKED_MAX_CELLS))
+        return fail(FPE_E_UNSUPPORTED, "selected_packed holds 14-bit grid indices: the map has more than 16383 rows or columns");
     if (cp.useBits)
         FPE_HIP(fpe::launch_plan_bits(dev_map(*cp.snap), cp.bits, cp.pc, h->lut(), d_poses, B, n_cycles, d_out, stream));
     else
@@ -846,8 +864,13 @@ int prepare_opt(const fpe_params* params, const fpe_opt_params* opt, const CallP
 // The host-buffer form of the plan and / or the opt track: one device arena, the launches back to back on one
 // stream, the results copied out.  `out` NULL: no plan products are returned (the plan still runs when the opt track
 // needs its cycle flags and the caller gave none).
+struct GateGeom {  // what the service call's host-side (lateral) gate needs from the call's snapshot and constants
+    fpe::MapGeom g;
+    double isosLen, isosWid, drift;
+};
 int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt, const fpe_pose* poses, int32_t B, int32_t n_cycles,
-              const fpe_plan_out* out, const uint8_t* cycleOkIn, const fpe_opt_out* oout) {
+              const fpe_plan_out* out, const uint8_t* cycleOkIn, const fpe_opt_out* oout, GateGeom* gateGeom = nullptr,
+              bool* optDropped = nullptr) {
     if (!poses || (!out && !oout)) return fail(FPE_E_INVALID_ARG, "null argument");
     if (B <= 0 || n_cycles <= 0 || n_cycles > 255) return fail(FPE_E_INVALID_ARG, "B and n_cycles must be in [1, ..] / [1, 255]");
     float maxRadius = 0.0f;
@@ -868,7 +891,7 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
     const bool runPlan = out != nullptr || (oout && !cycleOkIn);
     const bool needOkDev = po.cycle_ok != nullptr || oout != nullptr;  // device copy of the cycle flags
     // one device arena + one pinned arena:
-    // [poses | nominal | centroid | default | cycle_ok | stance | selected | status | opt footholds | opt cycles | gate]
+    // [poses | nominal | centroid | default | cycle_ok | stance | selected | status | packed | opt footholds | opt cycles | gate]
     const size_t nRec = static_cast<size_t>(B) * n_cycles * 4;
     const size_t nCyc = static_cast<size_t>(B) * n_cycles;
     const size_t szPose = align256(static_cast<size_t>(B) * sizeof(fpe_pose));
@@ -879,22 +902,33 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
     const size_t szSt = po.stance ? align256(static_cast<size_t>(B) * 12 * sizeof(double)) : 0;
     const size_t szSel = po.selected ? align256(nRec * sizeof(fpe_selected_foothold)) : 0;
     const size_t szPs = po.pose_status ? align256(static_cast<size_t>(B)) : 0;
+    const size_t szPk = po.selected_packed ? align256(nRec * sizeof(fpe_selected_packed)) : 0;
     const size_t szOf = (oout && oout->footholds) ? align256(nRec * sizeof(fpe_opt_foothold)) : 0;
     const size_t szOc = (oout && oout->cycles) ? align256(nCyc * sizeof(fpe_opt_cycle)) : 0;
     const size_t szOg = (oout && oout->gate_fail_cycle) ? align256(static_cast<size_t>(B)) : 0;
-    const size_t total = szPose + szNom + szCen + szDef + szOk + szSt + szSel + szPs + szOf + szOc + szOg;
+    const size_t szOr = (oout && oout->rows_after) ? align256(static_cast<size_t>(B) * 2 * sizeof(double)) : 0;
+    const size_t total = szPose + szNom + szCen + szDef + szOk + szSt + szSel + szPs + szPk + szOf + szOc + szOg + szOr;
     if (!h) return fail(FPE_E_INVALID_ARG, "null handle or params");
+    CallPlan cp;  // declared before the lease: on an early exit the lease waits for the stream BEFORE the snapshot / bit planes are released
     CtxLease lease(h->ctxPool);
     CallCtx& cx = *lease.ctx;
     FPE_HIP(hipSetDevice(h->device));
     FPE_HIP(cx.reserve(total));
-    CallPlan cp;
+    cx.inFlight = true;  // (prepare_call may already queue a bit-plane build)
     int rc = prepare_call(h, params, maxRadius, cp, cx.stream, runPlan);
     if (rc != FPE_OK) return rc;
+    if (gateGeom) *gateGeom = GateGeom{cp.snap->g, cp.pc.isosLen, cp.pc.isosWid, cp.pc.drift};
     fpe::OptConsts oc;
     if (oout) {
         rc = prepare_opt(params, opt, cp, maxRadius, oc);
-        if (rc != FPE_OK) return rc;
+        // optOptional: the opt track was asked for its gate verdict only (fpe_plan_service* under service_opt_gate 1 / 2) and
+        // is not supported for this geometry: the plan's own products must not fail with it
+        if (rc == FPE_E_UNSUPPORTED && optDropped && runPlan) {
+            *optDropped = true;
+            oout = nullptr;
+        } else if (rc != FPE_OK) {
+            return rc;
+        }
     }
     unsigned char* dp = cx.dev;
     unsigned char* hp = cx.pinned;
@@ -906,9 +940,11 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
     const size_t oSt = off; off += szSt;
     const size_t oSel = off; off += szSel;
     const size_t oPs = off; off += szPs;
+    const size_t oPk = off; off += szPk;
     const size_t oOf = off; off += szOf;
     const size_t oOc = off; off += szOc;
-    const size_t oOg = off;
+    const size_t oOg = off; off += szOg;
+    const size_t oOr = off;
     std::memcpy(hp, poses, static_cast<size_t>(B) * sizeof(fpe_pose));
     if (oout && cycleOkIn) std::memcpy(hp + oOk, cycleOkIn, nCyc);
     // Small calls (the plan_global_footholds service: one pose) skip both DMA copies: the kernels read the
@@ -942,6 +978,7 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
         if (po.stance) d.stance = reinterpret_cast<double*>(dp + oSt);
         if (po.selected) d.selected = reinterpret_cast<fpe_selected_foothold*>(dp + oSel);
         if (po.pose_status) d.pose_status = dp + oPs;
+        if (po.selected_packed) d.selected_packed = reinterpret_cast<fpe_selected_packed*>(dp + oPk);
         // every (pose, cycle, leg) record is written by the kernel (trot: all legs each cycle; walk: each
         // leg in its phase), so the buffers need no clearing
         rc = launch_plan(h, cp, dPoses ? dPoses : reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, d, cx.stream);
@@ -953,6 +990,7 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
         if (oout->footholds) od.footholds = reinterpret_cast<fpe_opt_foothold*>(dp + oOf);
         if (oout->cycles) od.cycles = reinterpret_cast<fpe_opt_cycle*>(dp + oOc);
         if (oout->gate_fail_cycle) od.gate_fail_cycle = dp + oOg;
+        if (oout->rows_after) od.rows_after = reinterpret_cast<double*>(dp + oOr);
         FPE_HIP(fpe::launch_opt_track(dev_map(*cp.snap), cp.pc, oc, dPoses ? dPoses : reinterpret_cast<const fpe_pose*>(dp), B, n_cycles,
                                       dp + oOk, od, cx.stream));
     }
@@ -961,7 +999,7 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
         size_t off, len;
         void* dst;
     };
-    Seg segs[10];
+    Seg segs[13];
     int nSeg = 0;
     auto add = [&](size_t o, size_t len, void* dst) {
         if (dst && len) segs[nSeg++] = Seg{o, len, dst};
@@ -973,11 +1011,14 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
     add(oSt, static_cast<size_t>(B) * 12 * sizeof(double), po.stance);
     add(oSel, nRec * sizeof(fpe_selected_foothold), po.selected);
     add(oPs, static_cast<size_t>(B), po.pose_status);
-    if (szOf) add(oOf, nRec * sizeof(fpe_opt_foothold), oout->footholds);
-    if (szOc) add(oOc, nCyc * sizeof(fpe_opt_cycle), oout->cycles);
-    if (szOg) add(oOg, static_cast<size_t>(B), oout->gate_fail_cycle);
+    add(oPk, nRec * sizeof(fpe_selected_packed), po.selected_packed);
+    if (oout && szOf) add(oOf, nRec * sizeof(fpe_opt_foothold), oout->footholds);
+    if (oout && szOc) add(oOc, nCyc * sizeof(fpe_opt_cycle), oout->cycles);
+    if (oout && szOg) add(oOg, static_cast<size_t>(B), oout->gate_fail_cycle);
+    if (oout && szOr) add(oOr, static_cast<size_t>(B) * 2 * sizeof(double), oout->rows_after);
     if (zeroCopy) {  // the kernels wrote into the pinned arena itself
         FPE_HIP(hipStreamSynchronize(cx.stream));
+        cx.inFlight = false;
         for (int k = 0; k < nSeg; ++k) std::memcpy(segs[k].dst, hp + segs[k].off, segs[k].len);
         return FPE_OK;
     }
@@ -988,7 +1029,7 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
     // FootholdPlanner.plan_outputs(pinned=True) carves them out of ONE fpe_host_alloc block in this order) leave in ONE copy:
     // a DMA transfer has a fixed cost of some ten microseconds, and seven of them in a row are a third of a 4 096-pose call.
     size_t staged = 0;
-    bool pinnedSeg[10];
+    bool pinnedSeg[13];
     for (int k = 0; k < nSeg; ++k) pinnedSeg[k] = is_pinned_host(segs[k].dst);
     for (int k = 0; k < nSeg; ++k) {
         if (!pinnedSeg[k]) {
@@ -1057,8 +1098,9 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
         }
     }
     CopyPool::wait(batch);
-    if (evErr != hipSuccess) return fail_hip(evErr, "result copy");
+    if (evErr != hipSuccess) return fail_hip(evErr, "result copy");  // (the lease waits for the stream)
     FPE_HIP(hipStreamSynchronize(cx.stream));  // the direct (pinned-destination) copies
+    cx.inFlight = false;
     return FPE_OK;
 }
 }  // namespace
@@ -1137,11 +1179,12 @@ int fpe_search_legs(fpe_handle h, const fpe_params* params, const fpe_leg_query*
     if (!h) return fail(FPE_E_INVALID_ARG, "null handle or params");
     const size_t szQ = align256(static_cast<size_t>(n) * sizeof(fpe_leg_query));
     const size_t szO = align256(static_cast<size_t>(n) * sizeof(fpe_foothold));
+    CallPlan cp;  // (before the lease, as in plan_host)
     CtxLease lease(h->ctxPool);
     CallCtx& cx = *lease.ctx;
     FPE_HIP(hipSetDevice(h->device));
     FPE_HIP(cx.reserve(szQ + szO));
-    CallPlan cp;
+    cx.inFlight = true;
     int rc = prepare_call(h, params, maxRadius, cp, cx.stream, false);
     if (rc != FPE_OK) return rc;
     std::memcpy(cx.pinned, queries, static_cast<size_t>(n) * sizeof(fpe_leg_query));
@@ -1150,7 +1193,15 @@ int fpe_search_legs(fpe_handle h, const fpe_params* params, const fpe_leg_query*
                                     reinterpret_cast<fpe_foothold*>(cx.dev + szQ), cx.stream));
     FPE_HIP(hipMemcpyAsync(cx.pinned + szQ, cx.dev + szQ, static_cast<size_t>(n) * sizeof(fpe_foothold), hipMemcpyDeviceToHost, cx.stream));
     FPE_HIP(hipStreamSynchronize(cx.stream));
+    cx.inFlight = false;
     std::memcpy(out, cx.pinned + szQ, static_cast<size_t>(n) * sizeof(fpe_foothold));
+    return FPE_OK;
+}
+
+int fpe_last_service_gate(fpe_handle h, fpe_service_gate* out) {
+    if (!h || !out) return fail(FPE_E_INVALID_ARG, "null argument");
+    if (g_gateEngine != h) return fail(FPE_E_INVALID_ARG, "no fpe_plan_service* call was made with this engine on this thread");
+    *out = g_gate;
     return FPE_OK;
 }
 
@@ -1178,6 +1229,8 @@ int fpe_plan_service_opt(fpe_handle h, const fpe_params* params, const fpe_opt_p
                          double* default_footholds, int32_t* n_default_rows, fpe_track_report* nominal_report,
                          fpe_track_report* centroid_report, fpe_global_footholds* opt_msg, fpe_track_report* opt_report,
                          fpe_opt_cycle* opt_cycles) {
+    g_gate = fpe_service_gate{255, FPE_GATE_NONE, 0, 0, {0, 0, 0, 0}, 0.0, 0.0};
+    g_gateEngine = h;
     if (!initial_position || !response) return fail(FPE_E_INVALID_ARG, "null argument");
     if (default_footholds && !n_default_rows) return fail(FPE_E_INVALID_ARG, "n_default_rows is required with default_footholds");
     fpe_pose pose;
@@ -1214,28 +1267,63 @@ int fpe_plan_service_opt(fpe_handle h, const fpe_params* params, const fpe_opt_p
         out.stance = stance;
         if (centroid || centroid_report) out.centroid = cen.data();
         if (default_footholds) out.default_next = dflt.data();
-        // the opt track's chain next to the plan (same stream, same call): its gate decides the handler's return value in
-        // EVERY cycle (cpp:920-934), its feet centres are part of the centroid path (cpp:946)
+        // The handler's gate (cpp:920-934; include/fpe.h "service-shaped call"): cycle 0 by the plan kernels, the y side of
+        // every cycle here on the host, the x side of cycles >= 1 by the opt track's chain — build-defined, run only when
+        // an opt product is asked for or fpe_set_tuning("service_opt_gate", 1 | 2) wants its verdict.
         fpe_opt_out oout;
         std::memset(&oout, 0, sizeof(oout));
         uint8_t gateFail = 255;
         oout.gate_fail_cycle = &gateFail;
         oout.footholds = optf.data();
         oout.cycles = opt_cycles;
-        // fpe_set_tuning("service_cycle0_gate_only", 1): a latency-critical caller that asks for none of the opt products
-        // may skip the opt track's chain; the handler's return value is then exact for the first cycle only (round-2 behaviour)
-        bool skipOpt = false;
-        if (h && !opt_msg && !opt_report && !opt_cycles && !centroid_report) {
+        double rowsAfter[2] = {0.0, 0.0};
+        oout.rows_after = rowsAfter;
+        int optGate = 0;
+        if (h) {
             std::lock_guard<std::mutex> lk(h->mu);
-            skipOpt = h->tuning.serviceCycle0GateOnly != 0;
+            optGate = h->tuning.serviceOptGate;
         }
+        const bool wantOptProduct = opt_msg || opt_report || opt_cycles || centroid_report;
+        const bool runChain = wantOptProduct || optGate != 0;
         uint8_t poseStatus = 0;
-        if (skipOpt) out.pose_status = &poseStatus;
-        int rc = plan_host(h, params, opt, &pose, 1, N, &out, nullptr, skipOpt ? nullptr : &oout);
+        out.pose_status = &poseStatus;
+        GateGeom gg;
+        bool optDropped = false;
+        int rc = plan_host(h, params, opt, &pose, 1, N, &out, nullptr, runChain ? &oout : nullptr, &gg, wantOptProduct ? nullptr : &optDropped);
         if (rc != FPE_OK) return rc;
-        if (skipOpt && (poseStatus & FPE_POSE_OPT_SUBMAP_FAILED)) gateFail = 0;
-        if (gateFail != 255) {
-            // getGaitCycleSearchGridMap fails in cycle gateFail: the reference's handler logs "Failed to get gait-cycle
+        // exact verdicts: the first cycle (stance feet), then the lateral side of every cycle
+        int lateral = 255;
+        {
+            double adjY = 0.0;  // ajustedPose_[1], cpp:759
+            for (int c = 0; c < N; ++c) {
+                const double py = pose.position[1] + adjY;  // cpp:2329
+                // (x at the map's centre: the x side of getSubmap passes there, what is left is the y side)
+                const bool okY = std::fabs(py) <= 1e6 && std::fabs(gg.g.posX) <= 1e6 && fpe::submap_info(gg.g, gg.g.posX, py, gg.isosLen, gg.isosWid).ok;
+                if (!okY) {
+                    lateral = c;
+                    break;
+                }
+                adjY += gg.drift;  // cpp:1578
+            }
+        }
+        const bool chainRan = runChain && !optDropped;
+        fpe_service_gate gate = g_gate;  // (reset at entry)
+        gate.chain_ran = chainRan ? 1 : 0;
+        gate.lf_current_row = chainRan ? rowsAfter[0] : 0.0;
+        gate.rh_current_row = chainRan ? rowsAfter[1] : 0.0;
+        auto verdict = [&](int cycle, int kind) {
+            gate.fail_cycle = static_cast<uint8_t>(cycle);
+            gate.fail_kind = static_cast<uint8_t>(kind);
+        };
+        if (poseStatus & FPE_POSE_OPT_SUBMAP_FAILED) verdict(0, FPE_GATE_CYCLE0);
+        else if (lateral != 255) verdict(lateral, FPE_GATE_LATERAL);  // (exact kinds first: the reference refuses in cycle `lateral` at the latest)
+        else if (chainRan && gateFail != 255) verdict(gateFail, gateFail == 0 ? FPE_GATE_CYCLE0 : FPE_GATE_BUILD_DEFINED);
+        const bool refuse = gate.fail_kind == FPE_GATE_CYCLE0 || gate.fail_kind == FPE_GATE_LATERAL ||
+                            (gate.fail_kind == FPE_GATE_BUILD_DEFINED && optGate == 2);
+        gate.returned_false = refuse ? 1 : 0;
+        g_gate = gate;
+        if (refuse) {
+            // getGaitCycleSearchGridMap fails in cycle gate.fail_cycle: the reference's handler logs "Failed to get gait-cycle
             // search gridmap." and returns false (cpp:931-934); the ROS response is never assigned (cpp:1588 is not reached)
             std::memset(response, 0, sizeof(*response));
             if (centroid) std::memset(centroid, 0, sizeof(*centroid));
@@ -1244,8 +1332,9 @@ int fpe_plan_service_opt(fpe_handle h, const fpe_params* params, const fpe_opt_p
             if (centroid_report) std::memset(centroid_report, 0, sizeof(*centroid_report));
             if (opt_msg) std::memset(opt_msg, 0, sizeof(*opt_msg));
             if (opt_report) std::memset(opt_report, 0, sizeof(*opt_report));
-            return fail(FPE_E_SERVICE_FALSE, "getGaitCycleSearchGridMap: getSubmap failed in gait cycle " + std::to_string(static_cast<int>(gateFail)) +
-                                                 " (cpp:931-934)");
+            static const char* const kinds[] = {"", "first gait cycle", "lateral side", "x side, build-defined optimiser"};
+            return fail(FPE_E_SERVICE_FALSE, "getGaitCycleSearchGridMap: getSubmap failed in gait cycle " + std::to_string(static_cast<int>(gate.fail_cycle)) +
+                                                 " (" + kinds[gate.fail_kind] + "; cpp:931-934)");
         }
     }
     fpe::assemble_global_footholds(nominal.data(), ok.data(), stance, N, response);

@@ -1355,6 +1355,27 @@ __device__ __forceinline__ void store_foothold(fpe_foothold* dst, const NominalO
     store_record<kStream>(dst, f);
 }
 
+// The two exchange forms of a nominal foothold (include/fpe.h): the 16-byte fpe_selected_foothold and the 8-byte
+// fpe_selected_packed (row / col in 14 bits each, -1 as 0x3FFF, valid and source above them).
+template <bool kStream>
+__device__ __forceinline__ void store_selected(const fpe_plan_out& out, size_t o, int row, int col, float z, int valid, int source, int leg,
+                                               int cyc) {
+    if (out.selected) {
+        fpe_selected_foothold sf;
+        sf.row = row; sf.col = col; sf.z = z;
+        sf.valid = static_cast<uint8_t>(valid); sf.source = static_cast<uint8_t>(source);
+        sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
+        store_record<kStream>(out.selected + o, sf);
+    }
+    if (out.selected_packed) {
+        fpe_selected_packed sp;
+        sp.cell = (static_cast<uint32_t>(row) & 0x3FFFu) | ((static_cast<uint32_t>(col) & 0x3FFFu) << 14) |
+                  ((static_cast<uint32_t>(valid) & 1u) << 28) | ((static_cast<uint32_t>(source) & 3u) << 29);
+        sp.z = z;
+        store_record<kStream>(out.selected_packed + o, sp);
+    }
+}
+
 // getPolygonCenter (cpp:2421-2463): feet[leg][xyz] in LDS.  Only the centre's x is computed: the next
 // centre takes y from initialPose_/ajustedPose_ (cpp:2201, 2272) and getDefaultFootholdNext zeroes z
 // (cpp:2411-2418), so the y and z of the centre never reach a result (two f64 divisions saved per track).
@@ -1564,13 +1585,7 @@ __device__ __forceinline__ void leg_phase(const DevMap& m, const PlanConsts& pc,
             if (live) {
                 const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
                 if (out.nominal) store_foothold(out.nominal + o, no, leg, cyc);
-                if (out.selected) {
-                    fpe_selected_foothold sf;
-                    sf.row = no.row; sf.col = no.col; sf.z = no.z;
-                    sf.valid = static_cast<uint8_t>(no.valid); sf.source = static_cast<uint8_t>(no.source);
-                    sf.foot_id = static_cast<uint8_t>(leg); sf.gait_cycle_id = static_cast<uint8_t>(cyc);
-                    store_record<false>(out.selected + o, sf);
-                }
+                store_selected<false>(out, o, no.row, no.col, no.z, no.valid, no.source, leg, cyc);
                 if (out.centroid) {
                     fpe_centroid_foothold cf;
                     cf.x = co.x; cf.y = co.y; cf.z = co.z; cf.row = co.row; cf.col = co.col;

@@ -1,14 +1,28 @@
 // fpe_multi.cpp — several GPUs behind the C ABI (include/fpe.h, "multi-device" section).
 //
 // north_star: "Host code stays C++/ROS calling the kernels through a thin C-ABI shim; a batch of candidate body
-// trajectories is the parallel axis and shards across the 8 GPUs of one node".  A C++ host (the ROS node) that owns
-// ALL the GPUs of a node in ONE process uses this group handle: one engine per device, the map replicated on every
-// device, the pose batch split into contiguous blocks (the same rule as quadrupedal_foothold_planner_amd/dist.py:
-// the first B % n shards get one pose more), one host thread per device, results written straight into the caller's
-// arrays at their global positions — with host buffers the "all-gather" is the shards' D2H copies landing side by
-// side.  (One process PER GPU with RCCL is the other deployment: torch.distributed + fpe_plan_device, bench.py.)
+// trajectories is the parallel axis and shards across the 8 GPUs of one node with an RCCL all-gather of selected
+// footholds over xGMI".  A C++ host (the ROS node) that owns ALL the GPUs of a node in ONE process uses this group
+// handle: one engine per device, the map replicated on every device, the pose batch split into contiguous blocks (the
+// same rule as quadrupedal_foothold_planner_amd/dist.py: the first B % n shards get one pose more).  Two forms:
+//   * fpe_multi_plan — host buffers: one RESIDENT worker thread per device (condition-variable hand-off: a 29 us plan
+//     must not pay for a thread start per call), results written straight into the caller's arrays at their global
+//     positions — the "all-gather" is the shards' D2H copies landing side by side;
+//   * fpe_multi_plan_device — device-resident shards: every device plans its block on its own stream and the selected
+//     records of ALL blocks reach EVERY device by one RCCL collective (ncclAllGather, or grouped ncclBroadcasts when
+//     the blocks are uneven) inside ncclGroupStart / ncclGroupEnd on those same streams — the xGMI all-gather of
+//     north_star without Python.  RCCL is bound at run time (dlopen "librccl.so.1": the ROCm one, or the copy a hosting
+//     process such as PyTorch has already loaded); a process that never gathers never loads it.
+// (One process PER GPU with torch.distributed is the other deployment: fpe_plan_device + dist.py, bench.py.)
 // Built on the single-device entry points only; no kernel code here.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -17,11 +31,132 @@
 
 #include "../../include/fpe.h"
 
+namespace {
+
+// The few RCCL entry points the gather needs, resolved once per process.
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+    bool ok = false;
+};
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) {
+            r.err = std::string("librccl.so.1 not loadable: ") + dlerror();
+            return;
+        }
+        bool all = true;
+        auto sym = [&](const char* name) {
+            void* p = dlsym(r.lib, name);
+            if (!p) {
+                all = false;
+                r.err = std::string("RCCL symbol missing: ") + name;
+            }
+            return p;
+        };
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.ok = all;
+    });
+    return r;
+}
+
+// One resident host thread of a device: runs the job it is handed, reports status and the engine's (thread-local)
+// error text, sleeps on its condition variable in between.
+class Worker {
+  public:
+    Worker() : th_([this] { run(); }) {}
+    ~Worker() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    void post(std::function<int()> job, fpe_handle engine) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = std::move(job);
+            engine_ = engine;
+            has_ = true;
+            done_ = false;
+        }
+        cv_.notify_all();
+    }
+    int wait(std::string* msg) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return done_; });
+        if (rc_ != FPE_OK) *msg = msg_;
+        return rc_;
+    }
+
+  private:
+    void run() {
+        for (;;) {
+            std::function<int()> job;
+            fpe_handle engine;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || has_; });
+                if (stop_ && !has_) return;
+                job = std::move(job_);
+                engine = engine_;
+                has_ = false;
+            }
+            const int rc = job();
+            std::string msg;
+            if (rc != FPE_OK) msg = fpe_last_error(engine);  // thread-local text of THIS worker
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                rc_ = rc;
+                msg_ = std::move(msg);
+                done_ = true;
+            }
+            cv_.notify_all();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::function<int()> job_;
+    fpe_handle engine_ = nullptr;
+    bool has_ = false, done_ = true, stop_ = false;
+    int rc_ = FPE_OK;
+    std::string msg_;
+    std::thread th_;  // last member: the thread starts with everything above constructed
+};
+
+}  // namespace
+
 struct fpe_multi {
     std::vector<fpe_handle> engines;
     std::vector<int> devices;
+    std::vector<std::unique_ptr<Worker>> workers;  // [k - 1] for device k >= 1 (device 0 runs on the calling thread)
+    std::mutex callMu;                             // one fan-out at a time (the workers hold one job each)
     std::mutex mu;
     std::string err;
+    // device-resident form: the group's own stream per device and the RCCL communicators (created by the first gather)
+    std::vector<hipStream_t> streams;
+    std::vector<ncclComm_t> comms;
 };
 
 namespace {
@@ -44,23 +179,47 @@ void shard_range(long total, int rank, int world, long* lo, long* hi) {
     *hi = *lo + base + (rank < rem ? 1 : 0);
 }
 
-// Run fn(k) for k = 0..n-1 on one thread each; returns the first non-OK status and its message.
+// Run fn(k) for k = 0..n-1, device k >= 1 on its resident worker, device 0 on the calling thread; returns the first
+// non-OK status and its message.
 template <class F>
 int for_each_device(fpe_multi* h, F fn) {
+    std::lock_guard<std::mutex> call(h->callMu);
     const int n = static_cast<int>(h->engines.size());
-    std::vector<int> rc(n, FPE_OK);
-    std::vector<std::string> msg(n);
-    std::vector<std::thread> th;
-    for (int k = 1; k < n; ++k)
-        th.emplace_back([&, k]() {
-            rc[k] = fn(k);
-            if (rc[k] != FPE_OK) msg[k] = fpe_last_error(h->engines[k]);  // thread-local text of THIS worker
-        });
+    for (int k = 1; k < n; ++k) h->workers[static_cast<size_t>(k - 1)]->post([&fn, k]() { return fn(k); }, h->engines[static_cast<size_t>(k)]);
+    std::vector<int> rc(static_cast<size_t>(n), FPE_OK);
+    std::vector<std::string> msg(static_cast<size_t>(n));
     rc[0] = fn(0);
     if (rc[0] != FPE_OK) msg[0] = fpe_last_error(h->engines[0]);
-    for (auto& t : th) t.join();
+    for (int k = 1; k < n; ++k) rc[static_cast<size_t>(k)] = h->workers[static_cast<size_t>(k - 1)]->wait(&msg[static_cast<size_t>(k)]);
     for (int k = 0; k < n; ++k)
-        if (rc[k] != FPE_OK) return mfail(h, rc[k], "device " + std::to_string(h->devices[k]) + ": " + msg[k]);
+        if (rc[static_cast<size_t>(k)] != FPE_OK)
+            return mfail(h, rc[static_cast<size_t>(k)], "device " + std::to_string(h->devices[static_cast<size_t>(k)]) + ": " + msg[static_cast<size_t>(k)]);
+    return FPE_OK;
+}
+
+int ensure_streams(fpe_multi* h) {
+    if (!h->streams.empty()) return FPE_OK;
+    std::vector<hipStream_t> st(h->engines.size(), nullptr);
+    for (size_t k = 0; k < st.size(); ++k) {
+        hipError_t e = hipSetDevice(h->devices[k]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            for (size_t q = 0; q < k; ++q) (void)hipStreamDestroy(st[q]);
+            return mfail(h, FPE_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        }
+    }
+    h->streams = std::move(st);
+    return FPE_OK;
+}
+
+int ensure_comms(fpe_multi* h) {
+    if (!h->comms.empty()) return FPE_OK;
+    Rccl& r = rccl();
+    if (!r.ok) return mfail(h, FPE_E_UNSUPPORTED, "RCCL unavailable: " + r.err);
+    std::vector<ncclComm_t> comms(h->engines.size(), nullptr);
+    const ncclResult_t rc = r.CommInitAll(comms.data(), static_cast<int>(comms.size()), h->devices.data());
+    if (rc != ncclSuccess) return mfail(h, FPE_E_HIP, std::string("ncclCommInitAll: ") + r.GetErrorString(rc));
+    h->comms = std::move(comms);
     return FPE_OK;
 }
 
@@ -72,6 +231,9 @@ int fpe_multi_create(const int32_t* device_ids, int32_t n_devices, fpe_multi_han
     if (!out) return mfail(nullptr, FPE_E_INVALID_ARG, "null out handle");
     *out = nullptr;
     if (!device_ids || n_devices <= 0 || n_devices > 64) return mfail(nullptr, FPE_E_INVALID_ARG, "bad device list");
+    for (int a = 0; a < n_devices; ++a)
+        for (int b = a + 1; b < n_devices; ++b)
+            if (device_ids[a] == device_ids[b]) return mfail(nullptr, FPE_E_INVALID_ARG, "a device appears twice in the list");
     fpe_multi* h = new (std::nothrow) fpe_multi();
     if (!h) return mfail(nullptr, FPE_E_NOMEM, "out of host memory");
     for (int k = 0; k < n_devices; ++k) {
@@ -86,12 +248,27 @@ int fpe_multi_create(const int32_t* device_ids, int32_t n_devices, fpe_multi_han
         h->engines.push_back(e);
         h->devices.push_back(device_ids[k]);
     }
+    for (int k = 1; k < n_devices; ++k) h->workers.emplace_back(new Worker());
     *out = h;
     return FPE_OK;
 }
 
 int fpe_multi_destroy(fpe_multi_handle h) {
     if (!h) return FPE_OK;
+    h->workers.clear();  // joins the resident threads
+    for (size_t k = 0; k < h->streams.size(); ++k) {
+        (void)hipSetDevice(h->devices[k]);
+        (void)hipStreamSynchronize(h->streams[k]);
+    }
+    if (!h->comms.empty()) {
+        Rccl& r = rccl();
+        for (ncclComm_t c : h->comms)
+            if (c) (void)r.CommDestroy(c);
+    }
+    for (size_t k = 0; k < h->streams.size(); ++k) {
+        (void)hipSetDevice(h->devices[k]);
+        (void)hipStreamDestroy(h->streams[k]);
+    }
     for (fpe_handle e : h->engines) fpe_destroy(e);
     delete h;
     return FPE_OK;
@@ -101,7 +278,7 @@ int fpe_multi_device_count(fpe_multi_handle h) { return h ? static_cast<int>(h->
 
 fpe_handle fpe_multi_engine(fpe_multi_handle h, int32_t k) {
     if (!h || k < 0 || k >= static_cast<int>(h->engines.size())) return nullptr;
-    return h->engines[k];
+    return h->engines[static_cast<size_t>(k)];
 }
 
 const char* fpe_multi_last_error(fpe_multi_handle h) {
@@ -113,7 +290,7 @@ const char* fpe_multi_last_error(fpe_multi_handle h) {
 
 int fpe_multi_upload_map(fpe_multi_handle h, const fpe_map_desc* desc, const float* traversability, const float* elevation) {
     if (!h) return mfail(nullptr, FPE_E_INVALID_ARG, "null handle");
-    return for_each_device(h, [&](int k) { return fpe_upload_map(h->engines[k], desc, traversability, elevation); });
+    return for_each_device(h, [&](int k) { return fpe_upload_map(h->engines[static_cast<size_t>(k)], desc, traversability, elevation); });
 }
 
 int fpe_multi_set_tuning(fpe_multi_handle h, const char* key, int32_t value) {
@@ -122,6 +299,15 @@ int fpe_multi_set_tuning(fpe_multi_handle h, const char* key, int32_t value) {
         const int rc = fpe_set_tuning(e, key, value);
         if (rc != FPE_OK) return mfail(h, rc, fpe_last_error(e));
     }
+    return FPE_OK;
+}
+
+int fpe_multi_shard_range(int32_t B, int32_t k, int32_t n_devices, int32_t* first, int32_t* count) {
+    if (B < 0 || n_devices <= 0 || k < 0 || k >= n_devices || !first || !count) return FPE_E_INVALID_ARG;
+    long lo, hi;
+    shard_range(B, k, n_devices, &lo, &hi);
+    *first = static_cast<int32_t>(lo);
+    *count = static_cast<int32_t>(hi - lo);
     return FPE_OK;
 }
 
@@ -144,8 +330,91 @@ int fpe_multi_plan(fpe_multi_handle h, const fpe_params* params, const fpe_pose*
         if (out->stance) o.stance = out->stance + static_cast<size_t>(lo) * 12;
         if (out->selected) o.selected = out->selected + rec;
         if (out->pose_status) o.pose_status = out->pose_status + lo;
-        return fpe_plan(h->engines[k], params, poses + lo, static_cast<int32_t>(hi - lo), n_cycles, &o);
+        if (out->selected_packed) o.selected_packed = out->selected_packed + rec;
+        return fpe_plan(h->engines[static_cast<size_t>(k)], params, poses + lo, static_cast<int32_t>(hi - lo), n_cycles, &o);
     });
+}
+
+int fpe_multi_plan_device(fpe_multi_handle h, const fpe_params* params, const fpe_multi_device_io* io, int32_t B, int32_t n_cycles,
+                          int32_t record_kind) {
+    if (!h || !params || !io) return mfail(h, FPE_E_INVALID_ARG, "null argument");
+    if (B <= 0 || n_cycles <= 0 || n_cycles > 255) return mfail(h, FPE_E_INVALID_ARG, "B and n_cycles must be in [1, ..] / [1, 255]");
+    if (record_kind != FPE_EXCHANGE_NONE && record_kind != FPE_EXCHANGE_SELECTED && record_kind != FPE_EXCHANGE_PACKED)
+        return mfail(h, FPE_E_INVALID_ARG, "unknown exchange record kind");
+    const int n = static_cast<int>(h->engines.size());
+    if (B < n) return mfail(h, FPE_E_INVALID_ARG, "fewer poses than devices");
+    std::lock_guard<std::mutex> call(h->callMu);
+    int rc = ensure_streams(h);
+    if (rc != FPE_OK) return rc;
+    const bool gather = record_kind != FPE_EXCHANGE_NONE;
+    const size_t recBytes = record_kind == FPE_EXCHANGE_PACKED ? sizeof(fpe_selected_packed) : sizeof(fpe_selected_foothold);
+    for (int k = 0; k < n; ++k) {
+        const fpe_multi_device_io& d = io[k];
+        if (!d.d_poses) return mfail(h, FPE_E_INVALID_ARG, "device " + std::to_string(h->devices[static_cast<size_t>(k)]) + ": null poses");
+        if (gather) {
+            const void* src = record_kind == FPE_EXCHANGE_PACKED ? static_cast<const void*>(d.d_out.selected_packed) : static_cast<const void*>(d.d_out.selected);
+            if (!src || !d.d_gathered) return mfail(h, FPE_E_INVALID_ARG, "the exchange needs the record product and d_gathered on every device");
+        }
+    }
+    if (gather) {
+        rc = ensure_comms(h);
+        if (rc != FPE_OK) return rc;
+    }
+    // every device plans its block, asynchronously on its stream
+    for (int k = 0; k < n; ++k) {
+        long lo, hi;
+        shard_range(B, k, n, &lo, &hi);
+        hipStream_t st = io[k].stream ? static_cast<hipStream_t>(io[k].stream) : h->streams[static_cast<size_t>(k)];
+        rc = fpe_plan_device(h->engines[static_cast<size_t>(k)], params, io[k].d_poses, static_cast<int32_t>(hi - lo), n_cycles, &io[k].d_out, st);
+        if (rc != FPE_OK)
+            return mfail(h, rc, "device " + std::to_string(h->devices[static_cast<size_t>(k)]) + ": " + fpe_last_error(h->engines[static_cast<size_t>(k)]));
+    }
+    if (!gather) return FPE_OK;
+    // ... and the blocks' records reach every device: ONE fused group of collectives on the plans' own streams (stream
+    // order makes each device's contribution wait for its plan kernel; nothing synchronises the host)
+    Rccl& r = rccl();
+    const bool even = (B % n) == 0;
+    const size_t poseBytes = static_cast<size_t>(n_cycles) * 4 * recBytes;
+    ncclResult_t nrc = r.GroupStart();
+    for (int k = 0; k < n && nrc == ncclSuccess; ++k) {
+        hipStream_t st = io[k].stream ? static_cast<hipStream_t>(io[k].stream) : h->streams[static_cast<size_t>(k)];
+        const void* src = record_kind == FPE_EXCHANGE_PACKED ? static_cast<const void*>(io[k].d_out.selected_packed) : static_cast<const void*>(io[k].d_out.selected);
+        if (even) {
+            nrc = r.AllGather(src, io[k].d_gathered, static_cast<size_t>(B / n) * poseBytes, ncclChar, h->comms[static_cast<size_t>(k)], st);
+        } else {
+            // uneven blocks: block q travels as a broadcast from its owner into its place of the whole batch
+            for (int q = 0; q < n && nrc == ncclSuccess; ++q) {
+                long lo, hi;
+                shard_range(B, q, n, &lo, &hi);
+                const void* qsrc = record_kind == FPE_EXCHANGE_PACKED ? static_cast<const void*>(io[q].d_out.selected_packed) : static_cast<const void*>(io[q].d_out.selected);
+                unsigned char* dst = static_cast<unsigned char*>(io[k].d_gathered) + static_cast<size_t>(lo) * poseBytes;
+                nrc = r.Broadcast(k == q ? qsrc : static_cast<const void*>(dst), dst, static_cast<size_t>(hi - lo) * poseBytes, ncclChar, q,
+                                  h->comms[static_cast<size_t>(k)], st);  // (the send buffer only counts on the root)
+            }
+        }
+    }
+    const ncclResult_t erc = r.GroupEnd();
+    if (nrc == ncclSuccess) nrc = erc;
+    if (nrc != ncclSuccess) return mfail(h, FPE_E_HIP, std::string("RCCL all-gather: ") + r.GetErrorString(nrc));
+    return FPE_OK;
+}
+
+int fpe_multi_synchronize(fpe_multi_handle h) {
+    if (!h) return mfail(nullptr, FPE_E_INVALID_ARG, "null handle");
+    std::lock_guard<std::mutex> call(h->callMu);
+    for (size_t k = 0; k < h->streams.size(); ++k) {
+        hipError_t e = hipSetDevice(h->devices[k]);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->streams[k]);
+        if (e != hipSuccess) return mfail(h, FPE_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    }
+    return FPE_OK;
+}
+
+void* fpe_multi_stream(fpe_multi_handle h, int32_t k) {
+    if (!h || k < 0 || k >= static_cast<int>(h->engines.size())) return nullptr;
+    std::lock_guard<std::mutex> call(h->callMu);
+    if (ensure_streams(h) != FPE_OK) return nullptr;
+    return h->streams[static_cast<size_t>(k)];
 }
 
 }  // extern "C"

@@ -596,6 +596,10 @@ __global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts 
         if (g.sub == 0 && out.footholds) out.footholds[oCyc * 4 + leg] = fh;
     }
     if (lane == 0 && out.gate_fail_cycle) out.gate_fail_cycle[b] = static_cast<uint8_t>(failCycle);
+    if (lane == 0 && out.rows_after) {  // lfCurrentRow / rhCurrentRow as this call leaves them (cpp:1561-1568)
+        out.rows_after[2 * static_cast<size_t>(b)] = lfRow;
+        out.rows_after[2 * static_cast<size_t>(b) + 1] = rhRow;
+    }
 }
 
 hipError_t launch_opt_track(const DevMap& m, const PlanConsts& pc, const OptConsts& oc, const fpe_pose* d_poses, int B, int nCycles,

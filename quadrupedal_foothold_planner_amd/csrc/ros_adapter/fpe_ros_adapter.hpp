@@ -123,7 +123,7 @@ public:
         std::vector<fpe_opt_cycle> cycles(std::max<size_t>(gaitCycles, 1));
         if (fpe_plan_service_opt(h_, &params, &optParams, initialPose, gaitCycles, resp.get(), nullptr, nullptr, nullptr, nullptr, nullptr,
                                  opt.get(), repOpt.get(), cycles.data()) != FPE_OK)
-            return false;  // FPE_E_SERVICE_FALSE: getGaitCycleSearchGridMap failed in some cycle (cpp:931-934)
+            return false;  // FPE_E_SERVICE_FALSE: getGaitCycleSearchGridMap failed (cpp:931-934; kinds: fpe_service_gate)
         fill(*resp, msg, true);
         const uint8_t keepGaitCycles = optMsg.gait_cycles;  // never written by the reference (cpp:743)
         fill(*opt, optMsg, false);
@@ -131,12 +131,14 @@ public:
         const fpe_track_report& rep = *repOpt;
         cogSpeedOpt.assign(rep.cog_speed, rep.cog_speed + rep.n_kpi);
         feetDistanceOpt.assign(rep.feet_distance, rep.feet_distance + rep.n_kpi);
-        // cpp:1561-1568: the rows of the last COMMITTED cycle's LF / RH feet on that cycle's gait-cycle submap
-        for (int g = 0; g < gaitCycles; ++g)
-            if (cycles[static_cast<size_t>(g)].committed) {
-                lfRhCurrentRow[0] = cycles[static_cast<size_t>(g)].x[0];
-                lfRhCurrentRow[1] = cycles[static_cast<size_t>(g)].x[2];
-            }
+        // cpp:1561-1568: lfCurrentRow / rhCurrentRow as the engine's chain left them — gaitMap_.getIndex of the committed LF /
+        // RH POSITIONS (not the optimiser's x: the two differ when getPosition failed for a leg and the previous Position was
+        // kept, cpp:1284-1312), unchanged by cycles that did not commit
+        fpe_service_gate gate;
+        if (fpe_last_service_gate(h_, &gate) == FPE_OK && gate.chain_ran) {
+            lfRhCurrentRow[0] = gate.lf_current_row;
+            lfRhCurrentRow[1] = gate.rh_current_row;
+        }
         return true;
     }
 

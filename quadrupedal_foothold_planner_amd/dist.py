@@ -137,16 +137,20 @@ class BatchedFootholdExchange:
         ex.drain()
     """
 
-    def __init__(self, local_bytes, device, batch=8, depth=2):
+    def __init__(self, local_bytes, device, batch=8, depth=2, force_collective=False):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        # force_collective: run the all-gather even in a process group of ONE rank (functional check of the RCCL path —
+        # init, the collective on device records, the work-handle waits — on a single-GPU box)
+        self.collective = self.world > 1 or (bool(force_collective) and dist.is_initialized())
         self.batch = max(1, int(batch))
         self.depth = depth
         self.local_bytes = int(local_bytes)
         n = self.local_bytes * self.batch
         self.stage = [torch.zeros(n, dtype=torch.uint8, device=device) for _ in range(depth)]
-        self.out = [torch.empty(n * self.world, dtype=torch.uint8, device=device) if self.world > 1 else None for _ in range(depth)]
+        self.out = [torch.empty(n * self.world, dtype=torch.uint8, device=device) if self.collective else None for _ in range(depth)]
         self.work = [None] * depth
         self.launched = [-1] * depth  # last step whose batch was gathered from this buffer
+        self.collectives = 0          # all-gathers launched so far
 
     def _slot(self, k):
         return (k // self.batch) % self.depth
@@ -179,15 +183,21 @@ class BatchedFootholdExchange:
     def _launch(self, k):
         slot = self._slot(k)
         self.launched[slot] = k
-        if self.world > 1:
+        if self.collective:
             self.work[slot] = dist.all_gather_into_tensor(self.out[slot], self.stage[slot], async_op=True)
+            self.collectives += 1
 
     def result(self, k):
         """Records of step k from every rank, rank order (waits for that batch's all-gather)."""
         slot = self._slot(k)
         lb = self.local_bytes
         sub = k % self.batch
-        if self.world == 1:
+        # the batch of step k must be the one this buffer was last gathered for: not yet gathered (no flush), or already
+        # overwritten by a later batch (depth buffers are cycled), would silently hand out stale or foreign records
+        if self.launched[slot] < k or self.launched[slot] // self.batch != k // self.batch:
+            raise RuntimeError(f"result({k}): the batch of step {k} is not the one held by its buffer (last gathered step: "
+                               f"{self.launched[slot]}; call gather()/flush() first, and read a batch before {self.depth} later ones start)")
+        if not self.collective:
             return self.stage[slot][sub * lb:(sub + 1) * lb]
         self._wait(slot)
         n = lb * self.batch

@@ -13,8 +13,22 @@ import numpy as np
 
 from . import _capi
 from ._capi import (CENTROID_DTYPE, FOOTHOLD_DTYPE, GLOBAL_FOOTHOLDS_DTYPE, OPT_CYCLE_DTYPE, OPT_FOOTHOLD_DTYPE, OPT_PARAMS_DTYPE,
-                    POSE_DTYPE, PARAMS_DTYPE, QUERY_DTYPE, SELECTED_DTYPE, TRACK_REPORT_DTYPE, EngineUnavailable, MapDesc, OptOut,
-                    PlanOut, ptr)
+                    PACKED_DTYPE, POSE_DTYPE, PARAMS_DTYPE, QUERY_DTYPE, SELECTED_DTYPE, TRACK_REPORT_DTYPE, EngineUnavailable, MapDesc,
+                    OptOut, PlanOut, ptr)
+
+# products of a chained plan in the order of fpe_plan_out's fields (= the order of the engine's device arena)
+PRODUCT_ORDER = ("nominal", "centroid", "default", "cycle_ok", "stance", "selected", "pose_status", "selected_packed")
+PRODUCT_FIELDS = {"nominal": "nominal", "centroid": "centroid", "default": "default_next", "cycle_ok": "cycle_ok", "stance": "stance",
+                  "selected": "selected", "pose_status": "pose_status", "selected_packed": "selected_packed"}
+
+
+def product_shapes(B, n_cycles):
+    return {
+        "nominal": ((B, n_cycles, 4), FOOTHOLD_DTYPE), "centroid": ((B, n_cycles, 4), CENTROID_DTYPE),
+        "default": ((B, n_cycles, 4, 3), np.float64), "cycle_ok": ((B, n_cycles), np.uint8),
+        "stance": ((B, 4, 3), np.float64), "selected": ((B, n_cycles, 4), SELECTED_DTYPE), "pose_status": ((B,), np.uint8),
+        "selected_packed": ((B, n_cycles, 4), PACKED_DTYPE),
+    }
 
 
 class FpeError(RuntimeError):
@@ -144,7 +158,7 @@ class FootholdPlanner:
         return buf.value.decode()
 
     def set_tuning(self, **kw):
-        """fpe_set_tuning: plan_group, literal_discs, no_mid_variant, no_bits (build-defined test / tuning knobs)."""
+        """fpe_set_tuning: plan_group, literal_discs, no_mid_variant, no_bits, service_opt_gate (build-defined test / tuning knobs)."""
         for k, v in kw.items():
             self._check(self._lib.fpe_set_tuning(self._h, k.encode(), int(v)))
             self._tuning[k] = int(v)
@@ -177,16 +191,12 @@ class FootholdPlanner:
 
     def plan_outputs(self, B, n_cycles, products=("nominal", "centroid", "default", "cycle_ok", "stance", "selected", "pose_status"),
                      pinned=False):
-        shapes = {
-            "nominal": ((B, n_cycles, 4), FOOTHOLD_DTYPE), "centroid": ((B, n_cycles, 4), CENTROID_DTYPE),
-            "default": ((B, n_cycles, 4, 3), np.float64), "cycle_ok": ((B, n_cycles), np.uint8),
-            "stance": ((B, 4, 3), np.float64), "selected": ((B, n_cycles, 4), SELECTED_DTYPE), "pose_status": ((B,), np.uint8),
-        }
+        shapes = product_shapes(B, n_cycles)
         if not pinned:
             return {k: np.zeros(shapes[k][0], dtype=shapes[k][1]) for k in products}
         # ONE pinned block, the products behind one another in the order of the engine's device arena (each rounded up to
         # 256 bytes as there): fpe_plan then moves neighbours without padding in between in one DMA transfer
-        order = [k for k in ("nominal", "centroid", "default", "cycle_ok", "stance", "selected", "pose_status") if k in products]
+        order = [k for k in PRODUCT_ORDER if k in products]
         sizes = [int(np.prod(shapes[k][0])) * np.dtype(shapes[k][1]).itemsize for k in order]
         offs, total = [], 0
         for n in sizes:
@@ -202,13 +212,8 @@ class FootholdPlanner:
         reuse the arrays instead of allocating ~100 B per foothold per call)."""
         poses = np.ascontiguousarray(poses, dtype=POSE_DTYPE)
         B = poses.shape[0]
-        shapes = {
-            "nominal": ((B, n_cycles, 4), FOOTHOLD_DTYPE), "centroid": ((B, n_cycles, 4), CENTROID_DTYPE),
-            "default": ((B, n_cycles, 4, 3), np.float64), "cycle_ok": ((B, n_cycles), np.uint8),
-            "stance": ((B, 4, 3), np.float64), "selected": ((B, n_cycles, 4), SELECTED_DTYPE), "pose_status": ((B,), np.uint8),
-        }
-        fields = {"nominal": "nominal", "centroid": "centroid", "default": "default_next", "cycle_ok": "cycle_ok",
-                  "stance": "stance", "selected": "selected", "pose_status": "pose_status"}
+        shapes = product_shapes(B, n_cycles)
+        fields = PRODUCT_FIELDS
         if out is None:
             out = {k: np.zeros(shapes[k][0], dtype=shapes[k][1]) for k in products}
         else:
@@ -230,22 +235,22 @@ class FootholdPlanner:
 
     # ---- chained plan, device-resident (torch tensors / raw pointers) ----------------------------------
     def plan_device(self, d_poses_ptr, B, n_cycles, d_nominal_ptr=0, d_centroid_ptr=0, d_default_ptr=0,
-                    d_cycle_ok_ptr=0, d_stance_ptr=0, stream=0, d_selected_ptr=0, d_pose_status_ptr=0):
+                    d_cycle_ok_ptr=0, d_stance_ptr=0, stream=0, d_selected_ptr=0, d_pose_status_ptr=0, d_selected_packed_ptr=0):
         po = PlanOut(d_nominal_ptr or None, d_centroid_ptr or None, d_default_ptr or None, d_cycle_ok_ptr or None,
-                     d_stance_ptr or None, d_selected_ptr or None, d_pose_status_ptr or None)
+                     d_stance_ptr or None, d_selected_ptr or None, d_pose_status_ptr or None, d_selected_packed_ptr or None)
         self._check(self._lib.fpe_plan_device(self._h, ptr(self.params), C.c_void_p(d_poses_ptr), int(B), int(n_cycles),
                                               C.byref(po), C.c_void_p(stream or 0)))
 
     # ---- the opt track of a batch (cpp:913-1319, 1485-1568; build-defined optimiser) ---------------------------
     def plan_opt(self, poses, n_cycles, cycle_ok=None):
         """fpe_plan_opt with host buffers; cycle_ok: the nominal plan's flags [B, n_cycles] (None: the engine plans first).
-        Returns {"footholds" [B, n, 4], "cycles" [B, n], "gate_fail_cycle" [B]}."""
+        Returns {"footholds" [B, n, 4], "cycles" [B, n], "gate_fail_cycle" [B], "rows_after" [B, 2]}."""
         poses = np.ascontiguousarray(poses, dtype=POSE_DTYPE)
         B = poses.shape[0]
         out = {"footholds": np.zeros((B, n_cycles, 4), OPT_FOOTHOLD_DTYPE), "cycles": np.zeros((B, n_cycles), OPT_CYCLE_DTYPE),
-               "gate_fail_cycle": np.zeros(B, np.uint8)}
+               "gate_fail_cycle": np.zeros(B, np.uint8), "rows_after": np.zeros((B, 2), np.float64)}
         ok = None if cycle_ok is None else np.ascontiguousarray(cycle_ok, dtype=np.uint8).reshape(B, n_cycles)
-        oo = OptOut(ptr(out["footholds"]), ptr(out["cycles"]), ptr(out["gate_fail_cycle"]))
+        oo = OptOut(ptr(out["footholds"]), ptr(out["cycles"]), ptr(out["gate_fail_cycle"]), ptr(out["rows_after"]))
         self._check(self._lib.fpe_plan_opt(self._h, ptr(self.params), ptr(self.opt_params), ptr(poses), B, int(n_cycles), ptr(ok),
                                            C.byref(oo)))
         return out
@@ -277,6 +282,13 @@ class FootholdPlanner:
             "footholds": m["footholds"][:n].copy(),
         }
 
+    def last_service_gate(self):
+        """fpe_last_service_gate: verdict of the handler's gate for this thread's last globalFootholdPlan call."""
+        g = _capi.ServiceGate()
+        self._check(self._lib.fpe_last_service_gate(self._h, C.byref(g)))
+        return {"fail_cycle": int(g.fail_cycle), "fail_kind": int(g.fail_kind), "chain_ran": bool(g.chain_ran),
+                "returned_false": bool(g.returned_false), "lf_current_row": float(g.lf_current_row), "rh_current_row": float(g.rh_current_row)}
+
     @staticmethod
     def _report(r):
         return {"path": r["feet_center_path"][: int(r["n_path"])].copy(),
@@ -285,7 +297,9 @@ class FootholdPlanner:
 
     def globalFootholdPlan(self, gait_cycles, initial_position, all_tracks=False):
         """Response content of the service, or False where the reference's handler returns false
-        (getGaitCycleSearchGridMap fails in the first gait cycle, cpp:920-934); with all_tracks also the centroid message, the default-track
+        (getGaitCycleSearchGridMap fails, cpp:920-934: in the first gait cycle, or on its lateral side in any cycle — the x side of
+        later cycles follows the build-defined optimiser and refuses only under set_tuning(service_opt_gate=2); last_service_gate()
+        tells the kinds apart); with all_tracks also the centroid message, the default-track
         rows (global_footholds_centroid, globalFootholdsResult_.defaultFootholds), and per track the
         feet-centre path and KPIs (nominal/centroid_feet_center_path, footholdsKPI_)."""
         msg = np.zeros(1, dtype=GLOBAL_FOOTHOLDS_DTYPE)
@@ -365,6 +379,35 @@ class MultiFootholdPlanner:
         rows, cols = trav.shape
         d = MapDesc(rows, cols, float(resolution), (C.c_double * 2)(*map(float, position)), (C.c_int32 * 2)(0, 0), 1)
         self._check(self._lib.fpe_multi_upload_map(self._h, C.byref(d), ptr(trav), ptr(elev)))
+
+    def engine(self, k):
+        return self._lib.fpe_multi_engine(self._h, int(k))
+
+    def shard_range(self, B, k):
+        first, count = C.c_int32(0), C.c_int32(0)
+        rc = self._lib.fpe_multi_shard_range(int(B), int(k), self.device_count, C.byref(first), C.byref(count))
+        if rc != _capi.FPE_OK:
+            raise FpeError(rc, "bad shard arguments")
+        return first.value, first.value + count.value
+
+    def stream(self, k):
+        return self._lib.fpe_multi_stream(self._h, int(k))
+
+    def synchronize(self):
+        self._check(self._lib.fpe_multi_synchronize(self._h))
+
+    def plan_device(self, B, n_cycles, ios, record_kind=_capi.EXCHANGE_SELECTED):
+        """fpe_multi_plan_device.  `ios`: per device a dict {"d_poses": ptr, "d_gathered": ptr, "stream": ptr or 0, and any of the
+        product names of PRODUCT_ORDER: ptr} of DEVICE pointers on that device."""
+        arr = (_capi.MultiDeviceIO * len(ios))()
+        for k, d in enumerate(ios):
+            arr[k].d_poses = d["d_poses"]
+            for name, field in PRODUCT_FIELDS.items():
+                if d.get(name):
+                    setattr(arr[k].d_out, field, d[name])
+            arr[k].d_gathered = d.get("d_gathered") or None
+            arr[k].stream = d.get("stream") or None
+        self._check(self._lib.fpe_multi_plan_device(self._h, ptr(self.params), arr, int(B), int(n_cycles), int(record_kind)))
 
     def plan(self, poses, n_cycles):
         poses = np.ascontiguousarray(poses, dtype=POSE_DTYPE)

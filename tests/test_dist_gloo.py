@@ -130,6 +130,12 @@ def _batched_worker(rank, world, port, B, n_cycles, steps, batch, tmpdir):
     # EVERY step's records reach every rank (the last `depth` batches are still held by the exchange)
     first_held = max(0, ((steps - 1) // batch - 1) * batch)
     ok = all(ex.result(k).numpy().tobytes() == expected[k] for k in range(first_held, steps))
+    if first_held > 0:  # a batch whose buffer has been reused must be refused, not served from foreign records
+        try:
+            ex.result(0)
+            ok = False
+        except RuntimeError:
+            pass
     ex.drain()
     open(os.path.join(tmpdir, f"result{rank}"), "w").write("ok" if ok else "mismatch")
     dist.barrier()
@@ -147,6 +153,44 @@ def test_pipelined_exchange_overlaps_without_mixing_steps(tmp_path):
     port = 29500 + (os.getpid() + 977) % 2000
     mp.spawn(_pipelined_worker, args=(2, port, 32, 3, 5, str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / "result0").read() == "ok" and open(tmp_path / "result1").read() == "ok"
+
+
+def test_exchange_refuses_steps_it_does_not_hold_and_runs_a_forced_one_rank_collective():
+    """BatchedFootholdExchange.result(k) before the batch of step k was gathered raises (it used to return whatever the
+    staging buffer held); force_collective runs the all-gather in a process group of ONE rank (the functional check of the
+    RCCL path that bench.py makes on a single-GPU box, here over gloo)."""
+    from quadrupedal_foothold_planner_amd import dist as fdist
+
+    port = 29500 + (os.getpid() + 555) % 2000
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        ex = fdist.BatchedFootholdExchange(64, torch.device("cpu"), batch=4, force_collective=True)
+        assert ex.collective and ex.world == 1
+        for k in range(6):
+            ex.acquire(k).fill_(k + 1)
+            ex.gather(k)
+            if k == 1:
+                with pytest.raises(RuntimeError):
+                    ex.result(1)  # its batch (steps 0-3) has not been gathered yet
+        with pytest.raises(RuntimeError):
+            ex.result(5)  # trailing partial batch: needs flush()
+        ex.flush(5)
+        assert ex.collectives == 2
+        for k in range(6):
+            assert ex.result(k).eq(k + 1).all()
+        ex.drain()
+        plain = fdist.BatchedFootholdExchange(64, torch.device("cpu"), batch=2)  # one rank, no collective
+        assert not plain.collective
+        plain.acquire(0).fill_(9)
+        with pytest.raises(RuntimeError):
+            plain.result(0)
+        plain.gather(0)
+        plain.acquire(1).fill_(7)
+        plain.gather(1)
+        assert plain.result(0).eq(9).all() and plain.result(1).eq(7).all() and plain.collectives == 0
+    finally:
+        dist.destroy_process_group()
 
 
 def test_shard_ranges_partition_exactly():

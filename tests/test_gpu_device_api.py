@@ -220,12 +220,125 @@ def test_service_returns_false_where_the_opt_track_gate_fails(planner):
     assert np.array_equal(out["pose_status"], want)
     assert want.any() and not want.all()
     for k in range(xs.size):
-        r = planner.globalFootholdPlan(3, poses["position"][k])
+        r = util.service_enforced(planner, 3, poses["position"][k])
         gate = util.oracle_service_gate(omap, planner, poses["position"][k], 3)
         assert (gate == 0) == bool(want[k] & _capi.FPE_POSE_OPT_SUBMAP_FAILED)  # the plan kernels' bit is the cycle-0 gate
         assert (r is False) == (gate != 255)
         if r is not False:
             assert r["gait_cycles"] == 3
+
+
+def test_service_gate_kinds_default_advisory_enforce(planner):
+    """The handler's `return false` (cpp:931-934) by kind (include/fpe.h, fpe_service_gate).  Exact kinds — the first gait
+    cycle (stance feet) and the LATERAL side of any cycle (the drift, cpp:1578: independent of the optimiser) — refuse in every
+    mode, without the opt track's chain; the x side of a cycle >= 1 follows the build-defined optimiser: ignored by default
+    (chain not run), reported under service_opt_gate = 1, refused under 2.  Checked against the oracle's gate functions."""
+    planner.params = _capi.params_yaml()
+    trav, elev = synth.rough_map(300, 300, 0.02, seed=61, bad_frac=0.04)  # 6 x 6 m
+    planner.gridmapCallback(trav, elev, 0.02)
+    omap = fpo.OracleMap(trav, elev, 0.02)
+    rng = np.random.default_rng(5)
+    # poses near the -y edge (the drift carries the gait-cycle submap out: lateral), near the +x edge (the walk reaches the far
+    # edge in a later cycle: x side, build-defined), outside (cycle 0), and well inside (no failure)
+    pos = [[rng.uniform(-2, 0), -3.0 + rng.uniform(0.003, 0.045), 0.0] for _ in range(6)]
+    pos += [[rng.uniform(1.5, 2.7), rng.uniform(-1, 1), 0.0] for _ in range(8)]
+    pos += [[3.3, 0.0, 0.0], [-3.4, 0.5, 0.0]]
+    pos += [[rng.uniform(-2.5, -1.0), rng.uniform(-1, 1), 0.0] for _ in range(4)]
+    n = 8
+    kinds = {k: 0 for k in range(4)}
+    for p in pos:
+        for mode in (0, 1, 2):
+            refuse, kind, cyc = util.oracle_service_verdict(omap, planner, p, n, opt_gate=mode)
+            with planner.tuning(service_opt_gate=mode):
+                r = planner.globalFootholdPlan(n, p)
+                g = planner.last_service_gate()
+            assert (r is False) == refuse, (p, mode, kind, cyc, g)
+            assert g["returned_false"] == refuse and g["chain_ran"] == (mode != 0)
+            assert (g["fail_kind"], g["fail_cycle"]) == (kind, cyc), (p, mode, g, kind, cyc)
+            if r is not False:
+                assert r["gait_cycles"] == n
+            if mode == 1:
+                kinds[kind] += 1
+    assert all(v > 0 for v in kinds.values()), kinds  # every kind occurred
+    # the default call equals the enforced one wherever the exact kinds decide
+    planner.params = _capi.params_yaml()
+
+
+def test_service_survives_a_geometry_the_opt_track_does_not_support(planner):
+    """ADVICE r3: on a fine map with a large search radius the opt track is unsupported (its blocked-row mask holds 128 rows);
+    the service call — which no longer needs the chain for its return value — still answers, under every gate mode."""
+    planner.params = _capi.params_yaml()
+    planner.params["searchRadius"] = np.float32(0.34)
+    trav, elev = synth.rough_map(700, 500, 0.005, seed=9)
+    planner.gridmapCallback(trav, elev, 0.005)
+    for mode in (0, 1, 2):
+        with planner.tuning(service_opt_gate=mode):
+            r = planner.globalFootholdPlan(2, [-0.9, 0.0, 0.0])
+            g = planner.last_service_gate()
+        assert r is not False and r["gait_cycles"] == 2 and not g["chain_ran"]
+    with pytest.raises(FpeError) as e:  # the opt products themselves stay unsupported, and say so
+        planner.globalFootholdPlan(2, [-0.9, 0.0, 0.0], all_tracks=True)
+    assert e.value.code == _capi.FPE_E_UNSUPPORTED
+    planner.params = _capi.params_yaml()
+
+
+def test_selected_packed_is_the_selected_record_in_eight_bytes(planner):
+    """fpe_selected_packed (the halved exchange record): same grid index, flags and f32 height as `selected` / `nominal`, on
+    every kernel family (3x3-only, generic 8-lane, one wavefront per pose, direct)."""
+    cases = [(0.02, {}, {}), (0.01, {}, {}), (0.01, {"searchRadius": np.float32(0.15)}, {}), (0.02, {}, {"no_bits": 1})]
+    for res, prm, tun in cases:
+        planner.params = _capi.params_yaml()
+        for k, v in prm.items():
+            planner.params[k] = v
+        trav, elev = synth.rough_map(260, 240, res, seed=33, bad_frac=0.12, nan_frac=0.01)
+        planner.gridmapCallback(trav, elev, res)
+        poses = synth.poses_in_map(96, 260 * res, 240 * res, 5, 0.18, seed=34, margin=0.2)
+        poses["gait"][::3] = 1
+        with planner.tuning(**tun):
+            out = planner.plan(poses, 5, products=("nominal", "selected", "selected_packed", "cycle_ok"))
+        un = _capi.unpack_selected(out["selected_packed"])
+        for f in ("row", "col", "valid", "source", "foot_id", "gait_cycle_id"):
+            assert np.array_equal(un[f], out["selected"][f]), (res, prm, tun, f)
+        assert np.array_equal(un["z"].view(np.uint32), out["selected"]["z"].view(np.uint32))
+        assert (out["selected"]["valid"] == 0).any() and (out["selected"]["source"] == 1).any()
+        only = planner.plan(poses, 5, products=("selected_packed",))
+        assert only["selected_packed"].tobytes() == out["selected_packed"].tobytes()
+    planner.params = _capi.params_yaml()
+
+
+def test_multi_plan_device_gathers_over_rccl(planner):
+    """fpe_multi_plan_device: the C++ host's device-resident multi-GPU plan with the RCCL all-gather of the selected records
+    (ncclCommInitAll / ncclGroupStart / ncclAllGather / ncclGroupEnd behind the C ABI, no Python collective).  One device on
+    this box: the communicator has one rank, the collective still runs through RCCL; both record kinds, and an uneven batch
+    (grouped broadcasts).  Offsets for more devices are covered on the CPU (test_cpu_abi_and_host)."""
+    import torch
+
+    from quadrupedal_foothold_planner_amd.planner import MultiFootholdPlanner
+
+    planner.params = _capi.params_yaml()
+    trav, elev = synth.rough_map(300, 300, 0.02, seed=7)
+    poses = synth.poses_in_map(257, 6.0, 6.0, 8, 0.18, seed=8, margin=0.7)
+    planner.gridmapCallback(trav, elev, 0.02)
+    want = planner.plan(poses, 8, products=("nominal", "selected", "selected_packed", "cycle_ok"))
+    mp = MultiFootholdPlanner([0])
+    try:
+        mp.gridmapCallback(trav, elev, 0.02)
+        dev = torch.device("cuda:0")
+        B, n = poses.shape[0], 8
+        d_poses = torch.from_numpy(poses.view(np.uint8).reshape(B, -1).copy()).to(dev)
+        for kind, name, dt in ((_capi.EXCHANGE_SELECTED, "selected", _capi.SELECTED_DTYPE), (_capi.EXCHANGE_PACKED, "selected_packed", _capi.PACKED_DTYPE)):
+            d_rec = torch.zeros(B * n * 4 * dt.itemsize, dtype=torch.uint8, device=dev)
+            d_all = torch.zeros(B * n * 4 * dt.itemsize, dtype=torch.uint8, device=dev)
+            d_ok = torch.zeros(B * n, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            mp.plan_device(B, n, [{"d_poses": d_poses.data_ptr(), name: d_rec.data_ptr(), "cycle_ok": d_ok.data_ptr(),
+                                   "d_gathered": d_all.data_ptr()}], record_kind=kind)
+            mp.synchronize()
+            got = d_all.cpu().numpy().view(dt).reshape(B, n, 4)
+            assert got.tobytes() == want[name].tobytes(), name
+            assert np.array_equal(d_ok.cpu().numpy().reshape(B, n), want["cycle_ok"])
+    finally:
+        mp.close()
 
 
 def test_foot_radius_much_larger_than_search_radius(planner):

@@ -157,6 +157,33 @@ def test_opt_track_device_entry_point(planner):
     util.assert_opt_equal(eng2, ora)
 
 
+def test_rows_after_are_what_the_next_cycle_would_use(planner):
+    """fpe_opt_out.rows_after (lfCurrentRow / rhCurrentRow as a call leaves them, cpp:1561-1568 — what the ROS adapter carries
+    into the next service call): equal to the values the oracle's cycle N uses in a plan of N + 1 cycles, for every
+    pose whose first N cycles ran; the service call reports the same pair through fpe_last_service_gate."""
+    reset(planner)
+    trav, elev = synth.rough_map(300, 300, 0.02, seed=61, bad_frac=0.08)
+    poses = synth.poses_in_map(96, 6.0, 6.0, 7, 0.18, seed=64, margin=0.8)
+    planner.gridmapCallback(trav, elev, 0.02)
+    omap = fpo.OracleMap(trav, elev, 0.02)
+    op, oo, opo = util.to_oracle_params(planner.params), util.to_oracle_opt_params(planner.opt_params), util.to_oracle_poses(poses)
+    n = 5
+    plan = planner.plan(poses, n + 1, products=("cycle_ok",))
+    eng = planner.plan_opt(poses, n, plan["cycle_ok"][:, :n].copy())
+    ora = omap.plan_opt(op, oo, opo, n + 1, plan["cycle_ok"])
+    ran = ora["gate_fail_cycle"] > n  # cycle n ran: its record holds the rows left by cycle n - 1
+    assert ran.sum() > 50
+    assert np.array_equal(eng["rows_after"][ran, 0], ora["cycles"]["lf_current_row"][ran, n])
+    assert np.array_equal(eng["rows_after"][ran, 1], ora["cycles"]["rh_current_row"][ran, n])
+    assert (eng["rows_after"][ran] != 0).any() and (ora["cycles"]["committed"][ran, :n] == 0).any()
+    with planner.tuning(service_opt_gate=1):
+        for b in np.nonzero(ran)[0][:6]:
+            r = planner.globalFootholdPlan(n, poses["position"][b])
+            g = planner.last_service_gate()
+            assert r is not False and g["chain_ran"]
+            assert (g["lf_current_row"], g["rh_current_row"]) == tuple(eng["rows_after"][b])
+
+
 def test_service_opt_products_and_return_value(planner):
     """plan_global_footholds: global_footholds_opt, the opt KPIs, the centroid path interleaved with the opt track's feet
     centres (cpp:946), and the handler's `return false` in the cycle whose gate fails."""
@@ -176,10 +203,10 @@ def test_service_opt_products_and_return_value(planner):
         opo = util.to_oracle_poses(np.array([(tuple(pos), 0, (0, 0, 0, 0), (0, 0, 0, 0))], dtype=_capi.POSE_DTYPE))
         oplan = omap.plan(op, opo, n)
         oopt = omap.plan_opt(op, oo, opo, n, oplan["cycle_ok"])
-        res = planner.globalFootholdPlan(n, pos, all_tracks=True)
+        res = util.service_enforced(planner, n, pos, all_tracks=True)
         if oopt["gate_fail_cycle"][0] != 255:
             assert res is False, f"pose {pos}: the reference's handler returns false in cycle {oopt['gate_fail_cycle'][0]}"
-            assert planner.globalFootholdPlan(n, pos) is False
+            assert util.service_enforced(planner, n, pos) is False
             seen_false += 1
             continue
         seen_true += 1

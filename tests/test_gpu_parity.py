@@ -290,7 +290,7 @@ def test_service_message(planner):
     answered = 0
     for _ in range(40):
         pos = [rng.uniform(-3.2, -2.0), rng.uniform(-3, 3), 0.25]
-        msg = planner.globalFootholdPlan(8, pos)
+        msg = util.service_enforced(planner, 8, pos)
         o = omap.plan(util.to_oracle_params(planner.params), util.to_oracle_poses(make_poses([pos])), 8)
         ok = o["cycle_ok"][0]
         if util.oracle_service_gate(omap, planner, pos, 8, o) != 255:
@@ -346,7 +346,7 @@ def test_maximum_gait_cycles_255(planner):
     omap = fpo.OracleMap(trav, elev, 0.02)
     answered = 0
     for b in range(8):
-        msg = planner.globalFootholdPlan(255, poses["position"][b])
+        msg = util.service_enforced(planner, 255, poses["position"][b])
         if util.oracle_service_gate(omap, planner, poses["position"][b], 255) != 255:
             assert msg is False
             continue
@@ -365,7 +365,7 @@ def test_service_all_tracks(planner):
     seen_split = False
     for _ in range(48):
         pos = [rng.uniform(-3.2, -2.0), rng.uniform(-3, 3), 0.0]
-        r = planner.globalFootholdPlan(6, pos, all_tracks=True)
+        r = util.service_enforced(planner, 6, pos, all_tracks=True)
         o = omap.plan(util.to_oracle_params(planner.params), util.to_oracle_poses(make_poses([pos])), 6)
         if util.oracle_service_gate(omap, planner, pos, 6, o) != 255:
             assert r is False
@@ -404,7 +404,7 @@ def test_service_track_reports(planner, rf_first):
     committed = 0
     for _ in range(24):
         pos = [rng.uniform(-3.2, -2.0), rng.uniform(-3, 3), 0.0]
-        r = planner.globalFootholdPlan(7, pos, all_tracks=True)
+        r = util.service_enforced(planner, 7, pos, all_tracks=True)
         if util.oracle_service_gate(omap, planner, pos, 7) != 255:
             assert r is False
             continue
@@ -504,12 +504,17 @@ def test_concurrent_uploads_and_plans_see_whole_snapshots(planner):
             errors.append(repr(e))
 
     ths = [threading.Thread(target=uploader)] + [threading.Thread(target=client, args=(s,)) for s in (False, False, True)]
-    for t in ths:
-        t.start()
-    for t in ths[1:]:
-        t.join()
-    stop.set()
-    ths[0].join()
+    planner.set_tuning(service_opt_gate=2)  # the service client compares with the oracle's opt-track gate of ANY cycle
+    try:
+        for t in ths:
+            t.start()
+        for t in ths[1:]:
+            t.join()
+        stop.set()
+        ths[0].join()
+    finally:
+        stop.set()
+        planner.set_tuning(service_opt_gate=0)
     assert not errors, errors[:3]
     assert seen[0] + seen[1] == 120
 
