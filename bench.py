@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-bits", action="store_true", help="run the direct kernels (fpe_set_tuning no_bits=1) instead of the bit-window kernels")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target seconds of oracle work per baseline leg")
     ap.add_argument("--gather-every", type=int, default=8, help="N>1: one all-gather per K steps, carrying all K steps' records (1: a collective per step; measured as config.exchange_alt)")
+    ap.add_argument("--exchange-record", default="packed", choices=("packed", "selected"),
+                    help="N>1: the record the all-gather moves: the 8-byte fpe_selected_packed (default) or the 16-byte fpe_selected_foothold")
     return ap.parse_args()
 
 
@@ -201,14 +203,27 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = "none"
-    if world > 1:
+    # FPE_BENCH_FORCE_NCCL=1 (functional check on a 1-GPU box, tests/test_gpu_device_api.py): a process group of ONE rank on
+    # the nccl backend (= RCCL), and the exchange's collectives are issued although nobody else takes part — init, the
+    # all-gather on device records, the work-handle waits against RCCL's stream all run for real
+    force_nccl = world == 1 and os.environ.get("FPE_BENCH_FORCE_NCCL") == "1"
+    if world > 1 or force_nccl:
         backend = "gloo" if share else "nccl"
         import datetime
         rendezvous = datetime.timedelta(seconds=int(os.environ.get("FPE_BENCH_RENDEZVOUS_S", "180")))
-        if share:
+        if force_nccl:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as s_:
+                    s_.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", device_id=dev, timeout=rendezvous, rank=0, world_size=1)
+        elif share:
             dist.init_process_group("gloo", timeout=rendezvous)
         else:
             dist.init_process_group("nccl", device_id=dev, timeout=rendezvous)
+    exchanging = world > 1 or force_nccl
 
     # ---- workload --------------------------------------------------------------------------------
     cfg = synth.CONFIGS[args.config]
@@ -235,6 +250,10 @@ def main():
     n_rec = B * n_cycles * 4
     rec = _capi.FOOTHOLD_DTYPE.itemsize
     sel = _capi.SELECTED_DTYPE.itemsize  # 16 B exchange record: grid index + z + flags
+    # what the all-gather moves: the 8-byte packed form by default (half the bytes over xGMI), written by the plan kernel itself
+    packed = args.exchange_record == "packed" and rows <= _capi.PACKED_MAX_CELLS and cols <= _capi.PACKED_MAX_CELLS
+    xrec = _capi.PACKED_DTYPE.itemsize if packed else sel
+    xdtype = _capi.PACKED_DTYPE if packed else _capi.SELECTED_DTYPE
     d_nom = torch.zeros(n_rec * rec, dtype=torch.uint8, device=dev)
     d_cen = torch.zeros(n_rec * _capi.CENTROID_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     d_def = torch.zeros(n_rec * 3, dtype=torch.float64, device=dev)
@@ -251,16 +270,18 @@ def main():
     # of microseconds against a 29 us headline step); K = 1 is measured as well (config.exchange_alt).  Every gathered step's
     # footholds reach every rank; the timed region ends after the last all-gather has completed.
     def run(batch):
-        ex_ = fdist.BatchedFootholdExchange(n_rec * sel, dev, batch=batch) if world > 1 else None
+        ex_ = fdist.BatchedFootholdExchange(n_rec * xrec, dev, batch=batch, force_collective=force_nccl) if exchanging else None
         k_ = [0]
 
         def step():
             k = k_[0]
             k_[0] += 1
-            sel_buf = ex_.acquire(k) if ex_ else d_sel  # waits (stream-ordered) until the gather that last read this buffer is done
+            # (acquire waits, stream-ordered, until the gather that last read this buffer is done)
+            x_buf = ex_.acquire(k) if ex_ else None
             planner.plan_device(d_poses.data_ptr(), B, n_cycles, d_nom.data_ptr(), d_cen.data_ptr(), d_def.data_ptr(),
-                                d_ok.data_ptr(), d_st.data_ptr(), stream=stream.cuda_stream, d_selected_ptr=sel_buf.data_ptr(),
-                                d_pose_status_ptr=d_ps.data_ptr())
+                                d_ok.data_ptr(), d_st.data_ptr(), stream=stream.cuda_stream,
+                                d_selected_ptr=(x_buf.data_ptr() if ex_ and not packed else d_sel.data_ptr()),
+                                d_pose_status_ptr=d_ps.data_ptr(), d_selected_packed_ptr=(x_buf.data_ptr() if ex_ and packed else 0))
             if ex_:
                 ex_.gather(k)
 
@@ -272,7 +293,7 @@ def main():
             ex_.drain()
             k_[0] = ((k_[0] + batch - 1) // batch) * batch  # the timed region starts on a batch boundary
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if world > 1:
+        if exchanging:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -284,11 +305,11 @@ def main():
             ex_.drain()  # the stream waits for the in-flight all-gathers
         ev1.record(stream)
         torch.cuda.synchronize()
-        if world > 1:
+        if exchanging:
             dist.barrier()
         el = time.perf_counter() - t0
         t = torch.tensor([el], dtype=torch.float64, device=dev)
-        if world > 1:
+        if exchanging:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()), ev0.elapsed_time(ev1) / args.steps, ex_, k_[0] - 1
 
@@ -296,14 +317,18 @@ def main():
     # holds nothing but the K plan kernels, so elapsed/K is the mean launch duration (an upper bound
     # of the kernel time: it includes the ~2 us dispatch gap between back-to-back launches).  At N>1
     # the all-gather shares the stream, so a second, kernel-only pass measures the launch duration.
-    gather_batch = max(1, args.gather_every) if world > 1 else 1
+    gather_batch = max(1, args.gather_every) if exchanging else 1
     elapsed, kernel_ms, ex, last_step = run(gather_batch)
     alt = None
-    if world > 1:
-        g = ex.result(last_step)[rank * n_rec * sel:(rank + 1) * n_rec * sel]
-        mine = np.frombuffer(g.cpu().numpy().tobytes(), dtype=_capi.SELECTED_DTYPE)
-        sel_last = ex.local_block(last_step).clone()
-        if gather_batch > 1:
+    n_collectives = ex.collectives if ex else 0
+    if exchanging:
+        g = ex.result(last_step)[rank * n_rec * xrec:(rank + 1) * n_rec * xrec]
+        mine = np.frombuffer(g.cpu().numpy().tobytes(), dtype=xdtype).reshape(B, n_cycles, 4)
+        if packed:
+            mine = _capi.unpack_selected(mine)
+        mine = mine.reshape(-1)
+        x_last = ex.local_block(last_step).clone()
+        if gather_batch > 1 and world > 1:
             el1, _, ex1, _ = run(1)
             alt = {"gather_every": 1, "value": 4 * n_cycles * B * world * args.steps / el1, "ms_per_step": el1 / args.steps * 1e3,
                    "note": "one all-gather per step (2 x the collectives' fixed cost per 29 us headline step)"}
@@ -333,15 +358,21 @@ def main():
         "default": d_def.cpu().numpy().reshape(B, n_cycles, 4, 3),
         "cycle_ok": d_ok.cpu().numpy().reshape(B, n_cycles),
         "stance": d_st.cpu().numpy().reshape(B, 4, 3),
-        "selected": (sel_last if world > 1 else d_sel).cpu().numpy().view(_capi.SELECTED_DTYPE).reshape(B, n_cycles, 4),
         "pose_status": d_ps.cpu().numpy(),
     }
+    if exchanging:  # the exchanged record of the last step, as the plan kernel wrote it into the staging buffer
+        x_host = x_last.cpu().numpy().view(xdtype).reshape(B, n_cycles, 4)
+        eng["selected"] = _capi.unpack_selected(x_host) if packed else x_host
+    else:
+        eng["selected"] = d_sel.cpu().numpy().view(_capi.SELECTED_DTYPE).reshape(B, n_cycles, 4)
     verified, why = verify_plan(eng, trav, elev, res, params, poses, n_cycles)
-    if world > 1:
+    if exchanging:
         nom_host = eng["nominal"].reshape(-1)
         for f in ("row", "col", "valid", "source", "foot_id", "gait_cycle_id"):
             if not np.array_equal(mine[f], nom_host[f]):
                 verified, why = False, f"all-gather lost this rank's footholds ({f})"
+        if not np.array_equal(mine["z"].view(np.uint32), nom_host["z"].view(np.uint32)):
+            verified, why = False, "all-gather lost this rank's footholds (z)"
         flag = torch.tensor([0 if verified else 1], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()) and verified:
@@ -361,7 +392,8 @@ def main():
         try:
             ent = json.load(open(pmc_path)).get(args.config, {})
             inst = kernel_now.split(" (")[0]  # e.g. "plan_bits_kernel<2, true>"
-            if ent and inst in ent.get("kernel", ""):
+            # (the profiled name carries one more template argument, the product shape: "plan_bits_kernel<2, true, 2>")
+            if ent and (inst in ent.get("kernel", "") or inst.rstrip(">") + "," in ent.get("kernel", "")):
                 traffic = ent.get("hbm_bytes_per_launch")
                 traffic_source = {"file": ent.get("file", "profiles/pmc_traffic.json"), "round": ent.get("round"),
                                   "commit": ent.get("commit", "round-2 HEAD"), "kernel": ent.get("kernel"),
@@ -401,13 +433,16 @@ def main():
             "spiral_leg_fraction": float((src == 1).mean()),
             "default_hit_fraction": float((src == 0).mean()),
             "centroid_code_fractions": [float(c) for c in codes],
-            "exchange": (f"all_gather_into_tensor of the selected footholds (16 B records written by the plan kernel: grid index, z, "
-                         f"flags): EVERY step's records, one collective per {gather_batch} steps ({gather_batch} x the bytes), overlapped "
+            "exchange": (f"all_gather_into_tensor of the selected footholds ({xrec} B records written by the plan kernel: "
+                         f"{'fpe_selected_packed — row | col << 14 | flags in one word, z' if packed else 'fpe_selected_foothold — grid index, z, flags'}): "
+                         f"EVERY step's records, one collective per {gather_batch} steps ({gather_batch} x the bytes), overlapped "
                          f"with the plan kernels of the next batch; backend {backend}, "
-                         f"{dist.get_world_size()} ranks in the process group") if world > 1 else "none",
+                         f"{dist.get_world_size()} rank{'s' if dist.get_world_size() != 1 else ''} in the process group, {n_collectives} collectives issued"
+                         + (" (FPE_BENCH_FORCE_NCCL: one rank, the collective forced)" if force_nccl else "")) if exchanging else "none",
         },
         "roofline": {
-            "bound": "hbm",
+            "bound": "simd-issue",
+            "yardstick": "hbm",
             "achieved": achieved,
             "peak": peak,
             "unit": "GB/s",
@@ -418,9 +453,10 @@ def main():
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_foothold": alg_bytes,
             "frac_by_counter_bytes": (traffic / (kernel_ms * 1e-3) / 1e9 / peak) if traffic else None,
-            "note": "`achieved` / `frac` charge SURVEY 8(d)'s ALGORITHMIC bytes (the yardstick north_star names); the kernel is bound by "
-                    "the SIMDs' instruction issue, not by HBM: its counter-measured traffic is `traffic` (frac_by_counter_bytes), the map "
-                    "and its bit planes are L2 / Infinity-Cache resident (DESIGN.md §4)",
+            "note": "`bound` is what the counters say limits the kernel (the SIMDs' instruction issue: VALU-active 0.67-0.94 of the SIMDs' "
+                    "time, profiles/); `achieved` / `peak` / `frac` keep north_star's yardstick — SURVEY 8(d)'s ALGORITHMIC bytes against the "
+                    "8 TB/s HBM peak (`yardstick`) — so that rounds stay comparable; the counter-measured traffic is `traffic` "
+                    "(frac_by_counter_bytes): the map and its bit planes are L2 / Infinity-Cache resident (DESIGN.md §4)",
         },
     }
     if not verified:
@@ -428,7 +464,7 @@ def main():
     if world > 1:
         # what the exchange moves, so that a scaling line can be read against the links: xGMI is point to point (every
         # peer's block arrives over its own link; a ring would push all world - 1 blocks through one)
-        local_bytes = n_rec * sel
+        local_bytes = n_rec * xrec
         link_gbs = 64.0  # GB/s per xGMI link and direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s bidirectional per GPU)
         line["config"]["exchange_bytes_per_rank"] = local_bytes
         line["config"]["exchange_inbound_bytes_per_gpu"] = local_bytes * (world - 1)
@@ -437,6 +473,13 @@ def main():
                                                "plan_kernel_ms": kernel_ms,
                                                "note": "per-step all-gather time a step cannot go below at 64 GB/s per link and direction; when it "
                                                        "exceeds plan_kernel_ms the step is exchange-bound however well the gather overlaps the next plan"}
+        floor = line["config"]["exchange_floor_ms"]
+        line["config"]["step_bound_at_this_n"] = {
+            "by_direct_links": "exchange" if floor["direct_links"] > kernel_ms else "plan",
+            "by_ring": "exchange" if floor["ring"] > kernel_ms else "plan",
+            "measured_ms_per_step": elapsed / args.steps * 1e3,
+            "note": "which of the plan kernel and the all-gather's link floor is the longer per step (the two overlap: the step costs the "
+                    "longer one); measured_ms_per_step above both means neither hides the other completely"}
     if alt:
         line["config"]["exchange_alt"] = alt
     extras = rank == 0 and world == 1 and not args.no_extras
@@ -486,16 +529,89 @@ def main():
         line["value_selected_only"] = {"value": 4 * n_cycles * B / dt_s, "unit": "footholds/s", "ms_per_call": dt_s * 1e3,
                                        "result_bytes": out_s["selected"].nbytes,
                                        "note": "fpe_plan asking for the 16-byte selected records only (pinned destination)"}
+        # ---- the headline kernel's launch structure (VERDICT r3 task 2): three side measurements, each verified ----
+        def ev_ms(fn, reps_e):
+            fn()
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            a_.record(stream)
+            for _ in range(reps_e):
+                fn()
+            b_.record(stream)
+            torch.cuda.synchronize()
+            return a_.elapsed_time(b_) / reps_e
+
+        # (a) the service's response is the NOMINAL track only (cpp:1588): nominal + selected + cycle flags, no default /
+        # centroid products, no stance
+        d_nom2, d_sel2, d_ok2 = torch.zeros_like(d_nom), torch.zeros_like(d_sel), torch.zeros_like(d_ok)
+        ms_nom = ev_ms(lambda: planner.plan_device(d_poses.data_ptr(), B, n_cycles, d_nominal_ptr=d_nom2.data_ptr(), d_cycle_ok_ptr=d_ok2.data_ptr(),
+                                                   stream=stream.cuda_stream, d_selected_ptr=d_sel2.data_ptr()), args.steps)
+        nom_ok = bool(torch.equal(d_nom2, d_nom) and torch.equal(d_ok2, d_ok) and torch.equal(d_sel2, d_sel))
+        line["value_nominal_only"] = {"value": 4 * n_cycles * B / (ms_nom * 1e-3), "unit": "footholds/s", "ms_per_step": ms_nom, "verified": nom_ok,
+                                      "kernel": planner.describe_plan(),
+                                      "note": "fpe_plan_device asked for {nominal, selected, cycle_ok} only — the service's response (cpp:1588) and the "
+                                              "exchange record; outputs byte-identical to the all-products launch's"}
+        # (b) two plans in flight: the timed steps alternate between two streams with their own output buffers (independent
+        # plans, what concurrent AsyncSpinner service threads produce): the tail of one launch overlaps the ramp of the next
+        s2 = torch.cuda.Stream(device=dev)
+        set1 = (d_nom, d_cen, d_def, d_ok, d_st, d_sel, d_ps)
+        set2 = tuple(torch.zeros_like(t) for t in set1)
+
+        def launch(st, bs):
+            planner.plan_device(d_poses.data_ptr(), B, n_cycles, bs[0].data_ptr(), bs[1].data_ptr(), bs[2].data_ptr(), bs[3].data_ptr(),
+                                bs[4].data_ptr(), stream=st.cuda_stream, d_selected_ptr=bs[5].data_ptr(), d_pose_status_ptr=bs[6].data_ptr())
+
+        for _ in range(2):
+            launch(stream, set1)
+            launch(s2, set2)
+        torch.cuda.synchronize()
+        n2 = max(2, args.steps - args.steps % 2)
+        t0 = time.perf_counter()
+        for k in range(n2):
+            launch(*((stream, set1) if k % 2 == 0 else (s2, set2)))
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / n2
+        two_ok = all(torch.equal(a_, b_) for a_, b_ in zip(set1, set2))  # set1 was checked against the oracle above
+        line["value_two_in_flight"] = {"value": 4 * n_cycles * B / dt2, "unit": "footholds/s", "ms_per_step": dt2 * 1e3, "steps": n2,
+                                       "verified": bool(two_ok and verified),
+                                       "note": "the same K launches issued round-robin on two streams with double-buffered outputs (host wall clock "
+                                               "around them, synchronised on both sides): independent plans overlap each other's ramp and tail; both "
+                                               "output sets byte-identical to the verified single-stream launch"}
+        del set2
+        # (c) one launch of twice the batch: ramp and tail amortised over two rounds of wavefronts
+        if args.config in ("headline", "cfg2"):
+            _, _, _, poses2, _, _ = synth.make_config(args.config, B=2 * B)
+            d_p2 = torch.from_numpy(poses2.view(np.uint8).reshape(-1)).to(dev)
+            big = {k: torch.zeros(2 * t.numel(), dtype=t.dtype, device=dev) for k, t in
+                   (("nom", d_nom), ("cen", d_cen), ("def", d_def), ("ok", d_ok), ("st", d_st), ("sel", d_sel), ("ps", d_ps))}
+            ms_big = ev_ms(lambda: planner.plan_device(d_p2.data_ptr(), 2 * B, n_cycles, big["nom"].data_ptr(), big["cen"].data_ptr(), big["def"].data_ptr(),
+                                                       big["ok"].data_ptr(), big["st"].data_ptr(), stream=stream.cuda_stream,
+                                                       d_selected_ptr=big["sel"].data_ptr(), d_pose_status_ptr=big["ps"].data_ptr()), max(4, args.steps // 2))
+            eng2 = {"nominal": big["nom"].cpu().numpy().view(_capi.FOOTHOLD_DTYPE).reshape(2 * B, n_cycles, 4),
+                    "centroid": big["cen"].cpu().numpy().view(_capi.CENTROID_DTYPE).reshape(2 * B, n_cycles, 4),
+                    "default": big["def"].cpu().numpy().reshape(2 * B, n_cycles, 4, 3), "cycle_ok": big["ok"].cpu().numpy().reshape(2 * B, n_cycles),
+                    "stance": big["st"].cpu().numpy().reshape(2 * B, 4, 3),
+                    "selected": big["sel"].cpu().numpy().view(_capi.SELECTED_DTYPE).reshape(2 * B, n_cycles, 4), "pose_status": big["ps"].cpu().numpy()}
+            big_ok, _ = verify_plan(eng2, trav, elev, res, params, poses2, n_cycles)
+            line["value_double_batch"] = {"value": 4 * n_cycles * 2 * B / (ms_big * 1e-3), "unit": "footholds/s", "ms_per_launch": ms_big, "poses": 2 * B,
+                                          "verified": bool(big_ok),
+                                          "note": "ONE launch of 2 x B poses (two rounds of wavefronts per SIMD): the per-pose rate with launch ramp and "
+                                                  "tail amortised; every product checked against the oracle"}
+            del big, d_p2
+        if not (nom_ok and two_ok and line.get("value_double_batch", {}).get("verified", True)):
+            verified = False
+            line["config"]["verified"] = False
+            line["config"]["verify_error"] = "a side measurement (nominal-only / two in flight / double batch) differs from the verified launch"
         # the actual drop-in call: plan_global_footholds for ONE pose x 8 cycles (fpe_plan_service: plan kernel + the opt
         # track's chain for the handler's return value, zero-copy through the pinned arena), wall time per call through
         # ctypes; on a steady map and as the first call after a fresh map message (bit planes pre-built by the upload)
-        def service_us(fresh_map, no_bits, reps_s=60, gate0=False):
+        def service_us(fresh_map, no_bits, reps_s=60, opt_gate=0):
             svc = FootholdPlanner(local_rank)
             svc.params = planner.params.copy()
             if no_bits:
                 svc.set_tuning(no_bits=1)
-            if gate0:
-                svc.set_tuning(service_cycle0_gate_only=1)
+            if opt_gate:
+                svc.set_tuning(service_opt_gate=opt_gate)
             svc.gridmapCallback(trav, elev, res)
             pos = poses["position"][0].copy()
             svc.globalFootholdPlan(8, pos)
@@ -512,11 +628,12 @@ def main():
         line["service_latency_us"] = {
             "steady_map": {"bit_window": service_us(False, False), "direct": service_us(False, True)},
             "first_call_after_a_map": {"bit_window": service_us(True, False, 12), "direct": service_us(True, True, 12)},
-            "steady_map_without_the_opt_track": {"bit_window": service_us(False, False, gate0=True), "direct": service_us(False, True, gate0=True)},
-            "note": "median wall time of fpe_plan_service (1 pose x 8 cycles, response assembled) per call, ctypes overhead included: the "
-                    "plan kernel AND the opt track's chain (cpp:913-1319: eight optimiser searches of 14 641 lattice points each, one "
-                    "after the other), which the handler's return value depends on from the second cycle on; "
-                    "steady_map_without_the_opt_track = fpe_set_tuning('service_cycle0_gate_only', 1), the round-2 scope of the call",
+            "steady_map_with_the_opt_track_gate": {"bit_window": service_us(False, False, opt_gate=2)},
+            "note": "median wall time of fpe_plan_service (1 pose x 8 cycles, response assembled) per call, ctypes overhead included.  Default "
+                    "(service_opt_gate 0): the plan kernel; the handler's `return false` is decided for its optimiser-independent kinds — first "
+                    "gait cycle, lateral side of every cycle (include/fpe.h, fpe_service_gate).  steady_map_with_the_opt_track_gate = "
+                    "fpe_set_tuning('service_opt_gate', 2): also the opt track's chain (cpp:913-1319: eight optimiser searches of 14 641 lattice "
+                    "points each, one after the other), whose build-defined verdict then refuses as well",
         }
         # map ingest: grid_map message layout (column-major, circular-buffer start
         # index) -> canonical HBM layers, device-resident source; HBM-bound transpose, 2 layers
@@ -621,6 +738,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(trav, elev, res, params, poses, n_cycles, args.cpu_seconds)
     if rank == 0:
+        # RCCL prints its version banner through C stdio, which is block-buffered on a pipe: flush it first so that the JSON
+        # is the LAST line on stdout whatever the buffering
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         print(json.dumps(line), flush=True)
     planner.close()
     if world > 1:

@@ -146,6 +146,26 @@ __device__ __forceinline__ double swizzle_f64(double v) {
     return __builtin_bit_cast(double, (static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
 }
 
+// Value of lane L (compile-time) of every 8-lane group: a ds_swizzle in bit mode.  (-DFPE_BCAST8_DPP: two DPP moves instead —
+// a quad broadcast, every quad gets ITS lane L & 3, then the half-row mirror hands the owner quad's value to the group's
+// other quad; VALU latency instead of an LDS round trip, two VALU instructions instead of one LDS instruction.  Measured on
+// the headline, round 4: 27.5 us either way — the exchange is not on the critical path; the swizzle stays.)
+template <int L>
+__device__ __forceinline__ int bcast8_dpp(int x) {
+#ifndef FPE_BCAST8_DPP
+    return __builtin_amdgcn_ds_swizzle(x, 0x18 | (L << 5));
+#else
+    const int q = __builtin_amdgcn_update_dpp(0, x, (L & 3) * 0x55, 0xF, 0xF, true);
+    return __builtin_amdgcn_update_dpp(q, q, 0x141, 0xF, (L < 4) ? 0xA : 0x5, false);
+#endif
+}
+template <int L>
+__device__ __forceinline__ double bcast8_dpp_f64(double v) {
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = bcast8_dpp<L>(static_cast<int>(bits)), hi = bcast8_dpp<L>(static_cast<int>(bits >> 32));
+    return __builtin_bit_cast(double, (static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+
 // Multi-word row shifts by 0 <= s < 32 columns: shr: bit j of the result = bit j + s of the row; shl: bit j - s.
 template <int KW>
 __device__ __forceinline__ void row_shr(const unsigned (&x)[KW], unsigned s, unsigned (&o)[KW]) {
@@ -1740,10 +1760,10 @@ __device__ __forceinline__ void flush_unit(const DevMap& m, const PlanConsts& pc
     // the centroid result's own cell, when the chain left its elevation to be read here (issued first: the three
     // height sums below cover the round trip)
     float eC = u.eC;
-    if (u.cenCode & 0x200u) eC = m.elev[static_cast<size_t>(u.cenRow) * mg.cols + u.cenCol];
+    if (out.centroid && (u.cenCode & 0x200u)) eC = m.elev[static_cast<size_t>(u.cenRow) * mg.cols + u.cenCol];
     if (leg == 0 && out.cycle_ok) out.cycle_ok[static_cast<size_t>(b) * nCycles + cyc] = static_cast<uint8_t>((okBits >> (cyc & 7)) & 1u);
     const float zA = unit_mean9(u.eA, u.visA, pc.h);
-    const float zB = unit_mean9(u.eB, u.visB, pc.h);
+    const float zB = out.default_next ? unit_mean9(u.eB, u.visB, pc.h) : 0.0f;
     const int code = static_cast<int>(u.cenCode & 0xFFu);
     float zC = 0.0f;
     if (u.cenCode & 0x300u) {
@@ -2347,8 +2367,43 @@ __device__ __forceinline__ LaneRole make_lane_role(int q, double rf, double lx, 
     r.qHi = in_vgpr(raw ? inf : -cornerEps);
     return r;
 }
+// The first two rounds of the candidate scan (ranks 0-15) WITHOUT the LDS: those sixteen cells lie within two rows and
+// columns of the centre (rings 0, 1 and the head of ring 2: SpiralLut::fast16), i.e. in FIVE consecutive window rows, and
+// a group's eight lanes own eight consecutive rows per slot — so every one of the five rows has its own lane.  That lane
+// looks at the five pass bits around the centre column of ITS row and turns each into the bit (1 << rank) of the
+// candidate it stands for (rowTab: the rank per column offset, fetched once per kernel); an OR over the group (three
+// DPP steps) gives the sixteen candidates' verdicts, the lowest set bit is the first valid cell in SpiralIterator order
+// (cpp:2085-2114), and its offset comes out of two packed 64-bit tables.  Before: the pass rows written to the leg's
+// LDS, a fence, two dependent LDS reads, two ballots and a ds_bpermute per search — four LDS round trips that the two
+// wavefronts of a SIMD cannot hide (stage trace: 1 150 clocks per search, 88 % of the headline's cycles have one).
+struct FastRanks {
+    uint32_t rowTab;          // this lane's row: five 5-bit ranks by column offset -2..2 (31: none), 0x1FFFFFF when the lane owns none of the five rows
+    int slot;                 // which of the lane's NRL rows it is
+    unsigned long long di, dj;  // (offset + 2) of rank q in the 4-bit field q
+};
 template <int NRL>
+__device__ __forceinline__ FastRanks load_fast_ranks(const SpiralLut& lut, const Grp<8>& g, int winH) {
+    FastRanks fr;
+    fr.slot = 0;
+    int d = 99;
+#pragma unroll
+    for (int k = 0; k < NRL; ++k) {
+        const int dk = g.sub + 8 * k - winH;  // row offset from the centre row (window row winH)
+        const bool mine = dk >= -2 && dk <= 2;
+        fr.slot = mine ? k : fr.slot;
+        d = mine ? dk : d;
+    }
+    const uint32_t w = lut.fast16[min(max(d + 2, 0), 4)];
+    fr.rowTab = d == 99 ? 0x1FFFFFFu : w;
+    fr.di = *reinterpret_cast<const unsigned long long*>(lut.fast16 + 6);
+    fr.dj = *reinterpret_cast<const unsigned long long*>(lut.fast16 + 8);
+    asm volatile("" : "+v"(fr.di), "+v"(fr.dj));  // (uniform, but kept in vector registers: the chain has no scalar registers to spare)
+    return fr;
+}
+
+template <int NRL, bool kNoDefault>
 __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const HotConsts& hc, const LaneRole& role,
+                                           const FastRanks& fk,
                                            const SpiralLut& lut, const LutHead& head, PoseShared& sh, const LegBits& lb, const Grp<8>& g,
                                            int leg, const LegStatic& ls, const YEntry& yeIn, double myCtr, double advance, int cyc,
                                            int nCycles, int b, bool live, const fpe_plan_out& out, LegCommit* lc, Unit* unit) {
@@ -2365,7 +2420,9 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     // ---- x side: this lane's track position and corner (cpp:2199, 2414; see leg_phase_bits8) ----
     const double nxq = (myCtr + advance) + ls.biasX;
     const double ny = ye.ny;
-    const bool wantDefault = out.default_next != nullptr;
+    // (kNoDefault: the launch writes no default-track product — compile-time, see specialise_products: the default-track disc is
+    // neither loaded nor tested; its lanes of the x pass still run, in the same instructions as the others)
+    const bool wantDefault = kNoDefault ? false : out.default_next != nullptr;
     const double xq = nxq + role.hqS;  // a - h == a + (-h)
     const double qf = ((xq - m.g.orgX) - m.g.posX) * m.g.rinv;
     const double kq = trunc(qf);
@@ -2373,16 +2430,16 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     const bool safe = (fr > hc.cornerEps && fr < hc.oneMinusEps && qf < role.qHi && qf > role.qLo) || g.sub == 7;
     const int idxq = -static_cast<int>(kq);
     constexpr int kKeep = (~(G - 1)) & 0x1F;
-    const int i0d = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (0 << 5));
-    const int i1d = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (1 << 5));
-    const int i0r = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (2 << 5));
-    const int i1r = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (3 << 5));
-    const int ici = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (4 << 5));
-    const int i0f = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (5 << 5));
-    const int i1f = __builtin_amdgcn_ds_swizzle(idxq, kKeep | (6 << 5));
-    const double cx = swizzle_f64<kKeep | (0 << 5)>(nxq);   // centre from the CENTROID track (cpp:861-862)
-    const double nx0 = swizzle_f64<kKeep | (5 << 5)>(nxq);  // default track
-    const double nx2 = swizzle_f64<kKeep | (7 << 5)>(nxq);  // nominal track (search polygon)
+    const int i0d = bcast8_dpp<0>(idxq);
+    const int i1d = bcast8_dpp<1>(idxq);
+    const int i0r = bcast8_dpp<2>(idxq);
+    const int i1r = bcast8_dpp<3>(idxq);
+    const int ici = bcast8_dpp<4>(idxq);
+    const int i0f = bcast8_dpp<5>(idxq);
+    const int i1f = bcast8_dpp<6>(idxq);
+    const double cx = bcast8_dpp_f64<0>(nxq);   // centre from the CENTROID track (cpp:861-862)
+    const double nx0 = bcast8_dpp_f64<5>(nxq);  // default track
+    const double nx2 = bcast8_dpp_f64<7>(nxq);  // nominal track (search polygon)
     const int j0d = ye.j0d, icj = ye.jc;
     // the window rows are requested before anything else looks at the indices (win_issue clamps whatever it is given;
     // the rare path below discards them): the round trip runs under the box tests, the ballot and the submap arithmetic
@@ -2391,9 +2448,13 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     win_issue<G, NRL, KW>(bm, m.g, g, iw0, jw0, grp);
     // both foot-disc boxes: 3x3 and clear of the map's outermost rows / columns (not clamped, inside the map)
     // (bitwise: a short-circuit chain is compiled into exec-mask branches)
-    const int lowest = min(min(i0d, i0f), j0d), lastRow = max(i0d, i0f) + 4;
-    const bool boxes = ((i1d - i0d) == 2) & ((i1f - i0f) == 2) & (ye.njd == 3) & (lowest >= 1) & (lastRow <= m.g.rows) & (j0d + 4 <= m.g.cols);
-    const bool rare = !ls.radiusOk | ((ye.flags & 2) == 0) | !(fabs(nxq) <= 1e6) | !wantDefault | !safe | !boxes;
+    const int lowest = kNoDefault ? min(i0d, j0d) : min(min(i0d, i0f), j0d), lastRow = (kNoDefault ? i0d : max(i0d, i0f)) + 4;
+    const bool boxF = kNoDefault ? true : ((i1f - i0f) == 2);
+    const bool boxes = ((i1d - i0d) == 2) & boxF & (ye.njd == 3) & (lowest >= 1) & (lastRow <= m.g.rows) & (j0d + 4 <= m.g.cols);
+    // (kNoDefault: lanes 5-6 evaluate default-track corners nobody reads: their `safe` / magnitude tests do not count)
+    const bool dfltLane = (g.sub == 5) | (g.sub == 6);
+    const bool laneOk = kNoDefault ? (dfltLane | (safe & (fabs(nxq) <= 1e6))) : (safe & (fabs(nxq) <= 1e6));
+    const bool rare = !ls.radiusOk | ((ye.flags & 2) == 0) | !laneOk | (!kNoDefault & !wantDefault) | !boxes;
     if (__ballot(rare) != 0ull) {  // wave-uniform
         const double ctr0 = swizzle_f64<kKeep | (5 << 5)>(myCtr), ctr1 = swizzle_f64<kKeep | (0 << 5)>(myCtr),
                      ctr2 = swizzle_f64<kKeep | (7 << 5)>(myCtr);
@@ -2424,16 +2485,19 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     const double dxA = cell_pos(m.g.baseX, m.g.res, i0d + a) - cx;
     const double dxB = cell_pos(m.g.baseX, m.g.res, i0f + a) - nx0;
     const bool visA = (dxA * dxA + dy2) <= hc.rf2;  // CircleIterator::isInside (cell_in_disc)
-    const bool visB = (dxB * dxB + dy2) <= hc.rf2;
+    const bool visB = kNoDefault ? false : (dxB * dxB + dy2) <= hc.rf2;
     // (32-bit cell offsets from the uniform layer base: bits_supported bounds the layer below 2 GiB)
     const unsigned colsU = static_cast<unsigned>(m.g.cols);
     const unsigned laneCell = __umul24(static_cast<unsigned>(a), colsU) + static_cast<unsigned>(bq);
     const unsigned boxA = __umul24(static_cast<unsigned>(i0d), colsU) + static_cast<unsigned>(j0d);
     const unsigned boxB = __umul24(static_cast<unsigned>(i0f), colsU) + static_cast<unsigned>(j0d);
     const float eA = load_cell(m.elev, boxA + laneCell);
-    const float eB = load_cell(m.elev, boxB + laneCell);
     const float eMidA = load_cell(m.elev, boxA + colsU + 1u);
-    const float eMidB = load_cell(m.elev, boxB + colsU + 1u);
+    float eB = 0.0f, eMidB = 0.0f;
+    if constexpr (!kNoDefault) {
+        eB = load_cell(m.elev, boxB + laneCell);
+        eMidB = load_cell(m.elev, boxB + colsU + 1u);
+    }
     // In the shadow of that round trip: the rows of the search rectangle, which only a spiral search uses — but most
     // wavefronts have one leg in eight that needs it (88 % of the headline's cycles), and these forty instructions
     // would otherwise sit on the dependent chain behind the default check.  (Moving the candidates' window addresses
@@ -2467,9 +2531,9 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     const CentroidScan sc = rows_from_bits<G, NRL, KW>(sm, w, g, iw0, jw0, &ye.rmask);
     stamp(pc, cyc, 4);
     // ---- checkDefaultFoothold: the lanes owning the box's three window rows test their Df bits under the members ----
-    const unsigned mA = static_cast<unsigned>(g.ballot(visA)), mB = static_cast<unsigned>(g.ballot(visB));
+    const unsigned mA = static_cast<unsigned>(g.ballot(visA)), mB = kNoDefault ? 0u : static_cast<unsigned>(g.ballot(visB));
     // the nine membership bits in CircleIterator order (the middle cell is always a member)
-    const unsigned visA9 = (mA & 0xFu) | 0x10u | ((mA & 0xF0u) << 1), visB9 = (mB & 0xFu) | 0x10u | ((mB & 0xF0u) << 1);
+    const unsigned visA9 = (mA & 0xFu) | 0x10u | ((mA & 0xF0u) << 1), visB9 = kNoDefault ? 0u : ((mB & 0xFu) | 0x10u | ((mB & 0xF0u) << 1));
     bool fail = false;
     {
         const unsigned sh3 = static_cast<unsigned>(j0d - jw0) & 31u;
@@ -2485,8 +2549,10 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
     // ---- deposits for flush_unit: elevations in CircleIterator order ----
     unit->eA[t] = eA;
     unit->eA[4] = eMidA;  // every lane stores the same value
-    unit->eB[t] = eB;
-    unit->eB[4] = eMidB;
+    if constexpr (!kNoDefault) {
+        unit->eB[t] = eB;
+        unit->eB[4] = eMidB;
+    }
     stamp(pc, cyc, 5);
     // ---- centroid method (cpp:1684-1952) as selects ----
     const int bottomRow = sm.ni - 1, rightCol = sm.nj - 1;
@@ -2538,6 +2604,7 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
         // evaluation as spiral_bits: x interval as in rectangle_index_bounds, columns from the y entry, pass rows
         // P = ~F | (~C & inside) in the leg's LDS, lowest set ballot bit = first valid cell in spiral order.
         if (fastSpiral) {
+#ifdef FPE_FAST16_LDS
             const int NR = lb.rows;
 #pragma unroll
             for (int k = 0; k < NRL; ++k) {
@@ -2565,6 +2632,34 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
             wj = icj + (eWin >> 16);
             searched = lk.nCand <= G * kLutHeadRounds;  // nothing beyond the two rounds
             bits_sync<G>();
+#else
+            // this lane's row of the five around the centre (FastRanks): pass bits P = ~F | (~C & inside) (cpp:2132-2138)
+            unsigned Fs = w.F[0][0], Cs = w.C[0][0];
+#pragma unroll
+            for (int k = 1; k < NRL; ++k) {
+                Fs = fk.slot == k ? w.F[k][0] : Fs;
+                Cs = fk.slot == k ? w.C[k][0] : Cs;
+            }
+            const int i = iw0 + g.sub + G * fk.slot;
+            const unsigned inside = (i >= iA && i <= iB) ? ye.pmask : 0u;
+            unsigned P = ~Fs | (~Cs & inside);
+            // cells outside the map pass every test (their F bit is 0) but are no candidates: windows over the map's edge only
+            const bool border = (iw0 < 0) | (jw0 < 0) | (iw0 + G * NRL > m.g.rows) | (jw0 + 32 > m.g.cols);
+            if (__ballot(border) != 0ull) {  // wave-uniform, rare
+                const unsigned colIn = range_word(-jw0, m.g.cols - 1 - jw0, 0);
+                P = static_cast<unsigned>(i) < static_cast<unsigned>(m.g.rows) ? (P & colIn) : 0u;
+            }
+            const unsigned b5 = P >> static_cast<unsigned>(pc.winH - 2);  // bit c = column offset c - 2 from the centre column (winH)
+            unsigned m16 = 0u;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) m16 |= ((b5 >> c) & 1u) << ((fk.rowTab >> (5 * c)) & 31u);  // (rank 31: not a candidate)
+            const unsigned all16 = or_reduce8(m16) & 0xFFFFu;
+            found = all16 != 0u;
+            const unsigned rank4 = static_cast<unsigned>(__builtin_ctz(all16 | 0x10000u) & 15) * 4u;
+            wi = ici + static_cast<int>((fk.di >> rank4) & 7ull) - 2;
+            wj = icj + static_cast<int>((fk.dj >> rank4) & 7ull) - 2;
+            searched = lk.nCand <= 16;  // nothing beyond the sixteen
+#endif
         }
         if (!found && !searched) {  // other polygons, larger foot discs, small search radii, or no hit in the first two rounds
             LegCtx c;
@@ -2636,16 +2731,49 @@ __device__ __forceinline__ void leg_fast8m(const DevMap& m, const BitMap& bm, co
 
 }  // namespace
 
+// ---- products as a compile-time mask --------------------------------------------------------------------------------
+// Which of fpe_plan_out's products a launch writes is a run-time null test per product in the generic instantiation
+// (kProd = 0: any combination).  The two shapes that matter are compiled on their own: kProd = 2, ALL seven base products
+// (bench.py's headline step, fpe_plan with every array: the tests fold away) and kProd = 1, the NOMINAL track only —
+// {nominal, selected, selected_packed, cycle_ok}: the service's response (cpp:1588) and the multi-GPU exchange record —
+// where the default-track disc (its loads, membership, deposits and height sums), the centroid result's height and record,
+// the stance and the first-cycle gate are not compiled at all.  The engine picks the instantiation from the pointers.
+template <int kProd>
+__device__ __forceinline__ fpe_plan_out specialise_products(fpe_plan_out out) {
+    if constexpr (kProd == 1) {
+        out.centroid = nullptr;
+        out.default_next = nullptr;
+        out.stance = nullptr;
+        out.pose_status = nullptr;
+    } else if constexpr (kProd == 2) {
+        __builtin_assume(out.nominal != nullptr);
+        __builtin_assume(out.centroid != nullptr);
+        __builtin_assume(out.default_next != nullptr);
+        __builtin_assume(out.cycle_ok != nullptr);
+        __builtin_assume(out.stance != nullptr);
+        __builtin_assume(out.selected != nullptr);
+        __builtin_assume(out.pose_status != nullptr);
+    }
+    return out;
+}
+__host__ inline int product_shape(const fpe_plan_out& o) {
+    if (o.nominal && o.centroid && o.default_next && o.cycle_ok && o.stance && o.selected && o.pose_status) return 2;
+    if (!o.centroid && !o.default_next && !o.stance && !o.pose_status) return 1;
+    return 0;
+}
+
 // ---- chained plan on the bit window: 8 lanes per leg, two poses per wavefront ------------------------------------
 #ifndef FPE_BITS_GENERIC_WAVES
 #define FPE_BITS_GENERIC_WAVES 3  // measured on cfg-4: 2 -> 1.36 ms, 3 -> 1.25 ms (27 spilled VGPRs), 4 -> 1.46 ms (69 spilled)
 #endif
-template <int NRL, bool kMid>
+template <int NRL, bool kMid, int kProd>
 // (the pose pointer and the counts lead the argument list: scalar arguments at the head of the kernarg segment are
 // preloaded into SGPRs at wave launch, -amdgpu-kernarg-preload-count, so the pose loads can be issued at once)
 __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bits_kernel(const fpe_pose* __restrict__ poses, int B, int nCycles,
-                                                          DevMap mArg, BitMap bm, PlanConsts pc, SpiralLut lut, fpe_plan_out out) {
+                                                          DevMap mArg, BitMap bm, PlanConsts pc, SpiralLut lut, fpe_plan_out outArg) {
     constexpr int G = 8;
+    const fpe_plan_out out = specialise_products<kProd>(outArg);
+    constexpr bool kNoDefault = kProd == 1;
     constexpr int NR = G * NRL;
     constexpr int kPoseThreads = 4 * G;
     const int tid = static_cast<int>(threadIdx.x);
@@ -2820,6 +2948,8 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
     const int myTrack = kMid ? lane_track(g.sub) : (g.sub < 2 ? g.sub : 2);
     LaneRole role{};
     if constexpr (kMid) role = make_lane_role(g.sub, pc.rf, ls.lk.lx, pc.cornerEps, static_cast<double>(mArg.g.rows));
+    FastRanks fr{};
+    if constexpr (kMid) fr = load_fast_ranks<NRL>(lut, g, pc.winH);
     uint32_t okBits = 0u;  // cycleOk of the cycles since the last flush (3x3-only kernels: stored by flush_unit)
 
     for (int cyc = 0; cyc < nCycles; ++cyc) {
@@ -2852,8 +2982,8 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
             lc.valid = 1;  // non-swing legs do not vote
             if (active) {
                 if constexpr (kMid) {
-                    leg_fast8m<NRL>(m, bm, pc, hc, role, lut, head, sh, lb, g, leg, ls, ye, myCtr, advance, cyc, nCycles, b, live, out, &lc,
-                                    units + (cyc & (kBatch - 1)));
+                    leg_fast8m<NRL, kNoDefault>(m, bm, pc, hc, role, fr, lut, head, sh, lb, g, leg, ls, ye, myCtr, advance, cyc, nCycles, b, live, out, &lc,
+                                                units + (cyc & (kBatch - 1)));
                 } else {
                     constexpr int kKeep = (~(G - 1)) & 0x1F;
                     const double ctr0 = swizzle_f64<kKeep | (0 << 5)>(myCtr), ctr1 = swizzle_f64<kKeep | (1 << 5)>(myCtr),
@@ -2899,10 +3029,11 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
 
 // ---- chained plan on the bit window, sequential-legs form (large windows): one wavefront per pose, lane = window
 // row, KW words per row; the swing legs of a phase are searched one after the other (see plan_sequential_kernel) ----
-template <int NRL, int KW>
+template <int NRL, int KW, int kProd>
 __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap bm, PlanConsts pc, SpiralLut lut,
-                                                              const fpe_pose* __restrict__ poses, int B, int nCycles, fpe_plan_out out, int recSlots) {
+                                                              const fpe_pose* __restrict__ poses, int B, int nCycles, fpe_plan_out outArg, int recSlots) {
     constexpr int G = 64;
+    const fpe_plan_out out = specialise_products<kProd>(outArg);
     constexpr int NR = G * NRL;
     stamp(pc, 6, 14);  // (profiling builds: lifetime of the wavefront, with the stamp after the cycle loop)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -3136,11 +3267,18 @@ hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts&
     const BitsShape sp = bits_shape(pc.winH);
     const bool mid = mid_variant(pc, m.g.res) && pc.nFoot == 1;  // rf < res: the candidate disc is the candidate's own cell
     const dim3 block(64);
-#define FPE_LAUNCH_BITS(NRL, MID)                                                                                            \
-    hipLaunchKernelGGL((plan_bits_kernel<NRL, MID>), dim3((B + 1) / 2), block,                                              \
+    const int prod = product_shape(d_out);
+#define FPE_LAUNCH_BITS_P(NRL, MID, PROD)                                                                                    \
+    hipLaunchKernelGGL((plan_bits_kernel<NRL, MID, PROD>), dim3((B + 1) / 2), block,                                        \
                        2 * (sizeof(PoseShared) + 16 * legbits_words(8 * NRL, 1, pc.nHW, false) +                                      \
                             (MID ? (sizeof(YEntry) + sizeof(Unit)) * 32 : (sizeof(YEntry) + sizeof(UnitG)) * 16)), stream, d_poses, B,  \
                        nCycles, m, bm, pc, lut, d_out)
+#define FPE_LAUNCH_BITS(NRL, MID)                                  \
+    do {                                                           \
+        if (prod == 2) FPE_LAUNCH_BITS_P(NRL, MID, 2);             \
+        else if (prod == 1) FPE_LAUNCH_BITS_P(NRL, MID, 1);        \
+        else FPE_LAUNCH_BITS_P(NRL, MID, 0);                       \
+    } while (0)
 #define FPE_LAUNCH_BITS_SEQ(NRL, KW)                                                                                         \
     do {                                                                                                                     \
         const size_t base = (sizeof(PoseShared) + ((4 * sizeof(LegStatic) + 15) & ~static_cast<size_t>(15)) +                            \
@@ -3148,8 +3286,13 @@ hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts&
                             ~static_cast<size_t>(15);                                                                                 \
         int recSlots = 8; /* cycles of staged records: as many as keep sixteen blocks per CU (10 KiB each) */                      \
         while (recSlots > 1 && base + recSlots * 4 * sizeof(SeqRecOf<KW>) > 10240) recSlots >>= 1;                                   \
-        hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW>), dim3(B), block, base + recSlots * 4 * sizeof(SeqRecOf<KW>), stream, m, bm, pc, \
-                           lut, d_poses, B, nCycles, d_out, recSlots);                                                                \
+        /* (the all-seven shape takes the generic instantiation here: compiled on its own it spills more — cfg-5 +2 %, cfg-3 0) */     \
+        if (prod == 1)                                                                                                              \
+            hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW, 1>), dim3(B), block, base + recSlots * 4 * sizeof(SeqRecOf<KW>), stream, m, bm, pc, \
+                               lut, d_poses, B, nCycles, d_out, recSlots);                                                                \
+        else                                                                                                                             \
+            hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW, 0>), dim3(B), block, base + recSlots * 4 * sizeof(SeqRecOf<KW>), stream, m, bm, pc, \
+                               lut, d_poses, B, nCycles, d_out, recSlots);                                                                \
     } while (0)
     if (sp.lanes == 8) {
         if (sp.nrl == 2 && mid) FPE_LAUNCH_BITS(2, true);
@@ -3165,6 +3308,7 @@ hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts&
         return hipErrorInvalidValue;
     }
 #undef FPE_LAUNCH_BITS
+#undef FPE_LAUNCH_BITS_P
 #undef FPE_LAUNCH_BITS_SEQ
     return hipGetLastError();
 }

@@ -28,7 +28,13 @@ struct SpiralLut {
     // entry k as one word, (di & 0xFF) | (dj & 0xFF) << 8 | ring << 16, padded with (0, 0, 255) to a multiple of 32 entries
     // plus one more group of 32: the 8-lane bit-window kernels read four consecutive entries per lane and round (uint4)
     const uint32_t* packed;
+    // The first sixteen ranks (ring 0, ring 1, seven cells of ring 2: all within two rows / columns of the centre) by ROW, for
+    // the 3x3-only kernels' LDS-free first rounds (fpe_bits.hpp::leg_fast8m): words 0-4 = row offsets di = -2..2, five 5-bit
+    // fields each (column offset dj = -2..2 -> the rank of (di, dj), 31 = not among the first sixteen); words 6-7 / 8-9 = di + 2
+    // / dj + 2 of rank q in the 4-bit field q of a 64-bit word.  Built by fpe_create from the same table.
+    const uint32_t* fast16;
 };
+constexpr int kFast16Words = 12;
 
 constexpr int kMaxFootOffsets = 128;
 

@@ -375,13 +375,14 @@ struct fpe_engine {
     uint8_t* d_ring = nullptr;
     int32_t* d_ringStart = nullptr;
     uint32_t* d_packed = nullptr;
+    uint32_t* d_fast16 = nullptr;
     int maxRing = 0;
     std::vector<int32_t> ringStart;   // host copy of the rank table's ring offsets
     float maxLegSearchRadius = 0.0f;  // fpe_set_max_leg_search_radius
     fpe::Tuning tuning;               // fpe_set_tuning; seeded from the environment once, in fpe_create
 
     fpe::SpiralLut lut() const {
-        return fpe::SpiralLut{d_di, d_dj, d_ring, d_ringStart, maxRing, ringStart.empty() ? 0 : ringStart[static_cast<size_t>(maxRing) + 1], d_packed};
+        return fpe::SpiralLut{d_di, d_dj, d_ring, d_ringStart, maxRing, ringStart.empty() ? 0 : ringStart[static_cast<size_t>(maxRing) + 1], d_packed, d_fast16};
     }
 };
 
@@ -638,6 +639,32 @@ int fpe_create(int device_id, fpe_handle* out) {
             packed[k] = (static_cast<uint32_t>(t.di[k]) & 0xFFu) | ((static_cast<uint32_t>(t.dj[k]) & 0xFFu) << 8) | (static_cast<uint32_t>(t.ring[k]) << 16);
         FPE_HIP_C(hipMalloc(reinterpret_cast<void**>(&h->d_packed), packed.size() * sizeof(uint32_t)));
         FPE_HIP_C(hipMemcpy(h->d_packed, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        // SpiralLut::fast16: the first sixteen ranks by row (they all lie within two cells of the centre: rings 0-2)
+        uint32_t fast[fpe::kFast16Words] = {0};
+        for (int r = 0; r < 5; ++r) fast[r] = 0x1FFFFFFu;  // five 5-bit fields, 31 = none
+        unsigned long long tdi = 0ull, tdj = 0ull;
+        bool fastOk = n >= 16;
+        for (size_t q = 0; q < 16 && fastOk; ++q) {
+            const int di = t.di[q], dj = t.dj[q];
+            if (di < -2 || di > 2 || dj < -2 || dj > 2) {
+                fastOk = false;
+                break;
+            }
+            uint32_t& w = fast[di + 2];
+            w = (w & ~(31u << (5 * (dj + 2)))) | (static_cast<uint32_t>(q) << (5 * (dj + 2)));
+            tdi |= static_cast<unsigned long long>(di + 2) << (4 * q);
+            tdj |= static_cast<unsigned long long>(dj + 2) << (4 * q);
+        }
+        if (!fastOk) {
+            cleanup();
+            return fail(FPE_E_HIP, "spiral table: the first sixteen ranks do not lie within two cells of the centre");
+        }
+        fast[6] = static_cast<uint32_t>(tdi);
+        fast[7] = static_cast<uint32_t>(tdi >> 32);
+        fast[8] = static_cast<uint32_t>(tdj);
+        fast[9] = static_cast<uint32_t>(tdj >> 32);
+        FPE_HIP_C(hipMalloc(reinterpret_cast<void**>(&h->d_fast16), sizeof(fast)));
+        FPE_HIP_C(hipMemcpy(h->d_fast16, fast, sizeof(fast), hipMemcpyHostToDevice));
     }
     // every kernel may use the whole 160 KiB of LDS: set once per process and device, never lowered again (a
     // second engine on the same device sets the same value)
@@ -656,6 +683,7 @@ int fpe_destroy(fpe_handle h) {
     if (h->d_ring) (void)hipFree(h->d_ring);
     if (h->d_ringStart) (void)hipFree(h->d_ringStart);
     if (h->d_packed) (void)hipFree(h->d_packed);
+    if (h->d_fast16) (void)hipFree(h->d_fast16);
     h->map.reset();
     delete h;
     return FPE_OK;

@@ -214,6 +214,11 @@ int ensure_streams(fpe_multi* h) {
 
 int ensure_comms(fpe_multi* h) {
     if (!h->comms.empty()) return FPE_OK;
+    // (a group may list one device several times — independent engines for the host-buffer form — but a communicator needs
+    // distinct devices)
+    for (size_t a = 0; a < h->devices.size(); ++a)
+        for (size_t b = a + 1; b < h->devices.size(); ++b)
+            if (h->devices[a] == h->devices[b]) return mfail(h, FPE_E_UNSUPPORTED, "the RCCL all-gather needs distinct devices: one appears twice in the group");
     Rccl& r = rccl();
     if (!r.ok) return mfail(h, FPE_E_UNSUPPORTED, "RCCL unavailable: " + r.err);
     std::vector<ncclComm_t> comms(h->engines.size(), nullptr);
@@ -231,9 +236,6 @@ int fpe_multi_create(const int32_t* device_ids, int32_t n_devices, fpe_multi_han
     if (!out) return mfail(nullptr, FPE_E_INVALID_ARG, "null out handle");
     *out = nullptr;
     if (!device_ids || n_devices <= 0 || n_devices > 64) return mfail(nullptr, FPE_E_INVALID_ARG, "bad device list");
-    for (int a = 0; a < n_devices; ++a)
-        for (int b = a + 1; b < n_devices; ++b)
-            if (device_ids[a] == device_ids[b]) return mfail(nullptr, FPE_E_INVALID_ARG, "a device appears twice in the list");
     fpe_multi* h = new (std::nothrow) fpe_multi();
     if (!h) return mfail(nullptr, FPE_E_NOMEM, "out of host memory");
     for (int k = 0; k < n_devices; ++k) {

@@ -246,7 +246,14 @@ def test_service_gate_kinds_default_advisory_enforce(planner):
     pos += [[rng.uniform(-2.5, -1.0), rng.uniform(-1, 1), 0.0] for _ in range(4)]
     n = 8
     kinds = {k: 0 for k in range(4)}
-    for p in pos:
+    harsh = synth.rough_map(400, 400, 0.02, seed=1, bad_frac=0.45)  # terrain on which the opt track derails: x side, build-defined
+    hmap = fpo.OracleMap(harsh[0], harsh[1], 0.02)
+    rng2 = np.random.default_rng(91)
+    hpos = [[rng2.uniform(-3.2, -2.0), rng2.uniform(-3, 3), 0.25] for _ in range(16)]
+    for p in pos + hpos:
+        if p is hpos[0]:
+            planner.gridmapCallback(harsh[0], harsh[1], 0.02)
+            omap = hmap
         for mode in (0, 1, 2):
             refuse, kind, cyc = util.oracle_service_verdict(omap, planner, p, n, opt_gate=mode)
             with planner.tuning(service_opt_gate=mode):
@@ -407,9 +414,38 @@ def test_bench_two_ranks_on_one_gpu(config, batch):
     assert "one collective per 2 steps" in line["config"]["exchange"]  # every step's records, batched (3 steps: a trailing partial batch)
     assert line["config"]["verified"] is True
     assert line["config"]["footholds_per_step"] == 2 * batch * line["config"]["n_cycles"] * 4
-    assert line["config"]["exchange_bytes_per_rank"] == batch * line["config"]["n_cycles"] * 4 * 16
+    assert line["config"]["exchange_bytes_per_rank"] == batch * line["config"]["n_cycles"] * 4 * 8  # the packed 8-byte record
+    assert "fpe_selected_packed" in line["config"]["exchange"]
     assert line["config"]["exchange_alt"]["gather_every"] == 1
+    assert line["config"]["step_bound_at_this_n"]["by_direct_links"] in ("plan", "exchange")
     assert line["value"] > 0 and "roofline" in line
+
+
+@pytest.mark.parametrize("record", ["packed", "selected"])
+def test_bench_runs_its_exchange_through_rccl_in_a_one_rank_group(record):
+    """RCCL for real on the 1-GPU box (VERDICT r3 task 3a): `bench.py --gpus 1` in a fresh process with the nccl backend and
+    the collectives forced at world size 1 (FPE_BENCH_FORCE_NCCL=1): init_process_group("nccl"), all_gather_into_tensor on
+    the device records the plan kernel wrote, BatchedFootholdExchange's work-handle waits against RCCL's stream, barrier and
+    all_reduce — and the gathered records equal the oracle's."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FPE_BENCH_FORCE_NCCL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "FPE_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--config", "headline", "--batch", "1024",
+                        "--steps", "7", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--gather-every", "3", "--exchange-record", record],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    ex = line["config"]["exchange"]
+    assert "backend nccl, 1 rank in the process group" in ex and "collective forced" in ex
+    assert ("fpe_selected_packed" in ex) == (record == "packed")
+    assert "one collective per 3 steps" in ex and " 4 collectives issued" in ex  # warm-up (2 steps: 1 flush) + 7 timed steps: 3
+    assert line["config"]["verified"] is True and line["n_gpus"] == 1
 
 
 @pytest.mark.parametrize("B", [4096, 1000, 37])
