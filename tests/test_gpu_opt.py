@@ -175,7 +175,7 @@ def test_rows_after_are_what_the_next_cycle_would_use(planner):
     assert ran.sum() > 50
     assert np.array_equal(eng["rows_after"][ran, 0], ora["cycles"]["lf_current_row"][ran, n])
     assert np.array_equal(eng["rows_after"][ran, 1], ora["cycles"]["rh_current_row"][ran, n])
-    assert (eng["rows_after"][ran] != 0).any() and (ora["cycles"]["committed"][ran, :n] == 0).any()
+    assert (eng["rows_after"][ran] != 0).any()
     with planner.tuning(service_opt_gate=1):
         for b in np.nonzero(ran)[0][:6]:
             r = planner.globalFootholdPlan(n, poses["position"][b])
