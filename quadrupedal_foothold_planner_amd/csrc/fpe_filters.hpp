@@ -166,6 +166,71 @@ __device__ __forceinline__ void jacobi_rotate(double& app, double& aqq, double& 
     }
 }
 
+// The symmetric 3 x 3 eigenproblem of a cell's scatter matrix -> the normal (eigenvector of the smallest eigenvalue, first of
+// equals; z axis for a rank-deficient matrix; pointing up), cyclic Jacobi as in oracle/fpo_filters.cpp.  wS / wL: smallest
+// eigenvalue and the scale it is compared with.
+__device__ __forceinline__ void normal_from_scatter(double a00, double a01, double a02, double a11, double a12, double a22, double& ex, double& ey,
+                                                    double& ez, double& wS, double& wL) {
+    double v0[3] = {1.0, 0.0, 0.0}, v1[3] = {0.0, 1.0, 0.0}, v2[3] = {0.0, 0.0, 1.0};  // columns of V
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        const double off = fabs(a01) + fabs(a02) + fabs(a12);
+        if (off == 0.0) break;
+        jacobi_rotate(a00, a11, a01, a02, a12, v0, v1);  // (p, q, r) = (0, 1, 2)
+        jacobi_rotate(a00, a22, a02, a01, a12, v0, v2);  // (0, 2, 1)
+        jacobi_rotate(a11, a22, a12, a01, a02, v1, v2);  // (1, 2, 0)
+    }
+    // the eigenvector of the smallest eigenvalue (first of equals); rank-deficient covariance -> z axis
+    wS = a00;
+    ex = v0[0]; ey = v0[1]; ez = v0[2];
+    if (a11 < wS) { wS = a11; ex = v1[0]; ey = v1[1]; ez = v1[2]; }
+    if (a22 < wS) { wS = a22; ex = v2[0]; ey = v2[1]; ez = v2[2]; }
+    wL = fmax(fmax(fmax(a00, 0.0), a11), a22);
+    if (!(wS > 3.0 * DBL_EPSILON * wL)) { ex = 0.0; ey = 0.0; ez = 1.0; }
+    if (ez < 0.0) { ex = -ex; ey = -ey; ez = -ez; }
+}
+
+// One cell of NormalVectorsFilter (area method) + SlopeFilter [+ RoughnessFilter of the same radius] by the LITERAL walks of
+// the published filters (points, mean, scatter about the mean, plane distances: three passes over the iterator's members).
+__device__ __forceinline__ void normals_cell_exact(const DiscLds& d, int li, int lj, int ti0, int tj0, double r, double slopeCritical, int fuseRough,
+                                                   double roughCritical, float& ox, float& oy, float& oz, float& os, float& orough) {
+    const double r2 = r * r;
+    int np = 0;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    disc_walk(d, li, lj, ti0, tj0, r2, [&](double x, double y, float z) {
+        if (isfinite(z)) { ++np; sx += x; sy += y; sz += static_cast<double>(z); }
+    });
+    const double nd = static_cast<double>(np);
+    const double mx = sx / nd, my = sy / nd, mz = sz / nd;
+    double a00 = 0.0, a01 = 0.0, a02 = 0.0, a11 = 0.0, a12 = 0.0, a22 = 0.0;
+    disc_walk(d, li, lj, ti0, tj0, r2, [&](double x, double y, float z) {
+        if (isfinite(z)) {
+            const double dx = x - mx, dy = y - my, dz = static_cast<double>(z) - mz;
+            a00 += dx * dx; a01 += dx * dy; a02 += dx * dz;
+            a11 += dy * dy; a12 += dy * dz; a22 += dz * dz;
+        }
+    });
+    double ex, ey, ez, wS, wL;
+    normal_from_scatter(a00, a01, a02, a11, a12, a22, ex, ey, ez, wS, wL);
+    ox = static_cast<float>(ex);
+    oy = static_cast<float>(ey);
+    oz = static_cast<float>(ez);
+    const double slope = acos(static_cast<double>(oz));  // SlopeFilter reads the float layer
+    os = slope < slopeCritical ? static_cast<float>(1.0 - slope / slopeCritical) : 0.0f;
+    if (fuseRough) {  // RoughnessFilter::update with the float normals just written
+        const double normalX = ox, normalY = oy, normalZ = oz;
+        const double planeParameter = mx * normalX + my * normalY + mz * normalZ;
+        double sum = 0.0;
+        disc_walk(d, li, lj, ti0, tj0, r2, [&](double x, double y, float z) {
+            if (isfinite(z)) {
+                const double dist = normalX * x + normalY * y + normalZ * static_cast<double>(z) - planeParameter;
+                sum += dist * dist;
+            }
+        });
+        const double roughness = sqrt(sum / (nd - 1.0));
+        orough = roughness < roughCritical ? static_cast<float>(1.0 - roughness / roughCritical) : 0.0f;
+    }
+}
+
 // NormalVectorsFilter (area method) + SlopeFilter; with fuseRough also the RoughnessFilter of the same radius (same
 // members in the same order, hence the same point count and mean: one walk and one tile load less than its own launch).
 __global__ __launch_bounds__(256) void filter_normals_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double r, int H, double slopeCritical,
@@ -180,54 +245,162 @@ __global__ __launch_bounds__(256) void filter_normals_kernel(MapGeom g, const fl
     const size_t cell = static_cast<size_t>(i) * g.cols + j;
     const float nanf = __builtin_nanf("");
     float ox = nanf, oy = nanf, oz = nanf, os = nanf, orough = nanf;
-    if (isfinite(d.tile[(li + H) * d.W + lj + H])) {
-        const double r2 = r * r;
-        int np = 0;
-        double sx = 0.0, sy = 0.0, sz = 0.0;
-        disc_walk(d, li, lj, ti0, tj0, r2, [&](double x, double y, float z) {
-            if (isfinite(z)) { ++np; sx += x; sy += y; sz += static_cast<double>(z); }
-        });
-        const double nd = static_cast<double>(np);
-        const double mx = sx / nd, my = sy / nd, mz = sz / nd;
-        double a00 = 0.0, a01 = 0.0, a02 = 0.0, a11 = 0.0, a12 = 0.0, a22 = 0.0;
-        disc_walk(d, li, lj, ti0, tj0, r2, [&](double x, double y, float z) {
-            if (isfinite(z)) {
-                const double dx = x - mx, dy = y - my, dz = static_cast<double>(z) - mz;
-                a00 += dx * dx; a01 += dx * dy; a02 += dx * dz;
-                a11 += dy * dy; a12 += dy * dz; a22 += dz * dz;
-            }
-        });
-        double v0[3] = {1.0, 0.0, 0.0}, v1[3] = {0.0, 1.0, 0.0}, v2[3] = {0.0, 0.0, 1.0};  // columns of V
-        for (int sweep = 0; sweep < 12; ++sweep) {
-            const double off = fabs(a01) + fabs(a02) + fabs(a12);
-            if (off == 0.0) break;
-            jacobi_rotate(a00, a11, a01, a02, a12, v0, v1);  // (p, q, r) = (0, 1, 2)
-            jacobi_rotate(a00, a22, a02, a01, a12, v0, v2);  // (0, 2, 1)
-            jacobi_rotate(a11, a22, a12, a01, a02, v1, v2);  // (1, 2, 0)
-        }
-        // the eigenvector of the smallest eigenvalue (first of equals); rank-deficient covariance -> z axis
-        double wS = a00, ex = v0[0], ey = v0[1], ez = v0[2];
-        if (a11 < wS) { wS = a11; ex = v1[0]; ey = v1[1]; ez = v1[2]; }
-        if (a22 < wS) { wS = a22; ex = v2[0]; ey = v2[1]; ez = v2[2]; }
-        const double wL = fmax(fmax(fmax(a00, 0.0), a11), a22);
-        if (!(wS > 3.0 * DBL_EPSILON * wL)) { ex = 0.0; ey = 0.0; ez = 1.0; }
-        if (ez < 0.0) { ex = -ex; ey = -ey; ez = -ez; }
-        ox = static_cast<float>(ex);
-        oy = static_cast<float>(ey);
-        oz = static_cast<float>(ez);
-        const double slope = acos(static_cast<double>(oz));  // SlopeFilter reads the float layer
-        os = slope < slopeCritical ? static_cast<float>(1.0 - slope / slopeCritical) : 0.0f;
-        if (fuseRough) {  // RoughnessFilter::update with the float normals just written
-            const double normalX = ox, normalY = oy, normalZ = oz;
-            const double planeParameter = mx * normalX + my * normalY + mz * normalZ;
-            double sum = 0.0;
-            disc_walk(d, li, lj, ti0, tj0, r2, [&](double x, double y, float z) {
-                if (isfinite(z)) {
-                    const double dist = normalX * x + normalY * y + normalZ * static_cast<double>(z) - planeParameter;
-                    sum += dist * dist;
+    if (isfinite(d.tile[(li + H) * d.W + lj + H])) normals_cell_exact(d, li, lj, ti0, tj0, r, slopeCritical, fuseRough, roughCritical, ox, oy, oz, os, orough);
+    L.nx[cell] = ox;
+    L.ny[cell] = oy;
+    L.nz[cell] = oz;
+    L.slope[cell] = os;
+    if (fuseRough) L.rough[cell] = orough;
+}
+
+// ---- the same three filters by ROW MOMENTS (round 4) -----------------------------------------------------------------------
+// A cell's disc is at most 2H + 1 row intervals (disc_walk: the members of a row are one interval).  Everything the three
+// filters need of the members — count, mean, the 3 x 3 scatter matrix about the mean, and the sum of squared plane
+// distances, which for the plane through the mean is n^T A n — is a function of the members' MOMENTS, and a row interval's
+// moments are differences of per-row prefix sums: six prefix arrays per tile row in LDS (count, sum of c, sum of c^2 as
+// integers, c = tile column; sum of z', z'^2, c z' in f64, z' = z - z0 with z0 one elevation of the tile), then two LDS
+// reads per quantity and ROW instead of one visit per MEMBER and pass (81 members x 3 passes x ~30 f64 operations at 1 cm).
+// Coordinates enter as exact integers (the lattice), recentred at the cell; metres only scale the finished matrix.
+// Not the oracle's summation order: the scatter matrix agrees with the two-pass walk to ~1e-14 relative (the bar of
+// tests/test_gpu_filters.py is one float ulp and 99.99 % bit-identical cells).  Where that is not enough — a (nearly)
+// rank-deficient matrix, smallest eigenvalue below 1e-10 of the scale: exact planes, flat synthetic ground, fewer than three
+// members, where the rank test and the last bits of a tiny component depend on the summation order — the cell takes the
+// literal walks above instead (wave-divergent; no natural terrain gets there).
+struct MomentLds {
+    int *pN, *pC, *pCC;       // [W][W + 1] prefix over the tile columns: valid cells, sum of c, sum of c^2
+    double *pZ, *pZZ, *pCZ;   // sum of z', z'^2, c z'
+};
+constexpr int kMomentMaxH = 12;
+__host__ __device__ inline size_t moment_lds_bytes(int H) {
+    const int W = kFT + 2 * H;
+    return static_cast<size_t>(W) * (W + 1) * (3 * 4 + 3 * 8) + 16;
+}
+__global__ __launch_bounds__(256) void filter_normals_moments_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double r, int H,
+                                                                      double slopeCritical, double roughCritical) {
+    extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
+    const DiscLds d = disc_carve(ldsRaw, H);
+    const int W = d.W, W1 = W + 1;
+    MomentLds ml;
+    {
+        char* p = ldsRaw + ((disc_lds_bytes(H) + 15) & ~static_cast<size_t>(15));
+        ml.pZ = reinterpret_cast<double*>(p); p += static_cast<size_t>(W) * W1 * 8;
+        ml.pZZ = reinterpret_cast<double*>(p); p += static_cast<size_t>(W) * W1 * 8;
+        ml.pCZ = reinterpret_cast<double*>(p); p += static_cast<size_t>(W) * W1 * 8;
+        ml.pN = reinterpret_cast<int*>(p); p += static_cast<size_t>(W) * W1 * 4;
+        ml.pC = reinterpret_cast<int*>(p); p += static_cast<size_t>(W) * W1 * 4;
+        ml.pCC = reinterpret_cast<int*>(p);
+    }
+    const int ti0 = blockIdx.y * kFT, tj0 = blockIdx.x * kFT;
+    disc_setup(d, g, elev, ti0, tj0, r);
+    // z0: one elevation of the tile (its first interior cell when valid): the prefix sums carry z - z0
+    const float zf = d.tile[H * W + H];
+    const double z0 = zf == zf ? static_cast<double>(zf) : 0.0;
+    {   // one thread per (tile row, quantity): a serial scan over the row's W cells
+        const int t = threadIdx.x;
+        for (int e = t; e < 6 * W; e += 256) {
+            const int row = e / 6, q = e - 6 * row;
+            const float* src = d.tile + row * W;
+            const int o = row * W1;
+            if (q < 3) {
+                int* dst = q == 0 ? ml.pN : (q == 1 ? ml.pC : ml.pCC);
+                int acc = 0;
+                dst[o] = 0;
+                for (int c = 0; c < W; ++c) {
+                    const float z = src[c];
+                    const int term = q == 0 ? 1 : (q == 1 ? c : c * c);
+                    acc += z == z ? term : 0;
+                    dst[o + c + 1] = acc;
                 }
-            });
-            const double roughness = sqrt(sum / (nd - 1.0));
+            } else {
+                double* dst = q == 3 ? ml.pZ : (q == 4 ? ml.pZZ : ml.pCZ);
+                double acc = 0.0;
+                dst[o] = 0.0;
+                for (int c = 0; c < W; ++c) {
+                    const float z = src[c];
+                    const double zz = z == z ? static_cast<double>(z) - z0 : 0.0;
+                    const double term = q == 3 ? zz : (q == 4 ? zz * zz : static_cast<double>(c) * zz);
+                    acc += term;
+                    dst[o + c + 1] = acc;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int li = threadIdx.x / kFT, lj = threadIdx.x % kFT;
+    const int i = ti0 + li, j = tj0 + lj;
+    if (i >= g.rows || j >= g.cols) return;
+    const size_t cell = static_cast<size_t>(i) * g.cols + j;
+    const float nanf = __builtin_nanf("");
+    float ox = nanf, oy = nanf, oz = nanf, os = nanf, orough = nanf;
+    if (isfinite(d.tile[(li + H) * W + lj + H])) {
+        // the iterator's rows and, per row, its column interval: disc_walk's own logic (same members)
+        const int D = 2 * H + 1;
+        const double r2 = r * r;
+        const int i0 = d.bi0[li], i1 = d.bi1[li];
+        const int maxL = j - d.bj0[lj], maxR = d.bj1[lj] - j;
+        const int dyC = lj * D + H, dxC = li * D + H - i;
+        const int cc = lj + H, vc = li + H;  // the cell's own tile column / row
+        int wL = 0, wR = 0;
+        int N = 0, Sc = 0, Scc = 0, Sv = 0, Svv = 0, Svc = 0;  // integer moments about the cell (dc = c - cc, dv = v - vc)
+        double Sz = 0.0, Szz = 0.0, Scz = 0.0, Svz = 0.0;
+        for (int ii = i0; ii <= i1; ++ii) {
+            const double a = d.dx2[dxC + ii];
+            if (!(a <= r2)) continue;
+            wR = min(wR, maxR);
+            wL = min(wL, maxL);
+            while (wR > 0 && !(a + d.dy2[dyC + wR] <= r2)) --wR;
+            while (wR < maxR && a + d.dy2[dyC + wR + 1] <= r2) ++wR;
+            while (wL > 0 && !(a + d.dy2[dyC - wL] <= r2)) --wL;
+            while (wL < maxL && a + d.dy2[dyC - wL - 1] <= r2) ++wL;
+            const int v = ii - ti0 + H, dv = v - vc;
+            const int lo = v * W1 + (cc - wL), hi = v * W1 + (cc + wR + 1);
+            const int n = ml.pN[hi] - ml.pN[lo];
+            const int sc = (ml.pC[hi] - ml.pC[lo]) - cc * n;                                  // sum of dc
+            const int scc = (ml.pCC[hi] - ml.pCC[lo]) - 2 * cc * (ml.pC[hi] - ml.pC[lo]) + cc * cc * n;  // sum of dc^2
+            const double z = ml.pZ[hi] - ml.pZ[lo], zz = ml.pZZ[hi] - ml.pZZ[lo];
+            const double cz = (ml.pCZ[hi] - ml.pCZ[lo]) - static_cast<double>(cc) * z;        // sum of dc z'
+            N += n;
+            Sc += sc;
+            Scc += scc;
+            Sv += dv * n;
+            Svv += dv * dv * n;
+            Svc += dv * sc;
+            Sz += z;
+            Szz += zz;
+            Scz += cz;
+            Svz += static_cast<double>(dv) * z;
+        }
+        const double nd = static_cast<double>(N);
+        // scatter about the mean: lattice part in exact integers (N S2 - S1^2 <= 81 * 81 * 24^2 * 2), z part in f64
+        const double Avv = static_cast<double>(N * Svv - Sv * Sv) / nd, Acc = static_cast<double>(N * Scc - Sc * Sc) / nd;
+        const double Avc = static_cast<double>(N * Svc - Sv * Sc) / nd;
+        const double Avz = Svz - static_cast<double>(Sv) * Sz / nd, Acz = Scz - static_cast<double>(Sc) * Sz / nd;
+        const double Azz = fmax(Szz - Sz * Sz / nd, 0.0);
+        // metres: x = x0 - res * dv, y = y0 - res * dc (cell centres decrease with the index)
+        const double res = g.res, res2 = res * res;
+        const double a00 = res2 * Avv, a01 = res2 * Avc, a02 = -(res * Avz), a11 = res2 * Acc, a12 = -(res * Acz), a22 = Azz;
+        double ex, ey, ez, eigS, eigL;
+        normal_from_scatter(a00, a01, a02, a11, a12, a22, ex, ey, ez, eigS, eigL);
+        // (nearly) rank-deficient, or a component of the normal at rounding-noise level (symmetric neighbourhoods: exactly 0
+        // here, ~1e-17 by the oracle's order of operations): the literal walks decide (see above)
+        // Thresholds: the matrix entries carry ~1e-16 of their scale, so the eigenvector is good to ~1e-15 rad whatever the
+        // smallest eigenvalue (its accuracy depends on the GAP to the next one), the roughness sqrt(n^T A n / (n - 1)) to
+        // ~1e-18 / roughness metres — both far inside a float ulp down to a ratio of 1e-10; a component below 1e-6 would
+        // keep fewer than nine digits.  A wavefront takes the literal walks when ANY of its 64 cells asks for them, so the
+        // thresholds are as low as the arithmetic allows (at 1e-7, 2 % of a smooth map's cells — 70 % of its wavefronts).
+        const double tinyC = 1e-6;
+        if (!(eigS > 1e-10 * eigL) || fabs(ex) < tinyC || fabs(ey) < tinyC || fabs(ez) < tinyC) {
+            normals_cell_exact(d, li, lj, ti0, tj0, r, slopeCritical, 1, roughCritical, ox, oy, oz, os, orough);
+        } else {
+            ox = static_cast<float>(ex);
+            oy = static_cast<float>(ey);
+            oz = static_cast<float>(ez);
+            const double slope = acos(static_cast<double>(oz));  // SlopeFilter reads the float layer
+            os = slope < slopeCritical ? static_cast<float>(1.0 - slope / slopeCritical) : 0.0f;
+            // RoughnessFilter: the plane through the mean with the FLOAT normal: sum of squared distances = n^T A n
+            const double nx = ox, ny = oy, nz = oz;
+            const double q = nx * (nx * a00 + 2.0 * (ny * a01 + nz * a02)) + ny * (ny * a11 + 2.0 * (nz * a12)) + nz * (nz * a22);
+            const double roughness = sqrt(fmax(q, 0.0) / (nd - 1.0));
             orough = roughness < roughCritical ? static_cast<float>(1.0 - roughness / roughCritical) : 0.0f;
         }
     }
@@ -235,7 +408,7 @@ __global__ __launch_bounds__(256) void filter_normals_kernel(MapGeom g, const fl
     L.ny[cell] = oy;
     L.nz[cell] = oz;
     L.slope[cell] = os;
-    if (fuseRough) L.rough[cell] = orough;
+    L.rough[cell] = orough;
 }
 
 // RoughnessFilter: needs the finished normal layers.
@@ -341,6 +514,18 @@ hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float*
     const int hN = filter_halo(fc.normalRadius, g.res), hR = filter_halo(fc.roughnessRadius, g.res);
     const int h1 = filter_halo(fc.stepFirstRadius, g.res), h2 = filter_halo(fc.stepSecondRadius, g.res);
     const int fuse = fc.roughnessRadius == fc.normalRadius ? 1 : 0;  // the published default chain: both 0.05 m
+#ifndef FPE_FILTERS_WALK_ONLY
+    if (fuse && hN <= kMomentMaxH) {  // row moments (see filter_normals_moments_kernel); the literal walks for what they do not cover
+        const size_t bytes = ((disc_lds_bytes(hN) + 15) & ~static_cast<size_t>(15)) + moment_lds_bytes(hN);
+        if (bytes > 48 * 1024) {  // (0.5 cm maps: the prefix arrays of a 38 x 38 tile need 66 KB)
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_normals_moments_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     static_cast<int>(bytes));
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(filter_normals_moments_kernel, grid, block, ((disc_lds_bytes(hN) + 15) & ~static_cast<size_t>(15)) + moment_lds_bytes(hN), stream,
+                           g, d_elev, L, fc.normalRadius, hN, fc.slopeCritical, fc.roughnessCritical);
+    } else
+#endif
     hipLaunchKernelGGL(filter_normals_kernel, grid, block, disc_lds_bytes(hN), stream, g, d_elev, L, fc.normalRadius, hN, fc.slopeCritical, fuse,
                        fc.roughnessCritical);
     if (!fuse)
