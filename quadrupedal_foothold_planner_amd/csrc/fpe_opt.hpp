@@ -219,9 +219,101 @@ __device__ int opt_solve_begin(const OptConsts& oc, const int (&nIdx)[8], const 
 // index t = ((a n2 + b) n4 + c) n6 + d.  Wavefront w takes the (a, b) pairs w, w + W, ..., its lanes the (c, d) pairs;
 // per lane t only grows, so "strictly better" keeps the first of equals, and the reduction orders by (violation,
 // objective, t): the lexicographically first minimum, as the oracle's nested loops find it.
+// The same search with the objective and the constraints taken apart by what they depend on (round 4): every f64 operation
+// below is one of the reference's expression, on the same operands, in the same order — a point's objective is
+//   ((w1 * S1 + w2 * S2) + w3 * (Uab + Ucd)) + w4 * (V1 + V2),   S = ((((((A0 + C1) + A2) + C3) + A4) + C5) + A6) + C7
+// (cpp:61-72, left to right) — but the sub-expressions of (x0, x2) alone are evaluated once per (a, b) pair and those of
+// (x4, x6) alone once per LANE (a lane keeps its one or two (c, d) pairs for the whole search): 31 operations per point
+// instead of ~110, and the values are bit for bit the ones opt_objective / opt_violation return (tests/test_gpu_opt.py).
+// Boxes with more than 128 (c, d) pairs take the plain loop (opt_solve_rows_plain).
+template <int W>
+__device__ OptBest opt_solve_rows_plain(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8],
+                                        double lfRow, double rhRow, int lane, int wave, const double (&x)[8]);
 template <int W>
 __device__ OptBest opt_solve_rows(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8],
                                   double lfRow, double rhRow, int lane, int wave, const double (&x)[8]) {
+    const double inf = __builtin_huge_val();
+    const int n0 = up[0] - lo[0] + 1, n2 = up[2] - lo[2] + 1, n4 = up[4] - lo[4] + 1, n6 = up[6] - lo[6] + 1;
+    const int nAB = n0 * n2, nCD = n4 * n6;
+    constexpr int kSlots = 2;
+    if (nCD > 64 * kSlots) return opt_solve_rows_plain<W>(oc, nIdx, cIdx, lo, up, lfRow, rhRow, lane, wave, x);
+    const double w1 = oc.w1, w2 = oc.w2, w3 = oc.w3, w4 = oc.w4, wr = oc.wr, wc = oc.wc;
+    const double L = oc.lbOverRes, K = oc.skew2OverRes;  // lengthBase/mapResolution, 2*skew/mapResolution
+    const double t1 = oc.t1, t2 = oc.t2, t3 = oc.t3, t4 = oc.t4, ctol = oc.ctol;
+    const double dlr = fabs(lfRow - rhRow), hlr = 0.5 * dlr;  // abs(lfCurrentRow - rhCurrentRow), 0.5*abs(...)
+    // column terms (the columns are decided: opt_solve_begin)
+    const double C1n = wc * fabs(x[1] - nIdx[1]), C3n = wc * fabs(x[3] - nIdx[3]), C5n = wc * fabs(x[5] - nIdx[5]), C7n = wc * fabs(x[7] - nIdx[7]);
+    const double C1c = wc * fabs(x[1] - cIdx[1]), C3c = wc * fabs(x[3] - cIdx[3]), C5c = wc * fabs(x[5] - cIdx[5]), C7c = wc * fabs(x[7] - cIdx[7]);
+    // this lane's (c, d) pairs
+    const float n6Inv = rcp_small(n6), n2Inv = rcp_small(n2);
+    bool live[kSlots], feasCD[kSlots];
+    double A4n[kSlots], A4c[kSlots], A6n[kSlots], A6c[kSlots], Dcd[kSlots], Ucd[kSlots], hcd[kSlots], V2[kSlots], rmCD[kSlots];
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+        const int cd = lane + 64 * s;
+        live[s] = cd < nCD;
+        int c, d;
+        divmod_small(live[s] ? cd : 0, n6, n6Inv, c, d);
+        const double y4 = lo[4] + c, y6 = lo[6] + d;
+        A4n[s] = wr * fabs(y4 - nIdx[4]);
+        A4c[s] = wr * fabs(y4 - cIdx[4]);
+        A6n[s] = wr * fabs(y6 - nIdx[6]);
+        A6c[s] = wr * fabs(y6 - cIdx[6]);
+        Dcd[s] = fabs(y4 - y6);
+        Ucd[s] = fabs(Dcd[s] - L);
+        hcd[s] = 0.5 * Dcd[s];
+        V2[s] = fabs(fabs(hcd[s] - hlr) - K);
+        const double c3 = t1 - Dcd[s], c4 = Dcd[s] - t2, G = 0.5 * fabs(Dcd[s] - dlr), c7 = t3 - G, c8 = G - t4;
+        feasCD[s] = c3 <= ctol && c4 <= ctol && c7 <= ctol && c8 <= ctol;
+        double rm = 0.0;
+        rm = c3 > rm ? c3 : rm;
+        rm = c4 > rm ? c4 : rm;
+        rm = c7 > rm ? c7 : rm;
+        rm = c8 > rm ? c8 : rm;
+        rmCD[s] = rm;
+    }
+    double bestKey = inf, bestF = inf;
+    unsigned bestT = 0xFFFFFFFFu;
+    for (int ab = wave; ab < nAB; ab += W) {
+        int a, b;
+        divmod_small(ab, n2, n2Inv, a, b);
+        const double y0 = lo[0] + a, y2 = lo[2] + b;
+        const double Pn = ((wr * fabs(y0 - nIdx[0]) + C1n) + wr * fabs(y2 - nIdx[2])) + C3n;
+        const double Pc = ((wr * fabs(y0 - cIdx[0]) + C1c) + wr * fabs(y2 - cIdx[2])) + C3c;
+        const double Dab = fabs(y0 - y2), Uab = fabs(Dab - L), hab = 0.5 * Dab;
+        const double c1 = t1 - Dab, c2 = Dab - t2;
+        const bool feasAB = c1 <= ctol && c2 <= ctol;
+        double rmAB = 0.0;
+        rmAB = c1 > rmAB ? c1 : rmAB;
+        rmAB = c2 > rmAB ? c2 : rmAB;
+        const unsigned tAB = static_cast<unsigned>(ab) * static_cast<unsigned>(nCD);
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+            const double S1 = (((Pn + A4n[s]) + C5n) + A6n[s]) + C7n;
+            const double S2 = (((Pc + A4c[s]) + C5c) + A6c[s]) + C7c;
+            const double V1 = fabs(fabs(hab - hcd[s]) - K);
+            const double f = ((w1 * S1 + w2 * S2) + w3 * (Uab + Ucd[s])) + w4 * (V1 + V2[s]);
+            const double E = 0.5 * fabs(Dab - Dcd[s]), c5 = t3 - E, c6 = E - t4;
+            const bool feasible = feasAB && feasCD[s] && c5 <= ctol && c6 <= ctol;
+            double rm = rmAB;  // (the maximum of the eight values and 0: the order of the comparisons does not matter)
+            rm = rmCD[s] > rm ? rmCD[s] : rm;
+            rm = c5 > rm ? c5 : rm;
+            rm = c6 > rm ? c6 : rm;
+            const double key = oc.useConstraints ? (feasible ? 0.0 : rm) : 0.0;
+            if (live[s] && (key < bestKey || (key == bestKey && f < bestF))) {  // (per lane t only grows: the first of equals stays)
+                bestKey = key;
+                bestF = f;
+                bestT = tAB + static_cast<unsigned>(lane + 64 * s);
+            }
+        }
+    }
+    opt_wave_min(bestKey, bestF, bestT);
+    return OptBest{bestKey, bestF, bestT, 0u};
+}
+
+template <int W>
+__device__ OptBest opt_solve_rows_plain(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8],
+                                        double lfRow, double rhRow, int lane, int wave, const double (&x)[8]) {
     const double inf = __builtin_huge_val();
     const int n0 = up[0] - lo[0] + 1, n2 = up[2] - lo[2] + 1, n4 = up[4] - lo[4] + 1, n6 = up[6] - lo[6] + 1;
     const int nAB = n0 * n2, nCD = n4 * n6;
