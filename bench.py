@@ -531,7 +531,8 @@ def main():
                                        "note": "fpe_plan asking for the 16-byte selected records only (pinned destination)"}
         # ---- the headline kernel's launch structure (VERDICT r3 task 2): three side measurements, each verified ----
         def ev_ms(fn, reps_e):
-            fn()
+            for _ in range(20):  # (the legs before this one are host-side copies: the GPU's clocks have to come back up first)
+                fn()
             a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             a_.record(stream)

@@ -1552,6 +1552,8 @@ struct Unit {
     float eA[9];  // centre disc (checkFoothold's centre, cpp:2029): elevations in CircleIterator order, [4] = middle cell
     float eB[9];  // default-track disc (cpp:2289-2301)
     float eC;     // centroid result's own cell (one-cell foot disc)
+    uint32_t pad0;  // (the eight words below start on a 16-byte boundary: lane 0 deposits them with two 16-byte LDS stores, the three
+                    // positions with one 16-byte and one 8-byte store — eleven separate stores before)
     uint32_t visA, visB;  // bit k: cell k visited; bit 31: the height was computed in the chain (direct pass) and is in e[0]
     int nomRow, nomCol;
     uint32_t nomFlags;    // valid | source << 8
@@ -1560,10 +1562,9 @@ struct Unit {
     double cx;    // search centre x (nominal x of a default hit / invalid leg; centroid x of code 0)
     double cenX;  // centroid result x (codes 1-4)
     double defX;  // default track x
-    uint32_t pad;
-    uint32_t written;
+    uint32_t pad[2];
 };
-static_assert(sizeof(Unit) == 144 && sizeof(Unit) % 16 == 0, "Unit layout");
+static_assert(sizeof(Unit) == 144 && sizeof(Unit) % 16 == 0 && offsetof(Unit, visA) == 80 && offsetof(Unit, cx) == 112, "Unit layout");
 
 // Two mean heights side by side — a disc around a known centre (bounding box + membership mask) and, optionally, a
 // cell-centred disc (offset table) — with the loads of both in ONE batch per eight cells.  Each sum is the ordered f32 sum
@@ -2952,7 +2953,25 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
     if constexpr (kMid) fr = load_fast_ranks<NRL>(lut, g, pc.winH);
     uint32_t okBits = 0u;  // cycleOk of the cycles since the last flush (3x3-only kernels: stored by flush_unit)
 
+    // Issue priority, 3x3-only kernels (two wavefronts per SIMD at the headline's batch): the SIMD's arbiter serves the OLDER of
+    // its two wavefronts first, so the older one finishes a sixth ahead (49 k against 59 k clocks, profiles/round3_residency.txt)
+    // and the younger one runs its tail alone at half the issue rate.  Three eighths into the chain the younger wavefront (odd
+    // hardware wave slot = launched second) raises its priority: the lead the older one built is what the younger one builds
+    // from there on, and the two finish together.  Measured (round 4, 50-step A/B, six repetitions): headline 26.8 -> 25.5 us,
+    // cfg-2 27.2 -> 26.0 us; switching at 2/8: the same, at 4/8: 25.9, at 1/8: 26.0, from the start (the plain reversal round 3
+    // tried): 26.7 = no change; handing the priority back near the end or alternating every one / two cycles: 26.1 - 26.3.
+    unsigned hwSlot = 0u;
+    if constexpr (kMid) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwSlot));
+        hwSlot &= 15u;
+    }
+#ifndef FPE_PRIO_SWAP_EIGHTHS
+#define FPE_PRIO_SWAP_EIGHTHS 3
+#endif
     for (int cyc = 0; cyc < nCycles; ++cyc) {
+#ifndef FPE_NO_PRIO_SWAP
+        if (kMid && cyc == (nCycles * FPE_PRIO_SWAP_EIGHTHS) / 8 && (hwSlot & 1u)) __builtin_amdgcn_s_setprio(2);
+#endif
         if ((cyc & (kBatch - 1)) == 0) {
             // y side of the next kBatch cycles: lane (leg, s) fills the entry of cycle cyc + s.  ajustedPose_[1] is the
             // reference's running sum (cpp:1578): cycle cyc + s has seen s more additions of the drift
