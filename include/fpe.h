@@ -36,7 +36,8 @@ enum fpe_status {
     FPE_E_UNSUPPORTED = -5, /* search radius / foot radius too large for the on-chip tile */
     FPE_E_NOMEM = -6,
     FPE_E_SERVICE_FALSE = -7 /* the reference's service handler returns false for this request:
-                                getGaitCycleSearchGridMap's getSubmap failed (cpp:920-934, 2345-2349) */
+                                getGaitCycleSearchGridMap's getSubmap failed (cpp:920-934, 2345-2349) — for a reason
+                                that does not depend on the optimiser (fpe_service_gate; "service_opt_gate" 2 widens it) */
 };
 
 /* ROS parameters of the path, with the reference's member types (readParameters cpp:248-314;
@@ -134,7 +135,7 @@ typedef struct fpe_selected_packed {
                                          getSubmap(next feet centre, isos_.length x isos_.width) — the reference's
                                          service handler returns false there (cpp:920-934).  This bit of the PLAN kernels
                                          covers cycle 0; later cycles follow the opt track's own feet: fpe_plan_opt*
-                                         (fpe_opt_out.gate_fail_cycle), which the fpe_plan_service* calls run. */
+                                         (fpe_opt_out.gate_fail_cycle; see fpe_service_gate for what the service calls do). */
 
 /* Output buffers of a chained plan; any pointer may be NULL (that product is skipped).
  * Index convention: record (b, g, leg) at ((b * n_cycles) + g) * 4 + leg. */
@@ -439,8 +440,9 @@ int fpe_plan_service_opt(fpe_handle h, const fpe_params* params, const fpe_opt_p
  * north_star: "a batch of candidate body trajectories is the parallel axis and shards across the 8 GPUs of one
  * node".  A C++ host that owns every GPU of the node (the ROS node) creates one group: an engine per device, the
  * map replicated by fpe_multi_upload_map, and fpe_multi_plan splitting the pose batch into contiguous blocks (the
- * first B % n devices take one pose more), one host thread per device, results written into the caller's arrays
- * at their global positions.  Same semantics, argument meaning and status codes as the single-device calls they
+ * first B % n devices take one pose more), one resident host thread per device, results written into the caller's
+ * arrays at their global positions.  (A group may list one device several times — independent engines — for the
+ * host-buffer form; the RCCL form needs distinct devices.)  Same semantics, argument meaning and status codes as the single-device calls they
  * fan out to (fpe_upload_map, fpe_plan: the seam at cpp:863-909 for every pose of the batch).  The
  * one-process-per-GPU deployment (torch.distributed + RCCL all-gather of fpe_plan_out.selected) uses the
  * single-device entry points instead (bench.py, quadrupedal_foothold_planner_amd/dist.py). */

@@ -30,7 +30,7 @@ for f in glob.glob("gpurun_out/prof_filters_pmc_*/**/*counter_collection.csv", r
         n = len(v) // 3
         cnt[k][c] = [x for _, x in v[n:2 * n]]
 if cnt:
-    cal = json.load(open("profiles/round3_headline_counters.json"))["calibration"]
+    cal = json.load(open("profiles/round4_headline_counters.json"))["calibration"]
     print("\ncounters per launch, 2000x2000 @ 0.01 m (mean over the map's launches):")
     for k, c in cnt.items():
         m = {name: sum(v) / len(v) for name, v in c.items() if v}
