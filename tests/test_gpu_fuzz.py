@@ -79,7 +79,10 @@ def test_random_differential_campaign():
         planner.set_tuning(plan_group=int(c["group"]), literal_discs=int(c["literal"]), no_bits=int(not c["bits"]))
         planner.params = c["params"]
         try:
-            eng, ora = util.run_both(planner, c["trav"], c["elev"], c["res"], c["poses"], c["n"], position=c["pos"], threads=8)
+            # every second case also asks for the 8-byte exchange record (the all-seven product shape is compiled on its own:
+            # both instantiations are exercised)
+            eng, ora = util.run_both(planner, c["trav"], c["elev"], c["res"], c["poses"], c["n"], position=c["pos"], threads=8,
+                                     products=util.ALL_PRODUCTS if k % 2 else None)
         except FpeError as e:
             assert e.code == _capi.FPE_E_UNSUPPORTED, e
             continue
@@ -122,6 +125,9 @@ def test_random_differential_campaign():
                 opt_status += np.bincount(oeng["cycles"]["solver_status"].ravel(), minlength=4)[:4]
                 opt_gates += int((oeng["gate_fail_cycle"] != 255).sum())
     planner.close()
+    print(f"random differential campaign: seeds {seed0} .. {seed0 + n_cases - 1} ({n_cases} cases), every product of every case equal to the oracle")
+    print("nominal sources (default hit, spiral candidate, none, radius over the tile bound):", src.tolist())
+    print("centroid codes 0..6:", codes.tolist())
     print("opt track: solver statuses", opt_status.tolist(), "poses with a failed gate", opt_gates)
     print("kernels exercised:", kernels)
     assert (src[:3] > 0).all() and (codes > 0).all(), (src, codes)

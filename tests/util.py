@@ -71,6 +71,11 @@ def assert_plan_equal(eng, ora, swing_only_mask=None):
         for f in ("row", "col", "valid", "source", "foot_id", "gait_cycle_id"):
             assert np.array_equal(sel[f], nom[f]), f"selected.{f} differs from nominal.{f}"
         assert np.array_equal(sel["z"].view(np.uint32), nom["z"].view(np.uint32)), "selected.z differs from nominal.z"
+    if "selected_packed" in eng:  # the 8-byte exchange record: the same index, flags and f32 height
+        un, nom = _capi.unpack_selected(eng["selected_packed"]), eng["nominal"]
+        for f in ("row", "col", "valid", "source", "foot_id", "gait_cycle_id"):
+            assert np.array_equal(un[f], nom[f]), f"selected_packed.{f} differs from nominal.{f}"
+        assert np.array_equal(un["z"].view(np.uint32), nom["z"].view(np.uint32)), "selected_packed.z differs from nominal.z"
     if "pose_status" in eng and "pose_status" in ora:
         assert np.array_equal(eng["pose_status"], ora["pose_status"]), "pose_status (opt-track gate of cycle 0) differs"
     d_e, d_o = eng["default"], ora["default"]
@@ -78,9 +83,12 @@ def assert_plan_equal(eng, ora, swing_only_mask=None):
     assert np.all(np.abs(d_e[..., 2] - d_o[..., 2]) <= Z_TOL), "default track z differs"
 
 
-def run_both(planner, trav, elev, res, poses, n_cycles, position=(0.0, 0.0), threads=4):
+ALL_PRODUCTS = ("nominal", "centroid", "default", "cycle_ok", "stance", "selected", "pose_status", "selected_packed")
+
+
+def run_both(planner, trav, elev, res, poses, n_cycles, position=(0.0, 0.0), threads=4, products=None):
     planner.gridmapCallback(trav, elev, res, position)
-    eng = planner.plan(poses, n_cycles)
+    eng = planner.plan(poses, n_cycles) if products is None else planner.plan(poses, n_cycles, products=products)
     omap = fpo.OracleMap(trav, elev, res, position)
     ora = omap.plan(to_oracle_params(planner.params), to_oracle_poses(poses), n_cycles, threads=threads)
     ora["pose_status"] = omap.pose_status(to_oracle_params(planner.params), to_oracle_poses(poses))
