@@ -434,7 +434,7 @@ def main():
             "default_hit_fraction": float((src == 0).mean()),
             "centroid_code_fractions": [float(c) for c in codes],
             "exchange": (f"all_gather_into_tensor of the selected footholds ({xrec} B records written by the plan kernel: "
-                         f"{'fpe_selected_packed — row | col << 14 | flags in one word, z' if packed else 'fpe_selected_foothold — grid index, z, flags'}): "
+                         f"{'fpe_selected_packed — biased row | col << 14 | flags in one word, z' if packed else 'fpe_selected_foothold — grid index, z, flags'}): "
                          f"EVERY step's records, one collective per {gather_batch} steps ({gather_batch} x the bytes), overlapped "
                          f"with the plan kernels of the next batch; backend {backend}, "
                          f"{dist.get_world_size()} rank{'s' if dist.get_world_size() != 1 else ''} in the process group, {n_collectives} collectives issued"

@@ -117,16 +117,18 @@ typedef struct fpe_selected_foothold {
 
 /* The same record in 8 bytes (build-defined; the exchange of a multi-GPU step moves HALF the bytes): one word holding
  * the grid index and the two flags, and the height.  foot_id / gait_cycle_id are positional (record (b, g, leg) sits at
- * ((b * n_cycles) + g) * 4 + leg on every rank).  Maps of up to 16383 x 16383 cells (fpe_plan* fail with
- * FPE_E_UNSUPPORTED when the product is requested on a larger map). */
+ * ((b * n_cycles) + g) * 4 + leg on every rank).  An index is stored with a bias of FPE_PACKED_BIAS in 14 bits: a default
+ * hit carries getIndex(centre) (cpp:2016), which lies up to a foot radius OUTSIDE the map for a centre just over its edge
+ * (found by the random campaign: col -3 of a valid foothold), and -1 ("no foothold") needs no code of its own.  Maps of up
+ * to FPE_PACKED_MAX_CELLS rows / columns (fpe_plan* fail with FPE_E_UNSUPPORTED when the product is requested on a larger map). */
 typedef struct fpe_selected_packed {
-    uint32_t cell; /* bits 0-13 row, 14-27 col (0x3FFF = -1: no foothold), bit 28 valid, bits 29-30 source, bit 31 zero */
+    uint32_t cell; /* bits 0-13 row + 256, 14-27 col + 256, bit 28 valid, bits 29-30 source, bit 31 zero */
     float z;
 } fpe_selected_packed;
-#define FPE_PACKED_NONE 0x3FFFu
-#define FPE_PACKED_MAX_CELLS 16383
-#define FPE_PACKED_ROW(c) ((int32_t)((c) & 0x3FFFu) == 0x3FFF ? -1 : (int32_t)((c) & 0x3FFFu))
-#define FPE_PACKED_COL(c) ((int32_t)(((c) >> 14) & 0x3FFFu) == 0x3FFF ? -1 : (int32_t)(((c) >> 14) & 0x3FFFu))
+#define FPE_PACKED_BIAS 256
+#define FPE_PACKED_MAX_CELLS (16383 - 2 * FPE_PACKED_BIAS)
+#define FPE_PACKED_ROW(c) ((int32_t)((c) & 0x3FFFu) - FPE_PACKED_BIAS)
+#define FPE_PACKED_COL(c) ((int32_t)(((c) >> 14) & 0x3FFFu) - FPE_PACKED_BIAS)
 #define FPE_PACKED_VALID(c) (((c) >> 28) & 1u)
 #define FPE_PACKED_SOURCE(c) (((c) >> 29) & 3u)
 

@@ -54,20 +54,18 @@ SELECTED_DTYPE = np.dtype(
     [("row", "<i4"), ("col", "<i4"), ("z", "<f4"), ("valid", "u1"), ("source", "u1"), ("foot_id", "u1"), ("gait_cycle_id", "u1")],
     align=True,
 )
-# fpe_selected_packed: the 8-byte exchange record (row | col << 14 | valid << 28 | source << 29, z); -1 indices are 0x3FFF
+# fpe_selected_packed: the 8-byte exchange record ((row + 256) | (col + 256) << 14 | valid << 28 | source << 29, z)
 PACKED_DTYPE = np.dtype([("cell", "<u4"), ("z", "<f4")], align=True)
-PACKED_NONE = 0x3FFF
-PACKED_MAX_CELLS = 16383
+PACKED_BIAS = 256
+PACKED_MAX_CELLS = 16383 - 2 * PACKED_BIAS
 
 
 def unpack_selected(packed):
     """fpe_selected_packed records -> SELECTED_DTYPE records (foot_id / gait_cycle_id from the positions [..., n_cycles, 4])."""
     c = packed["cell"]
     out = np.zeros(packed.shape, dtype=SELECTED_DTYPE)
-    row = (c & 0x3FFF).astype(np.int32)
-    col = ((c >> 14) & 0x3FFF).astype(np.int32)
-    out["row"] = np.where(row == PACKED_NONE, -1, row)
-    out["col"] = np.where(col == PACKED_NONE, -1, col)
+    out["row"] = (c & 0x3FFF).astype(np.int32) - PACKED_BIAS
+    out["col"] = ((c >> 14) & 0x3FFF).astype(np.int32) - PACKED_BIAS
     out["z"] = packed["z"]
     out["valid"] = (c >> 28) & 1
     out["source"] = (c >> 29) & 3

@@ -850,7 +850,7 @@ int fpe_map_info(fpe_handle h, fpe_map_desc* out) {
 static int launch_plan(fpe_engine* h, const CallPlan& cp, const fpe_pose* d_poses, int32_t B, int32_t n_cycles,
                        const fpe_plan_out& d_out, hipStream_t stream) {
     if (d_out.selected_packed && (cp.snap->g.rows > FPE_PACKED_MAX_CELLS || cp.snap->g.cols > FPE_PACKED_MAX_CELLS))
-        return fail(FPE_E_UNSUPPORTED, "selected_packed holds 14-bit grid indices: the map has more than 16383 rows or columns");
+        return fail(FPE_E_UNSUPPORTED, "selected_packed holds biased 14-bit grid indices: the map has more than 15871 rows or columns");
     if (cp.useBits)
         FPE_HIP(fpe::launch_plan_bits(dev_map(*cp.snap), cp.bits, cp.pc, h->lut(), d_poses, B, n_cycles, d_out, stream));
     else

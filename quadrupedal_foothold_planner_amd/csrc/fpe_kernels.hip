@@ -1359,7 +1359,7 @@ __device__ __forceinline__ void store_foothold(fpe_foothold* dst, const NominalO
 }
 
 // The two exchange forms of a nominal foothold (include/fpe.h): the 16-byte fpe_selected_foothold and the 8-byte
-// fpe_selected_packed (row / col in 14 bits each, -1 as 0x3FFF, valid and source above them).
+// fpe_selected_packed (row / col biased by FPE_PACKED_BIAS in 14 bits each, valid and source above them).
 template <bool kStream>
 __device__ __forceinline__ void store_selected(const fpe_plan_out& out, size_t o, int row, int col, float z, int valid, int source, int leg,
                                                int cyc) {
@@ -1372,7 +1372,7 @@ __device__ __forceinline__ void store_selected(const fpe_plan_out& out, size_t o
     }
     if (out.selected_packed) {
         fpe_selected_packed sp;
-        sp.cell = (static_cast<uint32_t>(row) & 0x3FFFu) | ((static_cast<uint32_t>(col) & 0x3FFFu) << 14) |
+        sp.cell = (static_cast<uint32_t>(row + FPE_PACKED_BIAS) & 0x3FFFu) | ((static_cast<uint32_t>(col + FPE_PACKED_BIAS) & 0x3FFFu) << 14) |
                   ((static_cast<uint32_t>(valid) & 1u) << 28) | ((static_cast<uint32_t>(source) & 3u) << 29);
         sp.z = z;
         store_record<kStream>(out.selected_packed + o, sp);

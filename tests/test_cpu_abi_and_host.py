@@ -53,14 +53,16 @@ def test_multi_device_shard_offsets_and_exchange_records():
     assert L.fpe_multi_shard_range(8, 3, 3, C.byref(C.c_int32()), C.byref(C.c_int32())) == _capi.FPE_E_INVALID_ARG
     assert _capi.SELECTED_DTYPE.itemsize == 16 and _capi.PACKED_DTYPE.itemsize == 8
     assert C.sizeof(_capi.PlanOut) == 8 * 8 and C.sizeof(_capi.MultiDeviceIO) == 8 + 64 + 8 + 8 and C.sizeof(_capi.ServiceGate) == 24
-    # the packed word: row | col << 14 | valid << 28 | source << 29, -1 as 0x3FFF
+    # the packed word: (row + 256) | (col + 256) << 14 | valid << 28 | source << 29 (-1 and the few cells a default hit's index
+    # can lie outside the map are ordinary values)
     rec = np.zeros((2, 3, 4), dtype=_capi.PACKED_DTYPE)
-    rec["cell"][0, 1, 2] = 123 | (16382 << 14) | (1 << 28) | (1 << 29)
-    rec["cell"][1, 2, 3] = 0x3FFF | (0x3FFF << 14) | (2 << 29)
+    rec["cell"][0, 1, 2] = (123 + 256) | ((15870 + 256) << 14) | (1 << 28) | (1 << 29)
+    rec["cell"][1, 2, 3] = 255 | (253 << 14) | (2 << 29)
     rec["z"][0, 1, 2] = np.float32(0.25)
     un = _capi.unpack_selected(rec)
-    assert (un["row"][0, 1, 2], un["col"][0, 1, 2], un["valid"][0, 1, 2], un["source"][0, 1, 2]) == (123, 16382, 1, 1)
-    assert (un["row"][1, 2, 3], un["col"][1, 2, 3], un["valid"][1, 2, 3], un["source"][1, 2, 3]) == (-1, -1, 0, 2)
+    assert (un["row"][0, 1, 2], un["col"][0, 1, 2], un["valid"][0, 1, 2], un["source"][0, 1, 2]) == (123, 15870, 1, 1)
+    assert (un["row"][1, 2, 3], un["col"][1, 2, 3], un["valid"][1, 2, 3], un["source"][1, 2, 3]) == (-1, -3, 0, 2)
+    assert _capi.PACKED_MAX_CELLS == 15871
     assert un["foot_id"][1, 2].tolist() == [0, 1, 2, 3] and un["gait_cycle_id"][0, :, 0].tolist() == [0, 1, 2]
     assert un["z"][0, 1, 2] == np.float32(0.25)
 

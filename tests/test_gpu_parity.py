@@ -189,6 +189,24 @@ def test_centroid_rectangle_reaching_the_index_past_the_far_edge(planner):
     assert (ora["centroid"]["code"][5, 0] == 6).any()
 
 
+def test_packed_record_of_a_default_hit_whose_index_lies_outside_the_map(planner):
+    """Random-campaign case 4400001 (round 4, found on the campaign's second case): a search centre just over the map's
+    edge whose foot disc still reaches map cells is a VALID default hit, and its record carries getIndex(centre) (cpp:2016) —
+    column -3 / -2 here.  The first form of the 8-byte exchange record kept 14 unsigned bits per index with a code for -1 and
+    lost such indices; the record is biased now (include/fpe.h, FPE_PACKED_BIAS)."""
+    from tests.test_gpu_fuzz import make_case
+    c = make_case(4400001)
+    for no_bits in (0, 1):
+        with planner.tuning(plan_group=0, literal_discs=0, no_bits=no_bits):
+            planner.params = c["params"]
+            eng, ora = util.run_both(planner, c["trav"], c["elev"], c["res"], c["poses"], c["n"], position=c["pos"], threads=8,
+                                     products=util.ALL_PRODUCTS)
+            util.assert_plan_equal(eng, ora)
+            nom = eng["nominal"]
+            assert ((nom["valid"] == 1) & (nom["col"] < -1)).any(), "the case must hold a valid foothold with an index outside the map"
+    set_params(planner)
+
+
 def test_open_loop_checkFoothold_with_arbitrary_polygons(planner):
     set_params(planner)
     trav, elev = synth.rough_map(400, 400, 0.02, seed=71)
