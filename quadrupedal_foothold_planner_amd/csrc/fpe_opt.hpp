@@ -178,6 +178,18 @@ struct OptProblem {
     double lfRow, rhRow;
 };
 
+// Index splits of the row lattice.  Its enumeration runs to kMaxLatticePoints = 2^24 and a pair index (ab, cd) to the same
+// when the other pair is a single point — past the range divmod_small is proven for (t < 2^22: the f32 estimate within one
+// of the quotient).  Larger indices take the exact division; the test is uniform wherever the index is.
+__device__ __forceinline__ void divmod_lattice(int t, int d, float dinv, int& q, int& r) {
+    if (t < (1 << 22)) {
+        divmod_small(t, d, dinv, q, r);
+    } else {
+        q = static_cast<int>(static_cast<unsigned>(t) / static_cast<unsigned>(d));
+        r = t - q * d;
+    }
+}
+
 // oracle/fpo_opt.cpp::solveLattice, first part (one wavefront): start x = x0 = centroidIndex (cpp:1180-1183), NLopt's
 // precondition (status 1), the four column variables.  Returns -1 when the row search is to run, else the final status.
 __device__ int opt_solve_begin(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8],
@@ -253,7 +265,7 @@ __device__ OptBest opt_solve_rows(const OptConsts& oc, const int (&nIdx)[8], con
         const int cd = lane + 64 * s;
         live[s] = cd < nCD;
         int c, d;
-        divmod_small(live[s] ? cd : 0, n6, n6Inv, c, d);
+        divmod_lattice(live[s] ? cd : 0, n6, n6Inv, c, d);
         const double y4 = lo[4] + c, y6 = lo[6] + d;
         A4n[s] = wr * fabs(y4 - nIdx[4]);
         A4c[s] = wr * fabs(y4 - cIdx[4]);
@@ -276,7 +288,7 @@ __device__ OptBest opt_solve_rows(const OptConsts& oc, const int (&nIdx)[8], con
     unsigned bestT = 0xFFFFFFFFu;
     for (int ab = wave; ab < nAB; ab += W) {
         int a, b;
-        divmod_small(ab, n2, n2Inv, a, b);
+        divmod_lattice(ab, n2, n2Inv, a, b);
         const double y0 = lo[0] + a, y2 = lo[2] + b;
         const double Pn = ((wr * fabs(y0 - nIdx[0]) + C1n) + wr * fabs(y2 - nIdx[2])) + C3n;
         const double Pc = ((wr * fabs(y0 - cIdx[0]) + C1c) + wr * fabs(y2 - cIdx[2])) + C3c;
@@ -325,13 +337,13 @@ __device__ OptBest opt_solve_rows_plain(const OptConsts& oc, const int (&nIdx)[8
     for (int k = 0; k < 8; ++k) y[k] = x[k];
     for (int ab = wave; ab < nAB; ab += W) {
         int a, b;
-        divmod_small(ab, n2, n2Inv, a, b);
+        divmod_lattice(ab, n2, n2Inv, a, b);
         y[0] = lo[0] + a;
         y[2] = lo[2] + b;
         const unsigned tAB = static_cast<unsigned>(ab) * static_cast<unsigned>(nCD);
         for (int cd = lane; cd < nCD; cd += 64) {
             int c, d;
-            divmod_small(cd, n6, n6Inv, c, d);
+            divmod_lattice(cd, n6, n6Inv, c, d);
             y[4] = lo[4] + c;
             y[6] = lo[6] + d;
             const double key = oc.useConstraints ? opt_violation(y, oc, lfRow, rhRow) : 0.0;
@@ -352,9 +364,9 @@ __device__ int opt_solve_end(const OptBest& best, const int (&lo)[8], const int 
     const int n2 = up[2] - lo[2] + 1, n4 = up[4] - lo[4] + 1, n6 = up[6] - lo[6] + 1;
     const int nCD = n4 * n6;
     int ab, cd, a, b, c, d;
-    divmod_small(static_cast<int>(best.t), nCD, rcp_small(nCD), ab, cd);
-    divmod_small(ab, n2, rcp_small(n2), a, b);
-    divmod_small(cd, n6, rcp_small(n6), c, d);
+    divmod_lattice(static_cast<int>(best.t), nCD, rcp_small(nCD), ab, cd);
+    divmod_lattice(ab, n2, rcp_small(n2), a, b);
+    divmod_lattice(cd, n6, rcp_small(n6), c, d);
     x[0] = lo[0] + a;
     x[2] = lo[2] + b;
     x[4] = lo[4] + c;

@@ -184,6 +184,32 @@ def test_rows_after_are_what_the_next_cycle_would_use(planner):
             assert (g["lf_current_row"], g["rh_current_row"]) == tuple(eng["rows_after"][b])
 
 
+def test_row_lattice_past_the_small_division_range_and_past_the_cap(planner):
+    """Fine maps make the row lattice large: tens of rows per leg at 3-4 mm are 2e6 ... 2e7 points.  Some solves have their
+    winner at an enumeration index past 2^22 — the range the f32-reciprocal index split is proven for (ADVICE r3;
+    divmod_lattice) — and some are past kMaxLatticePoints (solver_status 3: x stays at the start point)."""
+    reset(planner)
+    past_small, past_cap = 0, 0
+    for res, rows in ((0.004, 1000), (0.003, 1200)):
+        trav, elev = synth.rough_map(rows, rows, res, seed=91, bad_frac=0.01)
+        side = rows * res
+        poses = synth.poses_in_map(3, side, side, 2, 0.18, seed=92, margin=0.7)
+        eng, ora = both(planner, trav, elev, res, poses, 2)
+        util.assert_opt_equal(eng, ora)
+        c = eng["cycles"]
+        nn = (c["x_upper"].astype(np.int64) - c["x_lower"] + 1)[..., ::2]
+        n = nn.prod(axis=-1)
+        solved = (n <= (1 << 24)) & np.isin(c["solver_status"], (0, 2))
+        # the winner's index in the enumeration (a, b, c, d with d fastest)
+        k = (c["x"][..., ::2] - c["x_lower"][..., ::2]).astype(np.int64)
+        t = ((k[..., 0] * nn[..., 1] + k[..., 1]) * nn[..., 2] + k[..., 2]) * nn[..., 3] + k[..., 3]
+        past_small += int((solved & (t >= (1 << 22))).sum())
+        over = n > (1 << 24)
+        assert (c["solver_status"][over] == 3).all()
+        past_cap += int(over.sum())
+    assert past_small >= 1 and past_cap >= 1, (past_small, past_cap)
+
+
 def test_service_opt_products_and_return_value(planner):
     """plan_global_footholds: global_footholds_opt, the opt KPIs, the centroid path interleaved with the opt track's feet
     centres (cpp:946), and the handler's `return false` in the cycle whose gate fails."""
