@@ -52,25 +52,49 @@ __device__ __forceinline__ DiscLds disc_carve(char* base, int H) {
     return d;
 }
 // Tables and source tile of the workgroup's cells [ti0, ti0 + kFT) x [tj0, tj0 + kFT); ends with a barrier.
+// One phase, one barrier: every thread first REQUESTS its share of the tile (a wavefront takes every fourth tile row,
+// lane = tile column: no index division, up to 16 loads in flight per lane — the former one-load-one-store loop waited
+// for each of its five to ten loads in turn, and the kernels spent most of a wavefront's life there), computes its
+// table entries from cell_pos itself while the loads fly (the same values the position arrays hold), then stores.
 __device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, const float* __restrict__ src, int ti0, int tj0, double r) {
     const int H = d.H, W = d.W, t = threadIdx.x, D = 2 * H + 1;
+    static_assert(kFT + 2 * kFilterMaxH <= 64, "a tile row is one wavefront load");
+    // a wavefront instruction loads one tile row (W > 32) or two (lanes 0-31 / 32-63); eight rows in flight per lane
+    const int perInst = W <= 32 ? 2 : 1, laneCols = W <= 32 ? 32 : 64;
+    const int col = t & (laneCols - 1), sub = (t & 63) / laneCols, wv = t >> 6;
+    const int tj = tj0 - H + col;
+    const bool colOk = col < W && tj >= 0 && tj < g.cols;
+    const int rowStep = 4 * perInst;  // rows per workgroup instruction
+    const int firstRow = wv * perInst + sub;
+    constexpr int kBatch = 8;
+    float v[kBatch];
+    const auto request = [&](int base) {
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) {
+            const int row = base + firstRow + rowStep * q, ti = ti0 - H + row;
+            v[q] = __builtin_nanf("");
+            if (row < W && colOk && ti >= 0 && ti < g.rows) v[q] = src[static_cast<size_t>(ti) * g.cols + tj];
+        }
+    };
+    // invalid cells (GridMap::isValid = isfinite) enter the tile as quiet NaNs: the walks test `z == z`, and the float
+    // max / min of the step filter skip them by themselves
+    const auto deposit = [&](int base) {
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) {
+            const int row = base + firstRow + rowStep * q;
+            if (row < W && col < W) d.tile[row * W + col] = isfinite(v[q]) ? v[q] : __builtin_nanf("");
+        }
+    };
+    request(0);
     for (int k = t; k < 2 * W; k += 256) {
         if (k < W) d.xP[k] = cell_pos(g.baseX, g.res, ti0 - H + k);
         else d.yP[k - W] = cell_pos(g.baseY, g.res, tj0 - H + (k - W));
     }
-    for (int k = t; k < W * W; k += 256) {
-        const int i = ti0 - H + k / W, j = tj0 - H + k % W;
-        // invalid cells (GridMap::isValid = isfinite) enter the tile as quiet NaNs: the walks test `z == z`, and the
-        // float max / min of the step filter skip them by themselves
-        const float v = in_range(i, j, g.rows, g.cols) ? src[static_cast<size_t>(i) * g.cols + j] : __builtin_nanf("");
-        d.tile[k] = isfinite(v) ? v : __builtin_nanf("");
-    }
-    __syncthreads();
     if (t < 2 * kFT) {  // CircleIterator::findSubmapParameters per axis (circle_bbox), clamped onto the halo
         const bool isRow = t < kFT;
         const int l = isRow ? t : t - kFT;
         const int idx = (isRow ? ti0 : tj0) + l, n = isRow ? g.rows : g.cols;
-        const double c = isRow ? d.xP[l + H] : d.yP[l + H];
+        const double c = cell_pos(isRow ? g.baseX : g.baseY, g.res, idx);
         const double org = isRow ? g.orgX : g.orgY, pos = isRow ? g.posX : g.posY, len = isRow ? g.lenX : g.lenY;
         int a = index_of(bound_axis(c + r, org, pos, len), org, pos, g.res);
         int b = index_of(bound_axis(c - r, org, pos, len), org, pos, g.res);
@@ -83,9 +107,15 @@ __device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, c
         const bool isRow = k < kFT * D;
         const int e = isRow ? k : k - kFT * D;
         const int l = e / D, o = e % D;
-        const double* P = isRow ? d.xP : d.yP;
-        const double dd = P[l + o] - P[l + H];
+        const double base = isRow ? g.baseX : g.baseY;
+        const int first = (isRow ? ti0 : tj0) - H + l;
+        const double dd = cell_pos(base, g.res, first + o) - cell_pos(base, g.res, first + H);
         (isRow ? d.dx2 : d.dy2)[e] = dd * dd;
+    }
+    deposit(0);
+    for (int base = rowStep * kBatch; base < W; base += rowStep * kBatch) {  // (tiles of more than 32 / 64 rows)
+        request(base);
+        deposit(base);
     }
     __syncthreads();
 }
@@ -564,6 +594,160 @@ __global__ __launch_bounds__(256) void filter_step2_kernel(MapGeom g, FilterLaye
     L.trav[cell] = third * ((L.slope[cell] + out) + L.rough[cell]);
 }
 
+// ---- the step filter's two windows by ROW RUNS (round 4) -----------------------------------------------------------------
+// Both iterations of the StepFilter reduce a disc with max / min (and a count): order-free, so only the SET of members
+// matters.  On the uniform lattice the set is the same for every cell — row offset o holds the columns |dc| <= w(o) — except
+// for the few offsets that lie ON the circle ((0, R), (R, 0), (3, 4) R / 5 ...), where CircleIterator::isInside's rounding
+// decides cell by cell.  The host sorts the offsets (step_shape: squared distance against r^2 with a relative margin of
+// 1e-7 — position differences are good to 1e-12); the kernel then
+//   1. extends, for every (tile row, interior column), a run around the column one cell per side at a time up to the
+//      largest half-width, keeping the running max / min (count) in registers and storing it at the half-widths some row
+//      of the disc has ("classes") — 2 R + 1 LDS reads per run instead of one walk per cell;
+//   2. folds, per cell, one stored run per disc row: 2 R + 1 reads of LDS for a disc of ~pi R^2 members;
+//   3. tests the on-circle offsets with the iterator's own arithmetic (dx2 + dy2 <= r^2 on the tables of disc_setup, and
+//      the bounding box of the cell) and folds the members among them one by one.
+// Invalid cells are quiet NaNs in the tile: v_max / v_min skip them, `>` is false on them — what the iterator's isValid
+// test does.  Same members as disc_walk by construction: bit-identical layers (tests/test_gpu_filters.py).
+constexpr int kStepMaxClasses = 14;
+constexpr int kStepMaxEdge = 24;
+struct StepShape {
+    int8_t rowW[2 * kFilterMaxH + 1 + 3];  // per row offset o + H: its robust half-width, -1: no robust member
+    int8_t edgeR[kStepMaxEdge], edgeC[kStepMaxEdge];  // offsets on the circle
+    uint32_t storeMask;                // bit w: some row has half-width w — the run is stored at that width; its class = the number of set bits below w
+    int32_t nEdge, nClasses, wMax;
+    int32_t ok;                        // 0: the shape does not fit the tables (the walking kernels run)
+};
+__host__ inline StepShape step_shape(double r, double res, int H) {
+    StepShape sp{};
+    for (auto& c : sp.rowW) c = -1;
+    sp.ok = 1;
+    const double r2 = r * r, res2 = res * res, margin = 1e-7 * r2;
+    for (int o = -H; o <= H; ++o) {
+        int w = -1;
+        for (int k = 0; k <= H; ++k) {
+            const double d2 = (static_cast<double>(o) * o + static_cast<double>(k) * k) * res2;
+            if (d2 < r2 - margin) {
+                w = k;
+            } else if (d2 <= r2 + margin) {  // on the circle: decided per cell
+                for (int sgn = (k == 0 ? 1 : -1); sgn <= 1; sgn += 2) {
+                    if (sp.nEdge >= kStepMaxEdge) {
+                        sp.ok = 0;
+                        return sp;
+                    }
+                    sp.edgeR[sp.nEdge] = static_cast<int8_t>(o);
+                    sp.edgeC[sp.nEdge] = static_cast<int8_t>(sgn * k);
+                    ++sp.nEdge;
+                }
+            }
+        }
+        sp.rowW[o + H] = static_cast<int8_t>(w);
+        if (w >= 0) sp.storeMask |= 1u << w;
+        if (w > sp.wMax) sp.wMax = w;
+    }
+    sp.nClasses = __builtin_popcount(sp.storeMask);
+    if (sp.nClasses > kStepMaxClasses) sp.ok = 0;
+    return sp;
+}
+__host__ __device__ inline size_t step_lds_bytes(int H, int nClasses) {
+    const int W = kFT + 2 * H;
+    return ((disc_lds_bytes(H) + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(nClasses) * W * kFT * 8 + 128;
+}
+
+// kSecond false: step_height = max - min of the elevation over the first window.  true: the second window over the step
+// heights (their maximum and the number above the critical value), the step layer and the weighted sum of the three filters.
+template <bool kSecond>
+__global__ __launch_bounds__(256) void filter_step_runs_kernel(MapGeom g, const float* __restrict__ src, FilterLayers L, double r, int H, StepShape sp,
+                                                                double critical, float critDown, int nCritical) {
+    extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
+    const DiscLds d = disc_carve(ldsRaw, H);
+    const int W = d.W;
+    // stored runs: [class][tile row][interior column] pairs (max, min) or (max, count bits)
+    float2* runs = reinterpret_cast<float2*>(ldsRaw + ((disc_lds_bytes(H) + 15) & ~static_cast<size_t>(15)));
+    // the shape's per-row half-widths and on-circle offsets in LDS (read in loops below: from the kernel arguments every
+    // read is a scalar load the loop waits for)
+    int8_t* shp = reinterpret_cast<int8_t*>(runs + static_cast<size_t>(sp.nClasses) * W * kFT);
+    if (threadIdx.x < 2 * kFilterMaxH + 1) shp[threadIdx.x] = sp.rowW[threadIdx.x];
+    else if (threadIdx.x >= 64 && threadIdx.x < 64 + kStepMaxEdge) shp[threadIdx.x] = sp.edgeR[threadIdx.x - 64];
+    else if (threadIdx.x >= 96 && threadIdx.x < 96 + kStepMaxEdge) shp[threadIdx.x] = sp.edgeC[threadIdx.x - 96];
+    const unsigned storeMask = sp.storeMask;
+    const int ti0 = blockIdx.y * kFT, tj0 = blockIdx.x * kFT;
+    disc_setup(d, g, src, ti0, tj0, r);
+    const float ninf = -__builtin_huge_valf(), pinf = __builtin_huge_valf();
+    for (int e = threadIdx.x; e < W * kFT; e += 256) {  // 1. one run per (tile row, interior column)
+        const int row = e / kFT, c = e - row * kFT;
+        const float* p = d.tile + row * W + c + H;
+        const float z = p[0];
+        float hi = max_skip_nan(kSecond ? -1.0f : ninf, z), lo = kSecond ? 0.0f : min_skip_nan(pinf, z);
+        int cnt = (kSecond && z > critDown) ? 1 : 0;
+        float2* out = runs + row * kFT + c;  // class k at out[k * W * kFT]; classes in the order of their widths
+        if (storeMask & 1u) {
+            *out = make_float2(hi, kSecond ? __int_as_float(cnt) : lo);
+            out += W * kFT;
+        }
+#pragma unroll 4
+        for (int w = 1; w <= sp.wMax; ++w) {
+            const float a = p[-w], b = p[w];
+            hi = max_skip_nan(max_skip_nan(hi, a), b);
+            if (kSecond) cnt += (a > critDown ? 1 : 0) + (b > critDown ? 1 : 0);
+            else lo = min_skip_nan(min_skip_nan(lo, a), b);
+            if ((storeMask >> w) & 1u) {
+                *out = make_float2(hi, kSecond ? __int_as_float(cnt) : lo);
+                out += W * kFT;
+            }
+        }
+    }
+    __syncthreads();
+    const int li = threadIdx.x / kFT, lj = threadIdx.x % kFT;
+    const int i = ti0 + li, j = tj0 + lj;
+    if (i >= g.rows || j >= g.cols) return;
+    const size_t cell = static_cast<size_t>(i) * g.cols + j;
+    const float centre = d.tile[(li + H) * W + lj + H];
+    float hi = kSecond ? -1.0f : ninf, lo = pinf;
+    int cnt = 0;
+    if (kSecond || isfinite(centre)) {
+        // 2. one stored run per row of the disc (the cell's bounding box never cuts a robust member: it spans every row and
+        // column within r of the centre, and what lies outside the map is NaN in the tile)
+#pragma unroll 4
+        for (int o = -H; o <= H; ++o) {
+            const int w = shp[o + H];
+            if (w < 0) continue;
+            const int k = __builtin_popcount(storeMask & ((1u << w) - 1u));
+            const float2 v = runs[(k * W + (li + H + o)) * kFT + lj];
+            hi = max_skip_nan(hi, v.x);
+            if (kSecond) cnt += __float_as_int(v.y);
+            else lo = min_skip_nan(lo, v.y);
+        }
+        // 3. the offsets on the circle, by the iterator's own tests
+        const int D = 2 * H + 1;
+        const double r2 = r * r;
+        const int i0 = d.bi0[li], i1 = d.bi1[li], j0 = d.bj0[lj], j1 = d.bj1[lj];
+        for (int e = 0; e < sp.nEdge; ++e) {
+            const int o = shp[64 + e], oc = shp[96 + e];
+            const int ii = i + o, jj = j + oc;
+            if (ii < i0 || ii > i1 || jj < j0 || jj > j1) continue;
+            if (!(d.dx2[li * D + H + o] + d.dy2[lj * D + H + oc] <= r2)) continue;
+            const float z = d.tile[(li + H + o) * W + lj + H + oc];
+            hi = max_skip_nan(hi, z);
+            if (kSecond) cnt += z > critDown ? 1 : 0;
+            else lo = min_skip_nan(lo, z);
+        }
+    }
+    if constexpr (!kSecond) {
+        L.stepHeight[cell] = isfinite(centre) ? static_cast<float>(static_cast<double>(hi) - static_cast<double>(lo)) : __builtin_nanf("");
+    } else {
+        const bool valid = hi >= 0.0f;
+        float out = __builtin_nanf("");
+        if (valid) {
+            const double stepMax = static_cast<double>(hi);
+            const double step = fmin(stepMax, static_cast<double>(cnt) / static_cast<double>(nCritical) * stepMax);
+            out = step < critical ? static_cast<float>(1.0 - step / critical) : 0.0f;
+        }
+        L.step[cell] = out;
+        const float third = 1.0f / 3.0f;  // MathExpressionFilter on float matrices: (1.0 / 3.0) * (slope + step + roughness)
+        L.trav[cell] = third * ((L.slope[cell] + out) + L.rough[cell]);
+    }
+}
+
 __host__ inline int filter_halo(double r, double res) { return static_cast<int>(r / res) + 1; }
 
 }  // namespace
@@ -595,10 +779,28 @@ hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float*
                        fc.roughnessCritical);
     if (!fuse)
         hipLaunchKernelGGL(filter_roughness_kernel, grid, block, disc_lds_bytes(hR), stream, g, d_elev, L, fc.roughnessRadius, hR, fc.roughnessCritical);
-    hipLaunchKernelGGL(filter_step1_kernel, grid, block, disc_lds_bytes(h1), stream, g, d_elev, L, fc.stepFirstRadius, h1);
     float critDown = static_cast<float>(fc.stepCritical);
     if (static_cast<double>(critDown) > fc.stepCritical) critDown = std::nextafterf(critDown, -HUGE_VALF);
-    hipLaunchKernelGGL(filter_step2_kernel, grid, block, disc_lds_bytes(h2), stream, g, L, fc.stepSecondRadius, h2, fc.stepCritical, critDown,
-                       fc.stepCriticalCells);
+#ifndef FPE_FILTERS_WALK_ONLY
+    const StepShape s1 = step_shape(fc.stepFirstRadius, g.res, h1), s2 = step_shape(fc.stepSecondRadius, g.res, h2);
+#else
+    StepShape s1{}, s2{};
+#endif
+    const auto fits = [](const void* fn, size_t bytes) -> bool {  // the stored runs of a wide window need more than 48 KB
+        if (bytes <= 48 * 1024) return true;
+        if (bytes > 150 * 1024) return false;
+        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) == hipSuccess;
+    };
+    if (s1.ok && fits(reinterpret_cast<const void*>(filter_step_runs_kernel<false>), step_lds_bytes(h1, s1.nClasses)))
+        hipLaunchKernelGGL(filter_step_runs_kernel<false>, grid, block, step_lds_bytes(h1, s1.nClasses), stream, g, d_elev, L, fc.stepFirstRadius, h1, s1, 0.0,
+                           0.0f, 1);
+    else
+        hipLaunchKernelGGL(filter_step1_kernel, grid, block, disc_lds_bytes(h1), stream, g, d_elev, L, fc.stepFirstRadius, h1);
+    if (s2.ok && fits(reinterpret_cast<const void*>(filter_step_runs_kernel<true>), step_lds_bytes(h2, s2.nClasses)))
+        hipLaunchKernelGGL(filter_step_runs_kernel<true>, grid, block, step_lds_bytes(h2, s2.nClasses), stream, g, static_cast<const float*>(L.stepHeight), L,
+                           fc.stepSecondRadius, h2, s2, fc.stepCritical, critDown, fc.stepCriticalCells);
+    else
+        hipLaunchKernelGGL(filter_step2_kernel, grid, block, disc_lds_bytes(h2), stream, g, L, fc.stepSecondRadius, h2, fc.stepCritical, critDown,
+                           fc.stepCriticalCells);
     return hipGetLastError();
 }

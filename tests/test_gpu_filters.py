@@ -140,6 +140,27 @@ def test_random_layers_and_parameters(planner, seed):
     assert_layers_equal(layers, ora, max_ulp_cells=5e-3)
 
 
+@pytest.mark.parametrize("res,r1,r2,pos", [(0.01, 0.05, 0.10, (0.0, 0.0)), (0.01, 0.13, 0.05, (1234.567, -987.654)), (0.02, 0.10, 0.26, (55.5, 44.25)),
+                                           (0.005, 0.025, 0.085, (-3.3, 7.7)), (0.01, 0.23, 0.20, (0.0, 0.0)), (0.04, 0.08, 0.2, (-700.0, 300.1))])
+def test_step_windows_with_members_on_the_circle(planner, res, r1, r2, pos):
+    """The step filter's windows by row runs (filter_step_runs_kernel): radii that are whole numbers of cells put lattice
+    offsets ON the circle — (0, R), (3, 4) R / 5, (5, 12) R / 13, (6, 8) R / 10 — where CircleIterator::isInside's rounding
+    decides cell by cell (more so far from the origin); a window of 23 cells has more distinct half-widths than the stored
+    runs hold and takes the walking kernels.  The step heights are a max minus a min: bit-identical or wrong."""
+    rng = np.random.default_rng(int(r1 * 1000) * 7 + int(r2 * 1000))
+    rows, cols = 96, 110
+    ii, jj = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
+    elev = (0.2 * np.sin(ii * res * 9.0) + 0.1 * jj * res + rng.normal(0, 5e-3, (rows, cols))).astype(np.float32)
+    elev[40:, 30:60] += np.float32(0.15)
+    elev[rng.random((rows, cols)) < 0.03] = np.nan
+    fp = planner.filter_params(step_first_radius=r1, step_second_radius=r2, step_critical_cells=5)
+    _, layers = planner.traversability_from_elevation(elev, res, position=pos, params=fp, want_layers=True)
+    ora = fpo.traversability_filters(elev, res, position=pos, params=oracle_params(fp))
+    assert_layers_equal(layers, ora, max_ulp_cells=5e-3)
+    for name in ("step_height", "step"):
+        assert np.array_equal(layers[name], ora[name], equal_nan=True), f"{name}: not bit-identical"
+
+
 def test_filter_argument_errors(planner):
     elev = np.zeros((8, 8), np.float32)
     with pytest.raises(Exception):
