@@ -342,6 +342,51 @@ __global__ __launch_bounds__(256) void filter_normals_kernel(MapGeom g, const fl
     if (fuseRough) L.rough[cell] = orough;
 }
 
+// ---- the disc as a lattice SHAPE -------------------------------------------------------------------------------------------
+// On the uniform lattice the members of a cell's disc are the same offsets for every cell — row offset o holds the columns
+// |dc| <= w(o) — except for the few offsets that lie ON the circle ((0, R), (R, 0), (3, 4) R / 5 ...), where
+// CircleIterator::isInside's rounding decides cell by cell.  step_shape sorts the offsets on the host: squared distance
+// against r^2 with a relative margin of 1e-7 (position differences are good to 1e-12).
+constexpr int kStepMaxClasses = 14;
+constexpr int kStepMaxEdge = 24;
+struct StepShape {
+    int8_t rowW[2 * kFilterMaxH + 1 + 3];  // per row offset o + H: its robust half-width, -1: no robust member
+    int8_t edgeR[kStepMaxEdge], edgeC[kStepMaxEdge];  // offsets on the circle
+    uint32_t storeMask;                // bit w: some row has half-width w — the run is stored at that width; its class = the number of set bits below w
+    int32_t nEdge, nClasses, wMax;
+    int32_t ok;                        // 0: the shape does not fit the tables (the walking kernels run)
+};
+__host__ inline StepShape step_shape(double r, double res, int H) {
+    StepShape sp{};
+    for (auto& c : sp.rowW) c = -1;
+    sp.ok = 1;
+    const double r2 = r * r, res2 = res * res, margin = 1e-7 * r2;
+    for (int o = -H; o <= H; ++o) {
+        int w = -1;
+        for (int k = 0; k <= H; ++k) {
+            const double d2 = (static_cast<double>(o) * o + static_cast<double>(k) * k) * res2;
+            if (d2 < r2 - margin) {
+                w = k;
+            } else if (d2 <= r2 + margin) {  // on the circle: decided per cell
+                for (int sgn = (k == 0 ? 1 : -1); sgn <= 1; sgn += 2) {
+                    if (sp.nEdge >= kStepMaxEdge) {
+                        sp.ok = 0;
+                        return sp;
+                    }
+                    sp.edgeR[sp.nEdge] = static_cast<int8_t>(o);
+                    sp.edgeC[sp.nEdge] = static_cast<int8_t>(sgn * k);
+                    ++sp.nEdge;
+                }
+            }
+        }
+        sp.rowW[o + H] = static_cast<int8_t>(w);
+        if (w >= 0) sp.storeMask |= 1u << w;
+        if (w > sp.wMax) sp.wMax = w;
+    }
+    sp.nClasses = __builtin_popcount(sp.storeMask);
+    if (sp.nClasses > kStepMaxClasses) sp.ok = 0;
+    return sp;
+}
 // ---- the same three filters by ROW MOMENTS (round 4) -----------------------------------------------------------------------
 // A cell's disc is at most 2H + 1 row intervals (disc_walk: the members of a row are one interval).  Everything the three
 // filters need of the members — count, mean, the 3 x 3 scatter matrix about the mean, and the sum of squared plane
@@ -362,10 +407,10 @@ struct MomentLds {
 constexpr int kMomentMaxH = 12;
 __host__ __device__ inline size_t moment_lds_bytes(int H) {
     const int W = kFT + 2 * H;
-    return static_cast<size_t>(W) * (W + 1) * (3 * 4 + 3 * 8) + 16;
+    return static_cast<size_t>(W) * (W + 1) * (3 * 4 + 3 * 8) + 16 + 64;
 }
 __global__ __launch_bounds__(256) void filter_normals_moments_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double r, int H,
-                                                                      double slopeCritical, double roughCritical) {
+                                                                      double slopeCritical, double roughCritical, StepShape sp) {
     extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
     const DiscLds d = disc_carve(ldsRaw, H);
     const int W = d.W, W1 = W + 1;
@@ -379,6 +424,9 @@ __global__ __launch_bounds__(256) void filter_normals_moments_kernel(MapGeom g, 
         ml.pC = reinterpret_cast<int*>(p); p += static_cast<size_t>(W) * W1 * 4;
         ml.pCC = reinterpret_cast<int*>(p);
     }
+    // the robust half-width of every row offset (step_shape) behind the prefix arrays
+    int8_t* rowW = reinterpret_cast<int8_t*>(ml.pCC + static_cast<size_t>(W) * W1);
+    if (threadIdx.x < 2 * kFilterMaxH + 1) rowW[threadIdx.x] = sp.rowW[threadIdx.x];
     const int ti0 = blockIdx.y * kFT, tj0 = blockIdx.x * kFT;
     disc_setup(d, g, elev, ti0, tj0, r);
     // z0: one elevation of the tile (its first interior cell when valid): the prefix sums carry z - z0
@@ -429,18 +477,19 @@ __global__ __launch_bounds__(256) void filter_normals_moments_kernel(MapGeom g, 
         const int maxL = j - d.bj0[lj], maxR = d.bj1[lj] - j;
         const int dyC = lj * D + H, dxC = li * D + H - i;
         const int cc = lj + H, vc = li + H;  // the cell's own tile column / row
-        int wL = 0, wR = 0;
         int N = 0, Sc = 0, Scc = 0, Sv = 0, Svv = 0, Svc = 0;  // integer moments about the cell (dc = c - cc, dv = v - vc)
         double Sz = 0.0, Szz = 0.0, Scz = 0.0, Svz = 0.0;
         for (int ii = i0; ii <= i1; ++ii) {
+            // the row's column interval: its robust half-width, and one more column either side when the iterator's own
+            // test says so — that column is on the circle or robustly outside (the test is then false), and whatever lies
+            // beyond it is a lattice unit farther out.  (disc_walk finds the same interval by stepping from the previous
+            // row's: four `while` loops per row, half of this kernel's instructions before.)
             const double a = d.dx2[dxC + ii];
             if (!(a <= r2)) continue;
-            wR = min(wR, maxR);
-            wL = min(wL, maxL);
-            while (wR > 0 && !(a + d.dy2[dyC + wR] <= r2)) --wR;
-            while (wR < maxR && a + d.dy2[dyC + wR + 1] <= r2) ++wR;
-            while (wL > 0 && !(a + d.dy2[dyC - wL] <= r2)) --wL;
-            while (wL < maxL && a + d.dy2[dyC - wL - 1] <= r2) ++wL;
+            const int w0 = rowW[ii - i + H];
+            const int k1 = min(w0 + 1, H);  // (w0 = H cannot be: the halo is one cell wider than the radius)
+            const int wR = min(w0 < 0 ? 0 : w0 + (a + d.dy2[dyC + k1] <= r2 ? 1 : 0), maxR);
+            const int wL = min(w0 < 0 ? 0 : w0 + (a + d.dy2[dyC - k1] <= r2 ? 1 : 0), maxL);
             const int v = ii - ti0 + H, dv = v - vc;
             const int lo = v * W1 + (cc - wL), hi = v * W1 + (cc + wR + 1);
             const int n = ml.pN[hi] - ml.pN[lo];
@@ -608,46 +657,6 @@ __global__ __launch_bounds__(256) void filter_step2_kernel(MapGeom g, FilterLaye
 //      the bounding box of the cell) and folds the members among them one by one.
 // Invalid cells are quiet NaNs in the tile: v_max / v_min skip them, `>` is false on them — what the iterator's isValid
 // test does.  Same members as disc_walk by construction: bit-identical layers (tests/test_gpu_filters.py).
-constexpr int kStepMaxClasses = 14;
-constexpr int kStepMaxEdge = 24;
-struct StepShape {
-    int8_t rowW[2 * kFilterMaxH + 1 + 3];  // per row offset o + H: its robust half-width, -1: no robust member
-    int8_t edgeR[kStepMaxEdge], edgeC[kStepMaxEdge];  // offsets on the circle
-    uint32_t storeMask;                // bit w: some row has half-width w — the run is stored at that width; its class = the number of set bits below w
-    int32_t nEdge, nClasses, wMax;
-    int32_t ok;                        // 0: the shape does not fit the tables (the walking kernels run)
-};
-__host__ inline StepShape step_shape(double r, double res, int H) {
-    StepShape sp{};
-    for (auto& c : sp.rowW) c = -1;
-    sp.ok = 1;
-    const double r2 = r * r, res2 = res * res, margin = 1e-7 * r2;
-    for (int o = -H; o <= H; ++o) {
-        int w = -1;
-        for (int k = 0; k <= H; ++k) {
-            const double d2 = (static_cast<double>(o) * o + static_cast<double>(k) * k) * res2;
-            if (d2 < r2 - margin) {
-                w = k;
-            } else if (d2 <= r2 + margin) {  // on the circle: decided per cell
-                for (int sgn = (k == 0 ? 1 : -1); sgn <= 1; sgn += 2) {
-                    if (sp.nEdge >= kStepMaxEdge) {
-                        sp.ok = 0;
-                        return sp;
-                    }
-                    sp.edgeR[sp.nEdge] = static_cast<int8_t>(o);
-                    sp.edgeC[sp.nEdge] = static_cast<int8_t>(sgn * k);
-                    ++sp.nEdge;
-                }
-            }
-        }
-        sp.rowW[o + H] = static_cast<int8_t>(w);
-        if (w >= 0) sp.storeMask |= 1u << w;
-        if (w > sp.wMax) sp.wMax = w;
-    }
-    sp.nClasses = __builtin_popcount(sp.storeMask);
-    if (sp.nClasses > kStepMaxClasses) sp.ok = 0;
-    return sp;
-}
 __host__ __device__ inline size_t step_lds_bytes(int H, int nClasses) {
     const int W = kFT + 2 * H;
     return ((disc_lds_bytes(H) + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(nClasses) * W * kFT * 8 + 128;
@@ -772,7 +781,7 @@ hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float*
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(filter_normals_moments_kernel, grid, block, ((disc_lds_bytes(hN) + 15) & ~static_cast<size_t>(15)) + moment_lds_bytes(hN), stream,
-                           g, d_elev, L, fc.normalRadius, hN, fc.slopeCritical, fc.roughnessCritical);
+                           g, d_elev, L, fc.normalRadius, hN, fc.slopeCritical, fc.roughnessCritical, step_shape(fc.normalRadius, g.res, hN));
     } else
 #endif
     hipLaunchKernelGGL(filter_normals_kernel, grid, block, disc_lds_bytes(hN), stream, g, d_elev, L, fc.normalRadius, hN, fc.slopeCritical, fuse,
