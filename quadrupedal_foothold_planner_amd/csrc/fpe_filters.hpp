@@ -56,6 +56,8 @@ __device__ __forceinline__ DiscLds disc_carve(char* base, int H) {
 // lane = tile column: no index division, up to 16 loads in flight per lane — the former one-load-one-store loop waited
 // for each of its five to ten loads in turn, and the kernels spent most of a wavefront's life there), computes its
 // table entries from cell_pos itself while the loads fly (the same values the position arrays hold), then stores.
+// kTables false: the tile and the bounding boxes only (the step filter's row runs need no per-axis distance tables).
+template <bool kTables = true>
 __device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, const float* __restrict__ src, int ti0, int tj0, double r) {
     const int H = d.H, W = d.W, t = threadIdx.x, D = 2 * H + 1;
     static_assert(kFT + 2 * kFilterMaxH <= 64, "a tile row is one wavefront load");
@@ -86,9 +88,11 @@ __device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, c
         }
     };
     request(0);
-    for (int k = t; k < 2 * W; k += 256) {
-        if (k < W) d.xP[k] = cell_pos(g.baseX, g.res, ti0 - H + k);
-        else d.yP[k - W] = cell_pos(g.baseY, g.res, tj0 - H + (k - W));
+    if constexpr (kTables) {
+        for (int k = t; k < 2 * W; k += 256) {
+            if (k < W) d.xP[k] = cell_pos(g.baseX, g.res, ti0 - H + k);
+            else d.yP[k - W] = cell_pos(g.baseY, g.res, tj0 - H + (k - W));
+        }
     }
     if (t < 2 * kFT) {  // CircleIterator::findSubmapParameters per axis (circle_bbox), clamped onto the halo
         const bool isRow = t < kFT;
@@ -103,14 +107,16 @@ __device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, c
         (isRow ? d.bi0 : d.bj0)[l] = a;
         (isRow ? d.bi1 : d.bj1)[l] = b;
     }
-    for (int k = t; k < 2 * kFT * D; k += 256) {  // CircleIterator::isInside, per axis
-        const bool isRow = k < kFT * D;
-        const int e = isRow ? k : k - kFT * D;
-        const int l = e / D, o = e % D;
-        const double base = isRow ? g.baseX : g.baseY;
-        const int first = (isRow ? ti0 : tj0) - H + l;
-        const double dd = cell_pos(base, g.res, first + o) - cell_pos(base, g.res, first + H);
-        (isRow ? d.dx2 : d.dy2)[e] = dd * dd;
+    if constexpr (kTables) {
+        for (int k = t; k < 2 * kFT * D; k += 256) {  // CircleIterator::isInside, per axis
+            const bool isRow = k < kFT * D;
+            const int e = isRow ? k : k - kFT * D;
+            const int l = e / D, o = e % D;
+            const double base = isRow ? g.baseX : g.baseY;
+            const int first = (isRow ? ti0 : tj0) - H + l;
+            const double dd = cell_pos(base, g.res, first + o) - cell_pos(base, g.res, first + H);
+            (isRow ? d.dx2 : d.dy2)[e] = dd * dd;
+        }
     }
     deposit(0);
     for (int base = rowStep * kBatch; base < W; base += rowStep * kBatch) {  // (tiles of more than 32 / 64 rows)
@@ -680,7 +686,7 @@ __global__ __launch_bounds__(256) void filter_step_runs_kernel(MapGeom g, const 
     else if (threadIdx.x >= 96 && threadIdx.x < 96 + kStepMaxEdge) shp[threadIdx.x] = sp.edgeC[threadIdx.x - 96];
     const unsigned storeMask = sp.storeMask;
     const int ti0 = blockIdx.y * kFT, tj0 = blockIdx.x * kFT;
-    disc_setup(d, g, src, ti0, tj0, r);
+    disc_setup<false>(d, g, src, ti0, tj0, r);
     const float ninf = -__builtin_huge_valf(), pinf = __builtin_huge_valf();
     for (int e = threadIdx.x; e < W * kFT; e += 256) {  // 1. one run per (tile row, interior column)
         const int row = e / kFT, c = e - row * kFT;
@@ -727,14 +733,16 @@ __global__ __launch_bounds__(256) void filter_step_runs_kernel(MapGeom g, const 
             else lo = min_skip_nan(lo, v.y);
         }
         // 3. the offsets on the circle, by the iterator's own tests
-        const int D = 2 * H + 1;
+        // (squared axis distances as disc_setup's tables hold them: the difference of two cell positions, squared)
         const double r2 = r * r;
         const int i0 = d.bi0[li], i1 = d.bi1[li], j0 = d.bj0[lj], j1 = d.bj1[lj];
+        const double xc = cell_pos(g.baseX, g.res, i), yc = cell_pos(g.baseY, g.res, j);
         for (int e = 0; e < sp.nEdge; ++e) {
             const int o = shp[64 + e], oc = shp[96 + e];
             const int ii = i + o, jj = j + oc;
             if (ii < i0 || ii > i1 || jj < j0 || jj > j1) continue;
-            if (!(d.dx2[li * D + H + o] + d.dy2[lj * D + H + oc] <= r2)) continue;
+            const double ddx = cell_pos(g.baseX, g.res, ii) - xc, ddy = cell_pos(g.baseY, g.res, jj) - yc;
+            if (!(ddx * ddx + ddy * ddy <= r2)) continue;
             const float z = d.tile[(li + H + o) * W + lj + H + oc];
             hi = max_skip_nan(hi, z);
             if (kSecond) cnt += z > critDown ? 1 : 0;
