@@ -216,8 +216,9 @@ class FootholdPlanner:
         fields = PRODUCT_FIELDS
         if out is None:
             out = {k: np.zeros(shapes[k][0], dtype=shapes[k][1]) for k in products}
-        else:
-            products = tuple(k for k in products if k in out)
+        else:  # the arrays of `out` are the products asked for (whatever `products` says)
+            products = tuple(k for k in PRODUCT_ORDER if k in out)
+            assert len(products) == len(out), f"unknown product in out: {sorted(set(out) - set(products))}"
         # the checked argument block of an `out` dict is kept for its next use (timing loops call with the same arrays: comparing
         # seven structured dtypes and taking seven pointers costs more Python time than the engine needs for its launches)
         key = (id(out), B, int(n_cycles), products) + tuple(out[k].ctypes.data for k in products)

@@ -310,6 +310,9 @@ def test_selected_packed_is_the_selected_record_in_eight_bytes(planner):
         assert (out["selected"]["valid"] == 0).any() and (out["selected"]["source"] == 1).any()
         only = planner.plan(poses, 5, products=("selected_packed",))
         assert only["selected_packed"].tobytes() == out["selected_packed"].tobytes()
+        again = planner.plan_outputs(poses.shape[0], 5, products=("selected_packed",), pinned=True)  # caller-owned (pinned) array, re-used
+        planner.plan(poses, 5, out=again)
+        assert again["selected_packed"].tobytes() == out["selected_packed"].tobytes()
     planner.params = _capi.params_yaml()
 
 
