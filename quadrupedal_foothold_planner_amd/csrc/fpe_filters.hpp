@@ -360,13 +360,26 @@ struct StepShape {
     int8_t edgeR[kStepMaxEdge], edgeC[kStepMaxEdge];  // offsets on the circle
     uint32_t storeMask;                // bit w: some row has half-width w — the run is stored at that width; its class = the number of set bits below w
     int32_t nEdge, nClasses, wMax;
-    int32_t ok;                        // 0: the shape does not fit the tables (the walking kernels run)
+    int32_t ok;                        // 0: the shape does not fit the step kernels' tables (the walking kernels run)
+    int32_t rowsOk;                    // 0: not even the rows' half-widths are to be trusted (map too far from the origin)
 };
-__host__ inline StepShape step_shape(double r, double res, int H) {
+// reach: the largest |coordinate| of a cell of the map — a position difference carries ~2 ulp of that, which decides how wide
+// the band of offsets is that the per-cell arithmetic must settle.
+__host__ inline StepShape step_shape(double r, double res, int H, double reach) {
     StepShape sp{};
     for (auto& c : sp.rowW) c = -1;
     sp.ok = 1;
-    const double r2 = r * r, res2 = res * res, margin = 1e-7 * r2;
+    sp.rowsOk = 1;
+    const double r2 = r * r, res2 = res * res;
+    // relative margin on squared distances: 1e-7 near the origin; far from it the rounding of the positions themselves
+    // (4 ulp of `reach` on a difference of one resolution, twice that on its square), with a factor of 16 to spare.
+    // Beyond 1e-3 two neighbouring offsets of a row could both be in doubt: the walking kernels take over.
+    const double rel = fmax(1e-7, 16.0 * 8.0 * 2.220446049250313e-16 * reach / res);
+    if (rel > 1e-3) {
+        sp.ok = sp.rowsOk = 0;
+        return sp;
+    }
+    const double margin = rel * r2;
     for (int o = -H; o <= H; ++o) {
         int w = -1;
         for (int k = 0; k <= H; ++k) {
@@ -376,12 +389,12 @@ __host__ inline StepShape step_shape(double r, double res, int H) {
             } else if (d2 <= r2 + margin) {  // on the circle: decided per cell
                 for (int sgn = (k == 0 ? 1 : -1); sgn <= 1; sgn += 2) {
                     if (sp.nEdge >= kStepMaxEdge) {
-                        sp.ok = 0;
-                        return sp;
+                        sp.ok = 0;  // (the rows' half-widths below stay valid: the normals kernel tests the next column itself)
+                    } else {
+                        sp.edgeR[sp.nEdge] = static_cast<int8_t>(o);
+                        sp.edgeC[sp.nEdge] = static_cast<int8_t>(sgn * k);
+                        ++sp.nEdge;
                     }
-                    sp.edgeR[sp.nEdge] = static_cast<int8_t>(o);
-                    sp.edgeC[sp.nEdge] = static_cast<int8_t>(sgn * k);
-                    ++sp.nEdge;
                 }
             }
         }
@@ -780,8 +793,15 @@ hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float*
     const int hN = filter_halo(fc.normalRadius, g.res), hR = filter_halo(fc.roughnessRadius, g.res);
     const int h1 = filter_halo(fc.stepFirstRadius, g.res), h2 = filter_halo(fc.stepSecondRadius, g.res);
     const int fuse = fc.roughnessRadius == fc.normalRadius ? 1 : 0;  // the published default chain: both 0.05 m
+    const double reach = std::fmax(std::fabs(g.posX) + g.orgX, std::fabs(g.posY) + g.orgY) + g.res;
 #ifndef FPE_FILTERS_WALK_ONLY
-    if (fuse && hN <= kMomentMaxH) {  // row moments (see filter_normals_moments_kernel); the literal walks for what they do not cover
+    const StepShape sN = step_shape(fc.normalRadius, g.res, hN, reach);
+    // The moment form takes the lattice as EXACT integers; the published filters (and the oracle) sum the cells' rounded f64
+    // positions.  Near the origin the two agree far inside a float ulp; at a coordinate of `reach` a position carries an error of
+    // ulp(reach) ~ 2e-16 reach against a spacing of res, and the normal follows it: beyond reach / res = 2e5 (2 km at 1 cm, 4e-11
+    // relative) the literal walks run instead (at 3 000 km a handful of cells differed by up to 8 float ulps; tests).
+    const bool latticeExact = reach / g.res < 2.0e5;
+    if (fuse && hN <= kMomentMaxH && sN.rowsOk && latticeExact) {  // row moments (see filter_normals_moments_kernel); the literal walks for what they do not cover
         const size_t bytes = ((disc_lds_bytes(hN) + 15) & ~static_cast<size_t>(15)) + moment_lds_bytes(hN);
         if (bytes > 48 * 1024) {  // (0.5 cm maps: the prefix arrays of a 38 x 38 tile need 66 KB)
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_normals_moments_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -789,7 +809,7 @@ hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float*
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(filter_normals_moments_kernel, grid, block, ((disc_lds_bytes(hN) + 15) & ~static_cast<size_t>(15)) + moment_lds_bytes(hN), stream,
-                           g, d_elev, L, fc.normalRadius, hN, fc.slopeCritical, fc.roughnessCritical, step_shape(fc.normalRadius, g.res, hN));
+                           g, d_elev, L, fc.normalRadius, hN, fc.slopeCritical, fc.roughnessCritical, sN);
     } else
 #endif
     hipLaunchKernelGGL(filter_normals_kernel, grid, block, disc_lds_bytes(hN), stream, g, d_elev, L, fc.normalRadius, hN, fc.slopeCritical, fuse,
@@ -799,7 +819,7 @@ hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float*
     float critDown = static_cast<float>(fc.stepCritical);
     if (static_cast<double>(critDown) > fc.stepCritical) critDown = std::nextafterf(critDown, -HUGE_VALF);
 #ifndef FPE_FILTERS_WALK_ONLY
-    const StepShape s1 = step_shape(fc.stepFirstRadius, g.res, h1), s2 = step_shape(fc.stepSecondRadius, g.res, h2);
+    const StepShape s1 = step_shape(fc.stepFirstRadius, g.res, h1, reach), s2 = step_shape(fc.stepSecondRadius, g.res, h2, reach);
 #else
     StepShape s1{}, s2{};
 #endif

@@ -141,12 +141,15 @@ def test_random_layers_and_parameters(planner, seed):
 
 
 @pytest.mark.parametrize("res,r1,r2,pos", [(0.01, 0.05, 0.10, (0.0, 0.0)), (0.01, 0.13, 0.05, (1234.567, -987.654)), (0.02, 0.10, 0.26, (55.5, 44.25)),
-                                           (0.005, 0.025, 0.085, (-3.3, 7.7)), (0.01, 0.23, 0.20, (0.0, 0.0)), (0.04, 0.08, 0.2, (-700.0, 300.1))])
+                                           (0.005, 0.025, 0.085, (-3.3, 7.7)), (0.01, 0.23, 0.20, (0.0, 0.0)), (0.04, 0.08, 0.2, (-700.0, 300.1)),
+                                           (0.01, 0.05, 0.10, (3.0e6, -2.0e6)), (0.01, 0.05, 0.13, (2.0e9, 1.0e9))])
 def test_step_windows_with_members_on_the_circle(planner, res, r1, r2, pos):
     """The step filter's windows by row runs (filter_step_runs_kernel): radii that are whole numbers of cells put lattice
     offsets ON the circle — (0, R), (3, 4) R / 5, (5, 12) R / 13, (6, 8) R / 10 — where CircleIterator::isInside's rounding
     decides cell by cell (more so far from the origin); a window of 23 cells has more distinct half-widths than the stored
-    runs hold and takes the walking kernels.  The step heights are a max minus a min: bit-identical or wrong."""
+    runs hold and takes the walking kernels.  Thousands of kilometres from the origin the band of offsets in doubt widens
+    with the rounding of the positions (step_shape's `reach`); at 2e9 m nothing is trusted and every kernel walks.  The step
+    heights are a max minus a min: bit-identical or wrong."""
     rng = np.random.default_rng(int(r1 * 1000) * 7 + int(r2 * 1000))
     rows, cols = 96, 110
     ii, jj = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
