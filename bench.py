@@ -749,10 +749,10 @@ def main():
             line["config"]["verify_error"] = "filters: traversability layer differs from the oracle by more than one float ulp"
         line["filters"] = {"map": f"{rows}x{cols} @ {res} m elevation layer of this workload", "ms": f_ms, "cells_per_s": rows * cols / (f_ms * 1e-3),
                            "GB/s_by_layers": (1 + 8) * rows * cols * 4 / (f_ms * 1e-3) / 1e9, "verified": f_ok,
-                           "note": "fpe_traversability_device: 1 layer read + 8 layers written per cell (36 B) against ~10^3 f64 operations per "
-                                   "cell (published filters gather f64 points and a 3x3 covariance per cell): bound by the SIMDs' instruction issue (per 64 cells at "
-                                   "1 cm: 6.8 k VALU + 3.1 k SALU + 0.6 k LDS instructions, VALU-active 16 % of a wavefront's lifetime at 7 wavefronts per "
-                                   "SIMD, profiles/round3_filters.txt) — loop control and LDS reads as much as f64 arithmetic — not by HBM; "
+                           "note": "fpe_traversability_device: 1 layer read + 8 layers written per cell (36 B); normals / slope / roughness from row "
+                                   "moments of the disc with Newton's iteration for the eigenvector, the step filter's windows by row runs over a "
+                                   "host-sorted lattice shape (DESIGN 4.5): bound by the SIMDs' instruction issue (per 64 cells at 1 cm: normals 1.9 k VALU "
+                                   "+ 0.6 k SALU + 0.26 k LDS instructions, each step kernel 0.85 k + 0.58 k + 0.11 k; profiles/round4_filters.txt), not by HBM; "
                                    "`verified`: engine against oracle on a 96 x 96 corner of the layer taken as a map of its own"}
         del d_fe, d_ft, d_fl
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

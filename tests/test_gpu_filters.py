@@ -111,10 +111,9 @@ def test_device_resident_chain_feeds_the_planner(planner):
     util.assert_plan_equal(eng, ora)
 
 
-@pytest.mark.parametrize("seed", range(16))
-def test_random_layers_and_parameters(planner, seed):
-    """Differential campaign: random size, resolution, map position, hole density, terrain (steps, slopes, noise, spikes
-    of +-inf) and filter parameters — radii on and off multiples of the resolution, windows larger than the map."""
+def random_filter_case(planner, seed):
+    """One case of the differential campaign: random size, resolution, map position, hole density, terrain (steps, slopes, noise,
+    spikes of +-inf) and filter parameters — radii on and off multiples of the resolution, windows larger than the map."""
     rng = np.random.default_rng(9000 + seed)
     rows, cols = int(rng.integers(5, 90)), int(rng.integers(5, 90))
     res = float(rng.choice([0.005, 0.01, 0.02, 0.025, 0.04]))
@@ -138,6 +137,28 @@ def test_random_layers_and_parameters(planner, seed):
     _, layers = planner.traversability_from_elevation(elev, res, position=pos, params=fp, want_layers=True)
     ora = fpo.traversability_filters(elev, res, position=pos, params=oracle_params(fp))
     assert_layers_equal(layers, ora, max_ulp_cells=5e-3)
+    for name in ("step_height", "step"):  # max / min / count windows: bit-identical or wrong
+        assert np.array_equal(layers[name], ora[name], equal_nan=True), f"seed {seed}: {name} not bit-identical"
+    return rows * cols, float(np.isfinite(ora["traversability"]).mean())
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_layers_and_parameters(planner, seed):
+    random_filter_case(planner, seed)
+
+
+def test_random_filter_campaign(planner):
+    """FPE_FILTER_FUZZ_CASES more cases of the same generator in one test (default 48; the committed summary under profiles/
+    comes from a run with tens of thousands), seeds from FPE_FILTER_FUZZ_SEED."""
+    import os
+    n_cases, seed0 = int(os.environ.get("FPE_FILTER_FUZZ_CASES", "48")), int(os.environ.get("FPE_FILTER_FUZZ_SEED", "100"))
+    cells, valid = 0, []
+    for seed in range(seed0, seed0 + n_cases):
+        c, v = random_filter_case(planner, seed)
+        cells += c
+        valid.append(v)
+    print(f"random filter campaign: seeds {seed0} .. {seed0 + n_cases - 1} ({n_cases} maps, {cells} cells, mean valid share {np.mean(valid):.3f}): "
+          "every layer within one float ulp of the oracle, step heights and step layers bit-identical")
 
 
 @pytest.mark.parametrize("res,r1,r2,pos", [(0.01, 0.05, 0.10, (0.0, 0.0)), (0.01, 0.13, 0.05, (1234.567, -987.654)), (0.02, 0.10, 0.26, (55.5, 44.25)),
