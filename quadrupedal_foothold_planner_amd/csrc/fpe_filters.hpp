@@ -252,7 +252,10 @@ __device__ __forceinline__ bool normal_newton(double a00, double a01, double a02
     const double c0 = __builtin_fma(b02, __builtin_fma(b01, b12, -(b11 * b02)), __builtin_fma(b00, m0, -(b01 * __builtin_fma(b01, b22, -(b12 * b02)))));
     const double tol = 4e-16 * c2;
     double lam = c0 * rcp_refined(c1);
-    bool done = !(s > 0.0) || !(c1 > 0.0);  // (degenerate input: reported as not converged below)
+    // degenerate input — no matrix, or the two smaller eigenvalues both at rounding level (c1 ~ lambda2 lambda3 when lambda1 ~ 0:
+    // two members, collinear members): c0 / c1 would be a quotient of rounding noise.  Reported as not converged: the sweeps
+    // and the rank test decide.
+    bool done = !(s > 0.0) || !(c1 > 1e-9 * (c2 * c2));
     const bool bad = done;
     for (int it = 0; it < 16; ++it) {
         const double f = __builtin_fma(__builtin_fma(lam - c2, lam, c1), lam, -c0);
@@ -281,7 +284,10 @@ __device__ __forceinline__ bool normal_newton(double a00, double a01, double a02
     if (ez < 0.0) { ex = -ex; ey = -ey; ez = -ez; }
     wS = lam * s;
     wL = c2 * s;
-    return done && !bad && nn > 0.0 && lam >= 0.0;
+    // the next eigenvalue (the other two roots: sum S, product P): an eigenvector is only as good as its eigenvalue is apart
+    const double S = c2 - lam, P = __builtin_fma(-lam, S, c1);
+    const double lam2 = 0.5 * (S - sqrt(fmax(__builtin_fma(S, S, -4.0 * P), 0.0)));
+    return done && !bad && nn > 0.0 && lam >= 0.0 && (lam2 - lam) > 1e-6 * c2;
 }
 
 // One cell of NormalVectorsFilter (area method) + SlopeFilter [+ RoughnessFilter of the same radius] by the LITERAL walks of
@@ -712,7 +718,6 @@ __global__ __launch_bounds__(256) void filter_step_runs_kernel(MapGeom g, const 
             *out = make_float2(hi, kSecond ? __int_as_float(cnt) : lo);
             out += W * kFT;
         }
-#pragma unroll 4
         for (int w = 1; w <= sp.wMax; ++w) {
             const float a = p[-w], b = p[w];
             hi = max_skip_nan(max_skip_nan(hi, a), b);
@@ -735,7 +740,6 @@ __global__ __launch_bounds__(256) void filter_step_runs_kernel(MapGeom g, const 
     if (kSecond || isfinite(centre)) {
         // 2. one stored run per row of the disc (the cell's bounding box never cuts a robust member: it spans every row and
         // column within r of the centre, and what lies outside the map is NaN in the tile)
-#pragma unroll 4
         for (int o = -H; o <= H; ++o) {
             const int w = shp[o + H];
             if (w < 0) continue;

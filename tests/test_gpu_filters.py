@@ -3,8 +3,8 @@ the oracle's restatement (oracle/fpo_filters.cpp) on the same seeded elevation l
 
 Bar: the layers are float, computed through f64 like the published filters.  Engine and oracle run the same expression
 order, so the layers agree bit for bit except where the device's and the host's `acos` differ in the last place of the f64
-slope (the float result may then round the other way): every layer within ONE float ulp, and bit-identical on all but a
-handful of cells.  Holes (NaN) must coincide exactly."""
+slope (the float result may then round the other way): every layer within ONE float ulp (the weighted sum of three such
+layers within two), and bit-identical on all but a handful of cells.  Holes (NaN) must coincide exactly."""
 import ctypes as C
 
 import numpy as np
@@ -40,7 +40,9 @@ def assert_layers_equal(eng, ora, max_ulp_cells=1e-4):
         ok = ~np.isnan(a)
         ai, bi = a[ok].view(np.int32).astype(np.int64), b[ok].view(np.int32).astype(np.int64)
         d = np.abs(ai - bi)
-        assert d.max(initial=0) <= 1, f"{name}: {int((d > 1).sum())} cells differ by more than one float ulp (max {int(d.max())})"
+        # (the weighted sum adds three layers that may each be one ulp off: two ulps; 1 map in ~10^4 of the campaign has such a cell)
+        bar = 2 if name == "traversability" else 1
+        assert d.max(initial=0) <= bar, f"{name}: {int((d > bar).sum())} cells differ by more than {bar} float ulp (max {int(d.max())})"
         assert (d != 0).mean() <= max_ulp_cells, f"{name}: {int((d != 0).sum())} of {d.size} cells not bit-identical"
 
 
