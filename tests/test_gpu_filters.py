@@ -86,6 +86,25 @@ def test_map_border_holes_and_flat_ground(planner):
     assert np.all(trav[20:, :30] == layers["traversability"][20:, :30]) and np.nanmax(trav[30:50, 2:30]) > 0.9999
 
 
+def test_discs_with_two_or_collinear_members_keep_the_rank_test(planner):
+    """Campaign seed 700073: a disc with two members (or members on one line) has a rank-1 scatter matrix — two eigenvalues at
+    rounding level.  The eigen-solve by Newton's iteration must refuse it (normal_newton: c1 against c2^2) so that the sweeps
+    and the published rank test give the z axis, as the oracle does."""
+    res = 0.02
+    elev = np.full((40, 44), np.nan, np.float32)
+    elev[3, 3], elev[4, 4] = 0.10, 0.17          # two members, diagonal
+    elev[10, 20], elev[10, 22] = 0.0, 0.3        # two members, one row
+    elev[20, 5], elev[21, 5], elev[22, 5] = 0.1, 0.2, 0.3     # three members on a line (a column), a plane through them is not unique
+    elev[30, 30], elev[31, 31], elev[32, 32] = 0.3, 0.1, 0.25  # three on a diagonal, not coplanar with z linear
+    elev[15, 35], elev[16, 36], elev[15, 36] = 0.0, 0.1, 0.4   # three members spanning a plane: rank 2, an exact plane
+    fp = planner.filter_params(normal_radius=0.06, roughness_radius=0.06)
+    for pos in ((0.0, 0.0), (17.3, -4.9)):
+        _, layers = planner.traversability_from_elevation(elev, res, position=pos, params=fp, want_layers=True)
+        ora = fpo.traversability_filters(elev, res, position=pos, params=oracle_params(fp))
+        assert_layers_equal(layers, ora, max_ulp_cells=0.0)
+        assert layers["normal_z"][3, 3] == 1.0 and layers["normal_z"][21, 5] == 1.0
+
+
 def test_device_resident_chain_feeds_the_planner(planner):
     """elevation (HBM) -> fpe_traversability_device -> fpe_upload_map_device -> plan: the same plan as uploading the
     oracle's traversability layer from the host."""
