@@ -31,23 +31,24 @@ struct DiscLds {
     int *bi0, *bi1, *bj0, *bj1;  // [kFT] bounding rows / columns of the cell's iterator
     int H, W;
 };
-__host__ __device__ inline size_t disc_lds_bytes(int H) {
-    const int W = kFT + 2 * H;
-    return static_cast<size_t>(W) * W * 4 + 2 * static_cast<size_t>(W) * 8 + 2 * static_cast<size_t>(kFT) * (2 * H + 1) * 8 + 4 * kFT * 4 + 16;
+// (T: the tile edge — kFT for the walking kernels, 16 or 32 for the row-moment and row-run kernels)
+__host__ __device__ inline size_t disc_lds_bytes(int H, int T = kFT) {
+    const int W = T + 2 * H;
+    return static_cast<size_t>(W) * W * 4 + 2 * static_cast<size_t>(W) * 8 + 2 * static_cast<size_t>(T) * (2 * H + 1) * 8 + 4 * T * 4 + 16;
 }
-__device__ __forceinline__ DiscLds disc_carve(char* base, int H) {
+__device__ __forceinline__ DiscLds disc_carve(char* base, int H, int T = kFT) {
     DiscLds d;
     d.H = H;
-    d.W = kFT + 2 * H;
+    d.W = T + 2 * H;
     char* p = base;
     d.xP = reinterpret_cast<double*>(p); p += d.W * 8;
     d.yP = reinterpret_cast<double*>(p); p += d.W * 8;
-    d.dx2 = reinterpret_cast<double*>(p); p += kFT * (2 * H + 1) * 8;
-    d.dy2 = reinterpret_cast<double*>(p); p += kFT * (2 * H + 1) * 8;
-    d.bi0 = reinterpret_cast<int*>(p); p += kFT * 4;
-    d.bi1 = reinterpret_cast<int*>(p); p += kFT * 4;
-    d.bj0 = reinterpret_cast<int*>(p); p += kFT * 4;
-    d.bj1 = reinterpret_cast<int*>(p); p += kFT * 4;
+    d.dx2 = reinterpret_cast<double*>(p); p += T * (2 * H + 1) * 8;
+    d.dy2 = reinterpret_cast<double*>(p); p += T * (2 * H + 1) * 8;
+    d.bi0 = reinterpret_cast<int*>(p); p += T * 4;
+    d.bi1 = reinterpret_cast<int*>(p); p += T * 4;
+    d.bj0 = reinterpret_cast<int*>(p); p += T * 4;
+    d.bj1 = reinterpret_cast<int*>(p); p += T * 4;
     d.tile = reinterpret_cast<float*>(p);
     return d;
 }
@@ -57,16 +58,16 @@ __device__ __forceinline__ DiscLds disc_carve(char* base, int H) {
 // for each of its five to ten loads in turn, and the kernels spent most of a wavefront's life there), computes its
 // table entries from cell_pos itself while the loads fly (the same values the position arrays hold), then stores.
 // kTables false: the tile and the bounding boxes only (the step filter's row runs need no per-axis distance tables).
-template <bool kTables = true>
+template <bool kTables = true, int T = kFT>
 __device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, const float* __restrict__ src, int ti0, int tj0, double r) {
     const int H = d.H, W = d.W, t = threadIdx.x, D = 2 * H + 1;
-    static_assert(kFT + 2 * kFilterMaxH <= 64, "a tile row is one wavefront load");
+    constexpr int kThreads = T * T;  // (the launch makes sure that a tile row is at most one wavefront load: T + 2 H <= 64)
     // a wavefront instruction loads one tile row (W > 32) or two (lanes 0-31 / 32-63); eight rows in flight per lane
     const int perInst = W <= 32 ? 2 : 1, laneCols = W <= 32 ? 32 : 64;
     const int col = t & (laneCols - 1), sub = (t & 63) / laneCols, wv = t >> 6;
     const int tj = tj0 - H + col;
     const bool colOk = col < W && tj >= 0 && tj < g.cols;
-    const int rowStep = 4 * perInst;  // rows per workgroup instruction
+    const int rowStep = (kThreads / 64) * perInst;  // rows per workgroup instruction
     const int firstRow = wv * perInst + sub;
     constexpr int kBatch = 8;
     float v[kBatch];
@@ -89,14 +90,14 @@ __device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, c
     };
     request(0);
     if constexpr (kTables) {
-        for (int k = t; k < 2 * W; k += 256) {
+        for (int k = t; k < 2 * W; k += kThreads) {
             if (k < W) d.xP[k] = cell_pos(g.baseX, g.res, ti0 - H + k);
             else d.yP[k - W] = cell_pos(g.baseY, g.res, tj0 - H + (k - W));
         }
     }
-    if (t < 2 * kFT) {  // CircleIterator::findSubmapParameters per axis (circle_bbox), clamped onto the halo
-        const bool isRow = t < kFT;
-        const int l = isRow ? t : t - kFT;
+    if (t < 2 * T) {  // CircleIterator::findSubmapParameters per axis (circle_bbox), clamped onto the halo
+        const bool isRow = t < T;
+        const int l = isRow ? t : t - T;
         const int idx = (isRow ? ti0 : tj0) + l, n = isRow ? g.rows : g.cols;
         const double c = cell_pos(isRow ? g.baseX : g.baseY, g.res, idx);
         const double org = isRow ? g.orgX : g.orgY, pos = isRow ? g.posX : g.posY, len = isRow ? g.lenX : g.lenY;
@@ -108,9 +109,9 @@ __device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, c
         (isRow ? d.bi1 : d.bj1)[l] = b;
     }
     if constexpr (kTables) {
-        for (int k = t; k < 2 * kFT * D; k += 256) {  // CircleIterator::isInside, per axis
-            const bool isRow = k < kFT * D;
-            const int e = isRow ? k : k - kFT * D;
+        for (int k = t; k < 2 * T * D; k += kThreads) {  // CircleIterator::isInside, per axis
+            const bool isRow = k < T * D;
+            const int e = isRow ? k : k - T * D;
             const int l = e / D, o = e % D;
             const double base = isRow ? g.baseX : g.baseY;
             const int first = (isRow ? ti0 : tj0) - H + l;
@@ -430,18 +431,19 @@ struct MomentLds {
     double *pZ, *pZZ, *pCZ;   // sum of z', z'^2, c z'
 };
 constexpr int kMomentMaxH = 12;
-__host__ __device__ inline size_t moment_lds_bytes(int H) {
-    const int W = kFT + 2 * H;
+__host__ __device__ inline size_t moment_lds_bytes(int H, int T = kFT) {
+    const int W = T + 2 * H;
     return static_cast<size_t>(W) * (W + 1) * (3 * 4 + 3 * 8) + 16 + 64;
 }
-__global__ __launch_bounds__(256) void filter_normals_moments_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double r, int H,
+template <int T>
+__global__ __launch_bounds__(T * T) void filter_normals_moments_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double r, int H,
                                                                       double slopeCritical, double roughCritical, StepShape sp) {
     extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
-    const DiscLds d = disc_carve(ldsRaw, H);
+    const DiscLds d = disc_carve(ldsRaw, H, T);
     const int W = d.W, W1 = W + 1;
     MomentLds ml;
     {
-        char* p = ldsRaw + ((disc_lds_bytes(H) + 15) & ~static_cast<size_t>(15));
+        char* p = ldsRaw + ((disc_lds_bytes(H, T) + 15) & ~static_cast<size_t>(15));
         ml.pZ = reinterpret_cast<double*>(p); p += static_cast<size_t>(W) * W1 * 8;
         ml.pZZ = reinterpret_cast<double*>(p); p += static_cast<size_t>(W) * W1 * 8;
         ml.pCZ = reinterpret_cast<double*>(p); p += static_cast<size_t>(W) * W1 * 8;
@@ -452,14 +454,14 @@ __global__ __launch_bounds__(256) void filter_normals_moments_kernel(MapGeom g, 
     // the robust half-width of every row offset (step_shape) behind the prefix arrays
     int8_t* rowW = reinterpret_cast<int8_t*>(ml.pCC + static_cast<size_t>(W) * W1);
     if (threadIdx.x < 2 * kFilterMaxH + 1) rowW[threadIdx.x] = sp.rowW[threadIdx.x];
-    const int ti0 = blockIdx.y * kFT, tj0 = blockIdx.x * kFT;
-    disc_setup(d, g, elev, ti0, tj0, r);
+    const int ti0 = blockIdx.y * T, tj0 = blockIdx.x * T;
+    disc_setup<true, T>(d, g, elev, ti0, tj0, r);
     // z0: one elevation of the tile (its first interior cell when valid): the prefix sums carry z - z0
     const float zf = d.tile[H * W + H];
     const double z0 = zf == zf ? static_cast<double>(zf) : 0.0;
     {   // one thread per (tile row, quantity): a serial scan over the row's W cells
         const int t = threadIdx.x;
-        for (int e = t; e < 6 * W; e += 256) {
+        for (int e = t; e < 6 * W; e += T * T) {
             const int row = e / 6, q = e - 6 * row;
             const float* src = d.tile + row * W;
             const int o = row * W1;
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(256) void filter_normals_moments_kernel(MapGeom g, 
         }
     }
     __syncthreads();
-    const int li = threadIdx.x / kFT, lj = threadIdx.x % kFT;
+    const int li = threadIdx.x / T, lj = threadIdx.x % T;
     const int i = ti0 + li, j = tj0 + lj;
     if (i >= g.rows || j >= g.cols) return;
     const size_t cell = static_cast<size_t>(i) * g.cols + j;
@@ -682,41 +684,41 @@ __global__ __launch_bounds__(256) void filter_step2_kernel(MapGeom g, FilterLaye
 //      the bounding box of the cell) and folds the members among them one by one.
 // Invalid cells are quiet NaNs in the tile: v_max / v_min skip them, `>` is false on them — what the iterator's isValid
 // test does.  Same members as disc_walk by construction: bit-identical layers (tests/test_gpu_filters.py).
-__host__ __device__ inline size_t step_lds_bytes(int H, int nClasses) {
-    const int W = kFT + 2 * H;
-    return ((disc_lds_bytes(H) + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(nClasses) * W * kFT * 8 + 128;
+__host__ __device__ inline size_t step_lds_bytes(int H, int nClasses, int T = kFT) {
+    const int W = T + 2 * H;
+    return ((disc_lds_bytes(H, T) + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(nClasses) * W * T * 8 + 128;
 }
 
 // kSecond false: step_height = max - min of the elevation over the first window.  true: the second window over the step
 // heights (their maximum and the number above the critical value), the step layer and the weighted sum of the three filters.
-template <bool kSecond>
-__global__ __launch_bounds__(256) void filter_step_runs_kernel(MapGeom g, const float* __restrict__ src, FilterLayers L, double r, int H, StepShape sp,
+template <bool kSecond, int T>
+__global__ __launch_bounds__(T * T) void filter_step_runs_kernel(MapGeom g, const float* __restrict__ src, FilterLayers L, double r, int H, StepShape sp,
                                                                 double critical, float critDown, int nCritical) {
     extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
-    const DiscLds d = disc_carve(ldsRaw, H);
+    const DiscLds d = disc_carve(ldsRaw, H, T);
     const int W = d.W;
     // stored runs: [class][tile row][interior column] pairs (max, min) or (max, count bits)
-    float2* runs = reinterpret_cast<float2*>(ldsRaw + ((disc_lds_bytes(H) + 15) & ~static_cast<size_t>(15)));
+    float2* runs = reinterpret_cast<float2*>(ldsRaw + ((disc_lds_bytes(H, T) + 15) & ~static_cast<size_t>(15)));
     // the shape's per-row half-widths and on-circle offsets in LDS (read in loops below: from the kernel arguments every
     // read is a scalar load the loop waits for)
-    int8_t* shp = reinterpret_cast<int8_t*>(runs + static_cast<size_t>(sp.nClasses) * W * kFT);
+    int8_t* shp = reinterpret_cast<int8_t*>(runs + static_cast<size_t>(sp.nClasses) * W * T);
     if (threadIdx.x < 2 * kFilterMaxH + 1) shp[threadIdx.x] = sp.rowW[threadIdx.x];
     else if (threadIdx.x >= 64 && threadIdx.x < 64 + kStepMaxEdge) shp[threadIdx.x] = sp.edgeR[threadIdx.x - 64];
     else if (threadIdx.x >= 96 && threadIdx.x < 96 + kStepMaxEdge) shp[threadIdx.x] = sp.edgeC[threadIdx.x - 96];
     const unsigned storeMask = sp.storeMask;
-    const int ti0 = blockIdx.y * kFT, tj0 = blockIdx.x * kFT;
-    disc_setup<false>(d, g, src, ti0, tj0, r);
+    const int ti0 = blockIdx.y * T, tj0 = blockIdx.x * T;
+    disc_setup<false, T>(d, g, src, ti0, tj0, r);
     const float ninf = -__builtin_huge_valf(), pinf = __builtin_huge_valf();
-    for (int e = threadIdx.x; e < W * kFT; e += 256) {  // 1. one run per (tile row, interior column)
-        const int row = e / kFT, c = e - row * kFT;
+    for (int e = threadIdx.x; e < W * T; e += T * T) {  // 1. one run per (tile row, interior column)
+        const int row = e / T, c = e - row * T;
         const float* p = d.tile + row * W + c + H;
         const float z = p[0];
         float hi = max_skip_nan(kSecond ? -1.0f : ninf, z), lo = kSecond ? 0.0f : min_skip_nan(pinf, z);
         int cnt = (kSecond && z > critDown) ? 1 : 0;
-        float2* out = runs + row * kFT + c;  // class k at out[k * W * kFT]; classes in the order of their widths
+        float2* out = runs + row * T + c;  // class k at out[k * W * T]; classes in the order of their widths
         if (storeMask & 1u) {
             *out = make_float2(hi, kSecond ? __int_as_float(cnt) : lo);
-            out += W * kFT;
+            out += W * T;
         }
         for (int w = 1; w <= sp.wMax; ++w) {
             const float a = p[-w], b = p[w];
@@ -725,12 +727,12 @@ __global__ __launch_bounds__(256) void filter_step_runs_kernel(MapGeom g, const 
             else lo = min_skip_nan(min_skip_nan(lo, a), b);
             if ((storeMask >> w) & 1u) {
                 *out = make_float2(hi, kSecond ? __int_as_float(cnt) : lo);
-                out += W * kFT;
+                out += W * T;
             }
         }
     }
     __syncthreads();
-    const int li = threadIdx.x / kFT, lj = threadIdx.x % kFT;
+    const int li = threadIdx.x / T, lj = threadIdx.x % T;
     const int i = ti0 + li, j = tj0 + lj;
     if (i >= g.rows || j >= g.cols) return;
     const size_t cell = static_cast<size_t>(i) * g.cols + j;
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(256) void filter_step_runs_kernel(MapGeom g, const 
             const int w = shp[o + H];
             if (w < 0) continue;
             const int k = __builtin_popcount(storeMask & ((1u << w) - 1u));
-            const float2 v = runs[(k * W + (li + H + o)) * kFT + lj];
+            const float2 v = runs[(k * W + (li + H + o)) * T + lj];
             hi = max_skip_nan(hi, v.x);
             if (kSecond) cnt += __float_as_int(v.y);
             else lo = min_skip_nan(lo, v.y);
@@ -798,6 +800,17 @@ hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float*
     const int h1 = filter_halo(fc.stepFirstRadius, g.res), h2 = filter_halo(fc.stepSecondRadius, g.res);
     const int fuse = fc.roughnessRadius == fc.normalRadius ? 1 : 0;  // the published default chain: both 0.05 m
     const double reach = std::fmax(std::fabs(g.posX) + g.orgX, std::fabs(g.posY) + g.orgY) + g.res;
+    // Tile edge of the lattice kernels: 32 (1024 threads) when a tile row with its halo is still one wavefront load and the
+    // arrays fit the LDS — the halo is read 2.4 x instead of 4.5 x per cell at 1 cm, set-up and prefix scans per cell halve —
+    // else 16.  FPE_FILTER_TILE=16 (environment, read per call: a measurement switch) keeps the small tile.
+    static const int forcedTile = std::getenv("FPE_FILTER_TILE") ? std::atoi(std::getenv("FPE_FILTER_TILE")) : 0;
+    const auto tile_of = [&](int H, size_t bytes32) { return (forcedTile != 16 && 32 + 2 * H <= 64 && bytes32 <= 150 * 1024 && g.rows >= 64 && g.cols >= 64) ? 32 : 16; };
+    const auto grid_of = [&](int T) { return dim3((g.cols + T - 1) / T, (g.rows + T - 1) / T); };
+    const auto fits = [](const void* fn, size_t bytes) -> bool {  // beyond 48 KB of dynamic LDS a kernel has to be told
+        if (bytes <= 48 * 1024) return true;
+        if (bytes > 150 * 1024) return false;
+        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) == hipSuccess;
+    };
 #ifndef FPE_FILTERS_WALK_ONLY
     const StepShape sN = step_shape(fc.normalRadius, g.res, hN, reach);
     // The moment form takes the lattice as EXACT integers; the published filters (and the oracle) sum the cells' rounded f64
@@ -805,15 +818,19 @@ hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float*
     // ulp(reach) ~ 2e-16 reach against a spacing of res, and the normal follows it: beyond reach / res = 2e5 (2 km at 1 cm, 4e-11
     // relative) the literal walks run instead (at 3 000 km a handful of cells differed by up to 8 float ulps; tests).
     const bool latticeExact = reach / g.res < 2.0e5;
-    if (fuse && hN <= kMomentMaxH && sN.rowsOk && latticeExact) {  // row moments (see filter_normals_moments_kernel); the literal walks for what they do not cover
-        const size_t bytes = ((disc_lds_bytes(hN) + 15) & ~static_cast<size_t>(15)) + moment_lds_bytes(hN);
-        if (bytes > 48 * 1024) {  // (0.5 cm maps: the prefix arrays of a 38 x 38 tile need 66 KB)
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_normals_moments_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     static_cast<int>(bytes));
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(filter_normals_moments_kernel, grid, block, ((disc_lds_bytes(hN) + 15) & ~static_cast<size_t>(15)) + moment_lds_bytes(hN), stream,
-                           g, d_elev, L, fc.normalRadius, hN, fc.slopeCritical, fc.roughnessCritical, sN);
+    const auto moment_bytes = [&](int T) { return ((disc_lds_bytes(hN, T) + 15) & ~static_cast<size_t>(15)) + moment_lds_bytes(hN, T); };
+    // (the moment kernel only from a halo of nine cells on: its prefix scans occupy a quarter of a 1024-thread workgroup's
+    // lanes, and at 80 KB of LDS no second workgroup is there to fill the gap — measured: H = 3 52 -> 61 us, H = 6 302 -> 351 us,
+    // H = 11 721 -> 578 us; the row-run kernels gain at every size that fits: 1 cm 111 + 118 -> 75 + 81 us)
+    const int tN = hN >= 9 ? tile_of(hN, moment_bytes(32)) : 16;
+    const void* momentsFn = tN == 32 ? reinterpret_cast<const void*>(filter_normals_moments_kernel<32>) : reinterpret_cast<const void*>(filter_normals_moments_kernel<16>);
+    if (fuse && hN <= kMomentMaxH && sN.rowsOk && latticeExact && fits(momentsFn, moment_bytes(tN))) {  // row moments; the literal walks for what they do not cover
+        if (tN == 32)
+            hipLaunchKernelGGL(filter_normals_moments_kernel<32>, grid_of(32), dim3(1024), moment_bytes(32), stream, g, d_elev, L, fc.normalRadius, hN,
+                               fc.slopeCritical, fc.roughnessCritical, sN);
+        else
+            hipLaunchKernelGGL(filter_normals_moments_kernel<16>, grid, block, moment_bytes(16), stream, g, d_elev, L, fc.normalRadius, hN, fc.slopeCritical,
+                               fc.roughnessCritical, sN);
     } else
 #endif
     hipLaunchKernelGGL(filter_normals_kernel, grid, block, disc_lds_bytes(hN), stream, g, d_elev, L, fc.normalRadius, hN, fc.slopeCritical, fuse,
@@ -827,21 +844,29 @@ hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float*
 #else
     StepShape s1{}, s2{};
 #endif
-    const auto fits = [](const void* fn, size_t bytes) -> bool {  // the stored runs of a wide window need more than 48 KB
-        if (bytes <= 48 * 1024) return true;
-        if (bytes > 150 * 1024) return false;
-        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) == hipSuccess;
-    };
-    if (s1.ok && fits(reinterpret_cast<const void*>(filter_step_runs_kernel<false>), step_lds_bytes(h1, s1.nClasses)))
-        hipLaunchKernelGGL(filter_step_runs_kernel<false>, grid, block, step_lds_bytes(h1, s1.nClasses), stream, g, d_elev, L, fc.stepFirstRadius, h1, s1, 0.0,
-                           0.0f, 1);
-    else
+    const int t1 = tile_of(h1, step_lds_bytes(h1, s1.nClasses, 32)), t2 = tile_of(h2, step_lds_bytes(h2, s2.nClasses, 32));
+    const void* run1 = t1 == 32 ? reinterpret_cast<const void*>(filter_step_runs_kernel<false, 32>) : reinterpret_cast<const void*>(filter_step_runs_kernel<false, 16>);
+    const void* run2 = t2 == 32 ? reinterpret_cast<const void*>(filter_step_runs_kernel<true, 32>) : reinterpret_cast<const void*>(filter_step_runs_kernel<true, 16>);
+    if (s1.ok && fits(run1, step_lds_bytes(h1, s1.nClasses, t1))) {
+        if (t1 == 32)
+            hipLaunchKernelGGL((filter_step_runs_kernel<false, 32>), grid_of(32), dim3(1024), step_lds_bytes(h1, s1.nClasses, 32), stream, g, d_elev, L,
+                               fc.stepFirstRadius, h1, s1, 0.0, 0.0f, 1);
+        else
+            hipLaunchKernelGGL((filter_step_runs_kernel<false, 16>), grid, block, step_lds_bytes(h1, s1.nClasses, 16), stream, g, d_elev, L, fc.stepFirstRadius,
+                               h1, s1, 0.0, 0.0f, 1);
+    } else {
         hipLaunchKernelGGL(filter_step1_kernel, grid, block, disc_lds_bytes(h1), stream, g, d_elev, L, fc.stepFirstRadius, h1);
-    if (s2.ok && fits(reinterpret_cast<const void*>(filter_step_runs_kernel<true>), step_lds_bytes(h2, s2.nClasses)))
-        hipLaunchKernelGGL(filter_step_runs_kernel<true>, grid, block, step_lds_bytes(h2, s2.nClasses), stream, g, static_cast<const float*>(L.stepHeight), L,
-                           fc.stepSecondRadius, h2, s2, fc.stepCritical, critDown, fc.stepCriticalCells);
-    else
+    }
+    if (s2.ok && fits(run2, step_lds_bytes(h2, s2.nClasses, t2))) {
+        if (t2 == 32)
+            hipLaunchKernelGGL((filter_step_runs_kernel<true, 32>), grid_of(32), dim3(1024), step_lds_bytes(h2, s2.nClasses, 32), stream, g,
+                               static_cast<const float*>(L.stepHeight), L, fc.stepSecondRadius, h2, s2, fc.stepCritical, critDown, fc.stepCriticalCells);
+        else
+            hipLaunchKernelGGL((filter_step_runs_kernel<true, 16>), grid, block, step_lds_bytes(h2, s2.nClasses, 16), stream, g,
+                               static_cast<const float*>(L.stepHeight), L, fc.stepSecondRadius, h2, s2, fc.stepCritical, critDown, fc.stepCriticalCells);
+    } else {
         hipLaunchKernelGGL(filter_step2_kernel, grid, block, disc_lds_bytes(h2), stream, g, L, fc.stepSecondRadius, h2, fc.stepCritical, critDown,
                            fc.stepCriticalCells);
+    }
     return hipGetLastError();
 }
