@@ -21,14 +21,16 @@ for m, name in enumerate(names):
 import json
 cnt = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/prof_filters_pmc_*/**/*counter_collection.csv", recursive=True):
-    byk = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if "filter_" in r["Kernel_Name"]:
-            byk[(r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].split("::")[-1], r["Counter_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
-    for (k, c), v in byk.items():
-        v.sort()
-        n = len(v) // 3
-        cnt[k][c] = [x for _, x in v[n:2 * n]]
+    # the launches of one file in dispatch order: chains of three kernels, seven chains per map, three maps — the second map's
+    # launches are the ones summarised (kernel names carry the tile edge and may differ between the maps)
+    rows_f = [r for r in csv.DictReader(open(f)) if "filter_" in r["Kernel_Name"]]
+    disp = sorted({int(r["Dispatch_Id"]) for r in rows_f})
+    third = len(disp) // 3
+    middle = set(disp[third:2 * third])
+    for r in rows_f:
+        if int(r["Dispatch_Id"]) in middle:
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].split("::")[-1]
+            cnt[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 if cnt:
     cal = json.load(open("profiles/round4_headline_counters.json"))["calibration"]
     print("\ncounters per launch, 2000x2000 @ 0.01 m (mean over the map's launches):")
