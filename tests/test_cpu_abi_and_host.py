@@ -200,6 +200,29 @@ def test_ros_adapter_parses_against_the_mock_ros_types():
     assert "resp_" not in src.replace("repNominal_", "").replace("repCentroid_", ""), "no shared response members (AsyncSpinner)"
 
 
+def test_the_header_is_plain_c(tmp_path):
+    """include/fpe.h is the drop-in boundary: a C ABI.  It must compile as C99 with warnings on (a C or cgo host binds it as
+    it is), and a C program that only uses the parameter helpers must link against the library without a C++ runtime of its own."""
+    import subprocess
+
+    from quadrupedal_foothold_planner_amd import build as fbuild
+
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "fpe.h"\n#include <stdio.h>\nint main(void) { fpe_params p; fpe_opt_params o; fpe_filter_params f;\n'
+                   '  if (fpe_params_yaml(&p) || fpe_opt_params_yaml(&o) || fpe_filter_params_defaults(&f)) return 1;\n'
+                   '  printf("%s %.3f %.3f\\n", fpe_version(), (double)p.searchRadius, f.normal_radius); return 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lib = fbuild.build_engine()
+    exe = tmp_path / "hdr"
+    r = subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L" + os.path.dirname(lib),
+                        "-l:" + os.path.basename(lib), "-Wl,-rpath," + os.path.dirname(lib), "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)  # (no GPU needed: the helpers only fill structs)
+    assert r.returncode == 0 and r.stdout.startswith("fpe ") and "0.100 0.050" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
 def test_build_is_atomic_and_reports_what_it_did():
     from quadrupedal_foothold_planner_amd import build as fbuild
 
