@@ -241,9 +241,18 @@ __device__ int opt_solve_begin(const OptConsts& oc, const int (&nIdx)[8], const 
 template <int W>
 __device__ OptBest opt_solve_rows_plain(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8],
                                         double lfRow, double rhRow, int lane, int wave, const double (&x)[8]);
+constexpr int kOptListCap = 1024;  // surviving points a wavefront lists (LDS, 4 bytes each); more: every point is searched
+// LDS of the listed search: the lists (one per wavefront) and, for W > 1, what the wavefronts tell each other about their
+// share of the Dab values (per lane and (c, d) slot: smallest violation, mask of the values that attain it)
+template <int W>
+struct OptListLds {
+    unsigned list[W][W == 1 ? kOptListCap : kOptListCap / 4];
+    double partMin[W == 1 ? 1 : W][W == 1 ? 1 : 2][W == 1 ? 1 : 64];
+    unsigned long long partGood[W == 1 ? 1 : W][W == 1 ? 1 : 2][W == 1 ? 1 : 64];
+};
 template <int W>
 __device__ OptBest opt_solve_rows(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8],
-                                  double lfRow, double rhRow, int lane, int wave, const double (&x)[8]) {
+                                  double lfRow, double rhRow, int lane, int wave, const double (&x)[8], OptListLds<W>* ll = nullptr) {
     const double inf = __builtin_huge_val();
     const int n0 = up[0] - lo[0] + 1, n2 = up[2] - lo[2] + 1, n4 = up[4] - lo[4] + 1, n6 = up[6] - lo[6] + 1;
     const int nAB = n0 * n2, nCD = n4 * n6;
@@ -283,6 +292,137 @@ __device__ OptBest opt_solve_rows(const OptConsts& oc, const int (&nIdx)[8], con
         rm = c7 > rm ? c7 : rm;
         rm = c8 > rm ? c8 : rm;
         rmCD[s] = rm;
+    }
+    // ---- the points that can win, listed (round 4) ----
+    // The search orders points by (violation, objective, index), and the violation depends on a point only through
+    // Dab = |x0 - x2| and Dcd = |x4 - x6|.  With the constraints on, the smallest violation over the box follows from the <= 64
+    // values of Dab against this lane's (c, d) pairs (one pass: per-lane minimum with a mask of the Dab values that attain it,
+    // then the wave's minimum), and only points that attain it can win.  They are few — the reference's yaml constraint set
+    // has no feasible point and the smallest violation is attained along a curve of (Dab, Dcd) combinations: 1.5-4 % of the
+    // box — but they are spread over most (a, b) pairs, one to six lanes each (profiles/round4_opt_stage_trace.txt), so the
+    // wavefront LISTS them (ballot prefix into LDS: integer work only) and evaluates the objective on the list, 64 points at
+    // a time, with the same expressions on the same operands: the same winner, bit for bit.  Longer lists than kOptListCap
+    // (feasible problems: the whole band of violation 0), boxes with more than 64 values of Dab or 128 (c, d) pairs, and the
+    // eight-wavefront form search every point as before.
+    if (ll != nullptr && oc.useConstraints) {  // (uniform over the workgroup: every wavefront searches the same problem)
+        unsigned* list = ll->list[wave];
+        constexpr int kCap = W == 1 ? kOptListCap : kOptListCap / 4;
+        const int dLo = lo[0] - up[2], dHi = up[0] - lo[2];  // x0 - x2 takes every integer of [dLo, dHi]
+        const int dMin = (dLo <= 0 && dHi >= 0) ? 0 : min(abs(dLo), abs(dHi)), dMax = max(abs(dLo), abs(dHi));
+        const int nD = dMax - dMin + 1;
+        if (nD <= 64 && nAB <= 0xFFFF) {
+            double myMin[kSlots];
+            unsigned long long good[kSlots];
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s) {
+                myMin[s] = inf;
+                good[s] = 0ull;
+            }
+            for (int k = wave; k < nD; k += W) {  // (W > 1: this wavefront's share of the values; exchanged below)
+                const double Dab = dMin + k;
+                const double c1 = t1 - Dab, c2 = Dab - t2;
+                const bool feasAB = c1 <= ctol && c2 <= ctol;
+                double rmAB = 0.0;
+                rmAB = c1 > rmAB ? c1 : rmAB;
+                rmAB = c2 > rmAB ? c2 : rmAB;
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s) {
+                    const double E = 0.5 * fabs(Dab - Dcd[s]), c5 = t3 - E, c6 = E - t4;
+                    const bool feasible = feasAB && feasCD[s] && c5 <= ctol && c6 <= ctol;
+                    double rm = rmAB;
+                    rm = rmCD[s] > rm ? rmCD[s] : rm;
+                    rm = c5 > rm ? c5 : rm;
+                    rm = c6 > rm ? c6 : rm;
+                    const double key = feasible ? 0.0 : rm;
+                    if (live[s]) {
+                        if (key < myMin[s]) {
+                            myMin[s] = key;
+                            good[s] = 1ull << k;
+                        } else if (key == myMin[s]) {
+                            good[s] |= 1ull << k;
+                        }
+                    }
+                }
+            }
+            if constexpr (W > 1) {
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s) {
+                    ll->partMin[wave][s][lane] = myMin[s];
+                    ll->partGood[wave][s][lane] = good[s];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s) {
+                    double mn = inf;
+                    for (int w = 0; w < W; ++w) {
+                        const double o = ll->partMin[w][s][lane];
+                        mn = o < mn ? o : mn;
+                    }
+                    unsigned long long g = 0ull;
+                    for (int w = 0; w < W; ++w)
+                        if (ll->partMin[w][s][lane] == mn) g |= ll->partGood[w][s][lane];
+                    myMin[s] = mn;
+                    good[s] = g;
+                }
+            }
+            double minKey = myMin[0] < myMin[1] ? myMin[0] : myMin[1];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double o = __shfl_xor(minKey, off);
+                minKey = o < minKey ? o : minKey;
+            }
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s)
+                if (!(myMin[s] == minKey)) good[s] = 0ull;
+            // list the surviving points in enumeration order: entry = ab | cd << 16
+            int count = 0;
+            for (int ab = wave; ab < nAB; ab += W) {
+                int a, b;
+                divmod_lattice(ab, n2, n2Inv, a, b);
+                const int k = abs((lo[0] + a) - (lo[2] + b)) - dMin;
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s) {
+                    const bool hit = ((good[s] >> k) & 1ull) != 0ull;
+                    const unsigned long long bal = __ballot(hit);
+                    if (bal != 0ull) {
+                        const int at = count + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                        if (hit && at < kCap) list[at] = static_cast<unsigned>(ab) | (static_cast<unsigned>(lane + 64 * s) << 16);
+                        count += __builtin_popcountll(bal);
+                    }
+                }
+                if (count > kCap) break;
+            }
+            if (count <= kCap) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                double bestF = inf;
+                unsigned bestT = 0xFFFFFFFFu;
+                for (int p = lane; p < count; p += 64) {
+                    const unsigned e = list[p];
+                    const int ab = static_cast<int>(e & 0xFFFFu), cd = static_cast<int>(e >> 16);
+                    int a, b, c, d;
+                    divmod_lattice(ab, n2, n2Inv, a, b);
+                    divmod_lattice(cd, n6, n6Inv, c, d);
+                    const double y0 = lo[0] + a, y2 = lo[2] + b, y4 = lo[4] + c, y6 = lo[6] + d;
+                    const double Pn = ((wr * fabs(y0 - nIdx[0]) + C1n) + wr * fabs(y2 - nIdx[2])) + C3n;
+                    const double Pc = ((wr * fabs(y0 - cIdx[0]) + C1c) + wr * fabs(y2 - cIdx[2])) + C3c;
+                    const double Dab = fabs(y0 - y2), Uab = fabs(Dab - L), hab = 0.5 * Dab;
+                    const double a4n = wr * fabs(y4 - nIdx[4]), a4c = wr * fabs(y4 - cIdx[4]), a6n = wr * fabs(y6 - nIdx[6]), a6c = wr * fabs(y6 - cIdx[6]);
+                    const double dcd = fabs(y4 - y6), ucd = fabs(dcd - L), hcdP = 0.5 * dcd, v2 = fabs(fabs(hcdP - hlr) - K);
+                    const double S1 = (((Pn + a4n) + C5n) + a6n) + C7n;
+                    const double S2 = (((Pc + a4c) + C5c) + a6c) + C7c;
+                    const double V1 = fabs(fabs(hab - hcdP) - K);
+                    const double f = ((w1 * S1 + w2 * S2) + w3 * (Uab + ucd)) + w4 * (V1 + v2);
+                    if (f < bestF) {  // (per lane the index only grows: the first of equals stays)
+                        bestF = f;
+                        bestT = static_cast<unsigned>(ab) * static_cast<unsigned>(nCD) + static_cast<unsigned>(cd);
+                    }
+                }
+                double bestKey = minKey;
+                opt_wave_min(bestKey, bestF, bestT);
+                return OptBest{bestKey, bestF, bestT, 0u};
+            }
+        }
     }
     double bestKey = inf, bestF = inf;
     unsigned bestT = 0xFFFFFFFFu;
@@ -392,6 +532,7 @@ __global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts 
     __shared__ OptShared sh;
     __shared__ OptBest slots[W];
     __shared__ OptProblem probs[2];  // by cycle parity: wavefront 0 may publish cycle g + 1 while a helper still reads cycle g
+    __shared__ OptListLds<W> optLists;  // the listed search of opt_solve_rows
     const int b = blockIdx.x;
     if (b >= B) return;
     const int lane = static_cast<int>(threadIdx.x) & 63;
@@ -414,7 +555,7 @@ __global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts 
                     up[k] = prob.up[k];
                     x[k] = prob.x[k];
                 }
-                const OptBest mine = opt_solve_rows<W>(oc, nIdx, cIdx, lo, up, prob.lfRow, prob.rhRow, lane, wave, x);
+                const OptBest mine = opt_solve_rows<W>(oc, nIdx, cIdx, lo, up, prob.lfRow, prob.rhRow, lane, wave, x, &optLists);
                 if (lane == 0) slots[wave] = mine;
                 __syncthreads();  // (B) every slice's best is in place
             }
@@ -631,7 +772,7 @@ __global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts 
                 __syncthreads();  // (A)
             }
             if (status < 0) {
-                OptBest best = opt_solve_rows<W>(oc, nIdx, cIdx, lo, up, lfRow, rhRow, lane, 0, x);
+                OptBest best = opt_solve_rows<W>(oc, nIdx, cIdx, lo, up, lfRow, rhRow, lane, 0, x, &optLists);
                 if constexpr (W > 1) {
                     if (lane == 0) slots[0] = best;
                     __syncthreads();  // (B)
