@@ -755,6 +755,42 @@ def main():
                                    "+ 0.6 k SALU + 0.26 k LDS instructions, each step kernel 0.85 k + 0.58 k + 0.11 k; profiles/round4_filters.txt), not by HBM; "
                                    "`verified`: engine against oracle on a 96 x 96 corner of the layer taken as a map of its own"}
         del d_fe, d_ft, d_fl
+        # the opt track of the same batch (fpe_plan_opt_device; build-defined optimiser: DESIGN 4.6): the nominal
+        # plan's cycle flags in, global_footholds_opt + the per-cycle problems out, device-resident
+        from quadrupedal_foothold_planner_amd._capi import OPT_CYCLE_DTYPE, OPT_FOOTHOLD_DTYPE
+        d_of = torch.zeros(B * n_cycles * 4 * OPT_FOOTHOLD_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        d_oc = torch.zeros(B * n_cycles * OPT_CYCLE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        d_og = torch.zeros(B, dtype=torch.uint8, device=dev)
+        d_flags = d_ok  # (the timed launch's cycle flags)
+
+        def opt_step():
+            planner.plan_opt_device(d_poses.data_ptr(), B, n_cycles, d_flags.data_ptr(), d_of.data_ptr(), d_oc.data_ptr(), d_og.data_ptr(), stream=stream.cuda_stream)
+        for _ in range(2):
+            opt_step()
+        o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        o0.record(stream)
+        for _ in range(5):
+            opt_step()
+        o1.record(stream)
+        torch.cuda.synchronize()
+        o_ms = o0.elapsed_time(o1) / 5
+        n_chk = min(B, 8)  # engine against oracle on the first poses: every integer of the problems and solutions, x / y bit-exact
+        oc_host = d_oc.cpu().numpy().view(OPT_CYCLE_DTYPE).reshape(B, n_cycles)[:n_chk]
+        from tests import util as _util
+        _om = _fpo.OracleMap(trav, elev, res)
+        _op, _opo = _util.to_oracle_params(planner.params), _util.to_oracle_poses(poses[:n_chk])
+        _oplan = _om.plan(_op, _opo, n_cycles, threads=4)
+        _oopt = _om.plan_opt(_op, _util.to_oracle_opt_params(planner.opt_params), _opo, n_cycles, _oplan["cycle_ok"])
+        o_ok = all(np.array_equal(oc_host[f], _oopt["cycles"][f]) for f in ("x", "x_lower", "x_upper", "solver_status", "committed", "minf"))
+        if not o_ok:
+            verified = False
+            line["config"]["verified"] = False
+            line["config"]["verify_error"] = "opt track: problems / solutions differ from the oracle"
+        line["opt_track"] = {"ms": o_ms, "poses_per_s": B / (o_ms * 1e-3), "solves_per_s": B * n_cycles / (o_ms * 1e-3), "verified": o_ok,
+                             "note": "fpe_plan_opt_device on the step's batch: per pose and gait cycle the gait-cycle submap, centroid method, bounds and "
+                                     "the build-defined lattice optimiser (the points that attain the smallest constraint violation listed, the objective "
+                                     "evaluated on the list: DESIGN 4.6), positions, heights, commit; `verified`: first poses against the oracle"}
+        del d_of, d_oc, d_og
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(trav, elev, res, params, poses, n_cycles, args.cpu_seconds)
     if rank == 0:
