@@ -43,7 +43,9 @@ def assert_layers_equal(eng, ora, max_ulp_cells=1e-4):
         # (the weighted sum adds three layers that may each be one ulp off: two ulps; 1 map in ~10^4 of the campaign has such a cell)
         bar = 2 if name == "traversability" else 1
         assert d.max(initial=0) <= bar, f"{name}: {int((d > bar).sum())} cells differ by more than {bar} float ulp (max {int(d.max())})"
-        assert (d != 0).mean() <= max_ulp_cells, f"{name}: {int((d != 0).sum())} of {d.size} cells not bit-identical"
+        # (a share of the cells — and never fewer than two where any are allowed: the campaign's maps go down to a few dozen cells)
+        allowed = max(2, int(max_ulp_cells * d.size)) if max_ulp_cells > 0 else 0
+        assert int((d != 0).sum()) <= allowed, f"{name}: {int((d != 0).sum())} of {d.size} cells not bit-identical"
 
 
 @pytest.mark.parametrize("rows,cols,res,seed", [(160, 144, 0.02, 21), (150, 170, 0.01, 22), (96, 112, 0.005, 23), (130, 90, 0.03, 24)])
