@@ -1635,6 +1635,52 @@ __device__ __forceinline__ void seq_mean2(const float* __restrict__ elev, int ro
     zC = finish_mean(C.sum, C.last, C.cnt, h);
 }
 
+// The same for a box of up to 32 cells (the generic 8-lane kernels' units), walking the VISITED cells only: a foot disc of
+// radius two cells has 13 members in a box of 25 — two batches of eight loads instead of four, i.e. two dependent memory
+// round trips less per unit (the register-capped kernel cannot keep more than eight loads in flight: batches of 16 / 25 / 32
+// spill and lose, measured).  The members are taken in ascending cell order (lowest set bit first): CircleIterator order.
+template <int NA = 8, int NC = 8>
+__device__ __forceinline__ void seq_mean2_visited(const float* __restrict__ elev, int rows, int cols, int i0, int j0, int nj, uint32_t vis, bool wantC,
+                                                  int cRow, int cCol, const int8_t* da, const int8_t* db, int nFoot, double h, float& zBox, float& zC) {
+    static_assert(NC == 8, "the offset table is read eight entries (two 64-bit LDS words) at a time");
+    MeanAcc A{0.0f, 0.0f, 0}, C{0.0f, 0.0f, 0};
+    const int nC = wantC ? nFoot : 0;
+    uint32_t rem = vis;
+    const unsigned base = __umul24(static_cast<unsigned>(i0), static_cast<unsigned>(cols)) + static_cast<unsigned>(j0);
+    // t / nj for t < 32, 1 <= nj <= 32: floor(t * inv / 2^16) with inv = floor(2^16 / nj) + 1 (error below t / 2^16 < 1 / nj)
+    const unsigned inv = static_cast<unsigned>(65536.0f * __builtin_amdgcn_rcpf(static_cast<float>(nj))) + 1u;
+    for (int c0 = 0; rem != 0u || c0 < nC; c0 += NC) {
+        unsigned ba = 0u, bc = 0u;
+        float eA[NA], eC[NC];
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const bool v = rem != 0u;
+            const unsigned t = v ? static_cast<unsigned>(__builtin_ctz(rem)) : 0u;
+            rem &= rem - 1u;  // (0 stays 0)
+            const unsigned a = (t * inv) >> 16, b = t - a * static_cast<unsigned>(nj);
+            eA[u] = load_cell(elev, v ? base + __umul24(a, static_cast<unsigned>(cols)) + b : 0u);
+            ba |= v ? (1u << u) : 0u;
+        }
+        unsigned long long daW, dbW;
+        __builtin_memcpy(&daW, da + (c0 < nC ? c0 : 0), 8);
+        __builtin_memcpy(&dbW, db + (c0 < nC ? c0 : 0), 8);
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+            const int qi = cRow + static_cast<int8_t>((daW >> (8 * u)) & 0xFFull), qj = cCol + static_cast<int8_t>((dbW >> (8 * u)) & 0xFFull);
+            const bool visC = c0 + u < nC && in_range(qi, qj, rows, cols);
+            bc |= visC ? (1u << u) : 0u;
+            const unsigned cellC = visC ? __umul24(static_cast<unsigned>(qi), static_cast<unsigned>(cols)) + static_cast<unsigned>(qj) : 0u;
+            eC[u] = load_cell(elev, cellC);
+        }
+#pragma unroll
+        for (int u = 0; u < NA; ++u) mean_acc(A, ((ba >> u) & 1u) != 0u, eA[u]);
+#pragma unroll
+        for (int u = 0; u < NC; ++u) mean_acc(C, ((bc >> u) & 1u) != 0u, eC[u]);
+    }
+    zBox = finish_mean(A.sum, A.last, A.cnt, h);
+    zC = finish_mean(C.sum, C.last, C.cnt, h);
+}
+
 template <class Rec>
 __device__ __forceinline__ void flush_seqrec(const DevMap& m, const PlanConsts& pc, const int8_t* footDa, const int8_t* footDb, const Rec& rLds,
                                              int b, int cyc, int leg, int nCycles, const fpe_plan_out& out) {
@@ -1905,8 +1951,13 @@ __device__ __forceinline__ void flush_unit_g(const DevMap& m, const PlanConsts& 
     const bool wantC = !h1 && (u.flags & kUgCTable) != 0u && out.centroid != nullptr;
     const int nj = max(static_cast<int>(h1 ? (u.flags >> 24) : ((u.flags >> 16) & 0xFFu)), 1);
     float sBox, sC;
+#ifdef FPE_FLUSH_BOX_ORDER
     seq_mean2(m.elev, mg.rows, mg.cols, h1 ? u.bI0 : u.aI0, h1 ? u.bJ0 : u.aJ0, nj, wantBox ? static_cast<unsigned long long>(visW) : 0ull, 0ull,
               wantC, u.cenRow, u.cenCol, footDa, footDb, pc.nFoot, pc.h, sBox, sC);
+#else
+    seq_mean2_visited(m.elev, mg.rows, mg.cols, h1 ? u.bI0 : u.aI0, h1 ? u.bJ0 : u.aJ0, nj, wantBox ? visW : 0u, wantC, u.cenRow, u.cenCol, footDa,
+                      footDb, pc.nFoot, pc.h, sBox, sC);
+#endif
     const float zBox = pre ? __uint_as_float(visW) : sBox;
     const size_t o = (static_cast<size_t>(b) * nCycles + cyc) * 4 + leg;
     if (h1) {
