@@ -277,15 +277,15 @@ def test_single_blocked_cell_kat_on_gpu(planner):
     assert (r["valid"], r["source"], r["row"], r["col"]) == (1, 1, 101, 99)
 
 
-def test_grid_map_message_layout_is_canonicalised(planner):
-    """Column-major buffers with a circular-buffer start index give the same plan as the canonical map."""
+@pytest.mark.parametrize("rows,cols,si,sj", [(240, 200, 37, 151), (131, 167, 130, 1), (193, 128, 0, 127), (191, 260, 64, 128)])
+def test_grid_map_message_layout_is_canonicalised(planner, rows, cols, si, sj):
+    """Column-major buffers with a circular-buffer start index give the same plan as the canonical map (sizes on and off the
+    transpose's 64 x 64 tiles, row lengths that are and are not a multiple of four cells: 16-byte and 4-byte stores)."""
     set_params(planner)
-    rows, cols = 240, 200
     trav, elev = synth.rough_map(rows, cols, 0.02, seed=81)
     poses = synth.poses_in_map(64, rows * 0.02, cols * 0.02, 5, 0.18, seed=82, margin=0.7)
     planner.gridmapCallback(trav, elev, 0.02)
     ref = planner.plan(poses, 5)
-    si, sj = 37, 151
     # buffer (bi, bj) holds unwrapped ((bi - si) % rows, (bj - sj) % cols); stored column-major
     buf_t = np.roll(trav, (si, sj), axis=(0, 1))
     buf_e = np.roll(elev, (si, sj), axis=(0, 1))
