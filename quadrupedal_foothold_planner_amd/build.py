@@ -19,7 +19,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libfpe.so")
 LOCK_PATH = os.path.join(_HERE, ".libfpe.lock")
 SOURCES = ["fpe_kernels.hip", "fpe_engine.cpp", "fpe_host.cpp", "fpe_multi.cpp"]
-HEADERS = ["fpe_gridmath.hpp", "fpe_device.hpp", "fpe_host.hpp", "fpe_bits.hpp", "fpe_filters.hpp", "fpe_opt.hpp", os.path.join("..", "..", "include", "fpe.h")]
+HEADERS = ["fpe_gridmath.hpp", "fpe_device.hpp", "fpe_host.hpp", "fpe_bits.hpp", "fpe_filters.hpp", "fpe_filters_fused.hpp", "fpe_opt.hpp", os.path.join("..", "..", "include", "fpe.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950",

@@ -40,7 +40,8 @@ bool bits_supported(const PlanConsts& pc, const MapGeom& g);
 void describe_plan_kernel(const PlanConsts& pc, const MapGeom& g, char* buf, size_t n);
 // producer filters (fpe_filters.hpp part of fpe_kernels.hip)
 bool filters_supported(const FilterConsts& fc, const MapGeom& g);
-hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float* d_elev, const FilterLayers& L, hipStream_t stream);
+bool filters_trav_only_ok(const FilterConsts& fc, const MapGeom& g);
+hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float* d_elev, const FilterLayers& L, bool travOnly, hipStream_t stream);
 hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts& pc, const SpiralLut& lut,
                             const fpe_pose* d_poses, int B, int nCycles, const fpe_plan_out& d_out, hipStream_t stream);
 // opt track (fpe_opt.hpp part of fpe_kernels.hip)
@@ -380,6 +381,13 @@ struct fpe_engine {
     std::vector<int32_t> ringStart;   // host copy of the rank table's ring offsets
     float maxLegSearchRadius = 0.0f;  // fpe_set_max_leg_search_radius
     fpe::Tuning tuning;               // fpe_set_tuning; seeded from the environment once, in fpe_create
+    // The filter chain's step_height scratch, kept per STREAM: chains enqueued on one stream run in order, so the layer is
+    // reused from call to call without the pool's device synchronisation (a 10-20 Hz producer on its own stream never
+    // synchronises); a call on another stream swaps the buffer through the pool (dirty -> one synchronisation).
+    std::mutex filterMu;
+    hipStream_t filterStream = nullptr;
+    float* filterScratch = nullptr;
+    size_t filterCap = 0;
 
     fpe::SpiralLut lut() const {
         return fpe::SpiralLut{d_di, d_dj, d_ring, d_ringStart, maxRing, ringStart.empty() ? 0 : ringStart[static_cast<size_t>(maxRing) + 1], d_packed, d_fast16};
@@ -684,6 +692,7 @@ int fpe_destroy(fpe_handle h) {
     if (h->d_ringStart) (void)hipFree(h->d_ringStart);
     if (h->d_packed) (void)hipFree(h->d_packed);
     if (h->d_fast16) (void)hipFree(h->d_fast16);
+    if (h->filterScratch) (void)hipFree(h->filterScratch);
     h->map.reset();
     delete h;
     return FPE_OK;
@@ -802,10 +811,36 @@ int filters_common(fpe_engine* h, const fpe_map_desc* desc, const fpe_filter_par
         d_elev = canon;
     }
     float* d_layers = onDevice ? layers : nullptr;
+    // Nobody asked for the intermediate layers (device caller without a layer buffer, host caller without `layers`): the
+    // two-launch chain that stores step_height and traversability only, traversability straight into the caller's buffer
+    // when it is a device buffer.
+    const bool travOnly = !layers && fpe::filters_trav_only_ok(fc, g);
+    if (travOnly) {
+        float* d_step = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(h->filterMu);
+            if (!(h->filterScratch && h->filterStream == stream && h->filterCap >= n)) {
+                if (h->filterScratch) h->pool->give(h->filterCap, h->filterScratch, true);
+                h->filterScratch = nullptr;
+                FPE_HIP(alloc_units(*h->pool, n, &h->filterScratch, &h->filterCap));
+                h->filterStream = stream;
+            }
+            d_step = h->filterScratch;
+        }
+        float* d_trav = trav;
+        if (!onDevice) FPE_HIP(take(n, &d_trav));
+        const fpe::FilterLayers L{nullptr, nullptr, nullptr, nullptr, d_step, nullptr, nullptr, d_trav};
+        FPE_HIP(fpe::launch_filters(g, fc, d_elev, L, true, stream));
+        if (!onDevice) {
+            FPE_HIP(hipMemcpyAsync(trav, d_trav, n * sizeof(float), hipMemcpyDeviceToHost, stream));
+            FPE_HIP(hipStreamSynchronize(stream));
+        }
+        return FPE_OK;
+    }
     if (!d_layers) FPE_HIP(take(8 * n, &d_layers));
     const fpe::FilterLayers L{d_layers, d_layers + n, d_layers + 2 * n, d_layers + 3 * n, d_layers + 4 * n, d_layers + 5 * n,
                               d_layers + 6 * n, d_layers + 7 * n};
-    FPE_HIP(fpe::launch_filters(g, fc, d_elev, L, stream));
+    FPE_HIP(fpe::launch_filters(g, fc, d_elev, L, false, stream));
     if (onDevice) {
         if (trav != L.trav) FPE_HIP(hipMemcpyAsync(trav, L.trav, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
         // pooled scratch is handed back marked dirty: the next taker synchronises the device before reuse (BufferPool)

@@ -25,30 +25,32 @@ constexpr int kFT = 16;        // tile edge of the disc stencils
 constexpr int kFilterMaxH = 24;  // largest halo the tables are sized for (e.g. r 0.115 m at 0.5 cm)
 
 struct DiscLds {
-    float* tile;        // (kFT + 2H)^2 source cells, row-major, NaN outside the map
+    float* tile;        // (TR + 2H) x (TC + 2H) source cells, row-major, NaN outside the map
     double *xP, *yP;    // positions of the tile's rows / columns (halo included)
-    double *dx2, *dy2;  // [kFT][2H + 1] squared centre distance per axis
-    int *bi0, *bi1, *bj0, *bj1;  // [kFT] bounding rows / columns of the cell's iterator
-    int H, W;
+    double *dx2, *dy2;  // [TR][2H + 1] / [TC][2H + 1] squared centre distance per axis
+    int *bi0, *bi1, *bj0, *bj1;  // [TR] / [TC] bounding rows / columns of the cell's iterator
+    int H, WR, WC;      // halo, tile rows and columns with the halo
 };
-// (T: the tile edge — kFT for the walking kernels, 16 or 32 for the row-moment and row-run kernels)
-__host__ __device__ inline size_t disc_lds_bytes(int H, int T = kFT) {
-    const int W = T + 2 * H;
-    return static_cast<size_t>(W) * W * 4 + 2 * static_cast<size_t>(W) * 8 + 2 * static_cast<size_t>(T) * (2 * H + 1) * 8 + 4 * T * 4 + 16;
+// (TR x TC: the workgroup's cells — kFT x kFT for the walking kernels; 16 x 16, 32 x 16 (rows x columns) or 32 x 32 for the
+// row-moment and row-run kernels)
+__host__ __device__ inline size_t disc_lds_bytes(int H, int TR = kFT, int TC = kFT) {
+    const int WR = TR + 2 * H, WC = TC + 2 * H;
+    return static_cast<size_t>(WR) * WC * 4 + static_cast<size_t>(WR + WC) * 8 + static_cast<size_t>(TR + TC) * (2 * H + 1) * 8 + 2 * (TR + TC) * 4 + 16;
 }
-__device__ __forceinline__ DiscLds disc_carve(char* base, int H, int T = kFT) {
+__device__ __forceinline__ DiscLds disc_carve(char* base, int H, int TR = kFT, int TC = kFT) {
     DiscLds d;
     d.H = H;
-    d.W = T + 2 * H;
+    d.WR = TR + 2 * H;
+    d.WC = TC + 2 * H;
     char* p = base;
-    d.xP = reinterpret_cast<double*>(p); p += d.W * 8;
-    d.yP = reinterpret_cast<double*>(p); p += d.W * 8;
-    d.dx2 = reinterpret_cast<double*>(p); p += T * (2 * H + 1) * 8;
-    d.dy2 = reinterpret_cast<double*>(p); p += T * (2 * H + 1) * 8;
-    d.bi0 = reinterpret_cast<int*>(p); p += T * 4;
-    d.bi1 = reinterpret_cast<int*>(p); p += T * 4;
-    d.bj0 = reinterpret_cast<int*>(p); p += T * 4;
-    d.bj1 = reinterpret_cast<int*>(p); p += T * 4;
+    d.xP = reinterpret_cast<double*>(p); p += d.WR * 8;
+    d.yP = reinterpret_cast<double*>(p); p += d.WC * 8;
+    d.dx2 = reinterpret_cast<double*>(p); p += TR * (2 * H + 1) * 8;
+    d.dy2 = reinterpret_cast<double*>(p); p += TC * (2 * H + 1) * 8;
+    d.bi0 = reinterpret_cast<int*>(p); p += TR * 4;
+    d.bi1 = reinterpret_cast<int*>(p); p += TR * 4;
+    d.bj0 = reinterpret_cast<int*>(p); p += TC * 4;
+    d.bj1 = reinterpret_cast<int*>(p); p += TC * 4;
     d.tile = reinterpret_cast<float*>(p);
     return d;
 }
@@ -58,25 +60,30 @@ __device__ __forceinline__ DiscLds disc_carve(char* base, int H, int T = kFT) {
 // for each of its five to ten loads in turn, and the kernels spent most of a wavefront's life there), computes its
 // table entries from cell_pos itself while the loads fly (the same values the position arrays hold), then stores.
 // kTables false: the tile and the bounding boxes only (the step filter's row runs need no per-axis distance tables).
-template <bool kTables = true, int T = kFT>
+template <bool kTables = true, int TR = kFT, int TC = kFT, int HS = 0>
 __device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, const float* __restrict__ src, int ti0, int tj0, double r) {
-    const int H = d.H, W = d.W, t = threadIdx.x, D = 2 * H + 1;
-    constexpr int kThreads = T * T;  // (the launch makes sure that a tile row is at most one wavefront load: T + 2 H <= 64)
-    // a wavefront instruction loads one tile row (W > 32) or two (lanes 0-31 / 32-63); eight rows in flight per lane
-    const int perInst = W <= 32 ? 2 : 1, laneCols = W <= 32 ? 32 : 64;
+    // HS > 0: the halo is a compile-time constant (every loop bound, the divisions by 2 H + 1 and the number of tile rows a
+    // lane requests are then constants); 0: run time
+    const int H = HS > 0 ? HS : d.H, WR = TR + 2 * H, WC = TC + 2 * H, t = threadIdx.x, D = 2 * H + 1;
+    constexpr int kThreads = TR * TC;  // (the launch makes sure that a tile row is at most one wavefront load: TC + 2 H <= 64)
+    // a wavefront instruction loads one tile row (WC > 32) or two (lanes 0-31 / 32-63); up to eight rows in flight per lane
+    const int perInst = WC <= 32 ? 2 : 1, laneCols = WC <= 32 ? 32 : 64;
     const int col = t & (laneCols - 1), sub = (t & 63) / laneCols, wv = t >> 6;
     const int tj = tj0 - H + col;
-    const bool colOk = col < W && tj >= 0 && tj < g.cols;
+    const bool colOk = col < WC && tj >= 0 && tj < g.cols;
     const int rowStep = (kThreads / 64) * perInst;  // rows per workgroup instruction
     const int firstRow = wv * perInst + sub;
-    constexpr int kBatch = 8;
+    // rows a lane has in flight: all of the tile's when the halo is a constant (at most eight), else eight per round
+    constexpr int kStepC = (kThreads / 64) * ((TC + 2 * HS) <= 32 ? 2 : 1);
+    constexpr int kNeed = ((TR + 2 * HS) + kStepC - 1) / kStepC;
+    constexpr int kBatch = HS > 0 ? (kNeed < 8 ? kNeed : 8) : 8;
     float v[kBatch];
     const auto request = [&](int base) {
 #pragma unroll
         for (int q = 0; q < kBatch; ++q) {
             const int row = base + firstRow + rowStep * q, ti = ti0 - H + row;
             v[q] = __builtin_nanf("");
-            if (row < W && colOk && ti >= 0 && ti < g.rows) v[q] = src[static_cast<size_t>(ti) * g.cols + tj];
+            if (row < WR && colOk && ti >= 0 && ti < g.rows) v[q] = src[static_cast<size_t>(ti) * g.cols + tj];
         }
     };
     // invalid cells (GridMap::isValid = isfinite) enter the tile as quiet NaNs: the walks test `z == z`, and the float
@@ -85,33 +92,33 @@ __device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, c
 #pragma unroll
         for (int q = 0; q < kBatch; ++q) {
             const int row = base + firstRow + rowStep * q;
-            if (row < W && col < W) d.tile[row * W + col] = isfinite(v[q]) ? v[q] : __builtin_nanf("");
+            if (row < WR && col < WC) d.tile[row * WC + col] = isfinite(v[q]) ? v[q] : __builtin_nanf("");
         }
     };
     request(0);
     if constexpr (kTables) {
-        for (int k = t; k < 2 * W; k += kThreads) {
-            if (k < W) d.xP[k] = cell_pos(g.baseX, g.res, ti0 - H + k);
-            else d.yP[k - W] = cell_pos(g.baseY, g.res, tj0 - H + (k - W));
+        for (int k = t; k < WR + WC; k += kThreads) {
+            if (k < WR) d.xP[k] = cell_pos(g.baseX, g.res, ti0 - H + k);
+            else d.yP[k - WR] = cell_pos(g.baseY, g.res, tj0 - H + (k - WR));
         }
     }
-    if (t < 2 * T) {  // CircleIterator::findSubmapParameters per axis (circle_bbox), clamped onto the halo
-        const bool isRow = t < T;
-        const int l = isRow ? t : t - T;
+    if (t < TR + TC) {  // CircleIterator::findSubmapParameters per axis (circle_bbox), clamped onto the halo
+        const bool isRow = t < TR;
+        const int l = isRow ? t : t - TR;
         const int idx = (isRow ? ti0 : tj0) + l, n = isRow ? g.rows : g.cols;
         const double c = cell_pos(isRow ? g.baseX : g.baseY, g.res, idx);
         const double org = isRow ? g.orgX : g.orgY, pos = isRow ? g.posX : g.posY, len = isRow ? g.lenX : g.lenY;
-        int a = index_of(bound_axis(c + r, org, pos, len), org, pos, g.res);
-        int b = index_of(bound_axis(c - r, org, pos, len), org, pos, g.res);
+        int a = index_of_fast(bound_axis(c + r, org, pos, len), org, pos, g.res, g.rinv);
+        int b = index_of_fast(bound_axis(c - r, org, pos, len), org, pos, g.res, g.rinv);
         a = max(a, max(idx - H, 0));
         b = min(b, min(idx + H, n - 1));
         (isRow ? d.bi0 : d.bj0)[l] = a;
         (isRow ? d.bi1 : d.bj1)[l] = b;
     }
     if constexpr (kTables) {
-        for (int k = t; k < 2 * T * D; k += kThreads) {  // CircleIterator::isInside, per axis
-            const bool isRow = k < T * D;
-            const int e = isRow ? k : k - T * D;
+        for (int k = t; k < (TR + TC) * D; k += kThreads) {  // CircleIterator::isInside, per axis
+            const bool isRow = k < TR * D;
+            const int e = isRow ? k : k - TR * D;
             const int l = e / D, o = e % D;
             const double base = isRow ? g.baseX : g.baseY;
             const int first = (isRow ? ti0 : tj0) - H + l;
@@ -120,7 +127,7 @@ __device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, c
         }
     }
     deposit(0);
-    for (int base = rowStep * kBatch; base < W; base += rowStep * kBatch) {  // (tiles of more than 32 / 64 rows)
+    for (int base = rowStep * kBatch; base < WR; base += rowStep * kBatch) {  // (tiles of more rows than a round requests)
         request(base);
         deposit(base);
     }
@@ -132,7 +139,7 @@ __device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, c
 // instead of one test per cell of the bounding box.  Same members, same order as testing every cell.
 template <class F>
 __device__ __forceinline__ void disc_walk(const DiscLds& d, int li, int lj, int ti0, int tj0, double r2, F&& f) {
-    const int H = d.H, W = d.W, D = 2 * H + 1;
+    const int H = d.H, W = d.WC, D = 2 * H + 1;
     const int i = ti0 + li, j = tj0 + lj;
     const int i0 = d.bi0[li], i1 = d.bi1[li];
     const int maxL = j - d.bj0[lj], maxR = d.bj1[lj] - j;  // the bounding box's columns either side of the centre column
@@ -286,9 +293,10 @@ __device__ __forceinline__ bool normal_newton(double a00, double a01, double a02
     wS = lam * s;
     wL = c2 * s;
     // the next eigenvalue (the other two roots: sum S, product P): an eigenvector is only as good as its eigenvalue is apart
+    // lam2 = (S - sqrt(S^2 - 4 P)) / 2 > lam + 1e-6 c2 =: t  <=>  S - 2 t > 0 and (S - 2 t)^2 > S^2 - 4 P: no square root
     const double S = c2 - lam, P = __builtin_fma(-lam, S, c1);
-    const double lam2 = 0.5 * (S - sqrt(fmax(__builtin_fma(S, S, -4.0 * P), 0.0)));
-    return done && !bad && nn > 0.0 && lam >= 0.0 && (lam2 - lam) > 1e-6 * c2;
+    const double u = __builtin_fma(-2.0, __builtin_fma(1e-6, c2, lam), S);
+    return done && !bad && nn > 0.0 && lam >= 0.0 && u > 0.0 && u * u > fmax(__builtin_fma(S, S, -4.0 * P), 0.0);
 }
 
 // One cell of NormalVectorsFilter (area method) + SlopeFilter [+ RoughnessFilter of the same radius] by the LITERAL walks of
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(256) void filter_normals_kernel(MapGeom g, const fl
     const size_t cell = static_cast<size_t>(i) * g.cols + j;
     const float nanf = __builtin_nanf("");
     float ox = nanf, oy = nanf, oz = nanf, os = nanf, orough = nanf;
-    if (isfinite(d.tile[(li + H) * d.W + lj + H])) normals_cell_exact(d, li, lj, ti0, tj0, r, slopeCritical, fuseRough, roughCritical, ox, oy, oz, os, orough);
+    if (isfinite(d.tile[(li + H) * d.WC + lj + H])) normals_cell_exact(d, li, lj, ti0, tj0, r, slopeCritical, fuseRough, roughCritical, ox, oy, oz, os, orough);
     L.nx[cell] = ox;
     L.ny[cell] = oy;
     L.nz[cell] = oz;
@@ -369,6 +377,7 @@ struct StepShape {
     int32_t nEdge, nClasses, wMax;
     int32_t ok;                        // 0: the shape does not fit the step kernels' tables (the walking kernels run)
     int32_t rowsOk;                    // 0: not even the rows' half-widths are to be trusted (map too far from the origin)
+    uint64_t edgeRows;                 // bit o + H: row offset o holds an offset on the circle (complete also when the edge list overflowed)
 };
 // reach: the largest |coordinate| of a cell of the map — a position difference carries ~2 ulp of that, which decides how wide
 // the band of offsets is that the per-cell arithmetic must settle.
@@ -394,6 +403,7 @@ __host__ inline StepShape step_shape(double r, double res, int H, double reach) 
             if (d2 < r2 - margin) {
                 w = k;
             } else if (d2 <= r2 + margin) {  // on the circle: decided per cell
+                sp.edgeRows |= 1ull << (o + H);
                 for (int sgn = (k == 0 ? 1 : -1); sgn <= 1; sgn += 2) {
                     if (sp.nEdge >= kStepMaxEdge) {
                         sp.ok = 0;  // (the rows' half-widths below stay valid: the normals kernel tests the next column itself)
@@ -413,174 +423,20 @@ __host__ inline StepShape step_shape(double r, double res, int H, double reach) 
     if (sp.nClasses > kStepMaxClasses) sp.ok = 0;
     return sp;
 }
-// ---- the same three filters by ROW MOMENTS (round 4) -----------------------------------------------------------------------
+// ---- the same three filters by ROW MOMENTS (round 4; the kernel is round 5's filter_fused_kernel, fpe_filters_fused.hpp) -------
 // A cell's disc is at most 2H + 1 row intervals (disc_walk: the members of a row are one interval).  Everything the three
 // filters need of the members — count, mean, the 3 x 3 scatter matrix about the mean, and the sum of squared plane
 // distances, which for the plane through the mean is n^T A n — is a function of the members' MOMENTS, and a row interval's
-// moments are differences of per-row prefix sums: six prefix arrays per tile row in LDS (count, sum of c, sum of c^2 as
-// integers, c = tile column; sum of z', z'^2, c z' in f64, z' = z - z0 with z0 one elevation of the tile), then two LDS
-// reads per quantity and ROW instead of one visit per MEMBER and pass (81 members x 3 passes x ~30 f64 operations at 1 cm).
-// Coordinates enter as exact integers (the lattice), recentred at the cell; metres only scale the finished matrix.
+// moments are differences of per-row prefix sums (count, sum of c, sum of c^2 as integers, c = tile column; sum of z', z'^2,
+// c z' in f64, z' = z - z0 with z0 one elevation of the tile): two LDS reads per quantity and ROW instead of one visit per
+// MEMBER and pass (81 members x 3 passes x ~30 f64 operations at 1 cm).  Coordinates enter as exact integers (the lattice),
+// recentred at the cell; metres only scale the finished matrix.
 // Not the oracle's summation order: the scatter matrix agrees with the two-pass walk to ~1e-14 relative (the bar of
 // tests/test_gpu_filters.py is one float ulp and 99.99 % bit-identical cells).  Where that is not enough — a (nearly)
 // rank-deficient matrix, smallest eigenvalue below 1e-10 of the scale: exact planes, flat synthetic ground, fewer than three
 // members, where the rank test and the last bits of a tiny component depend on the summation order — the cell takes the
 // literal walks above instead (wave-divergent; no natural terrain gets there).
-struct MomentLds {
-    int *pN, *pC, *pCC;       // [W][W + 1] prefix over the tile columns: valid cells, sum of c, sum of c^2
-    double *pZ, *pZZ, *pCZ;   // sum of z', z'^2, c z'
-};
 constexpr int kMomentMaxH = 12;
-__host__ __device__ inline size_t moment_lds_bytes(int H, int T = kFT) {
-    const int W = T + 2 * H;
-    return static_cast<size_t>(W) * (W + 1) * (3 * 4 + 3 * 8) + 16 + 64;
-}
-template <int T>
-__global__ __launch_bounds__(T * T) void filter_normals_moments_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double r, int H,
-                                                                      double slopeCritical, double roughCritical, StepShape sp) {
-    extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
-    const DiscLds d = disc_carve(ldsRaw, H, T);
-    const int W = d.W, W1 = W + 1;
-    MomentLds ml;
-    {
-        char* p = ldsRaw + ((disc_lds_bytes(H, T) + 15) & ~static_cast<size_t>(15));
-        ml.pZ = reinterpret_cast<double*>(p); p += static_cast<size_t>(W) * W1 * 8;
-        ml.pZZ = reinterpret_cast<double*>(p); p += static_cast<size_t>(W) * W1 * 8;
-        ml.pCZ = reinterpret_cast<double*>(p); p += static_cast<size_t>(W) * W1 * 8;
-        ml.pN = reinterpret_cast<int*>(p); p += static_cast<size_t>(W) * W1 * 4;
-        ml.pC = reinterpret_cast<int*>(p); p += static_cast<size_t>(W) * W1 * 4;
-        ml.pCC = reinterpret_cast<int*>(p);
-    }
-    // the robust half-width of every row offset (step_shape) behind the prefix arrays
-    int8_t* rowW = reinterpret_cast<int8_t*>(ml.pCC + static_cast<size_t>(W) * W1);
-    if (threadIdx.x < 2 * kFilterMaxH + 1) rowW[threadIdx.x] = sp.rowW[threadIdx.x];
-    const int ti0 = blockIdx.y * T, tj0 = blockIdx.x * T;
-    disc_setup<true, T>(d, g, elev, ti0, tj0, r);
-    // z0: one elevation of the tile (its first interior cell when valid): the prefix sums carry z - z0
-    const float zf = d.tile[H * W + H];
-    const double z0 = zf == zf ? static_cast<double>(zf) : 0.0;
-    {   // one thread per (tile row, quantity): a serial scan over the row's W cells
-        const int t = threadIdx.x;
-        for (int e = t; e < 6 * W; e += T * T) {
-            const int row = e / 6, q = e - 6 * row;
-            const float* src = d.tile + row * W;
-            const int o = row * W1;
-            if (q < 3) {
-                int* dst = q == 0 ? ml.pN : (q == 1 ? ml.pC : ml.pCC);
-                int acc = 0;
-                dst[o] = 0;
-                for (int c = 0; c < W; ++c) {
-                    const float z = src[c];
-                    const int term = q == 0 ? 1 : (q == 1 ? c : c * c);
-                    acc += z == z ? term : 0;
-                    dst[o + c + 1] = acc;
-                }
-            } else {
-                double* dst = q == 3 ? ml.pZ : (q == 4 ? ml.pZZ : ml.pCZ);
-                double acc = 0.0;
-                dst[o] = 0.0;
-                for (int c = 0; c < W; ++c) {
-                    const float z = src[c];
-                    const double zz = z == z ? static_cast<double>(z) - z0 : 0.0;
-                    const double term = q == 3 ? zz : (q == 4 ? zz * zz : static_cast<double>(c) * zz);
-                    acc += term;
-                    dst[o + c + 1] = acc;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const int li = threadIdx.x / T, lj = threadIdx.x % T;
-    const int i = ti0 + li, j = tj0 + lj;
-    if (i >= g.rows || j >= g.cols) return;
-    const size_t cell = static_cast<size_t>(i) * g.cols + j;
-    const float nanf = __builtin_nanf("");
-    float ox = nanf, oy = nanf, oz = nanf, os = nanf, orough = nanf;
-    if (isfinite(d.tile[(li + H) * W + lj + H])) {
-        // the iterator's rows and, per row, its column interval: disc_walk's own logic (same members)
-        const int D = 2 * H + 1;
-        const double r2 = r * r;
-        const int i0 = d.bi0[li], i1 = d.bi1[li];
-        const int maxL = j - d.bj0[lj], maxR = d.bj1[lj] - j;
-        const int dyC = lj * D + H, dxC = li * D + H - i;
-        const int cc = lj + H, vc = li + H;  // the cell's own tile column / row
-        int N = 0, Sc = 0, Scc = 0, Sv = 0, Svv = 0, Svc = 0;  // integer moments about the cell (dc = c - cc, dv = v - vc)
-        double Sz = 0.0, Szz = 0.0, Scz = 0.0, Svz = 0.0;
-        for (int ii = i0; ii <= i1; ++ii) {
-            // the row's column interval: its robust half-width, and one more column either side when the iterator's own
-            // test says so — that column is on the circle or robustly outside (the test is then false), and whatever lies
-            // beyond it is a lattice unit farther out.  (disc_walk finds the same interval by stepping from the previous
-            // row's: four `while` loops per row, half of this kernel's instructions before.)
-            const double a = d.dx2[dxC + ii];
-            if (!(a <= r2)) continue;
-            const int w0 = rowW[ii - i + H];
-            const int k1 = min(w0 + 1, H);  // (w0 = H cannot be: the halo is one cell wider than the radius)
-            const int wR = min(w0 < 0 ? 0 : w0 + (a + d.dy2[dyC + k1] <= r2 ? 1 : 0), maxR);
-            const int wL = min(w0 < 0 ? 0 : w0 + (a + d.dy2[dyC - k1] <= r2 ? 1 : 0), maxL);
-            const int v = ii - ti0 + H, dv = v - vc;
-            const int lo = v * W1 + (cc - wL), hi = v * W1 + (cc + wR + 1);
-            const int n = ml.pN[hi] - ml.pN[lo];
-            const int sc = (ml.pC[hi] - ml.pC[lo]) - cc * n;                                  // sum of dc
-            const int scc = (ml.pCC[hi] - ml.pCC[lo]) - 2 * cc * (ml.pC[hi] - ml.pC[lo]) + cc * cc * n;  // sum of dc^2
-            const double z = ml.pZ[hi] - ml.pZ[lo], zz = ml.pZZ[hi] - ml.pZZ[lo];
-            const double cz = (ml.pCZ[hi] - ml.pCZ[lo]) - static_cast<double>(cc) * z;        // sum of dc z'
-            N += n;
-            Sc += sc;
-            Scc += scc;
-            Sv += dv * n;
-            Svv += dv * dv * n;
-            Svc += dv * sc;
-            Sz += z;
-            Szz += zz;
-            Scz += cz;
-            Svz += static_cast<double>(dv) * z;
-        }
-        const double nd = static_cast<double>(N);
-        const double invN = 1.0 / nd;
-        // scatter about the mean: lattice part in exact integers (N S2 - S1^2 <= 81 * 81 * 24^2 * 2), z part in f64
-        const double Avv = static_cast<double>(N * Svv - Sv * Sv) * invN, Acc = static_cast<double>(N * Scc - Sc * Sc) * invN;
-        const double Avc = static_cast<double>(N * Svc - Sv * Sc) * invN;
-        const double Avz = Svz - static_cast<double>(Sv) * Sz * invN, Acz = Scz - static_cast<double>(Sc) * Sz * invN;
-        const double Azz = fmax(Szz - Sz * Sz * invN, 0.0);
-        // metres: x = x0 - res * dv, y = y0 - res * dc (cell centres decrease with the index)
-        const double res = g.res, res2 = res * res;
-        const double a00 = res2 * Avv, a01 = res2 * Avc, a02 = -(res * Avz), a11 = res2 * Acc, a12 = -(res * Acz), a22 = Azz;
-        double ex, ey, ez, eigS, eigL;
-#ifdef FPE_FILTERS_JACOBI
-        normal_from_scatter(a00, a01, a02, a11, a12, a22, ex, ey, ez, eigS, eigL);
-#else
-        if (!normal_newton(a00, a01, a02, a11, a12, a22, ex, ey, ez, eigS, eigL))  // (eigenvalues too close for the iteration: the sweeps)
-            normal_from_scatter(a00, a01, a02, a11, a12, a22, ex, ey, ez, eigS, eigL);
-#endif
-        // (nearly) rank-deficient, or a component of the normal at rounding-noise level (symmetric neighbourhoods: exactly 0
-        // here, ~1e-17 by the oracle's order of operations): the literal walks decide (see above)
-        // Thresholds: the matrix entries carry ~1e-16 of their scale, so the eigenvector is good to ~1e-15 rad whatever the
-        // smallest eigenvalue (its accuracy depends on the GAP to the next one), the roughness sqrt(n^T A n / (n - 1)) to
-        // ~1e-18 / roughness metres — both far inside a float ulp down to a ratio of 1e-10; a component below 1e-6 would
-        // keep fewer than nine digits.  A wavefront takes the literal walks when ANY of its 64 cells asks for them, so the
-        // thresholds are as low as the arithmetic allows (at 1e-7, 2 % of a smooth map's cells — 70 % of its wavefronts).
-        const double tinyC = 1e-6;
-        if (!(eigS > 1e-10 * eigL) || fabs(ex) < tinyC || fabs(ey) < tinyC || fabs(ez) < tinyC) {
-            normals_cell_exact(d, li, lj, ti0, tj0, r, slopeCritical, 1, roughCritical, ox, oy, oz, os, orough);
-        } else {
-            ox = static_cast<float>(ex);
-            oy = static_cast<float>(ey);
-            oz = static_cast<float>(ez);
-            const double slope = acos(static_cast<double>(oz));  // SlopeFilter reads the float layer
-            os = slope < slopeCritical ? static_cast<float>(1.0 - slope / slopeCritical) : 0.0f;
-            // RoughnessFilter: the plane through the mean with the FLOAT normal: sum of squared distances = n^T A n
-            const double nx = ox, ny = oy, nz = oz;
-            const double q = nx * (nx * a00 + 2.0 * (ny * a01 + nz * a02)) + ny * (ny * a11 + 2.0 * (nz * a12)) + nz * (nz * a22);
-            const double roughness = sqrt(fmax(q, 0.0) / (nd - 1.0));
-            orough = roughness < roughCritical ? static_cast<float>(1.0 - roughness / roughCritical) : 0.0f;
-        }
-    }
-    L.nx[cell] = ox;
-    L.ny[cell] = oy;
-    L.nz[cell] = oz;
-    L.slope[cell] = os;
-    L.rough[cell] = orough;
-}
 
 // RoughnessFilter: needs the finished normal layers.
 __global__ __launch_bounds__(256) void filter_roughness_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double r, int H, double critical) {
@@ -628,7 +484,7 @@ __global__ __launch_bounds__(256) void filter_step1_kernel(MapGeom g, const floa
     const int i = ti0 + li, j = tj0 + lj;
     if (i >= g.rows || j >= g.cols) return;
     float out = __builtin_nanf("");
-    if (isfinite(d.tile[(li + H) * d.W + lj + H])) {
+    if (isfinite(d.tile[(li + H) * d.WC + lj + H])) {
         float hi = -__builtin_huge_valf(), lo = __builtin_huge_valf();
         disc_walk(d, li, lj, ti0, tj0, r * r, [&](double, double, float z) {
             hi = max_skip_nan(hi, z);
@@ -670,6 +526,8 @@ __global__ __launch_bounds__(256) void filter_step2_kernel(MapGeom g, FilterLaye
     L.trav[cell] = third * ((L.slope[cell] + out) + L.rough[cell]);
 }
 
+#include "fpe_filters_fused.hpp"
+
 // ---- the step filter's two windows by ROW RUNS (round 4) -----------------------------------------------------------------
 // Both iterations of the StepFilter reduce a disc with max / min (and a count): order-free, so only the SET of members
 // matters.  On the uniform lattice the set is the same for every cell — row offset o holds the columns |dc| <= w(o) — except
@@ -684,103 +542,206 @@ __global__ __launch_bounds__(256) void filter_step2_kernel(MapGeom g, FilterLaye
 //      the bounding box of the cell) and folds the members among them one by one.
 // Invalid cells are quiet NaNs in the tile: v_max / v_min skip them, `>` is false on them — what the iterator's isValid
 // test does.  Same members as disc_walk by construction: bit-identical layers (tests/test_gpu_filters.py).
-__host__ __device__ inline size_t step_lds_bytes(int H, int nClasses, int T = kFT) {
-    const int W = T + 2 * H;
-    return ((disc_lds_bytes(H, T) + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(nClasses) * W * T * 8 + 128;
+__host__ __device__ inline size_t step_lds_bytes(int H, int nClasses, int TR = kFT, int TC = kFT) {
+    const int WR = TR + 2 * H;
+    return ((disc_lds_bytes(H, TR, TC) + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(nClasses) * WR * TC * 8 + 128;
 }
 
 // kSecond false: step_height = max - min of the elevation over the first window.  true: the second window over the step
-// heights (their maximum and the number above the critical value), the step layer and the weighted sum of the three filters.
-template <bool kSecond, int T>
-__global__ __launch_bounds__(T * T) void filter_step_runs_kernel(MapGeom g, const float* __restrict__ src, FilterLayers L, double r, int H, StepShape sp,
-                                                                double critical, float critDown, int nCritical) {
-    extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
-    const DiscLds d = disc_carve(ldsRaw, H, T);
-    const int W = d.W;
+// heights (their maximum and the number above the critical value).  One tile's worth as a device function — every thread of
+// the workgroup takes part in the barriers; `live`: the thread's cell lies inside the map.  Returns the fold of the window
+// (hi; lo or cnt) and the centre value; the callers turn them into layers.
+// HS > 0: the halo as a compile-time constant (round 5: the windows of the published default chain at 2 cm and 1 cm, 5 and 9
+// cells) — the run extension and the fold over the disc's rows are unrolled, their LDS addresses immediates, the shape's
+// per-row entries scalar registers; HS = 0: any halo at run time (the shape's tables go through LDS).
+__device__ __forceinline__ float max3_skip_nan(float a, float b, float c) {  // v_max_f32(v_max_f32(a, b), c): quiet NaNs skipped
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float min3_skip_nan(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+template <bool kSecond, int TR, int TC, int HS>
+__device__ __forceinline__ void step_runs_phase(char* ldsRaw, const MapGeom& g, const float* __restrict__ src, double r, int Hrt, const StepShape& sp,
+                                                float critDown, int ti0, int tj0, bool live, float& hiOut, float& loOut, int& cntOut, float& centreOut) {
+    const int H = HS > 0 ? HS : Hrt;
+    const DiscLds d = disc_carve(ldsRaw, H, TR, TC);
+    const int WR = TR + 2 * H, WC = TC + 2 * H;
     // stored runs: [class][tile row][interior column] pairs (max, min) or (max, count bits)
-    float2* runs = reinterpret_cast<float2*>(ldsRaw + ((disc_lds_bytes(H, T) + 15) & ~static_cast<size_t>(15)));
-    // the shape's per-row half-widths and on-circle offsets in LDS (read in loops below: from the kernel arguments every
-    // read is a scalar load the loop waits for)
-    int8_t* shp = reinterpret_cast<int8_t*>(runs + static_cast<size_t>(sp.nClasses) * W * T);
+    float2* runs = reinterpret_cast<float2*>(ldsRaw + ((disc_lds_bytes(H, TR, TC) + 15) & ~static_cast<size_t>(15)));
+    // the shape's per-row half-widths and on-circle offsets in LDS (read in loops of run-time length: from the kernel arguments
+    // every read is a scalar load the loop waits for)
+    int8_t* shp = reinterpret_cast<int8_t*>(runs + static_cast<size_t>(sp.nClasses) * WR * TC);
     if (threadIdx.x < 2 * kFilterMaxH + 1) shp[threadIdx.x] = sp.rowW[threadIdx.x];
     else if (threadIdx.x >= 64 && threadIdx.x < 64 + kStepMaxEdge) shp[threadIdx.x] = sp.edgeR[threadIdx.x - 64];
     else if (threadIdx.x >= 96 && threadIdx.x < 96 + kStepMaxEdge) shp[threadIdx.x] = sp.edgeC[threadIdx.x - 96];
     const unsigned storeMask = sp.storeMask;
-    const int ti0 = blockIdx.y * T, tj0 = blockIdx.x * T;
-    disc_setup<false, T>(d, g, src, ti0, tj0, r);
+    // (with the per-axis distance tables: the on-circle offsets' tests below read them instead of recomputing two cell
+    // positions per offset and cell)
+    disc_setup<true, TR, TC, HS>(d, g, src, ti0, tj0, r);
     const float ninf = -__builtin_huge_valf(), pinf = __builtin_huge_valf();
-    for (int e = threadIdx.x; e < W * T; e += T * T) {  // 1. one run per (tile row, interior column)
-        const int row = e / T, c = e - row * T;
-        const float* p = d.tile + row * W + c + H;
+    for (int e = threadIdx.x; e < WR * TC; e += TR * TC) {  // 1. one run per (tile row, interior column)
+        const int row = e / TC, c = e - row * TC;
+        const float* p = d.tile + row * WC + c + H;
         const float z = p[0];
         float hi = max_skip_nan(kSecond ? -1.0f : ninf, z), lo = kSecond ? 0.0f : min_skip_nan(pinf, z);
         int cnt = (kSecond && z > critDown) ? 1 : 0;
-        float2* out = runs + row * T + c;  // class k at out[k * W * T]; classes in the order of their widths
+        float2* out = runs + row * TC + c;  // class k at out[k * WR * TC]; classes in the order of their widths
         if (storeMask & 1u) {
             *out = make_float2(hi, kSecond ? __int_as_float(cnt) : lo);
-            out += W * T;
+            out += WR * TC;
         }
-        for (int w = 1; w <= sp.wMax; ++w) {
+        const auto extend = [&](int w) {
             const float a = p[-w], b = p[w];
-            hi = max_skip_nan(max_skip_nan(hi, a), b);
+            hi = max3_skip_nan(hi, a, b);
             if (kSecond) cnt += (a > critDown ? 1 : 0) + (b > critDown ? 1 : 0);
-            else lo = min_skip_nan(min_skip_nan(lo, a), b);
+            else lo = min3_skip_nan(lo, a, b);
             if ((storeMask >> w) & 1u) {
                 *out = make_float2(hi, kSecond ? __int_as_float(cnt) : lo);
-                out += W * T;
+                out += WR * TC;
             }
+        };
+        if constexpr (HS > 0) {
+#pragma unroll
+            for (int w = 1; w < HS; ++w)  // (a robust half-width is below the halo: the halo is one cell wider than the radius)
+                if (w <= sp.wMax) extend(w);
+        } else {
+            for (int w = 1; w <= sp.wMax; ++w) extend(w);
         }
     }
     __syncthreads();
-    const int li = threadIdx.x / T, lj = threadIdx.x % T;
+    const int li = threadIdx.x / TC, lj = threadIdx.x % TC;
     const int i = ti0 + li, j = tj0 + lj;
-    if (i >= g.rows || j >= g.cols) return;
-    const size_t cell = static_cast<size_t>(i) * g.cols + j;
-    const float centre = d.tile[(li + H) * W + lj + H];
+    const float centre = d.tile[(li + H) * WC + lj + H];
     float hi = kSecond ? -1.0f : ninf, lo = pinf;
     int cnt = 0;
-    if (kSecond || isfinite(centre)) {
+    if (live && (kSecond || isfinite(centre))) {
         // 2. one stored run per row of the disc (the cell's bounding box never cuts a robust member: it spans every row and
         // column within r of the centre, and what lies outside the map is NaN in the tile)
-        for (int o = -H; o <= H; ++o) {
-            const int w = shp[o + H];
-            if (w < 0) continue;
+        const float2* const mine = runs + li * TC + lj;  // row offset o, class k: mine[(k * WR + H + o) * TC]
+        const auto fold = [&](int o, int w) {
             const int k = __builtin_popcount(storeMask & ((1u << w) - 1u));
-            const float2 v = runs[(k * W + (li + H + o)) * T + lj];
+            const float2 v = mine[(k * WR + H + o) * TC];
             hi = max_skip_nan(hi, v.x);
             if (kSecond) cnt += __float_as_int(v.y);
             else lo = min_skip_nan(lo, v.y);
+        };
+        if constexpr (HS > 0) {
+#pragma unroll
+            for (int o = -HS; o <= HS; ++o) {
+                const int w = sp.rowW[o + HS];  // (a scalar register: the kernel argument at a constant index)
+                if (w >= 0) fold(o, w);
+            }
+        } else {
+            for (int o = -H; o <= H; ++o) {
+                const int w = shp[o + H];
+                if (w >= 0) fold(o, w);
+            }
         }
-        // 3. the offsets on the circle, by the iterator's own tests
-        // (squared axis distances as disc_setup's tables hold them: the difference of two cell positions, squared)
+        // 3. the offsets on the circle, by the iterator's own tests: bounding box, and the squared axis distances of
+        // disc_setup's tables (the difference of two cell positions, squared — CircleIterator::isInside's operands)
         const double r2 = r * r;
         const int i0 = d.bi0[li], i1 = d.bi1[li], j0 = d.bj0[lj], j1 = d.bj1[lj];
-        const double xc = cell_pos(g.baseX, g.res, i), yc = cell_pos(g.baseY, g.res, j);
+        const int D = 2 * H + 1;
+        const double* const dxRow = d.dx2 + li * D + H;
+        const double* const dyRow = d.dy2 + lj * D + H;
+        const float* const tc = d.tile + (li + H) * WC + lj + H;
         for (int e = 0; e < sp.nEdge; ++e) {
             const int o = shp[64 + e], oc = shp[96 + e];
             const int ii = i + o, jj = j + oc;
-            if (ii < i0 || ii > i1 || jj < j0 || jj > j1) continue;
-            const double ddx = cell_pos(g.baseX, g.res, ii) - xc, ddy = cell_pos(g.baseY, g.res, jj) - yc;
-            if (!(ddx * ddx + ddy * ddy <= r2)) continue;
-            const float z = d.tile[(li + H + o) * W + lj + H + oc];
+            const bool in = ii >= i0 && ii <= i1 && jj >= j0 && jj <= j1 && dxRow[o] + dyRow[oc] <= r2;
+            const float z = in ? tc[o * WC + oc] : __builtin_nanf("");
             hi = max_skip_nan(hi, z);
             if (kSecond) cnt += z > critDown ? 1 : 0;
             else lo = min_skip_nan(lo, z);
         }
     }
+    hiOut = hi;
+    loOut = lo;
+    cntOut = cnt;
+    centreOut = centre;
+}
+// StepFilter's closing arithmetic on the second window's fold: the step layer's value (NaN where the window held no valid cell).
+__device__ __forceinline__ float step_value(float hi, int cnt, double critical, int nCritical) {
+    float out = __builtin_nanf("");
+    if (hi >= 0.0f) {
+        const double stepMax = static_cast<double>(hi);
+        const double step = fmin(stepMax, static_cast<double>(cnt) / static_cast<double>(nCritical) * stepMax);
+        out = step < critical ? static_cast<float>(1.0 - step / critical) : 0.0f;
+    }
+    return out;
+}
+
+// The two windows as launches of their own.  Tiles are numbered XCD-aware (xcd_tile): 1-D grid of tilesX * tilesY workgroups.
+template <bool kSecond, int TR, int TC, int HS>
+__global__ __launch_bounds__(TR * TC) void filter_step_runs_kernel(MapGeom g, const float* __restrict__ src, FilterLayers L, double r, int H, StepShape sp,
+                                                                double critical, float critDown, int nCritical, int tilesX, int nTiles) {
+    extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
+    int ty, tx;
+    xcd_tile(tilesX, nTiles, ty, tx);
+    const int ti0 = ty * TR, tj0 = tx * TC;
+    const int i = ti0 + static_cast<int>(threadIdx.x) / TC, j = tj0 + static_cast<int>(threadIdx.x) % TC;
+    const bool live = i < g.rows && j < g.cols;
+    float hi, lo, centre;
+    int cnt;
+    step_runs_phase<kSecond, TR, TC, HS>(ldsRaw, g, src, r, H, sp, critDown, ti0, tj0, live, hi, lo, cnt, centre);
+    if (!live) return;
+    const size_t cell = static_cast<size_t>(i) * g.cols + j;
     if constexpr (!kSecond) {
         L.stepHeight[cell] = isfinite(centre) ? static_cast<float>(static_cast<double>(hi) - static_cast<double>(lo)) : __builtin_nanf("");
     } else {
-        const bool valid = hi >= 0.0f;
-        float out = __builtin_nanf("");
-        if (valid) {
-            const double stepMax = static_cast<double>(hi);
-            const double step = fmin(stepMax, static_cast<double>(cnt) / static_cast<double>(nCritical) * stepMax);
-            out = step < critical ? static_cast<float>(1.0 - step / critical) : 0.0f;
-        }
+        const float out = step_value(hi, cnt, critical, nCritical);
         L.step[cell] = out;
         const float third = 1.0f / 3.0f;  // MathExpressionFilter on float matrices: (1.0 / 3.0) * (slope + step + roughness)
         L.trav[cell] = third * ((L.slope[cell] + out) + L.rough[cell]);
+    }
+}
+
+// ---- the chain's second launch (round 5): normals + slope + roughness by row moments and the StepFilter's second window over
+// the same 16 x 16 (32 x 32) cells, then the weighted sum.  kStep 0: the moment phase alone (the step window is a launch
+// of its own — its shape does not fit the row-run tables).  travOnly (run time, wave-uniform): store the traversability
+// layer and nothing else.
+template <int H, int TR, int TC, int HS>
+__global__ __launch_bounds__(TR * TC) void filter_fused_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double rN, double slopeCritical,
+                                                            double roughCritical, double invSlopeCritical, double invRoughCritical, StepShape sN, double r2nd, int h2nd, StepShape s2, double stepCritical,
+                                                            float critDown, int nCritical, int kStep, int travOnly, int tilesX, int nTiles) {
+    extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
+    int ty, tx;
+    xcd_tile(tilesX, nTiles, ty, tx);
+    const int ti0 = ty * TR, tj0 = tx * TC;
+    const int i = ti0 + static_cast<int>(threadIdx.x) / TC, j = tj0 + static_cast<int>(threadIdx.x) % TC;
+    const bool live = i < g.rows && j < g.cols;
+    float stepOut = 0.0f;
+#ifdef FPE_DBG_NO_STEP
+    if (kStep) stepOut = L.stepHeight[static_cast<size_t>(min(i, g.rows - 1)) * g.cols + min(j, g.cols - 1)];
+    if (false) {
+#else
+    if (kStep) {
+#endif
+        float hi, lo, centre;
+        int cnt;
+        step_runs_phase<true, TR, TC, HS>(ldsRaw, g, L.stepHeight, r2nd, h2nd, s2, critDown, ti0, tj0, live, hi, lo, cnt, centre);
+        stepOut = step_value(hi, cnt, stepCritical, nCritical);
+        __syncthreads();  // the moment phase reuses the LDS
+    }
+    float ox, oy, oz, os, orough;
+    moments_phase<H, TR, TC>(ldsRaw, g, elev, ti0, tj0, rN, sN, slopeCritical, roughCritical, invSlopeCritical, invRoughCritical, live, ox, oy, oz, os, orough);
+    if (!live) return;
+    const size_t cell = static_cast<size_t>(i) * g.cols + j;
+    if (!travOnly) {
+        L.nx[cell] = ox;
+        L.ny[cell] = oy;
+        L.nz[cell] = oz;
+        L.slope[cell] = os;
+        L.rough[cell] = orough;
+        if (kStep) L.step[cell] = stepOut;
+    }
+    if (kStep) {
+        const float third = 1.0f / 3.0f;  // MathExpressionFilter on float matrices: (1.0 / 3.0) * (slope + step + roughness)
+        L.trav[cell] = third * ((os + stepOut) + orough);
     }
 }
 
@@ -792,81 +753,160 @@ bool filters_supported(const FilterConsts& fc, const MapGeom& g) {
     const double rmax = std::fmax(std::fmax(fc.normalRadius, fc.roughnessRadius), std::fmax(fc.stepFirstRadius, fc.stepSecondRadius));
     return filter_halo(rmax, g.res) <= kFilterMaxH;
 }
-// Three launches on `stream` (four when the roughness radius differs from the normals'): normals + slope [+ roughness],
-// [roughness,] step heights, step + weighted sum.
-hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float* d_elev, const FilterLayers& L, hipStream_t stream) {
-    const dim3 grid((g.cols + kFT - 1) / kFT, (g.rows + kFT - 1) / kFT), block(256);
-    const int hN = filter_halo(fc.normalRadius, g.res), hR = filter_halo(fc.roughnessRadius, g.res);
-    const int h1 = filter_halo(fc.stepFirstRadius, g.res), h2 = filter_halo(fc.stepSecondRadius, g.res);
-    const int fuse = fc.roughnessRadius == fc.normalRadius ? 1 : 0;  // the published default chain: both 0.05 m
+// What a chain with these parameters can do without the caller's layer buffer: 1 = the two-launch chain that stores
+// step_height and traversability only (the fused kernel covers normals, slope, roughness and the second step window),
+// 0 = the intermediate layers have to exist (some filter runs as a launch of its own).
+struct FilterRoute {
+    StepShape sN, s1, s2;
+    int hN, hR, h1, h2;
+    int tF;          // tile COLUMNS of the fused kernel (its rows: 32), 0: the moment form does not apply (walking kernels)
+    int stepFused;   // the second step window rides in the fused kernel
+    int t1, t2;      // tile edges of the row-run launches
+    size_t fusedBytes;
+};
+namespace {
+template <int H, int TR, int TC, int HS = 0>
+hipError_t launch_fused_one(const MapGeom& g, const FilterConsts& fc, const float* d_elev, const FilterLayers& L, const FilterRoute& rt, float critDown, int travOnly,
+                            hipStream_t stream) {
+    const void* fn = reinterpret_cast<const void*>(filter_fused_kernel<H, TR, TC, HS>);
+    if (rt.fusedBytes > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(rt.fusedBytes));
+        if (e != hipSuccess) return e;
+    }
+    const int tilesX = (g.cols + TC - 1) / TC, nTiles = tilesX * ((g.rows + TR - 1) / TR);
+    hipLaunchKernelGGL((filter_fused_kernel<H, TR, TC, HS>), dim3(nTiles), dim3(TR * TC), rt.fusedBytes, stream, g, d_elev, L, fc.normalRadius, fc.slopeCritical,
+                       fc.roughnessCritical, 1.0 / fc.slopeCritical, 1.0 / fc.roughnessCritical, rt.sN, fc.stepSecondRadius, rt.h2, rt.s2, fc.stepCritical, critDown, fc.stepCriticalCells, rt.stepFused, travOnly,
+                       tilesX, nTiles);
+    return hipGetLastError();
+}
+// The fused kernel's tile: 32 rows x 16 columns (512 threads) for halos up to eight cells, 32 x 32 beyond.  Rows amortise: the
+// row runs of the step window are one per (tile row with halo, interior column), the prefix scans one lane per tile row.
+constexpr int kFusedRows = 32;
+constexpr int kFusedSmallMaxH = 8;
+int fused_tile(int H) { return H <= kFusedSmallMaxH ? 16 : 32; }
+}  // namespace
+FilterRoute filter_route(const FilterConsts& fc, const MapGeom& g) {
+    FilterRoute rt{};
+    rt.hN = filter_halo(fc.normalRadius, g.res);
+    rt.hR = filter_halo(fc.roughnessRadius, g.res);
+    rt.h1 = filter_halo(fc.stepFirstRadius, g.res);
+    rt.h2 = filter_halo(fc.stepSecondRadius, g.res);
     const double reach = std::fmax(std::fabs(g.posX) + g.orgX, std::fabs(g.posY) + g.orgY) + g.res;
-    // Tile edge of the lattice kernels: 32 (1024 threads) when a tile row with its halo is still one wavefront load and the
-    // arrays fit the LDS — the halo is read 2.4 x instead of 4.5 x per cell at 1 cm, set-up and prefix scans per cell halve —
-    // else 16.  FPE_FILTER_TILE=16 (environment, read per call: a measurement switch) keeps the small tile.
     static const int forcedTile = std::getenv("FPE_FILTER_TILE") ? std::atoi(std::getenv("FPE_FILTER_TILE")) : 0;
-    const auto tile_of = [&](int H, size_t bytes32) { return (forcedTile != 16 && 32 + 2 * H <= 64 && bytes32 <= 150 * 1024 && g.rows >= 64 && g.cols >= 64) ? 32 : 16; };
-    const auto grid_of = [&](int T) { return dim3((g.cols + T - 1) / T, (g.rows + T - 1) / T); };
-    const auto fits = [](const void* fn, size_t bytes) -> bool {  // beyond 48 KB of dynamic LDS a kernel has to be told
-        if (bytes <= 48 * 1024) return true;
-        if (bytes > 150 * 1024) return false;
-        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) == hipSuccess;
-    };
 #ifndef FPE_FILTERS_WALK_ONLY
-    const StepShape sN = step_shape(fc.normalRadius, g.res, hN, reach);
+    rt.sN = step_shape(fc.normalRadius, g.res, rt.hN, reach);
+    rt.s1 = step_shape(fc.stepFirstRadius, g.res, rt.h1, reach);
+    rt.s2 = step_shape(fc.stepSecondRadius, g.res, rt.h2, reach);
     // The moment form takes the lattice as EXACT integers; the published filters (and the oracle) sum the cells' rounded f64
     // positions.  Near the origin the two agree far inside a float ulp; at a coordinate of `reach` a position carries an error of
     // ulp(reach) ~ 2e-16 reach against a spacing of res, and the normal follows it: beyond reach / res = 2e5 (2 km at 1 cm, 4e-11
     // relative) the literal walks run instead (at 3 000 km a handful of cells differed by up to 8 float ulps; tests).
     const bool latticeExact = reach / g.res < 2.0e5;
-    const auto moment_bytes = [&](int T) { return ((disc_lds_bytes(hN, T) + 15) & ~static_cast<size_t>(15)) + moment_lds_bytes(hN, T); };
-    // (the moment kernel only from a halo of nine cells on: its prefix scans occupy a quarter of a 1024-thread workgroup's
-    // lanes, and at 80 KB of LDS no second workgroup is there to fill the gap — measured: H = 3 52 -> 61 us, H = 6 302 -> 351 us,
-    // H = 11 721 -> 578 us; the row-run kernels gain at every size that fits: 1 cm 111 + 118 -> 75 + 81 us)
-    const int tN = hN >= 9 ? tile_of(hN, moment_bytes(32)) : 16;
-    const void* momentsFn = tN == 32 ? reinterpret_cast<const void*>(filter_normals_moments_kernel<32>) : reinterpret_cast<const void*>(filter_normals_moments_kernel<16>);
-    if (fuse && hN <= kMomentMaxH && sN.rowsOk && latticeExact && fits(momentsFn, moment_bytes(tN))) {  // row moments; the literal walks for what they do not cover
-        if (tN == 32)
-            hipLaunchKernelGGL(filter_normals_moments_kernel<32>, grid_of(32), dim3(1024), moment_bytes(32), stream, g, d_elev, L, fc.normalRadius, hN,
-                               fc.slopeCritical, fc.roughnessCritical, sN);
-        else
-            hipLaunchKernelGGL(filter_normals_moments_kernel<16>, grid, block, moment_bytes(16), stream, g, d_elev, L, fc.normalRadius, hN, fc.slopeCritical,
-                               fc.roughnessCritical, sN);
-    } else
+    const bool sameDisc = fc.roughnessRadius == fc.normalRadius;  // the published default chain: both 0.05 m
+    if (sameDisc && rt.hN >= 1 && rt.hN <= kMomentMaxH && rt.sN.rowsOk && latticeExact) rt.tF = fused_tile(rt.hN);
 #endif
-    hipLaunchKernelGGL(filter_normals_kernel, grid, block, disc_lds_bytes(hN), stream, g, d_elev, L, fc.normalRadius, hN, fc.slopeCritical, fuse,
-                       fc.roughnessCritical);
-    if (!fuse)
-        hipLaunchKernelGGL(filter_roughness_kernel, grid, block, disc_lds_bytes(hR), stream, g, d_elev, L, fc.roughnessRadius, hR, fc.roughnessCritical);
+    // Tile edge of the row-run launches: 32 (1024 threads) when a tile row with its halo is still one wavefront load and the
+    // arrays fit the LDS, else 16.  FPE_FILTER_TILE=16 (environment: a measurement switch) keeps the small tile.
+    const auto tile_of = [&](int H, size_t bytes32) { return (forcedTile != 16 && 32 + 2 * H <= 64 && bytes32 <= 150 * 1024 && g.rows >= 64 && g.cols >= 64) ? 32 : 16; };
+    rt.t1 = tile_of(rt.h1, step_lds_bytes(rt.h1, rt.s1.nClasses, 32, 32));
+    rt.t2 = tile_of(rt.h2, step_lds_bytes(rt.h2, rt.s2.nClasses, 32, 32));
+    if (rt.tF) {
+        rt.fusedBytes = fused_moment_bytes(rt.hN, kFusedRows, rt.tF);
+        const size_t stepBytes = step_lds_bytes(rt.h2, rt.s2.nClasses, kFusedRows, rt.tF);
+        if (rt.s2.ok && rt.tF + 2 * rt.h2 <= 64 && stepBytes <= 150 * 1024) {
+            rt.stepFused = 1;
+            if (stepBytes > rt.fusedBytes) rt.fusedBytes = stepBytes;
+        }
+        if (rt.fusedBytes > 150 * 1024) rt.tF = rt.stepFused = 0;
+    }
+    return rt;
+}
+// 1: the chain can run without the seven intermediate layers (launch_filters with travOnly).
+bool filters_trav_only_ok(const FilterConsts& fc, const MapGeom& g) {
+    const FilterRoute rt = filter_route(fc, g);
+    return rt.tF != 0 && rt.stepFused != 0;
+}
+// The chain on `stream`: step heights, then normals + slope + roughness + second step window + weighted sum in one launch
+// (filter_fused_kernel); launches of their own for whatever the lattice forms do not cover.  travOnly: only L.stepHeight and
+// L.trav are valid pointers (filters_trav_only_ok must have said yes).
+hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float* d_elev, const FilterLayers& L, bool travOnly, hipStream_t stream) {
+    const dim3 grid((g.cols + kFT - 1) / kFT, (g.rows + kFT - 1) / kFT), block(256);
+    const FilterRoute rt = filter_route(fc, g);
+    if (travOnly && !(rt.tF && rt.stepFused)) return hipErrorInvalidValue;
+    const auto fits = [](const void* fn, size_t bytes) -> bool {  // beyond 48 KB of dynamic LDS a kernel has to be told
+        if (bytes <= 48 * 1024) return true;
+        if (bytes > 150 * 1024) return false;
+        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) == hipSuccess;
+    };
     float critDown = static_cast<float>(fc.stepCritical);
     if (static_cast<double>(critDown) > fc.stepCritical) critDown = std::nextafterf(critDown, -HUGE_VALF);
-#ifndef FPE_FILTERS_WALK_ONLY
-    const StepShape s1 = step_shape(fc.stepFirstRadius, g.res, h1, reach), s2 = step_shape(fc.stepSecondRadius, g.res, h2, reach);
-#else
-    StepShape s1{}, s2{};
-#endif
-    const int t1 = tile_of(h1, step_lds_bytes(h1, s1.nClasses, 32)), t2 = tile_of(h2, step_lds_bytes(h2, s2.nClasses, 32));
-    const void* run1 = t1 == 32 ? reinterpret_cast<const void*>(filter_step_runs_kernel<false, 32>) : reinterpret_cast<const void*>(filter_step_runs_kernel<false, 16>);
-    const void* run2 = t2 == 32 ? reinterpret_cast<const void*>(filter_step_runs_kernel<true, 32>) : reinterpret_cast<const void*>(filter_step_runs_kernel<true, 16>);
-    if (s1.ok && fits(run1, step_lds_bytes(h1, s1.nClasses, t1))) {
-        if (t1 == 32)
-            hipLaunchKernelGGL((filter_step_runs_kernel<false, 32>), grid_of(32), dim3(1024), step_lds_bytes(h1, s1.nClasses, 32), stream, g, d_elev, L,
-                               fc.stepFirstRadius, h1, s1, 0.0, 0.0f, 1);
-        else
-            hipLaunchKernelGGL((filter_step_runs_kernel<false, 16>), grid, block, step_lds_bytes(h1, s1.nClasses, 16), stream, g, d_elev, L, fc.stepFirstRadius,
-                               h1, s1, 0.0, 0.0f, 1);
-    } else {
-        hipLaunchKernelGGL(filter_step1_kernel, grid, block, disc_lds_bytes(h1), stream, g, d_elev, L, fc.stepFirstRadius, h1);
+    const auto tiles = [&](int T, int& tilesX) { tilesX = (g.cols + T - 1) / T; return tilesX * ((g.rows + T - 1) / T); };
+    // 1. step heights (first window)
+    {
+        const int t1 = rt.t1;
+        const void* run1 = t1 != 32 ? reinterpret_cast<const void*>(filter_step_runs_kernel<false, 16, 16, 0>)
+                           : (rt.h1 == 5 ? reinterpret_cast<const void*>(filter_step_runs_kernel<false, 32, 32, 5>)
+                                         : (rt.h1 == 9 ? reinterpret_cast<const void*>(filter_step_runs_kernel<false, 32, 32, 9>)
+                                                       : reinterpret_cast<const void*>(filter_step_runs_kernel<false, 32, 32, 0>)));
+        int tilesX;
+        const int nTiles = tiles(t1, tilesX);
+        if (rt.s1.ok && fits(run1, step_lds_bytes(rt.h1, rt.s1.nClasses, t1, t1))) {
+            const size_t bytes = step_lds_bytes(rt.h1, rt.s1.nClasses, t1, t1);
+#define FPE_STEP1(TT, HS) hipLaunchKernelGGL((filter_step_runs_kernel<false, TT, TT, HS>), dim3(nTiles), dim3(TT * TT), bytes, stream, g, d_elev, L, fc.stepFirstRadius, rt.h1, \
+                                            rt.s1, 0.0, 0.0f, 1, tilesX, nTiles)
+            if (t1 == 32 && rt.h1 == 5) FPE_STEP1(32, 5);
+            else if (t1 == 32 && rt.h1 == 9) FPE_STEP1(32, 9);
+            else if (t1 == 32) FPE_STEP1(32, 0);
+            else FPE_STEP1(16, 0);
+#undef FPE_STEP1
+        } else {
+            if (travOnly) return hipErrorInvalidValue;  // (filter_step1_kernel writes L.stepHeight only, but keep the contract simple)
+            hipLaunchKernelGGL(filter_step1_kernel, grid, block, disc_lds_bytes(rt.h1), stream, g, d_elev, L, fc.stepFirstRadius, rt.h1);
+        }
     }
-    if (s2.ok && fits(run2, step_lds_bytes(h2, s2.nClasses, t2))) {
-        if (t2 == 32)
-            hipLaunchKernelGGL((filter_step_runs_kernel<true, 32>), grid_of(32), dim3(1024), step_lds_bytes(h2, s2.nClasses, 32), stream, g,
-                               static_cast<const float*>(L.stepHeight), L, fc.stepSecondRadius, h2, s2, fc.stepCritical, critDown, fc.stepCriticalCells);
-        else
-            hipLaunchKernelGGL((filter_step_runs_kernel<true, 16>), grid, block, step_lds_bytes(h2, s2.nClasses, 16), stream, g,
-                               static_cast<const float*>(L.stepHeight), L, fc.stepSecondRadius, h2, s2, fc.stepCritical, critDown, fc.stepCriticalCells);
+    // 2. normals + slope + roughness [+ second step window + weighted sum]
+    bool stepDone = false;
+    if (rt.tF) {
+        hipError_t e = hipErrorInvalidValue;
+        // the published default chain at 2 cm and 1 cm (normals 0.05 m, second step window 0.08 m): the step window's halo is a
+        // compile-time constant too
+        if (rt.stepFused && rt.hN == 3 && rt.h2 == 5) e = launch_fused_one<3, kFusedRows, 16, 5>(g, fc, d_elev, L, rt, critDown, travOnly ? 1 : 0, stream);
+        else if (rt.stepFused && rt.hN == 6 && rt.h2 == 9) e = launch_fused_one<6, kFusedRows, 16, 9>(g, fc, d_elev, L, rt, critDown, travOnly ? 1 : 0, stream);
+        else switch (rt.hN) {
+#define FPE_FUSED_CASE(HH, TT) case HH: e = launch_fused_one<HH, kFusedRows, TT>(g, fc, d_elev, L, rt, critDown, travOnly ? 1 : 0, stream); break;
+            FPE_FUSED_CASE(1, 16) FPE_FUSED_CASE(2, 16) FPE_FUSED_CASE(3, 16) FPE_FUSED_CASE(4, 16) FPE_FUSED_CASE(5, 16) FPE_FUSED_CASE(6, 16)
+            FPE_FUSED_CASE(7, 16) FPE_FUSED_CASE(8, 16) FPE_FUSED_CASE(9, 32) FPE_FUSED_CASE(10, 32) FPE_FUSED_CASE(11, 32) FPE_FUSED_CASE(12, 32)
+#undef FPE_FUSED_CASE
+            default: break;
+        }
+        if (e != hipSuccess) return e;
+        stepDone = rt.stepFused != 0;
     } else {
-        hipLaunchKernelGGL(filter_step2_kernel, grid, block, disc_lds_bytes(h2), stream, g, L, fc.stepSecondRadius, h2, fc.stepCritical, critDown,
-                           fc.stepCriticalCells);
+        const int fuse = fc.roughnessRadius == fc.normalRadius ? 1 : 0;
+        hipLaunchKernelGGL(filter_normals_kernel, grid, block, disc_lds_bytes(rt.hN), stream, g, d_elev, L, fc.normalRadius, rt.hN, fc.slopeCritical, fuse,
+                           fc.roughnessCritical);
+        if (!fuse)
+            hipLaunchKernelGGL(filter_roughness_kernel, grid, block, disc_lds_bytes(rt.hR), stream, g, d_elev, L, fc.roughnessRadius, rt.hR, fc.roughnessCritical);
+    }
+    // 3. second step window + weighted sum, when it did not ride in the fused launch
+    if (!stepDone) {
+        const int t2 = rt.t2;
+        const void* run2 = t2 == 32 ? reinterpret_cast<const void*>(filter_step_runs_kernel<true, 32, 32, 0>) : reinterpret_cast<const void*>(filter_step_runs_kernel<true, 16, 16, 0>);
+        int tilesX;
+        const int nTiles = tiles(t2, tilesX);
+        if (rt.s2.ok && fits(run2, step_lds_bytes(rt.h2, rt.s2.nClasses, t2, t2))) {
+            if (t2 == 32)
+                hipLaunchKernelGGL((filter_step_runs_kernel<true, 32, 32, 0>), dim3(nTiles), dim3(1024), step_lds_bytes(rt.h2, rt.s2.nClasses, 32, 32), stream, g,
+                                   static_cast<const float*>(L.stepHeight), L, fc.stepSecondRadius, rt.h2, rt.s2, fc.stepCritical, critDown, fc.stepCriticalCells,
+                                   tilesX, nTiles);
+            else
+                hipLaunchKernelGGL((filter_step_runs_kernel<true, 16, 16, 0>), dim3(nTiles), block, step_lds_bytes(rt.h2, rt.s2.nClasses, 16, 16), stream, g,
+                                   static_cast<const float*>(L.stepHeight), L, fc.stepSecondRadius, rt.h2, rt.s2, fc.stepCritical, critDown, fc.stepCriticalCells,
+                                   tilesX, nTiles);
+        } else {
+            hipLaunchKernelGGL(filter_step2_kernel, grid, block, disc_lds_bytes(rt.h2), stream, g, L, fc.stepSecondRadius, rt.h2, fc.stepCritical, critDown,
+                               fc.stepCriticalCells);
+        }
     }
     return hipGetLastError();
 }

@@ -55,6 +55,9 @@ def test_filter_chain_matches_the_oracle(planner, rows, cols, res, seed):
     ora = fpo.traversability_filters(elev, res)
     assert np.array_equal(trav, layers["traversability"], equal_nan=True)
     assert_layers_equal(layers, ora)
+    # the chain without a layer buffer (step_height and traversability stored, the rest kept in registers): the same layer
+    only = planner.traversability_from_elevation(elev, res)
+    assert np.array_equal(only, trav, equal_nan=True)
     t = ora["traversability"]
     assert np.isfinite(t).mean() > 0.9 and np.nanmin(t) < 0.5 < 0.9 < np.nanmax(t)  # the terrain spans the planner's thresholds
 
@@ -162,6 +165,9 @@ def random_filter_case(planner, seed):
     assert_layers_equal(layers, ora, max_ulp_cells=5e-3)
     for name in ("step_height", "step"):  # max / min / count windows: bit-identical or wrong
         assert np.array_equal(layers[name], ora[name], equal_nan=True), f"seed {seed}: {name} not bit-identical"
+    # without a layer buffer the chain keeps the intermediate layers in registers where its kernels allow: the same layer
+    only = planner.traversability_from_elevation(elev, res, position=pos, params=fp)
+    assert np.array_equal(only, layers["traversability"], equal_nan=True), f"seed {seed}: traversability-only chain differs"
     return rows * cols, float(np.isfinite(ora["traversability"]).mean())
 
 
