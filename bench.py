@@ -721,19 +721,28 @@ def main():
                                      "track, no chain).  roofline_frac_by_convention charges every query the full 508 B window although a "
                                      "default hit reads ~18 cells; the counter-measured bytes are in profiles/ (DESIGN.md)"}
         # the map's producer: elevation layer of this workload's map -> traversability layer through the
-        # device filters (normals + slope, roughness, step heights, step + weighted sum: four launches), device-resident
+        # device filters, device-resident: two launches (step heights; normals + slope + roughness + second step window +
+        # weighted sum).  Timed in both forms: traversability only (no layer buffer: what the pipeline elevation -> filters ->
+        # fpe_upload_map_device uses; step_height and traversability are the only layers stored) and with all eight layers.
         d_fe = torch.from_numpy(np.ascontiguousarray(elev)).to(dev)
         d_ft = torch.empty_like(d_fe)
         d_fl = torch.empty(8 * rows * cols, dtype=torch.float32, device=dev)
-        for _ in range(2):
-            planner.traversability_device(d_fe.data_ptr(), d_ft.data_ptr(), rows, cols, res, d_layers_ptr=d_fl.data_ptr(), stream=stream.cuda_stream)
-        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        f0.record(stream)
-        for _ in range(5):
-            planner.traversability_device(d_fe.data_ptr(), d_ft.data_ptr(), rows, cols, res, d_layers_ptr=d_fl.data_ptr(), stream=stream.cuda_stream)
-        f1.record(stream)
-        torch.cuda.synchronize()
-        f_ms = f0.elapsed_time(f1) / 5
+
+        def _time_filters(layers_ptr, reps=25, blocks=9):
+            for _ in range(3):
+                planner.traversability_device(d_fe.data_ptr(), d_ft.data_ptr(), rows, cols, res, d_layers_ptr=layers_ptr, stream=stream.cuda_stream)
+            ts = []
+            for _ in range(blocks):
+                f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                f0.record(stream)
+                for _ in range(reps):
+                    planner.traversability_device(d_fe.data_ptr(), d_ft.data_ptr(), rows, cols, res, d_layers_ptr=layers_ptr, stream=stream.cuda_stream)
+                f1.record(stream)
+                torch.cuda.synchronize()
+                ts.append(f0.elapsed_time(f1) / reps)
+            return float(np.median(ts))
+        f_ms_all = _time_filters(d_fl.data_ptr())
+        f_ms = _time_filters(0)
         from oracle import fpo as _fpo
         # checked on a 96 x 96 corner taken as a map of its own, engine and oracle on identical inputs (cell positions of a
         # cut-out differ from the full map's in the last place, and membership at exactly one radius depends on them)
@@ -747,13 +756,21 @@ def main():
             verified = False
             line["config"]["verified"] = False
             line["config"]["verify_error"] = "filters: traversability layer differs from the oracle by more than one float ulp"
-        line["filters"] = {"map": f"{rows}x{cols} @ {res} m elevation layer of this workload", "ms": f_ms, "cells_per_s": rows * cols / (f_ms * 1e-3),
-                           "GB/s_by_layers": (1 + 8) * rows * cols * 4 / (f_ms * 1e-3) / 1e9, "verified": f_ok,
-                           "note": "fpe_traversability_device: 1 layer read + 8 layers written per cell (36 B); normals / slope / roughness from row "
-                                   "moments of the disc with Newton's iteration for the eigenvector, the step filter's windows by row runs over a "
-                                   "host-sorted lattice shape (DESIGN 4.5): bound by the SIMDs' instruction issue (per 64 cells at 1 cm: normals 1.9 k VALU "
-                                   "+ 0.6 k SALU + 0.26 k LDS instructions, each step kernel 0.85 k + 0.58 k + 0.11 k; profiles/round4_filters.txt), not by HBM; "
-                                   "`verified`: engine against oracle on a 96 x 96 corner of the layer taken as a map of its own"}
+        n_cells = rows * cols
+        line["filters"] = {"map": f"{rows}x{cols} @ {res} m elevation layer of this workload", "ms": f_ms, "cells_per_s": n_cells / (f_ms * 1e-3),
+                           "mode": "traversability only (no layer buffer)", "bytes_per_cell_by_layers": 12,
+                           "GB/s_by_layers": 12 * n_cells / (f_ms * 1e-3) / 1e9, "frac_of_hbm_peak_by_layers": 12 * n_cells / (f_ms * 1e-3) / 1e9 / peak,
+                           "bytes_per_cell_moved": 20,
+                           "all_layers": {"ms": f_ms_all, "bytes_per_cell_by_layers": 36, "GB/s_by_layers": 36 * n_cells / (f_ms_all * 1e-3) / 1e9,
+                                          "frac_of_hbm_peak_by_layers": 36 * n_cells / (f_ms_all * 1e-3) / 1e9 / peak},
+                           "verified": f_ok, "timing": "median of 9 blocks of 25 chains",
+                           "note": "fpe_traversability_device, two launches: filter_step_runs_kernel (step heights) and filter_fused_kernel (normals / slope / "
+                                   "roughness from row moments of the disc, Newton's iteration for the eigenvector, the step filter's second window by row "
+                                   "runs, the weighted sum).  12 B/cell by layers = elevation read + step_height and traversability written; the two "
+                                   "launches MOVE 20 B/cell (the second reads elevation and step_height again), measured fabric traffic 1.05 x that "
+                                   "(profiles/round5_filters.txt).  Bound by the SIMDs' instruction issue (per 64 cells at 1 cm: 0.36 k + 1.5 k VALU "
+                                   "instructions), not by HBM (DESIGN 4.5).  `verified`: engine against oracle on a 96 x 96 corner of the layer taken as a "
+                                   "map of its own"}
         del d_fe, d_ft, d_fl
         # the opt track of the same batch (fpe_plan_opt_device; build-defined optimiser: DESIGN 4.6): the nominal
         # plan's cycle flags in, global_footholds_opt + the per-cycle problems out, device-resident

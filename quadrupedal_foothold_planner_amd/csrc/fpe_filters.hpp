@@ -250,7 +250,7 @@ __device__ __forceinline__ double rcp_refined(double x) {
     return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
 }
 __device__ __forceinline__ bool normal_newton(double a00, double a01, double a02, double a11, double a12, double a22, double& ex, double& ey, double& ez,
-                                              double& wS, double& wL) {
+                                              double& wS, double& wL, double& gapRel) {
     const double s = fmax(fmax(a00, a11), a22);
     const double inv = rcp_refined(s);
     const double b00 = a00 * inv, b01 = a01 * inv, b02 = a02 * inv, b11 = a11 * inv, b12 = a12 * inv, b22 = a22 * inv;
@@ -259,7 +259,10 @@ __device__ __forceinline__ bool normal_newton(double a00, double a01, double a02
     const double c1 = (m0 + m1) + m2;
     const double c0 = __builtin_fma(b02, __builtin_fma(b01, b12, -(b11 * b02)), __builtin_fma(b00, m0, -(b01 * __builtin_fma(b01, b22, -(b12 * b02)))));
     const double tol = 4e-16 * c2;
-    double lam = c0 * rcp_refined(c1);
+    // start: Halley's step from 0 (f(0) = -c0, f'(0) = c1, f''(0) = -2 c2) — one order better than Newton's c0 / c1, one
+    // iteration less.  For a cubic with three real roots both steps stay left of the smallest root; were rounding to carry the
+    // start past it, Newton's next step returns to the left (f is concave and increasing up to c2 / 3).
+    double lam = c0 * c1 * rcp_refined(__builtin_fma(c1, c1, -(c0 * c2)));
     // degenerate input — no matrix, or the two smaller eigenvalues both at rounding level (c1 ~ lambda2 lambda3 when lambda1 ~ 0:
     // two members, collinear members): c0 / c1 would be a quotient of rounding noise.  Reported as not converged: the sweeps
     // and the rank test decide.
@@ -270,19 +273,29 @@ __device__ __forceinline__ bool normal_newton(double a00, double a01, double a02
         const double fp = __builtin_fma(__builtin_fma(3.0, lam, -2.0 * c2), lam, c1);
         const double dl = f * rcp_refined(fp);
         if (!done) lam -= dl;
+        // (stopping one step earlier, when the error a step LEAVES is below the tolerance, was tried in round 5: two more cells
+        // in 45 000 campaign maps left the one-ulp bar — steep faces, where the eigenvector takes every bit of lambda)
         done = done || fabs(dl) <= tol;
         if (__ballot(!done) == 0ull) break;
     }
     const double m00 = b00 - lam, m11 = b11 - lam, m22 = b22 - lam;
-    // cross products of the rows of A - lambda I, the longest one
+    // cross products of the rows of A - lambda I: where the lattice's x and y spread dominate the matrix (terrain below ~45
+    // degrees on a disc that is not cut down to a sliver: entries b00, b11 of order 1 after the scaling) rows 0 and 1 give the
+    // long product, squared length of order 1.  Below 0.05 — steep faces, whose z variance takes the scale and leaves rows 0
+    // and 1 small and their product cancellation-limited (the round-5 campaign's seeds 2505080, 2514166: normals 2-9 float ulps
+    // off with a looser bar), slivers at map borders — the other two are formed and the longest of the three taken, per lane:
+    // a cell's value never depends on the cells it shares a wavefront with.
     const double p0 = __builtin_fma(b01, b12, -(b02 * m11)), p1 = __builtin_fma(b02, b01, -(m00 * b12)), p2 = __builtin_fma(m00, m11, -(b01 * b01));
-    const double q0 = __builtin_fma(b01, m22, -(b02 * b12)), q1 = __builtin_fma(b02, b02, -(m00 * m22)), q2 = __builtin_fma(m00, b12, -(b01 * b02));
-    const double t0 = __builtin_fma(m11, m22, -(b12 * b12)), t1 = __builtin_fma(b12, b02, -(b01 * m22)), t2 = __builtin_fma(b01, b12, -(m11 * b02));
-    const double np = __builtin_fma(p0, p0, __builtin_fma(p1, p1, p2 * p2)), nq = __builtin_fma(q0, q0, __builtin_fma(q1, q1, q2 * q2));
-    const double nt = __builtin_fma(t0, t0, __builtin_fma(t1, t1, t2 * t2));
+    const double np = __builtin_fma(p0, p0, __builtin_fma(p1, p1, p2 * p2));
     double v0 = p0, v1 = p1, v2 = p2, nn = np;
-    if (nq > nn) { v0 = q0; v1 = q1; v2 = q2; nn = nq; }
-    if (nt > nn) { v0 = t0; v1 = t1; v2 = t2; nn = nt; }
+    const bool shortP = !(np > 0.05);
+    if (__ballot(shortP) != 0ull) {
+        const double q0 = __builtin_fma(b01, m22, -(b02 * b12)), q1 = __builtin_fma(b02, b02, -(m00 * m22)), q2 = __builtin_fma(m00, b12, -(b01 * b02));
+        const double t0 = __builtin_fma(m11, m22, -(b12 * b12)), t1 = __builtin_fma(b12, b02, -(b01 * m22)), t2 = __builtin_fma(b01, b12, -(m11 * b02));
+        const double nq = __builtin_fma(q0, q0, __builtin_fma(q1, q1, q2 * q2)), nt = __builtin_fma(t0, t0, __builtin_fma(t1, t1, t2 * t2));
+        if (shortP && nq > nn) { v0 = q0; v1 = q1; v2 = q2; nn = nq; }
+        if (shortP && nt > nn) { v0 = t0; v1 = t1; v2 = t2; nn = nt; }
+    }
     double y = __builtin_amdgcn_rsq(nn);  // 1 / sqrt(nn), refined twice
     y = y * __builtin_fma(-0.5 * nn, y * y, 1.5);
     y = y * __builtin_fma(-0.5 * nn, y * y, 1.5);
@@ -292,11 +305,14 @@ __device__ __forceinline__ bool normal_newton(double a00, double a01, double a02
     if (ez < 0.0) { ex = -ex; ey = -ey; ez = -ez; }
     wS = lam * s;
     wL = c2 * s;
-    // the next eigenvalue (the other two roots: sum S, product P): an eigenvector is only as good as its eigenvalue is apart
-    // lam2 = (S - sqrt(S^2 - 4 P)) / 2 > lam + 1e-6 c2 =: t  <=>  S - 2 t > 0 and (S - 2 t)^2 > S^2 - 4 P: no square root
+    // the next eigenvalue (the other two roots: sum S, product P): an eigenvector is only as good as its eigenvalue is apart.
+    // lam2 = (S - sqrt(S^2 - 4 P)) / 2 with the hardware's unrefined square root and reciprocal (1e-8: a threshold's worth);
+    // the caller weighs the relative gap against the smallest component of the normal.  (The cheaper bound lam2 >= P / S is
+    // useless where it matters: beside a riser two SMALL eigenvalues face one large one, and P / S falls below lam.)
     const double S = c2 - lam, P = __builtin_fma(-lam, S, c1);
-    const double u = __builtin_fma(-2.0, __builtin_fma(1e-6, c2, lam), S);
-    return done && !bad && nn > 0.0 && lam >= 0.0 && u > 0.0 && u * u > fmax(__builtin_fma(S, S, -4.0 * P), 0.0);
+    const double lam2 = 0.5 * (S - __builtin_amdgcn_sqrt(fmax(__builtin_fma(S, S, -4.0 * P), 0.0)));
+    gapRel = (lam2 - lam) * __builtin_amdgcn_rcp(c2);
+    return done && !bad && nn > 0.0 && lam >= 0.0 && gapRel > 1e-6;
 }
 
 // One cell of NormalVectorsFilter (area method) + SlopeFilter [+ RoughnessFilter of the same radius] by the LITERAL walks of
@@ -704,8 +720,10 @@ __global__ __launch_bounds__(TR * TC) void filter_step_runs_kernel(MapGeom g, co
 // the same 16 x 16 (32 x 32) cells, then the weighted sum.  kStep 0: the moment phase alone (the step window is a launch
 // of its own — its shape does not fit the row-run tables).  travOnly (run time, wave-uniform): store the traversability
 // layer and nothing else.
+// (512-thread workgroups: three of them per CU — six wavefronts per SIMD, 80 registers; without the hint the allocator takes 88
+// and a third of the CU's wavefronts with them: 0.283 -> 0.341 ms at 1 cm)
 template <int H, int TR, int TC, int HS>
-__global__ __launch_bounds__(TR * TC) void filter_fused_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double rN, double slopeCritical,
+__global__ __launch_bounds__(TR * TC) __attribute__((amdgpu_waves_per_eu(TR * TC == 512 ? 6 : 4))) void filter_fused_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double rN, double slopeCritical,
                                                             double roughCritical, double invSlopeCritical, double invRoughCritical, StepShape sN, double r2nd, int h2nd, StepShape s2, double stepCritical,
                                                             float critDown, int nCritical, int kStep, int travOnly, int tilesX, int nTiles) {
     extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
@@ -715,12 +733,7 @@ __global__ __launch_bounds__(TR * TC) void filter_fused_kernel(MapGeom g, const 
     const int i = ti0 + static_cast<int>(threadIdx.x) / TC, j = tj0 + static_cast<int>(threadIdx.x) % TC;
     const bool live = i < g.rows && j < g.cols;
     float stepOut = 0.0f;
-#ifdef FPE_DBG_NO_STEP
-    if (kStep) stepOut = L.stepHeight[static_cast<size_t>(min(i, g.rows - 1)) * g.cols + min(j, g.cols - 1)];
-    if (false) {
-#else
     if (kStep) {
-#endif
         float hi, lo, centre;
         int cnt;
         step_runs_phase<true, TR, TC, HS>(ldsRaw, g, L.stepHeight, r2nd, h2nd, s2, critDown, ti0, tj0, live, hi, lo, cnt, centre);
@@ -728,21 +741,25 @@ __global__ __launch_bounds__(TR * TC) void filter_fused_kernel(MapGeom g, const 
         __syncthreads();  // the moment phase reuses the LDS
     }
     float ox, oy, oz, os, orough;
-    moments_phase<H, TR, TC>(ldsRaw, g, elev, ti0, tj0, rN, sN, slopeCritical, roughCritical, invSlopeCritical, invRoughCritical, live, ox, oy, oz, os, orough);
-    if (!live) return;
-    const size_t cell = static_cast<size_t>(i) * g.cols + j;
-    if (!travOnly) {
-        L.nx[cell] = ox;
-        L.ny[cell] = oy;
-        L.nz[cell] = oz;
-        L.slope[cell] = os;
-        L.rough[cell] = orough;
-        if (kStep) L.step[cell] = stepOut;
+    const bool needWalk = moments_phase<H, TR, TC>(ldsRaw, g, elev, ti0, tj0, rN, sN, slopeCritical, roughCritical, invSlopeCritical, invRoughCritical, live, ox,
+                                                   oy, oz, os, orough);
+    if (live && !needWalk) {
+        const size_t cell = static_cast<size_t>(i) * g.cols + j;
+        if (!travOnly) {
+            L.nx[cell] = ox;
+            L.ny[cell] = oy;
+            L.nz[cell] = oz;
+            L.slope[cell] = os;
+            L.rough[cell] = orough;
+        }
+        if (kStep) {
+            const float third = 1.0f / 3.0f;  // MathExpressionFilter on float matrices: (1.0 / 3.0) * (slope + step + roughness)
+            L.trav[cell] = third * ((os + stepOut) + orough);
+        }
     }
-    if (kStep) {
-        const float third = 1.0f / 3.0f;  // MathExpressionFilter on float matrices: (1.0 / 3.0) * (slope + step + roughness)
-        L.trav[cell] = third * ((os + stepOut) + orough);
-    }
+    if (live && kStep && !travOnly) L.step[static_cast<size_t>(i) * g.cols + j] = stepOut;
+    // the cells that take the literal walks (rank-deficient scatter, components at rounding level): a phase of their own
+    walk_phase<H, TR, TC>(ldsRaw, g, L, sN, ti0, tj0, rN, slopeCritical, roughCritical, needWalk, stepOut, kStep, travOnly);
 }
 
 __host__ inline int filter_halo(double r, double res) { return static_cast<int>(r / res) + 1; }

@@ -1,26 +1,23 @@
 // fpe_filters_fused.hpp — round 5 of the producer's filters (included by fpe_filters.hpp inside its
 // anonymous namespace): NormalVectorsFilter + SlopeFilter + RoughnessFilter by row moments with the halo as a TEMPLATE
-// parameter, the StepFilter's second window in the same launch, and a chain that stores what the caller asked for.
+// parameter — the moment phase of filter_fused_kernel, which also runs the StepFilter's second window over the same cells.
 //
-// What changed against filter_normals_moments_kernel (round 4) and why — all three kernels of the chain are bound by the
-// SIMDs' instruction issue (profiles/round4_filters.txt: VALU-active = 4 clocks x VALU instructions per wavefront), so the
-// lever is instructions per cell:
-//   * H (halo) and T (tile edge) are compile-time: the loop over the disc's rows is unrolled, a row's LDS addresses are the
-//     thread's base plus an IMMEDIATE, the row offset is a constant operand of the integer multiply-adds;
-//   * a row's members need the iterator's own test only where an offset lies ON the circle (step_shape's edge list: no row
-//     at 2 cm / r 0.05, seven of eleven rows at 1 cm) — the other rows take their robust half-width from an SGPR;
-//   * the six prefix arrays are two arrays of 16-byte records ({n | sum c << 16, sum c^2, sum z'} and {sum z'^2, sum c z'}):
-//     four ds_read_b128 per row instead of twelve scalar reads, two integer subtractions instead of three;
-//   * the prefix scans run one wavefront per record field group, lane = tile row (no divergence inside a wavefront);
+// All kernels of the chain are bound by the SIMDs' instruction issue (profiles/round4_filters.txt, round5_filters.txt:
+// VALU-active = 4 clocks x VALU instructions per wavefront), so the lever is instructions per cell:
+//   * H (halo) and the tile TR x TC are compile-time: the loop over the disc's rows is unrolled, a row's LDS addresses are
+//     the thread's base plus an IMMEDIATE, the row offset is a constant operand of the integer multiply-adds;
+//   * a row's members need the iterator's own test only where an offset lies ON the circle (step_shape's edge rows: none at
+//     2 cm / r 0.05, seven of eleven rows at 1 cm) — the other rows take their robust half-width from an SGPR;
+//   * the six prefix arrays of round 4 are two arrays of 16-byte records ({n | sum c << 16, sum c^2, sum z'} and {sum z'^2,
+//     sum c z'}): four ds_read_b128 per row instead of twelve scalar reads, two integer subtractions instead of three;
+//   * the prefix scans run one wavefront per record field group, lane = tile row (no divergence inside a wavefront); tiles
+//     of 32 rows use 38-56 of the 64 lanes and halve the scans per cell against 16 x 16;
+//   * the closing arithmetic uses refined reciprocals and an fdlibm-style acos instead of IEEE division / library calls, the
+//     eigenvalue iteration starts from Halley's step and stops when the error LEFT by a step is below the tolerance;
 //   * the workgroup -> tile map is XCD-aware (a contiguous band of tiles per XCD: a tile's halo is its neighbours' interior,
-//     read through the same L2 instead of over the fabric — round 4 measured 6.2 x the layer in fabric reads);
-//   * kMode 2 ("traversability only", the caller passed no layer buffer): the normals, slope, roughness and step values
-//     stay in registers, only step_height (needed across the two windows) and traversability are stored — 20 bytes per
-//     cell move instead of 52.
+//     read through the same L2 — round 4 measured 6.2 x the layer in fabric reads, round 5 1.07 x).
 // The f64 arithmetic on the moments is the round-4 kernel's, operation for operation (same prefix sums, same differences,
-// same recentring), so the layers are bit-identical to that kernel's (which tests/test_gpu_filters.py and the 30 000-map
-// campaign of round 4 pinned against oracle/fpo_filters.cpp); cells the moment form cannot decide still take the literal
-// walks (normals_cell_exact).
+// same recentring); cells the moment form cannot decide still take the literal walks (normals_cell_exact).
 #pragma once
 
 struct __attribute__((aligned(16))) MomentA {
@@ -87,10 +84,11 @@ __device__ __forceinline__ double acos_unit(double x) {
 // filter_normals_moments_kernel (same thresholds for handing a cell to the literal walks) with the divisions as products by
 // refined reciprocals and acos / sqrt as above — every value within an f64 ulp or two of the round-4 kernel's, far inside the
 // float layers' rounding (tests/test_gpu_filters.py: one float ulp, >= 99.99 % of the cells bit-identical to the oracle).
-__device__ __forceinline__ void normals_from_moments(const DiscLds& d, const MapGeom& g, int li, int lj, int ti0, int tj0, double r, double slopeCritical,
-                                                     double roughCritical, double invSlopeCritical, double invRoughCritical, int N, int Sc, int Scc, int Sv,
-                                                     int Svv, int Svc, double Sz, double Szz, double Scz, double Svz, float& ox, float& oy, float& oz, float& os,
-                                                     float& orough) {
+// Returns true when the cell has to take the literal walks instead (the outputs are then not set): the caller queues it for
+// the workgroup's walking phase (walk_phase below).
+__device__ __forceinline__ bool normals_from_moments(const MapGeom& g, double slopeCritical, double roughCritical, double invSlopeCritical,
+                                                     double invRoughCritical, int N, int Sc, int Scc, int Sv, int Svv, int Svc, double Sz, double Szz, double Scz,
+                                                     double Svz, float& ox, float& oy, float& oz, float& os, float& orough) {
     const double nd = static_cast<double>(N);
     const double invN = rcp_refined(nd);
     const double Avv = static_cast<double>(N * Svv - Sv * Sv) * invN, Acc = static_cast<double>(N * Scc - Sc * Sc) * invN;
@@ -99,20 +97,25 @@ __device__ __forceinline__ void normals_from_moments(const DiscLds& d, const Map
     const double Azz = fmax(Szz - Sz * Sz * invN, 0.0);
     const double res = g.res, res2 = res * res;
     const double a00 = res2 * Avv, a01 = res2 * Avc, a02 = -(res * Avz), a11 = res2 * Acc, a12 = -(res * Acz), a22 = Azz;
-    double ex, ey, ez, eigS, eigL;
-#ifdef FPE_DBG_NO_EIG
-    ex = a02; ey = a12; ez = a00 + a11 + a22 + a01; eigS = 1.0; eigL = 1.0;
-#else
-    if (!normal_newton(a00, a01, a02, a11, a12, a22, ex, ey, ez, eigS, eigL)) normal_from_scatter(a00, a01, a02, a11, a12, a22, ex, ey, ez, eigS, eigL);
-#endif
-    const double tinyC = 1e-6;
-#ifdef FPE_DBG_NO_EXACT
-    if (false) {
-#else
-    if (!(eigS > 1e-10 * eigL) || fabs(ex) < tinyC || fabs(ey) < tinyC || fabs(ez) < tinyC) {
-#endif
-        normals_cell_exact(d, li, lj, ti0, tj0, r, slopeCritical, 1, roughCritical, ox, oy, oz, os, orough);
-    } else {
+    double ex, ey, ez, eigS, eigL, gapRel;
+    bool walk = false;
+    if (!normal_newton(a00, a01, a02, a11, a12, a22, ex, ey, ez, eigS, eigL, gapRel)) {
+        normal_from_scatter(a00, a01, a02, a11, a12, a22, ex, ey, ez, eigS, eigL);
+        walk = !(gapRel > 1e-3);  // eigenvalues this close: the sweeps on THIS matrix and on the oracle's (another order of summation) part ways
+    }
+    // The matrix entries carry ~1e-15 of their scale (prefix differences instead of the oracle's two-pass sums), the eigenvector
+    // that error over the relative gap to the next eigenvalue: dv ~ 1e-15 / gap.  A float component c is allowed its last bit
+    // (the tests' bar: one ulp, 6e-8 |c|) but not two: dv must stay well below 6e-8 |c|, i.e. |c| x gap well above 1.7e-8.
+    // Cells under 1e-7 take the literal walks — a component at rounding-noise level (symmetric neighbourhoods: exactly 0 here,
+    // ~1e-17 by the oracle's order), or a small one beside a narrow gap (beside the synthetic terrain's risers the gap is 0.005;
+    // campaign seeds 2512287, 2514166: components of 7e-6 and 2e-6 came out two and nine float ulps off) — and so do (nearly)
+    // rank-deficient matrices (exact planes, flat synthetic ground, fewer than three members: the rank test and exact zeros
+    // depend on the order of operations).  With the usual gap of 0.25 that is a component below 4e-7.  A wavefront walks when
+    // ANY of its 64 cells asks for it and a walk is some thirty times a cell's usual work, so the product is as low as the
+    // arithmetic allows (at 3e-7: 1.3e-4 of the synthetic terrain's cells, a fifth of the chain's time).
+    const double cMin = fmin(fmin(fabs(ex), fabs(ey)), fabs(ez));
+    if (walk || !(eigS > 1e-10 * eigL) || !(cMin * fmin(gapRel, 0.3) > 1e-7)) return true;
+    {
         ox = static_cast<float>(ex);
         oy = static_cast<float>(ey);
         oz = static_cast<float>(ez);
@@ -124,12 +127,13 @@ __device__ __forceinline__ void normals_from_moments(const DiscLds& d, const Map
         const double roughness = sqrt_refined(fmax(q, 0.0) * rcp_refined(nd - 1.0));  // (N >= 3 here: fewer members are rank-deficient)
         orough = roughness < roughCritical ? static_cast<float>(1.0 - roughness * invRoughCritical) : 0.0f;
     }
+    return false;
 }
 
 // The moment phase of one tile: tables and source tile (disc_setup, one barrier), the prefix records (one barrier), then the
 // calling thread's cell.  `live`: the thread's cell is inside the map (every thread takes part in the barriers).
 template <int H, int TR, int TC>
-__device__ __forceinline__ void moments_phase(char* ldsRaw, const MapGeom& g, const float* __restrict__ elev, int ti0, int tj0, double r,
+__device__ __forceinline__ bool moments_phase(char* ldsRaw, const MapGeom& g, const float* __restrict__ elev, int ti0, int tj0, double r,
                                               const StepShape& sp, double slopeCritical, double roughCritical, double invSlopeCritical,
                                               double invRoughCritical, bool live, float& ox, float& oy, float& oz, float& os, float& orough) {
     using Lay = FusedLayout<H, TR, TC>;
@@ -144,11 +148,7 @@ __device__ __forceinline__ void moments_phase(char* ldsRaw, const MapGeom& g, co
     const double z0 = zf == zf ? static_cast<double>(zf) : 0.0;
     {   // prefix records over the tile's columns: wavefront = field group, lane = tile row
         const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-#ifdef FPE_DBG_NO_SCAN
-        if (false) {
-#else
         if (lane < WR && grp < 4) {
-#endif
             const float* src = d.tile + lane * W;
             if (grp == 0) {
                 uint2* dst = reinterpret_cast<uint2*>(PA + lane * W1);
@@ -182,7 +182,7 @@ __device__ __forceinline__ void moments_phase(char* ldsRaw, const MapGeom& g, co
     const int i = ti0 + li, j = tj0 + lj;
     const float nanf = __builtin_nanf("");
     ox = oy = oz = os = orough = nanf;
-    if (!live || !isfinite(d.tile[(li + H) * W + lj + H])) return;
+    if (!live || !isfinite(d.tile[(li + H) * W + lj + H])) return false;
     const double r2 = r * r;
     const int i0 = d.bi0[li], i1 = d.bi1[li];
     const int maxL = j - d.bj0[lj], maxR = d.bj1[lj] - j;
@@ -198,18 +198,8 @@ __device__ __forceinline__ void moments_phase(char* ldsRaw, const MapGeom& g, co
     const double ccD = static_cast<double>(cc);
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef double f64x2 __attribute__((ext_vector_type(2)));
-#ifdef FPE_DBG_NO_ROWS
-    Sz = d.tile[threadIdx.x]; Szz = Sz * Sz + 1.0; Scz = 0.3 * Sz; Svz = 0.1; AnC = 21u | (21u * cc << 16); ACC = 21u * cc * cc + 50; Svv = 50;
-#else
 #pragma unroll
-#endif
-    for (int oo = 0; oo < (
-#ifdef FPE_DBG_NO_ROWS
-        0
-#else
-        D
-#endif
-        ); ++oo) {
+    for (int oo = 0; oo < D; ++oo) {
         const int o = oo - H;
         const int w0 = sp.rowW[oo];
         const bool edge = ((sp.edgeRows >> oo) & 1u) != 0u;
@@ -252,9 +242,149 @@ __device__ __forceinline__ void moments_phase(char* ldsRaw, const MapGeom& g, co
     const int Sc = SC - cc * N;
     const int Scc = static_cast<int>(ACC) - 2 * cc * SC + cc * cc * N;
     const int Svc = SvC - cc * Sv;
-#ifdef FPE_DBG_NO_FINISH
-    ox = static_cast<float>(Sz + Szz); oy = static_cast<float>(Scz + Svz); oz = static_cast<float>(N + Sc + Scc); os = static_cast<float>(Sv + Svv + Svc); orough = ox + oy;
-#else
-    normals_from_moments(d, g, li, lj, ti0, tj0, r, slopeCritical, roughCritical, invSlopeCritical, invRoughCritical, N, Sc, Scc, Sv, Svv, Svc, Sz, Szz, Scz, Svz, ox, oy, oz, os, orough);
-#endif
+    return normals_from_moments(g, slopeCritical, roughCritical, invSlopeCritical, invRoughCritical, N, Sc, Scc, Sv, Svv, Svc, Sz, Szz, Scz, Svz, ox, oy, oz, os, orough);
+}
+
+// The cell's iterator walk with the rows' column intervals taken from the lattice shape — the robust half-width of step_shape
+// and, on rows with an offset on the circle, the iterator's own tests for the row and the column either side (the moment
+// phase's logic: the same members) — instead of disc_walk's stepping from the previous row's interval, and with a row's cells
+// FETCHED TOGETHER: the 2 H - 1 columns a row can hold are static slots whose LDS reads issue back to back, the visitor then
+// runs over them in order with the cells outside the row's interval masked to NaN (a hole: every visitor skips holes).  A
+// lone lane walking a cell is bound by LDS round trips, not by arithmetic: disc_walk's chain of dependent reads per row and
+// per member made a walked cell cost 13 us at 2 cm and 32 us at 1 cm.  Same members, same order (rows outer, columns inner);
+// cells outside the map are NaN in the tile already.  rowW: the shape's half-widths in LDS (the row loop is not unrolled).
+template <int H, class F>
+__device__ __forceinline__ void disc_walk_rows(const DiscLds& d, const int8_t* rowW, unsigned long long edgeRows, int li, int lj, int ti0, int tj0, double r2,
+                                               F&& f) {
+    constexpr int D = 2 * H + 1, kSlots = 2 * H - 1;  // a robust half-width is at most H - 2, one more column by the edge test
+    const int WC = d.WC;
+    const int i = ti0 + li, j = tj0 + lj;
+    const int i0 = d.bi0[li], i1 = d.bi1[li];
+    const int maxL = j - d.bj0[lj], maxR = d.bj1[lj] - j;
+    const int dyC = lj * D + H;
+    const double* const yRow = d.yP + lj + H;
+    for (int oo = 0; oo < D; ++oo) {
+        const int o = oo - H;
+        const int w0 = rowW[oo];
+        const bool edge = ((edgeRows >> oo) & 1u) != 0u;
+        if (w0 < 0 && !edge) continue;
+        int wL = w0, wR = w0;
+        bool rowIn = true;
+        if (edge) {
+            const double a = d.dx2[li * D + oo];
+            const int ii = i + o;
+            rowIn = ii >= i0 && ii <= i1 && a <= r2;
+            const int k1 = w0 + 1 < H ? w0 + 1 : H;
+            wR = min(w0 < 0 ? 0 : w0 + (a + d.dy2[dyC + k1] <= r2 ? 1 : 0), maxR);
+            wL = min(w0 < 0 ? 0 : w0 + (a + d.dy2[dyC - k1] <= r2 ? 1 : 0), maxL);
+        }
+        if (!rowIn) wR = -1 - wL;  // empty interval
+        const int ri = li + oo;
+        const double x = d.xP[ri];
+        const float* const zRow = d.tile + ri * WC + lj + H;
+        constexpr int kChunk = 8;
+#pragma unroll
+        for (int c0 = 0; c0 < kSlots; c0 += kChunk) {
+            float zz[kChunk];
+            double yy[kChunk];
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k) {
+                const int dj = c0 + k - (H - 1);
+                if (c0 + k < kSlots) {
+                    zz[k] = zRow[dj];
+                    yy[k] = yRow[dj];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k) {
+                const int dj = c0 + k - (H - 1);
+                if (c0 + k < kSlots) f(x, yy[k], (dj >= -wL && dj <= wR) ? zz[k] : __builtin_nanf(""));
+            }
+        }
+    }
+}
+// normals_cell_exact (fpe_filters.hpp) on disc_walk_rows: the published filters' three passes, expression for expression.
+template <int H>
+__device__ __forceinline__ void normals_cell_exact_rows(const DiscLds& d, const int8_t* rowW, unsigned long long edgeRows, int li, int lj, int ti0, int tj0, double r, double slopeCritical,
+                                                        double roughCritical, float& ox, float& oy, float& oz, float& os, float& orough) {
+    const double r2 = r * r;
+    int np = 0;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    disc_walk_rows<H>(d, rowW, edgeRows, li, lj, ti0, tj0, r2, [&](double x, double y, float z) {
+        if (isfinite(z)) { ++np; sx += x; sy += y; sz += static_cast<double>(z); }
+    });
+    const double nd = static_cast<double>(np);
+    const double mx = sx / nd, my = sy / nd, mz = sz / nd;
+    double a00 = 0.0, a01 = 0.0, a02 = 0.0, a11 = 0.0, a12 = 0.0, a22 = 0.0;
+    disc_walk_rows<H>(d, rowW, edgeRows, li, lj, ti0, tj0, r2, [&](double x, double y, float z) {
+        if (isfinite(z)) {
+            const double dx = x - mx, dy = y - my, dz = static_cast<double>(z) - mz;
+            a00 += dx * dx; a01 += dx * dy; a02 += dx * dz;
+            a11 += dy * dy; a12 += dy * dz; a22 += dz * dz;
+        }
+    });
+    double ex, ey, ez, wS, wL;
+    normal_from_scatter(a00, a01, a02, a11, a12, a22, ex, ey, ez, wS, wL);
+    ox = static_cast<float>(ex);
+    oy = static_cast<float>(ey);
+    oz = static_cast<float>(ez);
+    const double slope = acos(static_cast<double>(oz));  // SlopeFilter reads the float layer
+    os = slope < slopeCritical ? static_cast<float>(1.0 - slope / slopeCritical) : 0.0f;
+    const double normalX = ox, normalY = oy, normalZ = oz;  // RoughnessFilter::update with the float normals just written
+    const double planeParameter = mx * normalX + my * normalY + mz * normalZ;
+    double sum = 0.0;
+    disc_walk_rows<H>(d, rowW, edgeRows, li, lj, ti0, tj0, r2, [&](double x, double y, float z) {
+        if (isfinite(z)) {
+            const double dist = normalX * x + normalY * y + normalZ * static_cast<double>(z) - planeParameter;
+            sum += dist * dist;
+        }
+    });
+    const double roughness = sqrt(sum / (nd - 1.0));
+    orough = roughness < roughCritical ? static_cast<float>(1.0 - roughness / roughCritical) : 0.0f;
+}
+
+// ---- the literal walks of the cells the moment form cannot decide, as a phase of their own ---------------------------------
+// Inlined into the cell loop (rounds 2-4) the walks cost the kernel a fifth of its time although one cell in 10^4 takes them:
+// three disc_walk bodies and the Jacobi sweeps raise the register count past the six-wavefront budget (88 registers: two
+// workgroups per CU instead of three), and a wavefront walks when ANY of its 64 cells asks for it.  Now a cell that needs the
+// walks is QUEUED (workgroup vote; the list lives in the LDS the prefix records no longer need) and the queue is walked
+// COMPACTED, one queued cell per lane: flat synthetic ground — every cell rank-deficient — fills every lane (1000 x 1000 flat
+// cells at 2 cm: 0.15 ms, as before), natural terrain leaves a workgroup in a few hundred with one or two lanes to walk, and
+// the registers the walks need beyond the budget are spilled in this phase only.  (A whole wavefront per queued cell, members
+// side by side and the ordered sums on v_readlane operands, was tried first: 20 us per cell — 3.4 ms for the flat map.)
+template <int H, int TR, int TC>
+__device__ __forceinline__ void walk_phase(char* ldsRaw, const MapGeom& g, const FilterLayers& L, const StepShape& sp, int ti0, int tj0, double r,
+                                           double slopeCritical, double roughCritical, bool needWalk, float stepOut, int kStep, int travOnly) {
+    using Lay = FusedLayout<H, TR, TC>;
+    if (!__syncthreads_or(needWalk ? 1 : 0)) return;  // (also: every thread is done with the prefix records)
+    const DiscLds d = disc_carve(ldsRaw, H, TR, TC);
+    int* const count = reinterpret_cast<int*>(ldsRaw + Lay::discBytes);
+    uint2* const list = reinterpret_cast<uint2*>(ldsRaw + Lay::discBytes + 16);  // (thread, step value bits); TR * TC entries fit the records' space
+    static_assert(2 * Lay::recBytes >= 16 + 8 * static_cast<size_t>(TR) * TC, "the walk list lives where the prefix records were");
+    int8_t* const rowW = reinterpret_cast<int8_t*>(list + TR * TC);  // the shape's half-widths (the walk's row loop reads them by index)
+    static_assert(2 * Lay::recBytes >= 16 + 8 * static_cast<size_t>(TR) * TC + 64, "... and the shape's half-widths behind it");
+    if (threadIdx.x == 0) *count = 0;
+    if (threadIdx.x < 2 * H + 1) rowW[threadIdx.x] = sp.rowW[threadIdx.x];
+    __syncthreads();
+    if (needWalk) list[atomicAdd(count, 1)] = make_uint2(threadIdx.x, __float_as_uint(stepOut));
+    __syncthreads();
+    const int n = *count;
+    if (static_cast<int>(threadIdx.x) >= n) return;
+    const uint2 e = list[threadIdx.x];
+    const int li = static_cast<int>(e.x) / TC, lj = static_cast<int>(e.x) % TC;
+    const float step = __uint_as_float(e.y);
+    float ox, oy, oz, os, orough;
+    normals_cell_exact_rows<H>(d, rowW, sp.edgeRows, li, lj, ti0, tj0, r, slopeCritical, roughCritical, ox, oy, oz, os, orough);
+    const size_t cell = static_cast<size_t>(ti0 + li) * g.cols + (tj0 + lj);
+    if (!travOnly) {
+        L.nx[cell] = ox;
+        L.ny[cell] = oy;
+        L.nz[cell] = oz;
+        L.slope[cell] = os;
+        L.rough[cell] = orough;
+    }
+    if (kStep) {
+        const float third = 1.0f / 3.0f;
+        L.trav[cell] = third * ((os + step) + orough);
+    }
 }
