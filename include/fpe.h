@@ -257,12 +257,16 @@ int fpe_destroy(fpe_handle h);
  * wavefront per pose), "literal_discs" (1: force the literal CircleIterator walk), "no_mid_variant"
  * (1: never launch the 3x3-only kernel variants), "no_bits" (1: never launch the bit-window kernels),
  * "service_opt_gate" — what the fpe_plan_service* calls do about the gate of gait cycles >= 1, whose x side follows the
- * opt track's feet, i.e. the BUILD-DEFINED optimiser (see fpe_service_gate below): 0 (default) the opt track's chain is
- * not run for the gate (it still runs when an opt product is asked for) and the call returns FPE_E_SERVICE_FALSE only on
- * the optimiser-independent failures; 1 advisory: the chain runs next to the plan (its own stream), its verdict is
- * reported by fpe_last_service_gate, the return value stays optimiser-independent; 2 enforce: as 1, and the call returns
- * FPE_E_SERVICE_FALSE on the build-defined verdict too (round 3's behaviour).  "service_cycle0_gate_only" (older name):
- * 1 = service_opt_gate 0, 0 = service_opt_gate 2.
+ * opt track's feet, i.e. the BUILD-DEFINED optimiser (see fpe_service_gate below): 2 (DEFAULT) enforce — the opt track's
+ * chain runs next to the plan (its own stream) and the call returns FPE_E_SERVICE_FALSE on its verdict too, as the
+ * reference's handler does at that gate whatever its optimiser (cpp:920-934); 1 advisory: the chain runs, its verdict is
+ * reported by fpe_last_service_gate, the return value stays optimiser-independent; 0: the chain is not run for the gate
+ * (latency-critical callers: 49 us instead of 181 us per call; it still runs when an opt product is asked for) and the call
+ * returns FPE_E_SERVICE_FALSE only on the optimiser-independent failures.  In modes 0 and 1 a call whose chain stopped at
+ * its gate still answers FPE_OK with the nominal / centroid / default products, but the OPT products (message, report, the
+ * opt points of the centroid path) come back EMPTY — never the truncated track of an aborted chain — and
+ * fpe_last_service_gate names kind FPE_GATE_BUILD_DEFINED and the cycle: a caller that wants the handler's behaviour checks
+ * fail_kind, not only the return value.  "service_cycle0_gate_only" (older name): 1 = service_opt_gate 0, 0 = 2.
  * Thread-safe: every plan / search call copies the knobs once, under the engine's lock, so a concurrent call runs
  * entirely with the values before or entirely with the values after a change (one key per call: callers that change
  * several keys while other threads plan get each key's change at its own moment). */
@@ -369,8 +373,8 @@ int fpe_search_legs_device(fpe_handle h, const fpe_params* params, const fpe_leg
  *     reference in cycle g at the latest, whatever its optimiser does;
  *   * its x side in cycles >= 1 follows the opt track's feet, i.e. NLopt's COBYLA iterates (cpp:1116-1211), which this
  *     build cannot reproduce (fpe_opt_params): BUILD-DEFINED, advisory by default.
- * These calls return FPE_E_SERVICE_FALSE (response zeroed) on the first two kinds; on the third only under
- * fpe_set_tuning("service_opt_gate", 2).  fpe_last_service_gate tells the kinds apart. */
+ * These calls return FPE_E_SERVICE_FALSE (response zeroed) on the first two kinds always, on the third under
+ * fpe_set_tuning("service_opt_gate", 2) — the default.  fpe_last_service_gate tells the kinds apart. */
 typedef struct fpe_service_gate {
     uint8_t fail_cycle;  /* gait cycle in which the handler's gate fails; 255 = it never does */
     uint8_t fail_kind;   /* FPE_GATE_* */
@@ -468,8 +472,9 @@ int fpe_multi_shard_range(int32_t B, int32_t k, int32_t n_devices, int32_t* firs
  * stream (NULL: the group's own stream of that device, fpe_multi_stream), and — when record_kind is not
  * FPE_EXCHANGE_NONE — d_gathered: room for the records of the WHOLE batch in pose order, [B * n_cycles * 4] records of
  * the chosen kind.  The call queues, per device, the plan of its block and then ONE fused RCCL collective
- * (ncclGroupStart / ncclAllGather per device / ncclGroupEnd; grouped ncclBroadcasts when B % n != 0) on the same
- * streams: d_gathered on every device holds every block's records once its stream has passed the call.  Nothing
+ * (ncclGroupStart / ncclAllGather per device / ncclGroupEnd) on the same streams; when B % n != 0 the blocks travel PADDED
+ * to ceil(B / n) poses through a staging buffer of the group (in-place all-gather) and n device-local copies put them at
+ * their places: d_gathered on every device holds every block's records once its stream has passed the call.  Nothing
  * synchronises the host.  RCCL is loaded at the first gathering call (librccl.so.1); FPE_E_UNSUPPORTED without it. */
 #define FPE_EXCHANGE_NONE 0
 #define FPE_EXCHANGE_SELECTED 1 /* fpe_selected_foothold, 16 bytes: d_out.selected is the block's contribution */

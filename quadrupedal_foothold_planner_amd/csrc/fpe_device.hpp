@@ -46,7 +46,7 @@ struct Tuning {
     int32_t literalDiscs = 0;
     int32_t noMidVariant = 0;
     int32_t noBits = 0;
-    int32_t serviceOptGate = 0;  // fpe_plan_service*: 0 exact gates only (no opt chain), 1 advisory (chain runs, reported), 2 enforce (include/fpe.h)
+    int32_t serviceOptGate = 2;  // fpe_plan_service*: 2 enforce (default: the handler's behaviour), 1 advisory (chain runs, reported), 0 exact gates only (no opt chain) (include/fpe.h)
 };
 
 struct PlanConsts {

@@ -1341,7 +1341,7 @@ int fpe_plan_service_opt(fpe_handle h, const fpe_params* params, const fpe_opt_p
         oout.cycles = opt_cycles;
         double rowsAfter[2] = {0.0, 0.0};
         oout.rows_after = rowsAfter;
-        int optGate = 0;
+        int optGate = 2;
         if (h) {
             std::lock_guard<std::mutex> lk(h->mu);
             optGate = h->tuning.serviceOptGate;
@@ -1400,9 +1400,17 @@ int fpe_plan_service_opt(fpe_handle h, const fpe_params* params, const fpe_opt_p
                                                  " (" + kinds[gate.fail_kind] + "; cpp:931-934)");
         }
     }
+    // The call answers although the opt track's chain stopped at its gate (modes 0 / 1: the verdict is advisory): the chain's
+    // products end where it stopped and the reference would not have published them — its handler returns false at that gate,
+    // whatever its optimiser (cpp:931-934).  They are handed back EMPTY, never as the truncated track of an aborted chain; the
+    // kind and cycle are in fpe_last_service_gate.
+    const bool chainAborted = g_gate.chain_ran && g_gate.fail_kind == FPE_GATE_BUILD_DEFINED;
     fpe::assemble_global_footholds(nominal.data(), ok.data(), stance, N, response);
     if (centroid) fpe::assemble_centroid_footholds(cen.data(), ok.data(), stance, N, centroid);
-    if (opt_msg) fpe::assemble_opt_footholds(optf.data(), ok.data(), stance, N, opt_msg);
+    if (opt_msg) {
+        if (chainAborted) std::memset(opt_msg, 0, sizeof(*opt_msg));
+        else fpe::assemble_opt_footholds(optf.data(), ok.data(), stance, N, opt_msg);
+    }
     if (nominal_report || centroid_report || opt_report) {
         if (!params) return fail(FPE_E_INVALID_ARG, "null params");
         std::vector<double> xyz(static_cast<size_t>(N) * 12);
@@ -1423,6 +1431,7 @@ int fpe_plan_service_opt(fpe_handle h, const fpe_params* params, const fpe_opt_p
                 xyz[k * 3 + 2] = static_cast<double>(optf[k].z);
             }
             fpe::assemble_track_report(xyz.data(), ok.data(), stance, N, *params, optRep.get());
+            if (chainAborted) std::memset(optRep.get(), 0, sizeof(fpe_track_report));  // (no opt path, no opt KPIs; the centroid path is then the centroid track's own)
             if (opt_report) std::memcpy(opt_report, optRep.get(), sizeof(*opt_report));
             if (centroid_report) {
                 for (size_t k = 0; k < static_cast<size_t>(N) * 4; ++k) {
@@ -1431,7 +1440,7 @@ int fpe_plan_service_opt(fpe_handle h, const fpe_params* params, const fpe_opt_p
                     xyz[k * 3 + 2] = static_cast<double>(cen[k].z);
                 }
                 fpe::assemble_track_report(xyz.data(), ok.data(), stance, N, *params, centroid_report);
-                fpe::interleave_centroid_path(centroid_report, *optRep);  // cpp:946: the opt track pushes onto the same path
+                if (!chainAborted) fpe::interleave_centroid_path(centroid_report, *optRep);  // cpp:946: the opt track pushes onto the same path
             }
         }
     }

@@ -9,8 +9,8 @@
 //     must not pay for a thread start per call), results written straight into the caller's arrays at their global
 //     positions — the "all-gather" is the shards' D2H copies landing side by side;
 //   * fpe_multi_plan_device — device-resident shards: every device plans its block on its own stream and the selected
-//     records of ALL blocks reach EVERY device by one RCCL collective (ncclAllGather, or grouped ncclBroadcasts when
-//     the blocks are uneven) inside ncclGroupStart / ncclGroupEnd on those same streams — the xGMI all-gather of
+//     records of ALL blocks reach EVERY device by one RCCL collective (ncclAllGather; uneven blocks travel padded to the
+//     largest and are put in place by device-local copies) inside ncclGroupStart / ncclGroupEnd on those same streams — the xGMI all-gather of
 //     north_star without Python.  RCCL is bound at run time (dlopen "librccl.so.1": the ROCm one, or the copy a hosting
 //     process such as PyTorch has already loaded); a process that never gathers never loads it.
 // (One process PER GPU with torch.distributed is the other deployment: fpe_plan_device + dist.py, bench.py.)
@@ -157,6 +157,12 @@ struct fpe_multi {
     // device-resident form: the group's own stream per device and the RCCL communicators (created by the first gather)
     std::vector<hipStream_t> streams;
     std::vector<ncclComm_t> comms;
+    // uneven batches (B % n != 0): per device a staging buffer of n blocks of ceil(B / n) poses for the PADDED in-place
+    // all-gather, and an event recorded behind the last copy out of it (a later call on another stream waits for it)
+    std::vector<unsigned char*> stage;
+    std::vector<size_t> stageBytes;
+    std::vector<hipEvent_t> stageFree;
+    bool gatherPadded = false;  // fpe_multi_set_tuning("gather_padded", 1): take the padded path for even batches too (tests)
 };
 
 namespace {
@@ -209,6 +215,32 @@ int ensure_streams(fpe_multi* h) {
         }
     }
     h->streams = std::move(st);
+    return FPE_OK;
+}
+
+// Staging of device k for `bytes`: grown when too small (the old buffer is freed behind a device synchronisation: growth is
+// rare), reused otherwise; `st` waits for the event recorded behind the last use.
+int ensure_stage(fpe_multi* h, size_t k, size_t bytes, hipStream_t st) {
+    if (h->stage.empty()) {
+        h->stage.assign(h->engines.size(), nullptr);
+        h->stageBytes.assign(h->engines.size(), 0);
+        h->stageFree.assign(h->engines.size(), nullptr);
+    }
+    hipError_t e = hipSetDevice(h->devices[k]);
+    if (e == hipSuccess && !h->stageFree[k]) e = hipEventCreateWithFlags(&h->stageFree[k], hipEventDisableTiming);
+    if (e == hipSuccess && h->stageBytes[k] < bytes) {
+        if (h->stage[k]) {
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipFree(h->stage[k]);
+            h->stage[k] = nullptr;
+            h->stageBytes[k] = 0;
+        }
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->stage[k]), bytes);
+        if (e == hipSuccess) h->stageBytes[k] = bytes;
+    } else if (e == hipSuccess) {
+        e = hipStreamWaitEvent(st, h->stageFree[k], 0);  // (a fresh event counts as complete)
+    }
+    if (e != hipSuccess) return mfail(h, FPE_E_HIP, std::string("all-gather staging: ") + hipGetErrorString(e));
     return FPE_OK;
 }
 
@@ -271,6 +303,12 @@ int fpe_multi_destroy(fpe_multi_handle h) {
         (void)hipSetDevice(h->devices[k]);
         (void)hipStreamDestroy(h->streams[k]);
     }
+    for (size_t k = 0; k < h->stage.size(); ++k) {
+        (void)hipSetDevice(h->devices[k]);
+        (void)hipDeviceSynchronize();
+        if (h->stage[k]) (void)hipFree(h->stage[k]);
+        if (h->stageFree[k]) (void)hipEventDestroy(h->stageFree[k]);
+    }
     for (fpe_handle e : h->engines) fpe_destroy(e);
     delete h;
     return FPE_OK;
@@ -297,6 +335,11 @@ int fpe_multi_upload_map(fpe_multi_handle h, const fpe_map_desc* desc, const flo
 
 int fpe_multi_set_tuning(fpe_multi_handle h, const char* key, int32_t value) {
     if (!h) return mfail(nullptr, FPE_E_INVALID_ARG, "null handle");
+    if (key && std::string(key) == "gather_padded") {  // the group's own knob (tests: the uneven batches' path on an even batch)
+        std::lock_guard<std::mutex> call(h->callMu);
+        h->gatherPadded = value != 0;
+        return FPE_OK;
+    }
     for (fpe_handle e : h->engines) {
         const int rc = fpe_set_tuning(e, key, value);
         if (rc != FPE_OK) return mfail(h, rc, fpe_last_error(e));
@@ -372,32 +415,58 @@ int fpe_multi_plan_device(fpe_multi_handle h, const fpe_params* params, const fp
             return mfail(h, rc, "device " + std::to_string(h->devices[static_cast<size_t>(k)]) + ": " + fpe_last_error(h->engines[static_cast<size_t>(k)]));
     }
     if (!gather) return FPE_OK;
-    // ... and the blocks' records reach every device: ONE fused group of collectives on the plans' own streams (stream
-    // order makes each device's contribution wait for its plan kernel; nothing synchronises the host)
+    // ... and the blocks' records reach every device: ONE ncclAllGather per device inside ncclGroupStart / End on the plans' own
+    // streams (stream order makes each device's contribution wait for its plan kernel; nothing synchronises the host).
+    // Even batches gather straight into d_gathered.  Uneven ones (B % n != 0; the first B % n blocks hold one pose more) are
+    // PADDED: every block travels as ceil(B / n) poses — device k copies its block into slot k of its staging buffer, the
+    // all-gather runs in place over n slots (send buffer = receive buffer + k * slot, RCCL's in-place form), and n copies
+    // put the blocks at their places of the whole batch in d_gathered.  One collective path for every batch (the
+    // n x n grouped broadcasts this replaces had never run with n > 1); the copies are device-local and stream-ordered.
     Rccl& r = rccl();
-    const bool even = (B % n) == 0;
+    const bool padded = (B % n) != 0 || h->gatherPadded;
     const size_t poseBytes = static_cast<size_t>(n_cycles) * 4 * recBytes;
+    const size_t slotPoses = static_cast<size_t>((B + n - 1) / n), slotBytes = slotPoses * poseBytes;
+    auto stream_of = [&](int k) { return io[k].stream ? static_cast<hipStream_t>(io[k].stream) : h->streams[static_cast<size_t>(k)]; };
+    auto record_of = [&](int k) {
+        return record_kind == FPE_EXCHANGE_PACKED ? static_cast<const void*>(io[k].d_out.selected_packed) : static_cast<const void*>(io[k].d_out.selected);
+    };
+    if (padded) {
+        for (int k = 0; k < n; ++k) {
+            rc = ensure_stage(h, static_cast<size_t>(k), slotBytes * static_cast<size_t>(n), stream_of(k));
+            if (rc != FPE_OK) return rc;
+            long lo, hi;
+            shard_range(B, k, n, &lo, &hi);
+            const hipError_t e = hipMemcpyAsync(h->stage[static_cast<size_t>(k)] + static_cast<size_t>(k) * slotBytes, record_of(k),
+                                                static_cast<size_t>(hi - lo) * poseBytes, hipMemcpyDeviceToDevice, stream_of(k));
+            if (e != hipSuccess) return mfail(h, FPE_E_HIP, std::string("all-gather staging copy: ") + hipGetErrorString(e));
+        }
+    }
     ncclResult_t nrc = r.GroupStart();
     for (int k = 0; k < n && nrc == ncclSuccess; ++k) {
-        hipStream_t st = io[k].stream ? static_cast<hipStream_t>(io[k].stream) : h->streams[static_cast<size_t>(k)];
-        const void* src = record_kind == FPE_EXCHANGE_PACKED ? static_cast<const void*>(io[k].d_out.selected_packed) : static_cast<const void*>(io[k].d_out.selected);
-        if (even) {
-            nrc = r.AllGather(src, io[k].d_gathered, static_cast<size_t>(B / n) * poseBytes, ncclChar, h->comms[static_cast<size_t>(k)], st);
+        if (!padded) {
+            nrc = r.AllGather(record_of(k), io[k].d_gathered, static_cast<size_t>(B / n) * poseBytes, ncclChar, h->comms[static_cast<size_t>(k)], stream_of(k));
         } else {
-            // uneven blocks: block q travels as a broadcast from its owner into its place of the whole batch
-            for (int q = 0; q < n && nrc == ncclSuccess; ++q) {
-                long lo, hi;
-                shard_range(B, q, n, &lo, &hi);
-                const void* qsrc = record_kind == FPE_EXCHANGE_PACKED ? static_cast<const void*>(io[q].d_out.selected_packed) : static_cast<const void*>(io[q].d_out.selected);
-                unsigned char* dst = static_cast<unsigned char*>(io[k].d_gathered) + static_cast<size_t>(lo) * poseBytes;
-                nrc = r.Broadcast(k == q ? qsrc : static_cast<const void*>(dst), dst, static_cast<size_t>(hi - lo) * poseBytes, ncclChar, q,
-                                  h->comms[static_cast<size_t>(k)], st);  // (the send buffer only counts on the root)
-            }
+            unsigned char* st = h->stage[static_cast<size_t>(k)];
+            nrc = r.AllGather(st + static_cast<size_t>(k) * slotBytes, st, slotBytes, ncclChar, h->comms[static_cast<size_t>(k)], stream_of(k));
         }
     }
     const ncclResult_t erc = r.GroupEnd();
     if (nrc == ncclSuccess) nrc = erc;
     if (nrc != ncclSuccess) return mfail(h, FPE_E_HIP, std::string("RCCL all-gather: ") + r.GetErrorString(nrc));
+    if (padded) {
+        for (int k = 0; k < n; ++k) {
+            hipError_t e = hipSetDevice(h->devices[static_cast<size_t>(k)]);
+            for (int q = 0; q < n && e == hipSuccess; ++q) {
+                long lo, hi;
+                shard_range(B, q, n, &lo, &hi);
+                e = hipMemcpyAsync(static_cast<unsigned char*>(io[k].d_gathered) + static_cast<size_t>(lo) * poseBytes,
+                                   h->stage[static_cast<size_t>(k)] + static_cast<size_t>(q) * slotBytes, static_cast<size_t>(hi - lo) * poseBytes,
+                                   hipMemcpyDeviceToDevice, stream_of(k));
+            }
+            if (e == hipSuccess) e = hipEventRecord(h->stageFree[static_cast<size_t>(k)], stream_of(k));
+            if (e != hipSuccess) return mfail(h, FPE_E_HIP, std::string("all-gather compaction: ") + hipGetErrorString(e));
+        }
+    }
     return FPE_OK;
 }
 

@@ -61,6 +61,7 @@ public:
         std::unique_ptr<fpe_global_footholds> resp(new fpe_global_footholds);  // per call: handlers may run concurrently
         // FPE_E_SERVICE_FALSE included: the reference's handler returns false there too (cpp:566 / cpp:931-934)
         if (fpe_plan_service(h_, &params, initialPose, gaitCycles, resp.get()) != FPE_OK) return false;
+        if (gateFailed()) return false;
         fill(*resp, msg, true);  // cpp:591 clears the nominal message
         return true;
     }
@@ -85,6 +86,7 @@ public:
         if (fpe_plan_service_report(h_, &params, initialPose, gaitCycles, resp.get(), cen.get(), rows.data(), &nRows,
                                     repNominal.get(), repCentroid.get()) != FPE_OK)
             return false;
+        if (gateFailed()) return false;
         fill(*resp, msg, true);
         // centroidGlobalFootholdsMsg_ is never cleared between calls (cpp:715): append; its gait_cycles field is
         // never written by the reference, so the caller's value is kept
@@ -124,6 +126,7 @@ public:
         if (fpe_plan_service_opt(h_, &params, &optParams, initialPose, gaitCycles, resp.get(), nullptr, nullptr, nullptr, nullptr, nullptr,
                                  opt.get(), repOpt.get(), cycles.data()) != FPE_OK)
             return false;  // FPE_E_SERVICE_FALSE: getGaitCycleSearchGridMap failed (cpp:931-934; kinds: fpe_service_gate)
+        if (gateFailed()) return false;
         fill(*resp, msg, true);
         const uint8_t keepGaitCycles = optMsg.gait_cycles;  // never written by the reference (cpp:743)
         fill(*opt, optMsg, false);
@@ -140,6 +143,14 @@ public:
             lfRhCurrentRow[1] = gate.rh_current_row;
         }
         return true;
+    }
+
+    // The handler's gate failed in a way the call did not refuse by itself: under fpe_set_tuning("service_opt_gate", 0 | 1) the
+    // engine answers FPE_OK although the opt track's chain stopped at its gate (kind FPE_GATE_BUILD_DEFINED, opt products
+    // empty).  The reference's handler returns false at that gate (cpp:931-934): so does this adapter, whatever the mode.
+    bool gateFailed() const {
+        fpe_service_gate gate;
+        return fpe_last_service_gate(h_, &gate) == FPE_OK && gate.fail_kind != FPE_GATE_NONE;
     }
 
     const char* lastError() const { return fpe_last_error(h_); }

@@ -50,6 +50,10 @@ def make_poses(xyz, gait=0, leg_search_radius=None, leg_polygon_kind=None):
     return poses
 
 
+# fpe_set_tuning's knobs whose engine default is not 0 (tuning() restores these after a with-block)
+TUNING_DEFAULTS = {"service_opt_gate": 2}
+
+
 class FootholdPlanner:
     """One engine per process per GPU."""
 
@@ -168,7 +172,7 @@ class FootholdPlanner:
         """Set knobs for the duration of a with-block, then restore the values they had through this object (a knob
         this object never set goes back to 0, the automatic default; knobs seeded from the environment in fpe_create are
         not visible here — set them through set_tuning instead when with-blocks are used)."""
-        before = {k: self._tuning.get(k, 0) for k in kw}
+        before = {k: self._tuning.get(k, TUNING_DEFAULTS.get(k, 0)) for k in kw}
         self.set_tuning(**kw)
         try:
             yield self
@@ -299,7 +303,7 @@ class FootholdPlanner:
     def globalFootholdPlan(self, gait_cycles, initial_position, all_tracks=False):
         """Response content of the service, or False where the reference's handler returns false
         (getGaitCycleSearchGridMap fails, cpp:920-934: in the first gait cycle, or on its lateral side in any cycle — the x side of
-        later cycles follows the build-defined optimiser and refuses only under set_tuning(service_opt_gate=2); last_service_gate()
+        later cycles follows the build-defined optimiser and refuses under set_tuning(service_opt_gate=2), the default; last_service_gate()
         tells the kinds apart); with all_tracks also the centroid message, the default-track
         rows (global_footholds_centroid, globalFootholdsResult_.defaultFootholds), and per track the
         feet-centre path and KPIs (nominal/centroid_feet_center_path, footholdsKPI_)."""

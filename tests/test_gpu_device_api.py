@@ -246,6 +246,7 @@ def test_service_gate_kinds_default_advisory_enforce(planner):
     pos += [[rng.uniform(-2.5, -1.0), rng.uniform(-1, 1), 0.0] for _ in range(4)]
     n = 8
     kinds = {k: 0 for k in range(4)}
+    n_aborted = 0
     harsh = synth.rough_map(400, 400, 0.02, seed=1, bad_frac=0.45)  # terrain on which the opt track derails: x side, build-defined
     hmap = fpo.OracleMap(harsh[0], harsh[1], 0.02)
     rng2 = np.random.default_rng(91)
@@ -266,7 +267,23 @@ def test_service_gate_kinds_default_advisory_enforce(planner):
                 assert r["gait_cycles"] == n
             if mode == 1:
                 kinds[kind] += 1
+            if mode == 2:  # the engine's default IS mode 2
+                planner.set_tuning(service_opt_gate=2)
+                assert (planner.globalFootholdPlan(n, p) is False) == refuse
+            if mode in (0, 1) and r is not False:
+                # every track asked for: the chain runs in both modes; stopped at its gate -> OK, opt products empty, kind reported
+                with planner.tuning(service_opt_gate=mode):
+                    full = planner.globalFootholdPlan(n, p, all_tracks=True)
+                    g2 = planner.last_service_gate()
+                assert full is not False and g2["chain_ran"]
+                aborted = g2["fail_kind"] == _capi.GATE_BUILD_DEFINED
+                assert aborted == (util.oracle_service_gate(omap, planner, p, n) != 255)
+                if aborted:
+                    n_aborted += 1
+                    assert len(full["opt"]["footholds"]) == 0 and full["opt"]["report"]["path"].shape[0] == 0
+                    assert full["centroid"]["report"]["path"].shape[0] <= n + 1  # the centroid track's own points only
     assert all(v > 0 for v in kinds.values()), kinds  # every kind occurred
+    assert n_aborted > 0
     # the default call equals the enforced one wherever the exact kinds decide
     planner.params = _capi.params_yaml()
 
@@ -319,8 +336,11 @@ def test_selected_packed_is_the_selected_record_in_eight_bytes(planner):
 def test_multi_plan_device_gathers_over_rccl(planner):
     """fpe_multi_plan_device: the C++ host's device-resident multi-GPU plan with the RCCL all-gather of the selected records
     (ncclCommInitAll / ncclGroupStart / ncclAllGather / ncclGroupEnd behind the C ABI, no Python collective).  One device on
-    this box: the communicator has one rank, the collective still runs through RCCL; both record kinds, and an uneven batch
-    (grouped broadcasts).  Offsets for more devices are covered on the CPU (test_cpu_abi_and_host)."""
+    this box: the communicator has one rank (B % 1 == 0: the direct all-gather), the collective still runs through RCCL; both
+    record kinds.  The path uneven batches take on a node — blocks padded to ceil(B / n) poses, staged, gathered in place, put in
+    place by device-local copies — is forced with the group's "gather_padded" knob and must give the same bytes; what this
+    one-GPU box cannot show is that path with n > 1 (its offsets follow fpe_multi_shard_range, covered on the CPU in
+    test_cpu_abi_and_host; a test for >= 2 devices is below)."""
     import torch
 
     from quadrupedal_foothold_planner_amd.planner import MultiFootholdPlanner
@@ -347,6 +367,53 @@ def test_multi_plan_device_gathers_over_rccl(planner):
             got = d_all.cpu().numpy().view(dt).reshape(B, n, 4)
             assert got.tobytes() == want[name].tobytes(), name
             assert np.array_equal(d_ok.cpu().numpy().reshape(B, n), want["cycle_ok"])
+            # the padded path (what B % n != 0 takes), twice: the staging buffer is reused behind its event
+            mp.set_tuning(gather_padded=1)
+            for _ in range(2):
+                d_all.zero_()
+                mp.plan_device(B, n, [{"d_poses": d_poses.data_ptr(), name: d_rec.data_ptr(), "cycle_ok": d_ok.data_ptr(),
+                                       "d_gathered": d_all.data_ptr()}], record_kind=kind)
+                mp.synchronize()
+                assert d_all.cpu().numpy().tobytes() == want[name].tobytes(), name + " (padded)"
+            mp.set_tuning(gather_padded=0)
+    finally:
+        mp.close()
+
+
+@pytest.mark.skipif(__import__("torch").cuda.device_count() < 2, reason="needs two GPUs (the driver's multi-GPU node; this pool's boxes have one)")
+def test_multi_plan_device_uneven_batch_on_two_devices(planner):
+    """B % n != 0 on a real multi-device group — every device's d_gathered must hold the single-device plan's records
+    of the WHOLE batch (padded in-place all-gather + compaction, csrc/fpe_multi.cpp)."""
+    import torch
+
+    from quadrupedal_foothold_planner_amd.planner import MultiFootholdPlanner
+
+    ndev = min(torch.cuda.device_count(), 4)
+    planner.params = _capi.params_yaml()
+    trav, elev = synth.rough_map(300, 300, 0.02, seed=7)
+    B, n = 64 * ndev + 1, 6
+    poses = synth.poses_in_map(B, 6.0, 6.0, n, 0.18, seed=8, margin=0.7)
+    planner.gridmapCallback(trav, elev, 0.02)
+    want = planner.plan(poses, n, products=("selected_packed",))["selected_packed"].tobytes()
+    mp = MultiFootholdPlanner(list(range(ndev)))
+    try:
+        mp.gridmapCallback(trav, elev, 0.02)
+        dt, ios, keep = _capi.PACKED_DTYPE, [], []
+        raw = poses.view(np.uint8).reshape(B, -1)
+        for k in range(ndev):
+            first, count = mp.shard_range(B, k)
+            dev = torch.device(f"cuda:{k}")
+            d_poses = torch.from_numpy(raw[first:first + count].copy()).to(dev)
+            d_rec = torch.zeros(count * n * 4 * dt.itemsize, dtype=torch.uint8, device=dev)
+            d_all = torch.zeros(B * n * 4 * dt.itemsize, dtype=torch.uint8, device=dev)
+            keep.append((d_poses, d_rec, d_all))
+            ios.append({"d_poses": d_poses.data_ptr(), "selected_packed": d_rec.data_ptr(), "d_gathered": d_all.data_ptr()})
+        for k in range(ndev):
+            torch.cuda.synchronize(k)
+        mp.plan_device(B, n, ios, record_kind=_capi.EXCHANGE_PACKED)
+        mp.synchronize()
+        for k in range(ndev):
+            assert keep[k][2].cpu().numpy().tobytes() == want, f"device {k}"
     finally:
         mp.close()
 

@@ -532,7 +532,7 @@ def test_concurrent_uploads_and_plans_see_whole_snapshots(planner):
         ths[0].join()
     finally:
         stop.set()
-        planner.set_tuning(service_opt_gate=0)
+        planner.set_tuning(service_opt_gate=2)  # (the default)
     assert not errors, errors[:3]
     assert seen[0] + seen[1] == 120
 

@@ -124,16 +124,17 @@ def assert_opt_equal(eng, ora):
 
 
 def service_enforced(planner, *args, **kw):
-    """globalFootholdPlan under fpe_set_tuning("service_opt_gate", 2): the call also refuses where only the build-defined
-    optimiser's feet make the gate fail (x side of a cycle >= 1) — comparable with the oracle's opt-track gate in any cycle."""
+    """globalFootholdPlan under fpe_set_tuning("service_opt_gate", 2) — the default, set explicitly here: the call also refuses
+    where only the build-defined optimiser's feet make the gate fail (x side of a cycle >= 1) — comparable with the oracle's
+    opt-track gate in any cycle."""
     with planner.tuning(service_opt_gate=2):
         return planner.globalFootholdPlan(*args, **kw)
 
 
-def oracle_service_verdict(omap, planner, pos, n_cycles, plan=None, opt_gate=0):
+def oracle_service_verdict(omap, planner, pos, n_cycles, plan=None, opt_gate=2):
     """What a service call must do about the handler's gate (include/fpe.h, fpe_service_gate): returns (refuse, kind, cycle).
     Exact kinds — the first gait cycle (stance feet) and the lateral side of any cycle — always refuse; the x side of a
-    later cycle follows the build-defined optimiser and refuses only under service_opt_gate = 2."""
+    later cycle follows the build-defined optimiser and refuses under service_opt_gate = 2 (the engine's default) only."""
     from quadrupedal_foothold_planner_amd import _capi
     from quadrupedal_foothold_planner_amd.planner import make_poses
 
