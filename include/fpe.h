@@ -273,6 +273,12 @@ int fpe_destroy(fpe_handle h);
 int fpe_set_tuning(fpe_handle h, const char* key, int32_t value);
 const char* fpe_last_error(fpe_handle h); /* thread-local text of the last failure on this thread */
 const char* fpe_version(void);
+/* Layout version of the structs this header passes by pointer (fpe_plan_out, fpe_opt_out, fpe_params, ... have no size
+ * field: fields are only ever APPENDED, and every append bumps this number).  A host compiled against this header checks
+ * fpe_abi_version() == FPE_ABI_VERSION once after loading the library — a library that reads a longer struct than the host
+ * passes would take whatever lies behind it for a device pointer (csrc/ros_adapter/fpe_ros_adapter.hpp and _capi.py do). */
+#define FPE_ABI_VERSION 5
+int fpe_abi_version(void);
 
 /* ---- map ingest: replaces GridMapRosConverter::fromMessage in gridmapCallback (cpp:504-536) ---
  * Host pointers, `rows*cols` floats per layer in desc->storage_order.  Uploads both layers to HBM

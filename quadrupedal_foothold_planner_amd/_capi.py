@@ -177,6 +177,7 @@ class FilterParams(C.Structure):
     ]
 
 
+ABI_VERSION = 5  # FPE_ABI_VERSION of include/fpe.h: the ctypes structures below mirror that layout
 FILTER_LAYERS = ("normal_x", "normal_y", "normal_z", "slope", "step_height", "step", "roughness", "traversability")
 
 # every symbol include/fpe.h declares (tests check the library exports each of them)
@@ -187,6 +188,7 @@ EXPORTED_SYMBOLS = [
     "fpe_destroy",
     "fpe_last_error",
     "fpe_version",
+    "fpe_abi_version",
     "fpe_upload_map",
     "fpe_upload_map_device",
     "fpe_map_info",
@@ -251,6 +253,9 @@ def lib():
         raise EngineUnavailable(f"cannot load {path}: {e}") from e
     vp, i32, f32, f64 = C.c_void_p, C.c_int32, C.c_float, C.c_double
     L.fpe_version.restype = C.c_char_p
+    L.fpe_abi_version.restype = C.c_int
+    if L.fpe_abi_version() != ABI_VERSION:
+        raise EngineUnavailable(f"libfpe.so has struct layout version {L.fpe_abi_version()}, this binding mirrors version {ABI_VERSION} of include/fpe.h")
     L.fpe_last_error.restype = C.c_char_p
     L.fpe_last_error.argtypes = [vp]
     L.fpe_params_yaml.argtypes = [vp]

@@ -595,7 +595,8 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
 
 extern "C" {
 
-const char* fpe_version(void) { return "fpe 0.4.0 (gfx950, wave64; bit-window plan kernels on tiled planes: 8 lanes per leg and two poses per wavefront, one wavefront per pose for large windows; opt track with a build-defined optimiser)"; }
+int fpe_abi_version(void) { return FPE_ABI_VERSION; }
+const char* fpe_version(void) { return "fpe 0.5.0 (gfx950, wave64; bit-window plan kernels on tiled planes: 8 lanes per leg and two poses per wavefront, one wavefront per pose for large windows; opt track with a build-defined optimiser)"; }
 
 const char* fpe_last_error(fpe_handle) { return g_err.c_str(); }
 

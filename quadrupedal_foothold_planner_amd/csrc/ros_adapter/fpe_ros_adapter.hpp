@@ -31,6 +31,10 @@ namespace fpe_ros {
 class Engine {
 public:
     explicit Engine(int device = 0) {
+        // the structs passed by pointer have no size field: a library of another layout version must not be driven with them
+        if (fpe_abi_version() != FPE_ABI_VERSION)
+            throw std::runtime_error("libfpe.so has struct layout version " + std::to_string(fpe_abi_version()) + ", this adapter was compiled against " +
+                                     std::to_string(FPE_ABI_VERSION));
         if (fpe_create(device, &h_) != FPE_OK) throw std::runtime_error(std::string("fpe_create: ") + fpe_last_error(nullptr));
     }
     ~Engine() { fpe_destroy(h_); }

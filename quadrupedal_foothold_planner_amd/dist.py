@@ -150,6 +150,7 @@ class BatchedFootholdExchange:
         self.out = [torch.empty(n * self.world, dtype=torch.uint8, device=device) if self.collective else None for _ in range(depth)]
         self.work = [None] * depth
         self.launched = [-1] * depth  # last step whose batch was gathered from this buffer
+        self.owner = [-1] * depth     # batch (step // batch) the buffer was last handed out for by acquire()
         self.collectives = 0          # all-gathers launched so far
 
     def _slot(self, k):
@@ -164,6 +165,7 @@ class BatchedFootholdExchange:
         slot = self._slot(k)
         if k % self.batch == 0:
             self._wait(slot)  # the gather that last read this buffer
+        self.owner[slot] = k // self.batch  # from here on later plans overwrite whatever batch the buffer held
         lb = self.local_bytes
         return self.stage[slot][(k % self.batch) * lb:(k % self.batch + 1) * lb]
 
@@ -198,6 +200,11 @@ class BatchedFootholdExchange:
             raise RuntimeError(f"result({k}): the batch of step {k} is not the one held by its buffer (last gathered step: "
                                f"{self.launched[slot]}; call gather()/flush() first, and read a batch before {self.depth} later ones start)")
         if not self.collective:
+            # no collective copied the batch out: the result IS the staging buffer, valid only until acquire() hands the
+            # buffer to a later batch (`launched` still names the old one then — ADVICE r4)
+            if self.owner[slot] != k // self.batch:
+                raise RuntimeError(f"result({k}): its buffer has been handed to batch {self.owner[slot]} since (read a batch before "
+                                   f"{self.depth} later ones start)")
             return self.stage[slot][sub * lb:(sub + 1) * lb]
         self._wait(slot)
         n = lb * self.batch

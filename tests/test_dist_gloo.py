@@ -189,6 +189,18 @@ def test_exchange_refuses_steps_it_does_not_hold_and_runs_a_forced_one_rank_coll
         plain.acquire(1).fill_(7)
         plain.gather(1)
         assert plain.result(0).eq(9).all() and plain.result(1).eq(7).all() and plain.collectives == 0
+        # without a collective the result IS the staging buffer: once acquire() has handed it to a later batch (depth = 2
+        # buffers, batches of 2 steps: step 4 reuses the buffer of steps 0-1) the old batch must be refused, not served
+        # from a buffer the later plans are writing
+        for k in (2, 3):
+            plain.acquire(k).fill_(5)
+            plain.gather(k)
+        plain.acquire(4).fill_(3)  # the buffer of steps 0-1, no gather yet: `launched` still names step 1
+        with pytest.raises(RuntimeError):
+            plain.result(0)
+        with pytest.raises(RuntimeError):
+            plain.result(1)
+        assert plain.result(2).eq(5).all()
     finally:
         dist.destroy_process_group()
 
