@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--blocks", type=int, default=25, help="timed blocks of --steps steps; ms_per_step is the median block (min / max reported)")
     ap.add_argument("--config", default="headline", help="headline | cfg2 | cfg3 | cfg4 | cfg5 (quadrupedal_foothold_planner_amd.synth.CONFIGS)")
     ap.add_argument("--batch", type=int, default=None, help="poses per GPU (default: the config's B; cfg4: B/8 = one shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -170,6 +171,16 @@ def verify_plan(eng, trav, elev, res, params, poses, n_cycles):
     return True, ""
 
 
+def kernel_sources_sha16():
+    """sha256 (first 16 hex digits) over the sources of the plan kernels: what profiles/pmc_traffic.json's counters belong to."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("fpe_kernels.hip", "fpe_bits.hpp", "fpe_device.hpp", "fpe_gridmath.hpp"):
+        with open(os.path.join(ROOT, "quadrupedal_foothold_planner_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -285,40 +296,49 @@ def main():
             if ex_:
                 ex_.gather(k)
 
-        # W warmup steps, then exactly K steps between barrier + synchronize pairs; MAX over ranks
+        # W warmup steps, then BLOCKS of exactly K steps, each between barrier + synchronize pairs; a block's time is the MAX
+        # over ranks, the reported step is the MEDIAN block (one block of 20 headline launches is half a
+        # millisecond — one mean, no spread, invisible to a sampler; 25 blocks make the timed region >= 10 ms and give the
+        # spread, reported as ms_per_step_min / _max)
         for _ in range(args.warmup):
             step()
         if ex_:
             ex_.flush(k_[0] - 1)
             ex_.drain()
             k_[0] = ((k_[0] + batch - 1) // batch) * batch  # the timed region starts on a batch boundary
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if exchanging:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ev0.record(stream)
-        for _ in range(args.steps):
-            step()
-        if ex_:
-            ex_.flush(k_[0] - 1)
-            ex_.drain()  # the stream waits for the in-flight all-gathers
-        ev1.record(stream)
-        torch.cuda.synchronize()
-        if exchanging:
-            dist.barrier()
-        el = time.perf_counter() - t0
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        if exchanging:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item()), ev0.elapsed_time(ev1) / args.steps, ex_, k_[0] - 1
+        walls, evs = [], []
+        for _ in range(args.blocks):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if exchanging:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ev0.record(stream)
+            for _ in range(args.steps):
+                step()
+            if ex_:
+                ex_.flush(k_[0] - 1)
+                ex_.drain()  # the stream waits for the in-flight all-gathers
+                k_[0] = ((k_[0] + batch - 1) // batch) * batch
+            ev1.record(stream)
+            torch.cuda.synchronize()
+            if exchanging:
+                dist.barrier()
+            el = time.perf_counter() - t0
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            if exchanging:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            walls.append(float(t.item()))
+            evs.append(ev0.elapsed_time(ev1) / args.steps)
+        return walls, float(np.median(evs)), ex_, k_[0] - 1
 
     # HIP events on the launch stream bracket the K launches of the timed region; at N=1 the region
     # holds nothing but the K plan kernels, so elapsed/K is the mean launch duration (an upper bound
     # of the kernel time: it includes the ~2 us dispatch gap between back-to-back launches).  At N>1
     # the all-gather shares the stream, so a second, kernel-only pass measures the launch duration.
     gather_batch = max(1, args.gather_every) if exchanging else 1
-    elapsed, kernel_ms, ex, last_step = run(gather_batch)
+    walls, kernel_ms, ex, last_step = run(gather_batch)
+    elapsed = float(np.median(walls))  # the median block of K steps
     alt = None
     n_collectives = ex.collectives if ex else 0
     if exchanging:
@@ -329,19 +349,23 @@ def main():
         mine = mine.reshape(-1)
         x_last = ex.local_block(last_step).clone()
         if gather_batch > 1 and world > 1:
-            el1, _, ex1, _ = run(1)
+            walls1, _, ex1, _ = run(1)
+            el1 = float(np.median(walls1))
             alt = {"gather_every": 1, "value": 4 * n_cycles * B * world * args.steps / el1, "ms_per_step": el1 / args.steps * 1e3,
                    "note": "one all-gather per step (2 x the collectives' fixed cost per 29 us headline step)"}
             del ex1
-        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        k0.record(stream)
-        for _ in range(args.steps):
-            planner.plan_device(d_poses.data_ptr(), B, n_cycles, d_nom.data_ptr(), d_cen.data_ptr(), d_def.data_ptr(),
-                                d_ok.data_ptr(), d_st.data_ptr(), stream=stream.cuda_stream, d_selected_ptr=d_sel.data_ptr(),
-                                d_pose_status_ptr=d_ps.data_ptr())
-        k1.record(stream)
-        torch.cuda.synchronize()
-        kernel_ms = k0.elapsed_time(k1) / args.steps
+        kms = []
+        for _ in range(args.blocks):
+            k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            k0.record(stream)
+            for _ in range(args.steps):
+                planner.plan_device(d_poses.data_ptr(), B, n_cycles, d_nom.data_ptr(), d_cen.data_ptr(), d_def.data_ptr(),
+                                    d_ok.data_ptr(), d_st.data_ptr(), stream=stream.cuda_stream, d_selected_ptr=d_sel.data_ptr(),
+                                    d_pose_status_ptr=d_ps.data_ptr())
+            k1.record(stream)
+            torch.cuda.synchronize()
+            kms.append(k0.elapsed_time(k1) / args.steps)
+        kernel_ms = float(np.median(kms))
 
     footholds_per_step = 4 * n_cycles * B * world
     value = footholds_per_step * args.steps / elapsed
@@ -386,6 +410,7 @@ def main():
     # profile of this configuration — reported only while the kernel the engine launches NOW is the kernel that profile
     # measured (same template instance), and always with its source
     traffic, traffic_source = None, None
+    sources_now = kernel_sources_sha16()
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     kernel_now = planner.describe_plan()
     if os.path.exists(pmc_path) and not args.no_bits:
@@ -397,20 +422,29 @@ def main():
                 traffic = ent.get("hbm_bytes_per_launch")
                 traffic_source = {"file": ent.get("file", "profiles/pmc_traffic.json"), "round": ent.get("round"),
                                   "commit": ent.get("commit", "round-2 HEAD"), "kernel": ent.get("kernel"),
-                                  "note": "static: measured by rocprofv3 --pmc passes when that profile was taken, not by this run"}
+                                  "kernel_sources_sha16": ent.get("kernel_sources_sha16"),
+                                  "traffic_stale": ent.get("kernel_sources_sha16") != sources_now,
+                                  "note": "static: measured by rocprofv3 --pmc passes when that profile was taken, not by this run; "
+                                          "traffic_stale: the plan kernels' sources (sha256 of csrc/fpe_kernels.hip, fpe_bits.hpp, fpe_device.hpp, "
+                                          "fpe_gridmath.hpp) have changed since that profile"}
             elif ent:
                 traffic_source = {"omitted": f"the committed profile measured `{ent.get('kernel')}`, this run launches `{inst}`"}
         except Exception:
             traffic, traffic_source = None, None
 
     line = {
-        "metric": "footholds/sec (4 legs x N cycles x B poses) on 1k^2 @2cm map",
+        "metric": "footholds/sec (4 legs x N cycles x B poses) on 1k^2 @2cm map; `value` = device-resident (poses and every product stay in HBM), "
+                  "`value_survey_8d` = SURVEY 8(d)'s wall time of fpe_plan with host buffers, result D2H included",
         "value": value,
         "unit": "footholds/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step_is": f"the median of {args.blocks} timed blocks of {args.steps} steps (each block between barrier + synchronize pairs, MAX over ranks)",
+        "ms_per_step_min": min(walls) / args.steps * 1e3,
+        "ms_per_step_max": max(walls) / args.steps * 1e3,
+        "timed_region_ms": sum(walls) * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -450,8 +484,13 @@ def main():
             "traffic": traffic,
             "traffic_source": traffic_source,
             "kernel": kernel_now,
+            "kernel_sources_sha16": sources_now,
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_foothold": alg_bytes,
+            "algorithmic_bytes_convention": ("SURVEY 8(d): 4 W^2 + 8 n_foot + 16 with W from fpe_params.searchRadius — charged to EVERY leg"
+                                             + ("; this configuration draws per-leg radii from U[0.06, 0.15] (mean window smaller than the "
+                                                "0.1 m one charged) and hexagon polygons: the figure is a convention, not the bytes a leg needs"
+                                                if args.config == "cfg5" else "")),
             "frac_by_counter_bytes": (traffic / (kernel_ms * 1e-3) / 1e9 / peak) if traffic else None,
             "note": "`bound` is what the counters say limits the kernel (the SIMDs' instruction issue: VALU-active 0.67-0.94 of the SIMDs' "
                     "time, profiles/); `achieved` / `peak` / `frac` keep north_star's yardstick — SURVEY 8(d)'s ALGORITHMIC bytes against the "
@@ -534,6 +573,14 @@ def main():
                                   "note": "fpe_plan (host buffers, ordinary pageable arrays): poses H2D + kernel + all seven products D2H in chunks "
                                           "through the engine's pinned arena, copied out by the engine's copy threads while later chunks are in "
                                           "flight; SURVEY 8(d) wall-time definition"}
+        # the same number under the name of its definition (`value` is the device-resident rate; SURVEY 8(d) defines the
+        # metric on the wall time of fpe_plan including the result D2H — this one)
+        line["value_survey_8d"] = {"value": 4 * n_cycles * B / dt, "unit": "footholds/s", "ms_per_call": dt * 1e3,
+                                   "pinned_destinations": 4 * n_cycles * B / dt_p,
+                                   "definition": "SURVEY 8(d): 4 legs x N cycles x B poses / wall time of fpe_plan (host buffers: poses H2D + kernel + all "
+                                                 "seven products D2H; map upload excluded), median of 20 calls; `pinned_destinations`: the same call with "
+                                                 "result arrays from fpe_host_alloc.  Bound by the PCIe link (plain_d2h_copy_GB/s_on_this_box in "
+                                                 "value_incl_d2h), not by the kernel: `value` is 13-18 x this"}
         line["value_incl_d2h_pinned"] = {"value": 4 * n_cycles * B / dt_p, "unit": "footholds/s", "ms_per_call": dt_p * 1e3,
                                          "result_bytes": res_bytes, "GB/s_results": res_bytes / dt_p / 1e9,
                                          "note": "same call, result arrays from fpe_host_alloc (pinned): every product is written by DMA straight "

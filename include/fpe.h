@@ -162,7 +162,11 @@ typedef struct fpe_plan_out {
  * unpinned by the reference, and COBYLA's iterates are not reproducible.  In its place: exhaustive search of the same
  * objective under the same constraints (tolerance ctol) over the INTEGER points of the same box — the reference
  * truncates x to int before using it (cpp:1287-1312) — feasible points by objective, else the point of least
- * constraint violation; deterministic tie-breaks (oracle/fpo_opt.cpp::solveLattice states the rule). */
+ * constraint violation; deterministic tie-breaks (oracle/fpo_opt.cpp::solveLattice states the rule).  Against scipy's
+ * COBYLA driving the same literal chain (tests/golden/cobyla_vs_lattice.json, build container only): identical x in 29 %
+ * of the cycles, median distance 2 rows + 1 column, the handler's gate verdict identical for 94.8 % of 1 280 poses — the
+ * opt products are a PLAUSIBLE track, not the reference's, and the gate verdict built on them is right about 19 times in 20
+ * against a different COBYLA (against NLopt's: unmeasurable here). */
 typedef struct fpe_opt_params {
     double w1, w2, w3, w4, wr, wc;         /* nlopt/w1..wc, cpp:297-303 */
     int32_t use_inequality_constraints;    /* nlopt/useInequalityConstraits, cpp:306 (code default 0, yaml 1) */

@@ -155,6 +155,7 @@ def lib():
         L.fpo_plan_opt.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 4
         L.fpo_plan_opt_products.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 5
         L.fpo_solve_lattice.argtypes = [C.c_void_p] * 5 + [C.c_double] * 5 + [C.c_void_p] * 2
+        L.fpo_plan_opt_forced.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.fpo_centroid_on_submap.argtypes = [C.c_void_p, C.c_void_p] + [C.c_double] * 6 + [C.c_float, C.c_void_p, C.c_void_p]
         L.fpo_filter_defaults.argtypes = [C.c_void_p]
         L.fpo_filters.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -273,6 +274,21 @@ class OracleMap:
                                 _ptr(out["cycles"]), _ptr(out["gate_fail_cycle"]))
         assert rc == 0
         return out
+
+    def plan_opt_forced(self, params, opt_params, pose, n_cycles, cycle_ok, forced_x):
+        """One pose's opt track with the optimiser's x of the first len(forced_x) cycles SUPPLIED (doubles, [k, 8]): the cycles'
+        records and the gate verdict (255: none).  An external optimiser drives the literal chain (make_cobyla_golden.py)."""
+        params = np.ascontiguousarray(params, dtype=PARAMS_DTYPE).reshape(1)
+        op = np.ascontiguousarray(opt_params, dtype=OPT_PARAMS_DTYPE).reshape(1)
+        pose = np.ascontiguousarray(pose, dtype=POSE_DTYPE).reshape(1)
+        ok = np.ascontiguousarray(cycle_ok, dtype=np.uint8).reshape(n_cycles)
+        fx = np.ascontiguousarray(forced_x, dtype=np.float64).reshape(-1, 8) if len(forced_x) else np.zeros((0, 8))
+        cycles = np.zeros(n_cycles, OPT_CYCLE_DTYPE)
+        gate = np.zeros(1, np.int32)
+        rc = lib().fpo_plan_opt_forced(self._h, _ptr(params), _ptr(op), _ptr(pose), int(n_cycles), _ptr(ok), _ptr(fx) if fx.size else None,
+                                       int(fx.shape[0]), _ptr(cycles), _ptr(gate))
+        assert rc == 0
+        return cycles, (255 if gate[0] < 0 else int(gate[0]))
 
     def plan_opt_products(self, params, opt_params, pose, n_cycles, cycle_ok):
         params = np.ascontiguousarray(params, dtype=PARAMS_DTYPE).reshape(1)

@@ -406,6 +406,37 @@ int fpo_plan_opt_products(const void* mapHandle, const Params* params, const Opt
     return 0;
 }
 
+// One pose's opt track with the optimiser's x of the first nForced cycles supplied by the caller (planOptTrack's forcedX): the
+// cycles' records (problem of every cycle that ran, x as truncated by the chain) and the gate verdict.  Test infrastructure of
+// tests/golden/make_cobyla_golden.py (an external optimiser drives the literal chain).
+int fpo_plan_opt_forced(const void* mapHandle, const Params* params, const OptParams* op, const PoseSpec* pose, int nCycles,
+                        const uint8_t* cycleOk, const double* forcedX, int nForced, fpo_opt_cycle* cycles, int32_t* gateFailCycle) {
+    const GridMap& map = *static_cast<const GridMap*>(mapHandle);
+    OptOutput out;
+    planOptTrack(map, *params, *op, *pose, nCycles, cycleOk, out, forcedX, nForced);
+    *gateFailCycle = out.gateFailCycle;
+    for (int g = 0; g < nCycles; ++g) {
+        const OptCycle& oc = out.cycles[(size_t)g];
+        fpo_opt_cycle& r = cycles[g];
+        std::memset(&r, 0, sizeof(r));
+        r.gate_failed = oc.gateFailed;
+        if (!(out.gateFailCycle < 0 || g < out.gateFailCycle)) continue;
+        for (int k = 0; k < 2; ++k) { r.gait_top_left[k] = oc.gaitTopLeft[k]; r.gait_size[k] = oc.gaitSize[k]; }
+        for (int k = 0; k < 8; ++k) {
+            r.nominal_index[k] = oc.nominalIndex[k]; r.centroid_index[k] = oc.centroidIndex[k];
+            r.x_lower[k] = oc.xLower[k]; r.x_upper[k] = oc.xUpper[k];
+            r.x[k] = static_cast<int32_t>(oc.x[k]);
+        }
+        for (int k = 0; k < 4; ++k) {
+            r.traversable_row[0][k] = oc.traversableRow[0][k]; r.traversable_row[1][k] = oc.traversableRow[1][k];
+            r.centroid_code[k] = oc.centroidCode[k];
+        }
+        r.minf = oc.minf; r.lf_current_row = oc.lfCurrentRow; r.rh_current_row = oc.rhCurrentRow;
+        r.committed = oc.committed; r.solver_status = oc.solverStatus;
+    }
+    return 0;
+}
+
 // the build-defined optimiser alone (tests: hand-made problems)
 int fpo_solve_lattice(const OptParams* op, const int32_t* nominalIndex, const int32_t* centroidIndex, const int32_t* lo,
                       const int32_t* up, double lengthBase, double skew, double mapResolution, double lfCurrentRow,

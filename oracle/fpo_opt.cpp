@@ -16,8 +16,15 @@
 // the last ulp — they cannot be reproduced here, and are not attempted.  `solveLattice` below minimises the SAME
 // objective under the SAME constraints (same tolerance ctol) over the integer points of the same box — the reference
 // truncates the optimiser's x to int before it uses it (cpp:1287-1312) — by exhaustive search, deterministic
-// tie-breaks.  The engine runs the identical algorithm on the GPU; their parity is bit-exact, their distance to
-// COBYLA's answer is unknowable in this environment.
+// tie-breaks.  The engine runs the identical algorithm on the GPU; their parity is bit-exact.  Their distance to NLopt's
+// COBYLA cannot be measured here; their distance to ANOTHER implementation of COBYLA (scipy 1.15's, in the build container
+// only) driving this file's literal chain is: tests/golden/make_cobyla_golden.py -> tests/golden/cobyla_vs_lattice.json —
+// 1 280 poses x 8 cycles on four synthetic maps: on identical problems the truncated x agrees in all eight variables in 29 %
+// of the cycles (rows 35 %, columns 43 %; median L1 distance 2 rows + 1 column; the lattice's objective is lower by a median
+// of 2.5, COBYLA's point being truncated after the fact), and the SERVICE GATE verdict — the cycle in which
+// getGaitCycleSearchGridMap fails — is the same for 94.8 % of the poses (26 refused by the lattice's feet only, 29 by COBYLA's
+// only, 12 by both in different cycles).  That is the weight fpe_set_tuning("service_opt_gate", 2) deserves: right for 19
+// requests in 20 against a different COBYLA, unknown against NLopt's.
 #include <cmath>
 #include <cstdlib>
 
@@ -170,8 +177,11 @@ int solveLattice(const OptParams& op, const int* nominalIndex, const int* centro
 // of the reference.  cycleOk[g] = footholdValidation_ of cycle g (the NOMINAL track's flags, cpp:1323): the opt track
 // commits with the other tracks (cpp:1332, 1485-1568).  The handler returns false in the cycle whose
 // getGaitCycleSearchGridMap fails (cpp:920-934): the chain stops there (gateFailCycle).
+// forcedX / nForced (test infrastructure for tests/golden/make_cobyla_golden.py): the optimiser's x of the first nForced cycles
+// is TAKEN from forcedX[g * 8 ..] (doubles, as an optimiser returns them — the reference truncates them afterwards, cpp:1287)
+// instead of computed: lets an optimiser that lives outside this file (scipy's COBYLA) drive the literal chain cycle by cycle.
 void planOptTrack(const GridMap& gridmap_, const Params& p, const OptParams& op, const PoseSpec& ps, int nCycles,
-                  const uint8_t* cycleOk, OptOutput& out) {
+                  const uint8_t* cycleOk, OptOutput& out, const double* forcedX, int nForced) {
     const Constants c = makeConstants(p);
     out.cycles.assign((size_t)nCycles, OptCycle());
     out.gateFailCycle = -1;
@@ -276,6 +286,11 @@ void planOptTrack(const GridMap& gridmap_, const Params& p, const OptParams& op,
         lo[4] = oc.traversableRow[0][0]; up[4] = oc.traversableRow[1][0];  // x5: RF
         lo[6] = oc.traversableRow[0][2]; up[6] = oc.traversableRow[1][2];  // x7: LH
         // ---- STEP(4) the optimiser (build-defined) ----
+        if (forcedX && gaitCycleIndex < nForced) {
+            for (int k = 0; k < 8; ++k) oc.x[k] = forcedX[(size_t)gaitCycleIndex * 8 + k];
+            oc.minf = 0.0;
+            oc.solverStatus = 255;  // not this file's optimiser
+        } else
         oc.solverStatus = static_cast<uint8_t>(solveLattice(op, oc.nominalIndex, oc.centroidIndex, lo, up, lengthBase, skew,
                                                             mapResolution, lfCurrentRow, rhCurrentRow, oc.x, &oc.minf));
         // ---- STEP(6) positions and heights on the gait-cycle submap, cpp:1283-1314 ----

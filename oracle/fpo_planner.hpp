@@ -154,7 +154,7 @@ int solveLattice(const OptParams& op, const int* nominalIndex, const int* centro
                  double lengthBase, double skew, double mapResolution, double lfCurrentRow, double rhCurrentRow, double* x,
                  double* minf);
 void planOptTrack(const GridMap& gridmap_, const Params& p, const OptParams& op, const PoseSpec& pose, int nCycles,
-                  const uint8_t* cycleOk, OptOutput& out);
+                  const uint8_t* cycleOk, OptOutput& out, const double* forcedX = nullptr, int nForced = 0);
 
 // "As-written" cost EMULATION: the reference passes grid_map::GridMap BY
 // VALUE (hpp:94,110,124,140,262,288), i.e. deep-copies every layer at each of those call sites.  When

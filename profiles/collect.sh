@@ -14,7 +14,7 @@ OUT=gpurun_out
 export TMPDIR=/tmp
 STEPS=50
 case $CFG in cfg3|cfg4|cfg5) STEPS=20;; esac
-BENCH="python3 bench.py --config $CFG --steps $STEPS --warmup 5 --no-cpu-baseline --no-extras $EXTRA"
+BENCH="python3 bench.py --config $CFG --steps $STEPS --warmup 5 --blocks 3 --no-cpu-baseline --no-extras $EXTRA"
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o $TAG -- $BENCH > $OUT/${TAG}_stats.log 2>&1
 if [ "$MODE" != "stats" ]; then

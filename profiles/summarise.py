@@ -97,6 +97,7 @@ if "FETCH_SIZE" in allc and "WRITE_SIZE" in allc:
     except Exception:
         commit = "unknown"
     tr[cfg] = {"hbm_bytes_per_launch": fetch_b + write_b, "round": rnd, "kernel": plan_row["Name"][:60], "commit": commit,
+               "kernel_sources_sha16": bench["roofline"].get("kernel_sources_sha16"),  # (of the tree the counters were taken on: bench.py's traffic_stale)
                "file": f"profiles/{rnd}_{cfg}_counters.json"}
     json.dump(tr, open(tp, "w"), indent=1)
 waves = allc.get("SQ_WAVES")
