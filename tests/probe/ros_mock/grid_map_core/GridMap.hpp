@@ -11,6 +11,23 @@ struct Vec2d { double v[2]; double x() const { return v[0]; } double y() const {
 struct Matrix {
     std::vector<float> v;  // column-major, as Eigen::MatrixXf
     const float* data() const { return v.data(); }
+    float& operator()(int i, int j);  // (declared for tests/probe/upstream_check.cpp's parse check: never defined, never linked)
+};
+// What tests/probe/upstream_check.cpp reads of the upstream types (Eigen::Vector2d / Array2d / Array2i upstream): DECLARATIONS
+// ONLY, for `g++ -fsyntax-only -DFPE_WITH_GRID_MAP` — the real comparison links the real grid_map_core on the maintainer's machine.
+struct Position {
+    Position();
+    Position(double x, double y);
+    double x() const;
+    double y() const;
+};
+struct Length {
+    Length(double x, double y);
+};
+struct Index {
+    Index();
+    Index(int i, int j);
+    int operator()(int k) const;
 };
 struct GridMap {
     Vec2i size{{0, 0}}, startIndex{{0, 0}};
@@ -23,5 +40,30 @@ struct GridMap {
     Vec2d getPosition() const { return position; }
     Vec2i getStartIndex() const { return startIndex; }
     const Matrix& operator[](const std::string& name) const { return layers.at(name); }
+    // ---- declared for upstream_check.cpp's parse check (see Position above) ----
+    GridMap() = default;
+    explicit GridMap(const std::vector<std::string>& layerNames);
+    void setGeometry(const Length& length, double resolution, const Position& position);
+    Matrix& operator[](const std::string& name);
+    bool getIndex(const Position& position, Index& index) const;
+    bool getPosition(const Index& index, Position& position) const;
+    GridMap getSubmap(const Position& position, const Length& length, bool& isSuccess) const;
+    float at(const std::string& layer, const Index& index) const;
+};
+struct CircleIterator {
+    CircleIterator(const GridMap& map, const Position& center, double radius);
+    bool isPastEnd() const;
+    CircleIterator& operator++();
+    const Index& operator*() const;
+};
+struct SpiralIterator {
+    SpiralIterator(GridMap& map, const Position& center, double radius);
+    bool isPastEnd() const;
+    SpiralIterator& operator++();
+    const Index& operator*() const;
+};
+struct Polygon {
+    void addVertex(const Position& vertex);
+    bool isInside(const Position& point) const;
 };
 }

@@ -200,6 +200,25 @@ def test_ros_adapter_parses_against_the_mock_ros_types():
     assert "resp_" not in src.replace("repNominal_", "").replace("repCentroid_", ""), "no shared response members (AsyncSpinner)"
 
 
+def test_upstream_check_parses_against_the_mock_and_its_harness_runs(tmp_path):
+    """tests/probe/upstream_check.cpp is the one-command pin for whoever has grid_map: the same seeded inputs
+    through the real grid_map_core and through oracle/fpo_gridmap.hpp, exit 1 at the first difference.  Here its upstream half can
+    only be PARSED (-DFPE_WITH_GRID_MAP against tests/probe/ros_mock's declarations), and its harness run with the restatement on
+    both sides (every section must report identical cases: the comparison code itself is exercised)."""
+    import subprocess
+
+    src = os.path.join(ROOT, "tests", "probe", "upstream_check.cpp")
+    inc = ["-I" + os.path.join(ROOT, "oracle")]
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-DFPE_WITH_GRID_MAP", "-I" + os.path.join(ROOT, "tests", "probe", "ros_mock")]
+                       + inc + [src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exe = str(tmp_path / "upstream_check_self")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-ffp-contract=off"] + inc + [src, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "3000"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.count("cases identical") == 5 and "harness self-test only" in r.stdout, r.stdout
+
+
 def test_the_header_is_plain_c(tmp_path):
     """include/fpe.h is the drop-in boundary: a C ABI.  It must compile as C99 with warnings on (a C or cgo host binds it as
     it is), and a C program that only uses the parameter helpers must link against the library without a C++ runtime of its own."""
