@@ -579,6 +579,14 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
                 ms->lastUse.store(++snap->useClock);
                 snap->masks.push_back(std::move(ms));
             }
+            // A host-buffer upload is synchronous already (the caller's arrays may be freed on return): it also waits for the
+            // planes it has just queued, so the snapshot it installs is COMPLETE and the first service call on the new map
+            // waits for nothing (bench.py service_latency_us: first_call_after_a_map was 16 us above steady_map — the plane
+            // build and its event on the call's critical path; the map stream is the 10-20 Hz path that can afford it).
+            if (!srcOnDevice && !pairs.empty()) {
+                FPE_HIP(hipStreamSynchronize(stream));
+                for (auto& ms : snap->masks) ms->readyDone.store(true, std::memory_order_release);
+            }
         }
     }
     std::shared_ptr<MapSnapshot> old;

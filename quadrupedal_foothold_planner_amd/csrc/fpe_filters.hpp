@@ -778,7 +778,7 @@ struct FilterRoute {
     int hN, hR, h1, h2;
     int tF;          // tile COLUMNS of the fused kernel (its rows: 32), 0: the moment form does not apply (walking kernels)
     int stepFused;   // the second step window rides in the fused kernel
-    int t1, t2;      // tile edges of the row-run launches
+    int t1, t2;      // tiles of the row-run launches: 32 = 32 x 32, 24 = 32 rows x 16 columns, 16 = 16 x 16
     size_t fusedBytes;
 };
 namespace {
@@ -824,9 +824,17 @@ FilterRoute filter_route(const FilterConsts& fc, const MapGeom& g) {
 #endif
     // Tile edge of the row-run launches: 32 (1024 threads) when a tile row with its halo is still one wavefront load and the
     // arrays fit the LDS, else 16.  FPE_FILTER_TILE=16 (environment: a measurement switch) keeps the small tile.
-    const auto tile_of = [&](int H, size_t bytes32) { return (forcedTile != 16 && 32 + 2 * H <= 64 && bytes32 <= 150 * 1024 && g.rows >= 64 && g.cols >= 64) ? 32 : 16; };
-    rt.t1 = tile_of(rt.h1, step_lds_bytes(rt.h1, rt.s1.nClasses, 32, 32));
-    rt.t2 = tile_of(rt.h2, step_lds_bytes(rt.h2, rt.s2.nClasses, 32, 32));
+    // (32 x 16 where a 32-column tile row with its halo is more than one wavefront load or the runs outgrow the LDS: windows of
+    // 15-24 cells — 0.08 m at 0.5 cm: against 16 x 16 the runs per cell drop from 3.1 to 2.1 and the CU holds eight wavefronts
+    // instead of four)
+    const auto tile_of = [&](int H, int nClasses) {
+        if (forcedTile == 16 || g.rows < 64 || g.cols < 64) return 16;
+        if (32 + 2 * H <= 64 && step_lds_bytes(H, nClasses, 32, 32) <= 150 * 1024) return 32;
+        if (16 + 2 * H <= 64 && step_lds_bytes(H, nClasses, 32, 16) <= 150 * 1024) return 24;
+        return 16;
+    };
+    rt.t1 = tile_of(rt.h1, rt.s1.nClasses);
+    rt.t2 = tile_of(rt.h2, rt.s2.nClasses);
     if (rt.tF) {
         rt.fusedBytes = fused_moment_bytes(rt.hN, kFusedRows, rt.tF);
         const size_t stepBytes = step_lds_bytes(rt.h2, rt.s2.nClasses, kFusedRows, rt.tF);
@@ -857,29 +865,36 @@ hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float*
     };
     float critDown = static_cast<float>(fc.stepCritical);
     if (static_cast<double>(critDown) > fc.stepCritical) critDown = std::nextafterf(critDown, -HUGE_VALF);
-    const auto tiles = [&](int T, int& tilesX) { tilesX = (g.cols + T - 1) / T; return tilesX * ((g.rows + T - 1) / T); };
-    // 1. step heights (first window)
-    {
-        const int t1 = rt.t1;
-        const void* run1 = t1 != 32 ? reinterpret_cast<const void*>(filter_step_runs_kernel<false, 16, 16, 0>)
-                           : (rt.h1 == 5 ? reinterpret_cast<const void*>(filter_step_runs_kernel<false, 32, 32, 5>)
-                                         : (rt.h1 == 9 ? reinterpret_cast<const void*>(filter_step_runs_kernel<false, 32, 32, 9>)
-                                                       : reinterpret_cast<const void*>(filter_step_runs_kernel<false, 32, 32, 0>)));
-        int tilesX;
-        const int nTiles = tiles(t1, tilesX);
-        if (rt.s1.ok && fits(run1, step_lds_bytes(rt.h1, rt.s1.nClasses, t1, t1))) {
-            const size_t bytes = step_lds_bytes(rt.h1, rt.s1.nClasses, t1, t1);
-#define FPE_STEP1(TT, HS) hipLaunchKernelGGL((filter_step_runs_kernel<false, TT, TT, HS>), dim3(nTiles), dim3(TT * TT), bytes, stream, g, d_elev, L, fc.stepFirstRadius, rt.h1, \
-                                            rt.s1, 0.0, 0.0f, 1, tilesX, nTiles)
-            if (t1 == 32 && rt.h1 == 5) FPE_STEP1(32, 5);
-            else if (t1 == 32 && rt.h1 == 9) FPE_STEP1(32, 9);
-            else if (t1 == 32) FPE_STEP1(32, 0);
-            else FPE_STEP1(16, 0);
-#undef FPE_STEP1
-        } else {
-            if (travOnly) return hipErrorInvalidValue;  // (filter_step1_kernel writes L.stepHeight only, but keep the contract simple)
-            hipLaunchKernelGGL(filter_step1_kernel, grid, block, disc_lds_bytes(rt.h1), stream, g, d_elev, L, fc.stepFirstRadius, rt.h1);
+    // one row-run launch (kSecond false: step heights from the elevation; true: step + weighted sum from the step heights)
+    const auto launch_runs = [&](auto second, int tcode, int H, const StepShape& sp, const float* src, double radius) -> bool {
+        constexpr bool kSecond = decltype(second)::value;
+        const int TR = tcode == 16 ? 16 : 32, TC = tcode == 32 ? 32 : 16;
+        const size_t bytes = step_lds_bytes(H, sp.nClasses, TR, TC);
+        const int tilesX = (g.cols + TC - 1) / TC, nTiles = tilesX * ((g.rows + TR - 1) / TR);
+        const double crit = kSecond ? fc.stepCritical : 0.0;
+        const float cd = kSecond ? critDown : 0.0f;
+        const int nCrit = kSecond ? fc.stepCriticalCells : 1;
+#define FPE_RUNS(TRR, TCC, HS)                                                                                                                          \
+    do {                                                                                                                                                \
+        if (!fits(reinterpret_cast<const void*>(filter_step_runs_kernel<kSecond, TRR, TCC, HS>), bytes)) return false;                                  \
+        hipLaunchKernelGGL((filter_step_runs_kernel<kSecond, TRR, TCC, HS>), dim3(nTiles), dim3(TRR * TCC), bytes, stream, g, src, L, radius, H, sp, crit, cd, \
+                           nCrit, tilesX, nTiles);                                                                                                      \
+        return true;                                                                                                                                    \
+    } while (0)
+        if (!sp.ok) return false;
+        if (tcode == 32) {
+            if (!kSecond && H == 5) FPE_RUNS(32, 32, 5);
+            if (!kSecond && H == 9) FPE_RUNS(32, 32, 9);
+            FPE_RUNS(32, 32, 0);
         }
+        if (tcode == 24) FPE_RUNS(32, 16, 0);
+        FPE_RUNS(16, 16, 0);
+#undef FPE_RUNS
+    };
+    // 1. step heights (first window)
+    if (!launch_runs(std::false_type{}, rt.t1, rt.h1, rt.s1, d_elev, fc.stepFirstRadius)) {
+        if (travOnly) return hipErrorInvalidValue;  // (filter_step1_kernel writes L.stepHeight only, but keep the contract simple)
+        hipLaunchKernelGGL(filter_step1_kernel, grid, block, disc_lds_bytes(rt.h1), stream, g, d_elev, L, fc.stepFirstRadius, rt.h1);
     }
     // 2. normals + slope + roughness [+ second step window + weighted sum]
     bool stepDone = false;
@@ -906,24 +921,8 @@ hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float*
             hipLaunchKernelGGL(filter_roughness_kernel, grid, block, disc_lds_bytes(rt.hR), stream, g, d_elev, L, fc.roughnessRadius, rt.hR, fc.roughnessCritical);
     }
     // 3. second step window + weighted sum, when it did not ride in the fused launch
-    if (!stepDone) {
-        const int t2 = rt.t2;
-        const void* run2 = t2 == 32 ? reinterpret_cast<const void*>(filter_step_runs_kernel<true, 32, 32, 0>) : reinterpret_cast<const void*>(filter_step_runs_kernel<true, 16, 16, 0>);
-        int tilesX;
-        const int nTiles = tiles(t2, tilesX);
-        if (rt.s2.ok && fits(run2, step_lds_bytes(rt.h2, rt.s2.nClasses, t2, t2))) {
-            if (t2 == 32)
-                hipLaunchKernelGGL((filter_step_runs_kernel<true, 32, 32, 0>), dim3(nTiles), dim3(1024), step_lds_bytes(rt.h2, rt.s2.nClasses, 32, 32), stream, g,
-                                   static_cast<const float*>(L.stepHeight), L, fc.stepSecondRadius, rt.h2, rt.s2, fc.stepCritical, critDown, fc.stepCriticalCells,
-                                   tilesX, nTiles);
-            else
-                hipLaunchKernelGGL((filter_step_runs_kernel<true, 16, 16, 0>), dim3(nTiles), block, step_lds_bytes(rt.h2, rt.s2.nClasses, 16, 16), stream, g,
-                                   static_cast<const float*>(L.stepHeight), L, fc.stepSecondRadius, rt.h2, rt.s2, fc.stepCritical, critDown, fc.stepCriticalCells,
-                                   tilesX, nTiles);
-        } else {
-            hipLaunchKernelGGL(filter_step2_kernel, grid, block, disc_lds_bytes(rt.h2), stream, g, L, fc.stepSecondRadius, rt.h2, fc.stepCritical, critDown,
-                               fc.stepCriticalCells);
-        }
-    }
+    if (!stepDone && !launch_runs(std::true_type{}, rt.t2, rt.h2, rt.s2, static_cast<const float*>(L.stepHeight), fc.stepSecondRadius))
+        hipLaunchKernelGGL(filter_step2_kernel, grid, block, disc_lds_bytes(rt.h2), stream, g, L, fc.stepSecondRadius, rt.h2, fc.stepCritical, critDown,
+                           fc.stepCriticalCells);
     return hipGetLastError();
 }
