@@ -306,7 +306,7 @@ def main():
             ex_.flush(k_[0] - 1)
             ex_.drain()
             k_[0] = ((k_[0] + batch - 1) // batch) * batch  # the timed region starts on a batch boundary
-        walls, evs = [], []
+        walls, evs, last_run = [], [], [k_[0] - 1]
         for _ in range(args.blocks):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             if exchanging:
@@ -316,10 +316,11 @@ def main():
             ev0.record(stream)
             for _ in range(args.steps):
                 step()
+            last_run[0] = k_[0] - 1  # the last step that ran (the block's trailing partial batch included)
             if ex_:
                 ex_.flush(k_[0] - 1)
                 ex_.drain()  # the stream waits for the in-flight all-gathers
-                k_[0] = ((k_[0] + batch - 1) // batch) * batch
+                k_[0] = ((k_[0] + batch - 1) // batch) * batch  # the next block starts on a batch boundary
             ev1.record(stream)
             torch.cuda.synchronize()
             if exchanging:
@@ -330,7 +331,7 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
             walls.append(float(t.item()))
             evs.append(ev0.elapsed_time(ev1) / args.steps)
-        return walls, float(np.median(evs)), ex_, k_[0] - 1
+        return walls, float(np.median(evs)), ex_, last_run[0]
 
     # HIP events on the launch stream bracket the K launches of the timed region; at N=1 the region
     # holds nothing but the K plan kernels, so elapsed/K is the mean launch duration (an upper bound
@@ -726,6 +727,27 @@ def main():
         line["ingest"] = {"map": f"{ir}x{ic} f32 x 2 layers, column-major + start index (1234,321), device source",
                           "ms": ing_ms, "GB/s": ing_bytes / (ing_ms * 1e-3) / 1e9, "bytes": ing_bytes,
                           "note": "canonicalise_layer_kernel x2 per upload, snapshot buffers recycled (no hipMalloc in steady state)"}
+        # ... and once the map stream is being PLANNED on (the engine then knows a threshold pair): the same upload also leaves the
+        # search bit planes of the new snapshot behind — since round 5 written by the traversability layer's own ingest kernel
+        # (a ballot per destination row while the tile is in LDS), not by a second pass over the layer
+        try:
+            ing.params = planner.params.copy()
+            ing.plan(synth.poses_in_map(4, ir * 0.005, ic * 0.005, 2, 0.18, seed=3, margin=0.7), 2)  # registers (thrDefault, thrCandidate)
+            for _ in range(2):
+                ing.upload_map_device(src_t.data_ptr(), src_e.data_ptr(), ir, ic, 0.005, start_index=(1234, 321), storage_order="col", stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            i0.record(stream)
+            for _ in range(reps):
+                ing.upload_map_device(src_t.data_ptr(), src_e.data_ptr(), ir, ic, 0.005, start_index=(1234, 321), storage_order="col", stream=stream.cuda_stream)
+            i1.record(stream)
+            torch.cuda.synchronize()
+            ingp_ms = i0.elapsed_time(i1) / reps
+            line["ingest"]["with_bit_planes"] = {"ms": ingp_ms, "extra_ms_for_the_planes": ingp_ms - ing_ms,
+                                                 "note": "the same upload on an engine that has planned: bit planes {D, Df, C, F} of the new "
+                                                         "snapshot for the pair in use, built inside canonicalise_layer_kernel (round 4: a pass of "
+                                                         "its own, ~13 us for this map)"}
+        except Exception as e_:  # (never fails the bench line)
+            line["ingest"]["with_bit_planes"] = {"error": str(e_)[:200]}
         ing.close()
         del src_t, src_e
         # open-loop mode: one independent checkFoothold query per (leg, cycle, pose) unit —

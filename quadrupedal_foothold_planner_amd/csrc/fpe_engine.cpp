@@ -27,8 +27,8 @@ hipError_t launch_plan_chained(const DevMap& m, const PlanConsts& pc, const Spir
                                int B, int nCycles, const fpe_plan_out& d_out, hipStream_t stream);
 hipError_t launch_search_legs(const DevMap& m, const PlanConsts& pc, const SpiralLut& lut, const fpe_leg_query* d_q,
                               int n, fpe_foothold* d_out, hipStream_t stream);
-hipError_t launch_canonicalise(const float* d_src, float* d_dst, int rows, int cols, int si, int sj, int srcRowMajor,
-                               hipStream_t stream);
+hipError_t launch_canonicalise(const float* d_src, float* d_dst, int rows, int cols, int si, int sj, int srcRowMajor, hipStream_t stream,
+                               uint32_t* d_planeWords = nullptr, float thrDefault = 0.0f, float thrCandidate = 0.0f);
 hipError_t set_max_lds(size_t planBytes, size_t searchBytes);
 size_t plan_lds_bytes(const PlanConsts& pc);
 size_t search_lds_bytes(const PlanConsts& pc);
@@ -418,7 +418,9 @@ struct CallPlan {
 };
 
 // Bit planes of `snap` for a threshold pair: queued on `stream`, event recorded.  cleanOnly as in alloc_units.
-int build_mask(MapSnapshot& snap, float thrD, float thrC, hipStream_t stream, bool cleanOnly, std::shared_ptr<MaskSet>& out) {
+// fill false: the buffer only — the caller's canonicalising kernel writes the planes while the layer passes through it
+// (launch_canonicalise with d_planeWords) and then calls mask_ready.
+int alloc_mask(MapSnapshot& snap, float thrD, float thrC, bool cleanOnly, std::shared_ptr<MaskSet>& out) {
     auto ms = std::make_shared<MaskSet>();
     ms->thrD = thrD;
     ms->thrC = thrC;
@@ -427,6 +429,22 @@ int build_mask(MapSnapshot& snap, float thrD, float thrC, hipStream_t stream, bo
     float* buf = nullptr;
     FPE_HIP(alloc_units(*snap.pool, need, &buf, &ms->cap, cleanOnly));
     ms->d_words = reinterpret_cast<uint32_t*>(buf);
+    out = std::move(ms);
+    return FPE_OK;
+}
+int mask_ready(MaskSet& ms, hipStream_t stream) {
+    hipError_t e = hipEventCreateWithFlags(&ms.ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ms.ready, stream);
+    if (e != hipSuccess) {
+        ms.asyncUsed.store(true);  // the build may be queued: hand the buffer back dirty
+        return fail_hip(e, "bit-plane build");
+    }
+    return FPE_OK;
+}
+int build_mask(MapSnapshot& snap, float thrD, float thrC, hipStream_t stream, bool cleanOnly, std::shared_ptr<MaskSet>& out) {
+    std::shared_ptr<MaskSet> ms;
+    const int rc0 = alloc_mask(snap, thrD, thrC, cleanOnly, ms);
+    if (rc0 != FPE_OK) return rc0;
     hipError_t e = fpe::launch_build_bitmap(snap.d_trav, snap.g.rows, snap.g.cols, thrD, thrC, ms->d_words, stream);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ms->ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventRecord(ms->ready, stream);
@@ -538,8 +556,33 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
     if (!srcOnDevice && !canonical) {
         FPE_HIP(alloc_units(*h->pool, n, &staging, &stagingGuard.cap));
     }
+    // Threshold pairs the CURRENT snapshot was planned with: their bit planes are built here, on the upload's stream — the
+    // upload is the 10-20 Hz path that may take a recycled ("dirty") buffer behind a device synchronisation; the first plan on
+    // the new map then finds its planes and pays nothing (include/fpe.h: "plans never pay for it").  The FIRST pair's planes
+    // ride in the kernel that moves the traversability layer anyway (canonicalise_layer_kernel ballots every destination row it
+    // holds; round 5) whenever the layer goes through a kernel — message layout, or a device source (then the kernel replaces
+    // the device-to-device copy): no second pass over the layer.  Further pairs (rare) by build_bitmap_kernel.
+    std::vector<std::pair<float, float>> pairs;
+    {
+        std::shared_ptr<MapSnapshot> cur;
+        {
+            std::lock_guard<std::mutex> lk(h->mu);
+            cur = h->map;
+        }
+        if (cur) {
+            std::lock_guard<std::mutex> lk(cur->mu);
+            for (auto& ms : cur->masks) pairs.emplace_back(ms->thrD, ms->thrC);
+        }
+    }
+    std::shared_ptr<MaskSet> folded;
+    const bool travThroughKernel = !canonical || srcOnDevice;
+    if (!pairs.empty() && travThroughKernel && desc->rows < (1 << 24) - 2 && desc->cols < (1 << 24) - 64) {
+        rc = alloc_mask(*snap, pairs[0].first, pairs[0].second, false, folded);
+        if (rc != FPE_OK) return rc;
+    }
     for (int l = 0; l < 2; ++l) {
-        if (canonical) {
+        uint32_t* planeWords = (l == 0 && folded) ? folded->d_words : nullptr;
+        if (canonical && !planeWords) {
             FPE_HIP(hipMemcpyAsync(dst[l], src[l], n * sizeof(float),
                                    srcOnDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
         } else {
@@ -548,8 +591,9 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
                 FPE_HIP(hipMemcpyAsync(staging, src[l], n * sizeof(float), hipMemcpyHostToDevice, stream));
                 dsrc = staging;
             }
-            FPE_HIP(fpe::launch_canonicalise(dsrc, dst[l], desc->rows, desc->cols, desc->start_index[0],
-                                             desc->start_index[1], desc->storage_order, stream));
+            FPE_HIP(fpe::launch_canonicalise(dsrc, dst[l], desc->rows, desc->cols, desc->start_index[0], desc->start_index[1],
+                                             desc->storage_order, stream, planeWords, planeWords ? folded->thrD : 0.0f,
+                                             planeWords ? folded->thrC : 0.0f));
         }
         if (!srcOnDevice) FPE_HIP(hipStreamSynchronize(stream));  // host buffers may be freed on return
     }
@@ -557,37 +601,26 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
     // asynchronous; host-source uploads have been synchronised above, the event is then already complete)
     FPE_HIP(hipEventCreateWithFlags(&snap->ready, hipEventDisableTiming));
     FPE_HIP(hipEventRecord(snap->ready, stream));
-    // Bit planes for the threshold pairs the CURRENT snapshot was planned with, built here on the upload's stream: the
-    // upload is the 10-20 Hz path that may take a recycled ("dirty") buffer behind a device synchronisation; the first
-    // plan on the new map then finds its planes and pays nothing (include/fpe.h: "plans never pay for it").
-    {
-        std::shared_ptr<MapSnapshot> cur;
-        {
-            std::lock_guard<std::mutex> lk(h->mu);
-            cur = h->map;
-        }
-        if (cur) {
-            std::vector<std::pair<float, float>> pairs;
-            {
-                std::lock_guard<std::mutex> lk(cur->mu);
-                for (auto& ms : cur->masks) pairs.emplace_back(ms->thrD, ms->thrC);
-            }
-            for (auto& pr : pairs) {
-                std::shared_ptr<MaskSet> ms;
-                rc = build_mask(*snap, pr.first, pr.second, stream, false, ms);
-                if (rc != FPE_OK) return rc;
-                ms->lastUse.store(++snap->useClock);
-                snap->masks.push_back(std::move(ms));
-            }
-            // A host-buffer upload is synchronous already (the caller's arrays may be freed on return): it also waits for the
-            // planes it has just queued, so the snapshot it installs is COMPLETE and the first service call on the new map
-            // waits for nothing (bench.py service_latency_us: first_call_after_a_map was 16 us above steady_map — the plane
-            // build and its event on the call's critical path; the map stream is the 10-20 Hz path that can afford it).
-            if (!srcOnDevice && !pairs.empty()) {
-                FPE_HIP(hipStreamSynchronize(stream));
-                for (auto& ms : snap->masks) ms->readyDone.store(true, std::memory_order_release);
-            }
-        }
+    if (folded) {
+        rc = mask_ready(*folded, stream);
+        if (rc != FPE_OK) return rc;
+        folded->lastUse.store(++snap->useClock);
+        snap->masks.push_back(folded);
+    }
+    for (size_t k = folded ? 1 : 0; k < pairs.size(); ++k) {
+        std::shared_ptr<MaskSet> ms;
+        rc = build_mask(*snap, pairs[k].first, pairs[k].second, stream, false, ms);
+        if (rc != FPE_OK) return rc;
+        ms->lastUse.store(++snap->useClock);
+        snap->masks.push_back(std::move(ms));
+    }
+    // A host-buffer upload is synchronous already (the caller's arrays may be freed on return): it also waits for the planes it
+    // has just queued, so the snapshot it installs is COMPLETE and the first service call on the new map waits for nothing
+    // (bench.py service_latency_us: first_call_after_a_map was 16 us above steady_map — the plane build and its event on the
+    // call's critical path; the map stream is the 10-20 Hz path that can afford it).
+    if (!srcOnDevice && !snap->masks.empty()) {
+        FPE_HIP(hipStreamSynchronize(stream));
+        for (auto& ms : snap->masks) ms->readyDone.store(true, std::memory_order_release);
     }
     std::shared_ptr<MapSnapshot> old;
     {

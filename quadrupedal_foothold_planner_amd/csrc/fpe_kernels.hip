@@ -1927,9 +1927,39 @@ __global__ __launch_bounds__(256) void search_legs_kernel(DevMap m, PlanConsts p
 // LDS so that both the column-major reads and the row-major writes are coalesced (round 4: 32 x 32 tiles moved 128 bytes
 // per wavefront instruction and 3.95 TB/s on two 4000 x 4000 layers; 64 x 64 with sixteen loads in flight per thread 4.6,
 // 16-byte stores where the destination's rows allow them 4.7 — the plain wrapped copy of a row-major source runs at 4.5).
+// Bit planes of the canonical layer while it passes through (round 5; SURVEY 8(f) N1 + the planes of fpe_bits.hpp): with
+// `planes.words` set, every wavefront ballots the 64 columns of a destination row it holds anyway — lane = column — and lanes 0 / 1
+// store the row's two word groups {D, Df, C, F}: the separate pass of build_bitmap_kernel over the traversability layer (13 us for
+// 4000 x 4000) is gone.  Same predicates, same layout (bit_group_index) as build_bitmap_kernel; the buffer's padding is zeroed by the
+// caller.  T = 64 only (a wavefront = one tile row).
+struct CanonPlanes {
+    uint4* words;  // null: no planes
+    int strideW, nw;
+    float thrD, thrC;
+};
+template <int T>
+__device__ __forceinline__ void canon_plane_row(const CanonPlanes& pl, float v, bool in, int i, int rows, int jBase) {
+    static_assert(T == 64, "a wavefront ballots one tile row of 64 columns");
+    const bool fin = in && __builtin_isfinite(v);
+    const bool d = in && v < pl.thrD;  // raw compare: NaN -> false, -inf -> true (cpp:1653, 1736)
+    const bool c = fin && v < pl.thrC;
+    const unsigned long long bD = __ballot(d), bDf = __ballot(d && fin), bC = __ballot(c), bF = __ballot(fin);
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    if (lane < 2 && i < rows) {
+        const int w = jBase / 32 + lane;
+        if (w < pl.nw) {
+            uint4 o;
+            o.x = static_cast<unsigned>(bD >> (32 * lane));
+            o.y = static_cast<unsigned>(bDf >> (32 * lane));
+            o.z = static_cast<unsigned>(bC >> (32 * lane));
+            o.w = static_cast<unsigned>(bF >> (32 * lane));
+            pl.words[bit_group_index(i, w, pl.strideW)] = o;
+        }
+    }
+}
 template <int T>
 __global__ __launch_bounds__(256) void canonicalise_layer_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                                  int rows, int cols, int si, int sj, int srcRowMajor) {
+                                                                  int rows, int cols, int si, int sj, int srcRowMajor, CanonPlanes planes) {
     // T x T tiles, a wavefront instruction moves T consecutive floats of one source column / destination row (T = 64: 256
     // bytes); every thread has T * T / 256 loads in flight before the first LDS store
     __shared__ float t[T][T + 1];
@@ -1941,10 +1971,16 @@ __global__ __launch_bounds__(256) void canonicalise_layer_kernel(const float* __
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
             const int i = iBase + ty + kStep * q, j = jBase + tx;
-            if (i < rows && j < cols) {
+            const bool in = i < rows && j < cols;
+            float v = 0.0f;
+            if (in) {
                 int bi = i + si; if (bi >= rows) bi -= rows;
                 int bj = j + sj; if (bj >= cols) bj -= cols;
-                dst[static_cast<size_t>(i) * cols + j] = src[static_cast<size_t>(bi) * cols + bj];
+                v = src[static_cast<size_t>(bi) * cols + bj];
+                dst[static_cast<size_t>(i) * cols + j] = v;
+            }
+            if constexpr (T == 64) {
+                if (planes.words) canon_plane_row<T>(planes, v, in, i, rows, jBase);  // (wave-uniform branch; every lane ballots)
             }
         }
         return;
@@ -1964,6 +2000,15 @@ __global__ __launch_bounds__(256) void canonicalise_layer_kernel(const float* __
 #pragma unroll
     for (int q = 0; q < kPer; ++q) t[ty + kStep * q][tx] = v[q];
     __syncthreads();
+    if constexpr (T == 64) {
+        if (planes.words) {  // the tile once more, lane = column of a destination row (t[column][row]: conflict-free reads)
+#pragma unroll 4
+            for (int q = 0; q < kPer; ++q) {
+                const int r = ty + kStep * q, i = iBase + r, j = jBase + tx;
+                canon_plane_row<T>(planes, t[tx][r], i < rows && j < cols, i, rows, jBase);
+            }
+        }
+    }
 #ifndef FPE_CANON_SCALAR_STORE
     if ((cols & 3) == 0) {  // rows of the destination start 16-byte aligned: four columns per thread, one 16-byte store
         constexpr int kGroups = T / 4, kRowsPerPass = 256 / kGroups;
@@ -2053,13 +2098,26 @@ hipError_t launch_search_legs(const DevMap& m, const PlanConsts& pc, const Spira
     return hipGetLastError();
 }
 
+size_t bitmap_words(int rows, int cols, int* strideW, int* nw);  // fpe_bits.hpp (part two of this translation unit)
+// d_planeWords: also build the bit planes of the destination layer for (thrDefault, thrCandidate) — the buffer zeroed here first
+// (padding rows / word groups; recycled buffers are dirty) — or null.
 hipError_t launch_canonicalise(const float* d_src, float* d_dst, int rows, int cols, int si, int sj, int srcRowMajor,
-                               hipStream_t stream) {
+                               hipStream_t stream, uint32_t* d_planeWords, float thrDefault, float thrCandidate) {
 #ifndef FPE_CANON_TILE
 #define FPE_CANON_TILE 64
 #endif
+    CanonPlanes pl{nullptr, 0, 0, 0.0f, 0.0f};
+    if (d_planeWords) {
+        if (FPE_CANON_TILE != 64) return hipErrorInvalidValue;
+        const size_t units = bitmap_words(rows, cols, &pl.strideW, &pl.nw);
+        const hipError_t e = hipMemsetAsync(d_planeWords, 0, units * 4, stream);
+        if (e != hipSuccess) return e;
+        pl.words = reinterpret_cast<uint4*>(d_planeWords);
+        pl.thrD = thrDefault;
+        pl.thrC = thrCandidate;
+    }
     dim3 grid((cols + FPE_CANON_TILE - 1) / FPE_CANON_TILE, (rows + FPE_CANON_TILE - 1) / FPE_CANON_TILE);
-    hipLaunchKernelGGL(canonicalise_layer_kernel<FPE_CANON_TILE>, grid, dim3(256), 0, stream, d_src, d_dst, rows, cols, si, sj, srcRowMajor);
+    hipLaunchKernelGGL(canonicalise_layer_kernel<FPE_CANON_TILE>, grid, dim3(256), 0, stream, d_src, d_dst, rows, cols, si, sj, srcRowMajor, pl);
     return hipGetLastError();
 }
 

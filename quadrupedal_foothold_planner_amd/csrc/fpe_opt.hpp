@@ -849,7 +849,10 @@ __global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts 
 
 hipError_t launch_opt_track(const DevMap& m, const PlanConsts& pc, const OptConsts& oc, const fpe_pose* d_poses, int B, int nCycles,
                             const uint8_t* d_cycleOk, const fpe_opt_out& d_out, hipStream_t stream) {
-    if (B <= 64) hipLaunchKernelGGL(opt_track_kernel<8>, dim3(B), dim3(64 * 8), 0, stream, m, pc, oc, d_poses, B, nCycles, d_cycleOk, d_out);
+#ifndef FPE_OPT_W_SMALL
+#define FPE_OPT_W_SMALL 8
+#endif
+    if (B <= 64) hipLaunchKernelGGL(opt_track_kernel<FPE_OPT_W_SMALL>, dim3(B), dim3(64 * FPE_OPT_W_SMALL), 0, stream, m, pc, oc, d_poses, B, nCycles, d_cycleOk, d_out);
     else hipLaunchKernelGGL(opt_track_kernel<1>, dim3(B), dim3(64), 0, stream, m, pc, oc, d_poses, B, nCycles, d_cycleOk, d_out);
     return hipGetLastError();
 }

@@ -475,7 +475,7 @@ def test_bench_two_ranks_on_one_gpu(config, batch):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", config, "--batch", str(batch),
-                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--gather-every", "2"],
+                        "--steps", "3", "--warmup", "1", "--blocks", "2", "--no-cpu-baseline", "--gather-every", "2"],
                        env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
@@ -507,7 +507,7 @@ def test_bench_runs_its_exchange_through_rccl_in_a_one_rank_group(record):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "FPE_BENCH_SHARE_GPU"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--config", "headline", "--batch", "1024",
-                        "--steps", "7", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--gather-every", "3", "--exchange-record", record],
+                        "--steps", "7", "--warmup", "2", "--blocks", "1", "--no-cpu-baseline", "--no-extras", "--gather-every", "3", "--exchange-record", record],
                        env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
