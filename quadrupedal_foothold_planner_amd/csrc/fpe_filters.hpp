@@ -887,7 +887,10 @@ hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float*
             if (!kSecond && H == 9) FPE_RUNS(32, 32, 9);
             FPE_RUNS(32, 32, 0);
         }
-        if (tcode == 24) FPE_RUNS(32, 16, 0);
+        if (tcode == 24) {
+            if (H == 17) FPE_RUNS(32, 16, 17);  // the published windows (0.08 m) at 0.5 cm
+            FPE_RUNS(32, 16, 0);
+        }
         FPE_RUNS(16, 16, 0);
 #undef FPE_RUNS
     };
