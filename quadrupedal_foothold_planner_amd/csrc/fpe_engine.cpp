@@ -856,7 +856,10 @@ int filters_common(fpe_engine* h, const fpe_map_desc* desc, const fpe_filter_par
     // Nobody asked for the intermediate layers (device caller without a layer buffer, host caller without `layers`): the
     // two-launch chain that stores step_height and traversability only, traversability straight into the caller's buffer
     // when it is a device buffer.
-    const bool travOnly = !layers && fpe::filters_trav_only_ok(fc, g);
+    // (not when the caller's traversability buffer IS — or overlaps — the elevation buffer: the fused launch writes traversability
+    // tile by tile while its neighbours still read their halos; the layer-buffer path below writes scratch and copies afterwards)
+    const bool inPlace = onDevice && trav < elev + n && elev < trav + n;
+    const bool travOnly = !layers && !inPlace && fpe::filters_trav_only_ok(fc, g);
     if (travOnly) {
         float* d_step = nullptr;
         {

@@ -260,3 +260,16 @@ def test_filter_argument_errors(planner):
         planner.traversability_from_elevation(elev, 0.02, params=planner.filter_params(step_critical_cells=0))
     with pytest.raises(Exception):  # a halo of more cells than the stencil tables hold
         planner.traversability_from_elevation(elev, 0.001, params=planner.filter_params(step_first_radius=0.2))
+
+
+def test_traversability_written_over_the_elevation_buffer(planner):
+    """fpe_traversability_device with d_traversability == d_elevation (a caller recycling its layer): the chain must not read
+    halos its own stores have overwritten — the engine takes the path that writes scratch and copies afterwards."""
+    import torch
+    rows, cols, res = 200, 180, 0.02
+    _, elev = synth.rough_map(rows, cols, res, 77)
+    want = planner.traversability_from_elevation(elev, res)
+    d = torch.from_numpy(elev.copy()).cuda()
+    planner.traversability_device(d.data_ptr(), d.data_ptr(), rows, cols, res)
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy(), want, equal_nan=True)
