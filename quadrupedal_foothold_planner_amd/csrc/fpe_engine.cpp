@@ -1382,7 +1382,9 @@ int fpe_plan_service_opt(fpe_handle h, const fpe_params* params, const fpe_opt_p
         std::memset(&oout, 0, sizeof(oout));
         uint8_t gateFail = 255;
         oout.gate_fail_cycle = &gateFail;
-        oout.footholds = optf.data();
+        // (the track's records only when a product is made of them: a call that wants the gate's verdict alone spares the chain
+        // its heights — getFootholdMeanHeight on the gait-cycle submap, an elevation round trip per cycle — and its stores)
+        oout.footholds = (opt_msg || opt_report || centroid_report) ? optf.data() : nullptr;
         oout.cycles = opt_cycles;
         double rowsAfter[2] = {0.0, 0.0};
         oout.rows_after = rowsAfter;

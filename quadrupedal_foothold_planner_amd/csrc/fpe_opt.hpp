@@ -152,6 +152,8 @@ __device__ __forceinline__ double opt_violation(const double (&x)[8], const OptC
 }
 
 // wave-wide lexicographic minimum of (key, f, t): every lane ends with the winner
+// (round 5: four DPP exchanges inside a row of 16 and the rows' winners by v_readlane instead of the six bpermute rounds were
+// measured — correct, and SLOWER: one pose 160 -> 168 us; the lane reads' wait states cost more than the LDS round trips they save)
 __device__ __forceinline__ void opt_wave_min(double& key, double& f, unsigned& t) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -814,8 +816,13 @@ __global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts 
                 }
             }
             const bool commit = ((okMask[(cyc >> 6) & 3] >> (cyc & 63)) & 1ull) != 0ull;  // footholdValidation_ of the NOMINAL track (cpp:1323-1332)
-            const float zLane = opt_mean_height(g, sh.vals[leg], gm.g, m.elev, m.g.cols, gm.i0, gm.j0, myX, myY, pc.rf, pc.rf2, pc.h);  // on gaitMap_
-            const float z = __shfl(zLane, 16 * leg);
+            // (heights feed the footholds' z and nothing the chain reads later — getPolygonCenter's x uses x and y only: a caller
+            // that asked for no footholds, the service's gate-only call, skips the elevation round trip; uniform over the workgroup)
+            float z = 0.0f;
+            if (out.footholds) {
+                const float zLane = opt_mean_height(g, sh.vals[leg], gm.g, m.elev, m.g.cols, gm.i0, gm.j0, myX, myY, pc.rf, pc.rf2, pc.h);  // on gaitMap_
+                z = __shfl(zLane, 16 * leg);
+            }
             fh.x = myX;
             fh.y = myY;
             fh.z = z;
