@@ -52,16 +52,30 @@ def assert_layers_equal(eng, ora, max_ulp_cells=1e-4, slope_critical=1.0):
     same_normal = np.ones(eng["normal_z"].shape, bool)
     for name in ("normal_x", "normal_y", "normal_z"):
         d = ulps(eng[name], ora[name])
+        # (a unit normal's component is good to ~1e-12 ABSOLUTE on the steepest faces — the row-moment sums carry the face's height
+        # range inside the tile — which is below a float ulp for any component above 2e-5 and a few ulps of a component of 7e-6:
+        # campaign seed 3196309, one cell in 2.2e8, a 68-degree face, 3.6e-12 apart.  Components within 1e-11 of each other are
+        # the same component; nothing downstream can tell them apart: slope reads normal_z, roughness n^T A n.)
+        d = np.where(np.abs(eng[name].astype(np.float64) - ora[name].astype(np.float64)) <= 1e-11, np.minimum(d, 1), d)
         assert d[ok_n].max(initial=0) <= 1, f"{name}: {int((d[ok_n] > 1).sum())} cells differ by more than 1 float ulp (max {int(d[ok_n].max())})"
         same_normal &= (d == 0) | ~ok_n
     for name in _capi.FILTER_LAYERS:
         a, b = eng[name], ora[name]
         ok = ~np.isnan(a)
         d = ulps(a, b)
+        if name.startswith("normal_"):  # (the absolute floor of a unit normal's components, see above)
+            d = np.where(np.abs(a.astype(np.float64) - b.astype(np.float64)) <= 1e-11, np.minimum(d, 1), d)
         # (the weighted sum adds three layers that may each be one ulp off: two ulps; 1 map in ~10^4 of the campaign has such a cell)
         bar = 2 if name == "traversability" else 1
         chained = name in ("slope", "roughness", "traversability")
         strict = ok & same_normal if chained else ok
+        if chained:
+            # slope / roughness are float(1 - x / critical) with x good to an f64 ulp or two (device acos / sqrt / reciprocal against
+            # the host's): where x comes within 1e-9 of the critical value the float result is the remainder of a cancellation,
+            # and an f64 ulp of x is many float ulps of it (campaign seed 3103907: a slope value of 1e-10, 16 float ulps = 2e-16
+            # apart).  Values within 1e-15 of each other are the same value.
+            near = np.abs(a.astype(np.float64) - b.astype(np.float64)) <= 1e-15
+            d = np.where(near & ok, 0, d)
         assert d[strict].max(initial=0) <= bar, f"{name}: {int((d[strict] > bar).sum())} cells differ by more than {bar} float ulp (max {int(d[strict].max())})"
         loose = ok & ~same_normal
         if chained and loose.any():
