@@ -144,8 +144,19 @@ __device__ __forceinline__ bool moments_phase(char* ldsRaw, const MapGeom& g, co
     MomentA* const PA = reinterpret_cast<MomentA*>(ldsRaw + Lay::discBytes);
     MomentB* const PB = reinterpret_cast<MomentB*>(ldsRaw + Lay::discBytes + Lay::recBytes);
     disc_setup<true, TR, TC, H>(d, g, elev, ti0, tj0, r);
-    const float zf = d.tile[H * W + H];
-    const double z0 = zf == zf ? static_cast<double>(zf) : 0.0;
+    // z0, the elevation the prefix sums are taken about: a VALID cell near the tile's centre (the sums' cancellation grows with the
+    // square of the largest |z - z0| in the tile: the centre halves it against a corner, and a hole at one fixed cell must not
+    // leave z0 = 0 — a map at an altitude of 100 m would then sum squares of 10^4).  Every wavefront looks at the same 64 cells —
+    // the centre first, then a diagonal sweep through the interior — and takes the first valid one.
+    double z0 = 0.0;
+    {
+        const int lane = threadIdx.x & 63;
+        const int k = (lane * 37) % (TR * TC);  // lane 0 -> offset 0 = the centre; the others spread over the interior
+        const int rr = (TR / 2 + k / TC) % TR, cq = (TC / 2 + k % TC) % TC;
+        const float zs = d.tile[(H + rr) * W + H + cq];
+        const unsigned long long fin = __ballot(zs == zs);
+        if (fin != 0ull) z0 = static_cast<double>(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(zs), __builtin_ctzll(fin))));
+    }
     {   // prefix records over the tile's columns: wavefront = field group, lane = tile row
         const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
         if (lane < WR && grp < 4) {

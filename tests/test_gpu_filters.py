@@ -287,3 +287,19 @@ def test_traversability_written_over_the_elevation_buffer(planner):
     planner.traversability_device(d.data_ptr(), d.data_ptr(), rows, cols, res)
     torch.cuda.synchronize()
     assert np.array_equal(d.cpu().numpy(), want, equal_nan=True)
+
+
+def test_map_at_altitude_with_holes_where_the_tiles_take_their_reference(planner):
+    """The row-moment sums are taken about one elevation of the tile (z0).  A map 250 m above the origin — float elevations with
+    an ulp of 1.5e-5 m — whose cells at the tiles' centres and first interior cells are holes must still find a VALID reference
+    (z0 = 0 would sum squares of 6e4 and lose the normals); every layer against the oracle at the usual bar."""
+    rows, cols, res = 150, 140, 0.02
+    _, elev = synth.rough_map(rows, cols, res, 88)
+    elev = (elev + np.float32(250.0)).astype(np.float32)
+    elev[0::32, 0::16] = np.nan          # first interior cell of every 32 x 16 tile
+    elev[16::32, 8::16] = np.nan         # ... and its centre
+    elev[0::16, 0::16] = np.nan
+    elev[8::16, 8::16] = np.nan
+    _, layers = planner.traversability_from_elevation(elev, res, want_layers=True)
+    ora = fpo.traversability_filters(elev, res)
+    assert_layers_equal(layers, ora, max_ulp_cells=5e-3)
