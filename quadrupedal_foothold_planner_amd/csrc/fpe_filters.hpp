@@ -895,10 +895,8 @@ hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float*
 #undef FPE_RUNS
     };
     // 1. step heights (first window)
-    if (!launch_runs(std::false_type{}, rt.t1, rt.h1, rt.s1, d_elev, fc.stepFirstRadius)) {
-        if (travOnly) return hipErrorInvalidValue;  // (filter_step1_kernel writes L.stepHeight only, but keep the contract simple)
+    if (!launch_runs(std::false_type{}, rt.t1, rt.h1, rt.s1, d_elev, fc.stepFirstRadius))  // (the walking kernel writes L.stepHeight only: fine for travOnly too)
         hipLaunchKernelGGL(filter_step1_kernel, grid, block, disc_lds_bytes(rt.h1), stream, g, d_elev, L, fc.stepFirstRadius, rt.h1);
-    }
     // 2. normals + slope + roughness [+ second step window + weighted sum]
     bool stepDone = false;
     if (rt.tF) {

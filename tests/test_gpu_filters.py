@@ -264,6 +264,9 @@ def test_step_windows_with_members_on_the_circle(planner, res, r1, r2, pos):
     assert_layers_equal(layers, ora, max_ulp_cells=5e-3)
     for name in ("step_height", "step"):
         assert np.array_equal(layers[name], ora[name], equal_nan=True), f"{name}: not bit-identical"
+    # the chain without a layer buffer, whichever kernels the windows take (a first window on the walking kernel included)
+    only = planner.traversability_from_elevation(elev, res, position=pos, params=fp)
+    assert np.array_equal(only, layers["traversability"], equal_nan=True)
 
 
 def test_filter_argument_errors(planner):
