@@ -861,8 +861,11 @@ int filters_common(fpe_engine* h, const fpe_map_desc* desc, const fpe_filter_par
     const bool inPlace = onDevice && trav < elev + n && elev < trav + n;
     const bool travOnly = !layers && !inPlace && fpe::filters_trav_only_ok(fc, g);
     if (travOnly) {
-        float* d_step = nullptr;
+        float* d_trav = trav;
+        if (!onDevice) FPE_HIP(take(n, &d_trav));
         {
+            // the lock is held until the chain is QUEUED: a concurrent call on another stream swaps the scratch out through the
+            // pool (dirty: its next taker synchronises the device — which only covers work already queued)
             std::lock_guard<std::mutex> lk(h->filterMu);
             if (!(h->filterScratch && h->filterStream == stream && h->filterCap >= n)) {
                 if (h->filterScratch) h->pool->give(h->filterCap, h->filterScratch, true);
@@ -870,12 +873,9 @@ int filters_common(fpe_engine* h, const fpe_map_desc* desc, const fpe_filter_par
                 FPE_HIP(alloc_units(*h->pool, n, &h->filterScratch, &h->filterCap));
                 h->filterStream = stream;
             }
-            d_step = h->filterScratch;
+            const fpe::FilterLayers L{nullptr, nullptr, nullptr, nullptr, h->filterScratch, nullptr, nullptr, d_trav};
+            FPE_HIP(fpe::launch_filters(g, fc, d_elev, L, true, stream));
         }
-        float* d_trav = trav;
-        if (!onDevice) FPE_HIP(take(n, &d_trav));
-        const fpe::FilterLayers L{nullptr, nullptr, nullptr, nullptr, d_step, nullptr, nullptr, d_trav};
-        FPE_HIP(fpe::launch_filters(g, fc, d_elev, L, true, stream));
         if (!onDevice) {
             FPE_HIP(hipMemcpyAsync(trav, d_trav, n * sizeof(float), hipMemcpyDeviceToHost, stream));
             FPE_HIP(hipStreamSynchronize(stream));

@@ -306,3 +306,38 @@ def test_map_at_altitude_with_holes_where_the_tiles_take_their_reference(planner
     _, layers = planner.traversability_from_elevation(elev, res, want_layers=True)
     ora = fpo.traversability_filters(elev, res)
     assert_layers_equal(layers, ora, max_ulp_cells=5e-3)
+
+
+def test_concurrent_chains_on_two_streams_keep_their_step_heights_apart(planner):
+    """The traversability-only chain keeps its step_height scratch per stream; two host threads running chains of DIFFERENT maps on
+    two streams swap that scratch through the engine's pool.  Every result must be its own map's layer."""
+    import threading
+
+    import torch
+    rows, cols, res = 220, 200, 0.02
+    maps = [synth.rough_map(rows, cols, res, 101 + k)[1] for k in range(2)]
+    want = [planner.traversability_from_elevation(m, res) for m in maps]
+    errors = []
+
+    def worker(k):
+        try:
+            s = torch.cuda.Stream()
+            d_e = torch.from_numpy(maps[k]).cuda()
+            d_t = torch.empty_like(d_e)
+            torch.cuda.synchronize()
+            for it in range(40):
+                planner.traversability_device(d_e.data_ptr(), d_t.data_ptr(), rows, cols, res, stream=s.cuda_stream)
+                if it % 8 == 7:
+                    s.synchronize()
+                    if not np.array_equal(d_t.cpu().numpy(), want[k], equal_nan=True):
+                        errors.append(f"thread {k}, call {it}: not this map's layer")
+            s.synchronize()
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors[:3]
