@@ -28,7 +28,11 @@ for rows, res in MAPS:
     ms = timed(d_l.data_ptr())       # every layer stored (the caller passed a layer buffer): 4 B read + 32 B written per cell
     t = d_t.cpu().numpy()
     ms_t = timed(0)                   # traversability only: step_height and traversability stored (12 B per cell by layers)
-    if not np.array_equal(t, d_t.cpu().numpy(), equal_nan=True): print("MISMATCH between the two modes")
+    t2 = d_t.cpu().numpy()   # (the two chains route cells with a normal component at rounding level differently: a last bit may differ)
+    okc = ~np.isnan(t)
+    du = np.abs(t[okc].view(np.int32).astype(np.int64) - t2[okc].view(np.int32))
+    if not np.array_equal(np.isnan(t), np.isnan(t2)) or du.max(initial=0) > 2: print("MISMATCH between the two modes")
+    modes = f"the two chains' layers: {int((du != 0).sum())} of {int(okc.sum())} cells differ, by at most {int(du.max(initial=0))} float ulp"
     print(f"{rows}x{rows} @ {res} m: all layers {ms:.3f} ms per chain, {rows*rows/ms/1e6:.2f} Gcell/s, {36*rows*rows/ms/1e6:.1f} GB/s by layers (36 B/cell); "
           f"traversability only {ms_t:.3f} ms, {rows*rows/ms_t/1e6:.2f} Gcell/s, {12*rows*rows/ms_t/1e6:.1f} GB/s (12 B/cell); "
-          f"traversability mean {np.nanmean(t):.3f}, below 0.7: {np.nanmean(t < 0.7):.3f}, holes {np.isnan(t).mean():.4f}")
+          f"traversability mean {np.nanmean(t):.3f}, below 0.7: {np.nanmean(t < 0.7):.3f}, holes {np.isnan(t).mean():.4f}; {modes}")

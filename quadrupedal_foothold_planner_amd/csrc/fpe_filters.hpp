@@ -21,6 +21,15 @@
 
 namespace {
 
+#ifndef FPE_FUSED_WAVES
+#define FPE_FUSED_WAVES 6
+#endif
+#ifdef FPE_FUSED_TIMELINE  // measurement builds only (scratch/): per-workgroup clock marks of the fused kernel
+__device__ unsigned long long g_fusedTimeline[8192][16];
+#define FPE_TL_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_fusedTimeline[blockIdx.x][k] = wall_clock64(); } while (0)
+#else
+#define FPE_TL_MARK(k) do { } while (0)
+#endif
 constexpr int kFT = 16;        // tile edge of the disc stencils
 constexpr int kFilterMaxH = 24;  // largest halo the tables are sized for (e.g. r 0.115 m at 0.5 cm)
 
@@ -598,6 +607,7 @@ __device__ __forceinline__ void step_runs_phase(char* ldsRaw, const MapGeom& g, 
     // (with the per-axis distance tables: the on-circle offsets' tests below read them instead of recomputing two cell
     // positions per offset and cell)
     disc_setup<true, TR, TC, HS>(d, g, src, ti0, tj0, r);
+    if (kSecond) FPE_TL_MARK(8);
     const float ninf = -__builtin_huge_valf(), pinf = __builtin_huge_valf();
     for (int e = threadIdx.x; e < WR * TC; e += TR * TC) {  // 1. one run per (tile row, interior column)
         const int row = e / TC, c = e - row * TC;
@@ -629,6 +639,7 @@ __device__ __forceinline__ void step_runs_phase(char* ldsRaw, const MapGeom& g, 
         }
     }
     __syncthreads();
+    if (kSecond) FPE_TL_MARK(9);
     const int li = threadIdx.x / TC, lj = threadIdx.x % TC;
     const int i = ti0 + li, j = tj0 + lj;
     const float centre = d.tile[(li + H) * WC + lj + H];
@@ -657,6 +668,7 @@ __device__ __forceinline__ void step_runs_phase(char* ldsRaw, const MapGeom& g, 
                 if (w >= 0) fold(o, w);
             }
         }
+        if (kSecond) FPE_TL_MARK(10);
         // 3. the offsets on the circle, by the iterator's own tests: bounding box, and the squared axis distances of
         // disc_setup's tables (the difference of two cell positions, squared — CircleIterator::isInside's operands)
         const double r2 = r * r;
@@ -665,14 +677,38 @@ __device__ __forceinline__ void step_runs_phase(char* ldsRaw, const MapGeom& g, 
         const double* const dxRow = d.dx2 + li * D + H;
         const double* const dyRow = d.dy2 + lj * D + H;
         const float* const tc = d.tile + (li + H) * WC + lj + H;
-        for (int e = 0; e < sp.nEdge; ++e) {
-            const int o = shp[64 + e], oc = shp[96 + e];
-            const int ii = i + o, jj = j + oc;
-            const bool in = ii >= i0 && ii <= i1 && jj >= j0 && jj <= j1 && dxRow[o] + dyRow[oc] <= r2;
-            const float z = in ? tc[o * WC + oc] : __builtin_nanf("");
-            hi = max_skip_nan(hi, z);
-            if (kSecond) cnt += z > critDown ? 1 : 0;
-            else lo = min_skip_nan(lo, z);
+        // four offsets at a time: their table and tile reads issue together (one offset after the other the loop waited for
+        // three dependent LDS round trips each: 1.6 of a workgroup's 13.8 us at 2 cm); entries past nEdge are (0, 0) and masked
+        constexpr int kG = 4;
+        const auto edge_group = [&](int e0, auto&& offs) {
+            int o[kG], oc[kG];
+            double a[kG], b[kG];
+            float z[kG];
+#pragma unroll
+            for (int k = 0; k < kG; ++k) offs(e0 + k, o[k], oc[k]);
+#pragma unroll
+            for (int k = 0; k < kG; ++k) {
+                a[k] = dxRow[o[k]];
+                b[k] = dyRow[oc[k]];
+                z[k] = tc[o[k] * WC + oc[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < kG; ++k) {
+                const int ii = i + o[k], jj = j + oc[k];
+                const bool in = e0 + k < sp.nEdge && ii >= i0 && ii <= i1 && jj >= j0 && jj <= j1 && a[k] + b[k] <= r2;
+                const float zk = in ? z[k] : __builtin_nanf("");
+                hi = max_skip_nan(hi, zk);
+                if (kSecond) cnt += zk > critDown ? 1 : 0;
+                else lo = min_skip_nan(lo, zk);
+            }
+        };
+        static_assert(kStepMaxEdge % kG == 0, "the edge list is read in whole groups");
+        if constexpr (HS > 0) {  // (the offsets are scalars: kernel arguments at constant indices)
+#pragma unroll
+            for (int e0 = 0; e0 < kStepMaxEdge; e0 += kG)
+                if (e0 < sp.nEdge) edge_group(e0, [&](int e, int& o, int& oc) { o = sp.edgeR[e]; oc = sp.edgeC[e]; });
+        } else {
+            for (int e0 = 0; e0 < sp.nEdge; e0 += kG) edge_group(e0, [&](int e, int& o, int& oc) { o = shp[64 + e]; oc = shp[96 + e]; });
         }
     }
     hiOut = hi;
@@ -723,7 +759,7 @@ __global__ __launch_bounds__(TR * TC) void filter_step_runs_kernel(MapGeom g, co
 // (512-thread workgroups: three of them per CU — six wavefronts per SIMD, 80 registers; without the hint the allocator takes 88
 // and a third of the CU's wavefronts with them: 0.283 -> 0.341 ms at 1 cm)
 template <int H, int TR, int TC, int HS>
-__global__ __launch_bounds__(TR * TC) __attribute__((amdgpu_waves_per_eu(TR * TC == 512 ? 6 : 4))) void filter_fused_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double rN, double slopeCritical,
+__global__ __launch_bounds__(TR * TC) __attribute__((amdgpu_waves_per_eu(TR * TC == 512 ? FPE_FUSED_WAVES : 4))) void filter_fused_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double rN, double slopeCritical,
                                                             double roughCritical, double invSlopeCritical, double invRoughCritical, StepShape sN, double r2nd, int h2nd, StepShape s2, double stepCritical,
                                                             float critDown, int nCritical, int kStep, int travOnly, int tilesX, int nTiles) {
     extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
@@ -733,6 +769,13 @@ __global__ __launch_bounds__(TR * TC) __attribute__((amdgpu_waves_per_eu(TR * TC
     const int i = ti0 + static_cast<int>(threadIdx.x) / TC, j = tj0 + static_cast<int>(threadIdx.x) % TC;
     const bool live = i < g.rows && j < g.cols;
     float stepOut = 0.0f;
+    FPE_TL_MARK(0);
+#ifdef FPE_FUSED_TIMELINE
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        g_fusedTimeline[blockIdx.x][6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+        g_fusedTimeline[blockIdx.x][7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    }
+#endif
     if (kStep) {
         float hi, lo, centre;
         int cnt;
@@ -740,8 +783,9 @@ __global__ __launch_bounds__(TR * TC) __attribute__((amdgpu_waves_per_eu(TR * TC
         stepOut = step_value(hi, cnt, stepCritical, nCritical);
         __syncthreads();  // the moment phase reuses the LDS
     }
+    FPE_TL_MARK(1);
     float ox, oy, oz, os, orough;
-    const bool needWalk = moments_phase<H, TR, TC>(ldsRaw, g, elev, ti0, tj0, rN, sN, slopeCritical, roughCritical, invSlopeCritical, invRoughCritical, live, ox,
+    const bool needWalk = moments_phase<H, TR, TC>(ldsRaw, g, elev, ti0, tj0, rN, travOnly == 0, sN, slopeCritical, roughCritical, invSlopeCritical, invRoughCritical, live, ox,
                                                    oy, oz, os, orough);
     if (live && !needWalk) {
         const size_t cell = static_cast<size_t>(i) * g.cols + j;
@@ -758,8 +802,10 @@ __global__ __launch_bounds__(TR * TC) __attribute__((amdgpu_waves_per_eu(TR * TC
         }
     }
     if (live && kStep && !travOnly) L.step[static_cast<size_t>(i) * g.cols + j] = stepOut;
+    FPE_TL_MARK(2);
     // the cells that take the literal walks (rank-deficient scatter, components at rounding level): a phase of their own
     walk_phase<H, TR, TC>(ldsRaw, g, L, sN, ti0, tj0, rN, slopeCritical, roughCritical, needWalk, stepOut, kStep, travOnly);
+    FPE_TL_MARK(3);
 }
 
 __host__ inline int filter_halo(double r, double res) { return static_cast<int>(r / res) + 1; }

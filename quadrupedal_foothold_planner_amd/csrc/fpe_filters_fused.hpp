@@ -88,7 +88,7 @@ __device__ __forceinline__ double acos_unit(double x) {
 // the workgroup's walking phase (walk_phase below).
 __device__ __forceinline__ bool normals_from_moments(const MapGeom& g, double slopeCritical, double roughCritical, double invSlopeCritical,
                                                      double invRoughCritical, int N, int Sc, int Scc, int Sv, int Svv, int Svc, double Sz, double Szz, double Scz,
-                                                     double Svz, float& ox, float& oy, float& oz, float& os, float& orough) {
+                                                     double Svz, bool normalsStored, float& ox, float& oy, float& oz, float& os, float& orough) {
     const double nd = static_cast<double>(N);
     const double invN = rcp_refined(nd);
     const double Avv = static_cast<double>(N * Svv - Sv * Sv) * invN, Acc = static_cast<double>(N * Scc - Sc * Sc) * invN;
@@ -113,8 +113,15 @@ __device__ __forceinline__ bool normals_from_moments(const MapGeom& g, double sl
     // depend on the order of operations).  With the usual gap of 0.25 that is a component below 4e-7.  A wavefront walks when
     // ANY of its 64 cells asks for it and a walk is some thirty times a cell's usual work, so the product is as low as the
     // arithmetic allows (at 3e-7: 1.3e-4 of the synthetic terrain's cells, a fifth of the chain's time).
+    // normalsStored false (the traversability-only chain): nobody reads the x and y components.  Slope and roughness see the
+    // eigenvector's error at SECOND order (the z component of a near-vertical normal; n^T A n about its minimiser) or, on a steep
+    // face, at dv = 1e-13 / gap against the z component's float ulp of 3e-8 — the small-component rule has nothing to protect, and
+    // the cells it sends to the walks (symmetric neighbourhoods beside the synthetic terrain's risers: 9 us of the chain's 65 at
+    // 2 cm, 32 of 300 at 1 cm, all of it the tail of the few workgroups that hold such a cell) stay on the moment path.  A gap
+    // below 1e-4 is a genuine degeneracy (members on a line): the oracle's normal is then decided by its own rounding — walk.
     const double cMin = fmin(fmin(fabs(ex), fabs(ey)), fabs(ez));
-    if (walk || !(eigS > 1e-10 * eigL) || !(cMin * fmin(gapRel, 0.3) > 1e-7)) return true;
+    if (walk || !(eigS > 1e-10 * eigL)) return true;
+    if (normalsStored ? !(cMin * fmin(gapRel, 0.3) > 1e-7) : !(gapRel > 1e-4)) return true;
     {
         ox = static_cast<float>(ex);
         oy = static_cast<float>(ey);
@@ -133,7 +140,7 @@ __device__ __forceinline__ bool normals_from_moments(const MapGeom& g, double sl
 // The moment phase of one tile: tables and source tile (disc_setup, one barrier), the prefix records (one barrier), then the
 // calling thread's cell.  `live`: the thread's cell is inside the map (every thread takes part in the barriers).
 template <int H, int TR, int TC>
-__device__ __forceinline__ bool moments_phase(char* ldsRaw, const MapGeom& g, const float* __restrict__ elev, int ti0, int tj0, double r,
+__device__ __forceinline__ bool moments_phase(char* ldsRaw, const MapGeom& g, const float* __restrict__ elev, int ti0, int tj0, double r, bool normalsStored,
                                               const StepShape& sp, double slopeCritical, double roughCritical, double invSlopeCritical,
                                               double invRoughCritical, bool live, float& ox, float& oy, float& oz, float& os, float& orough) {
     using Lay = FusedLayout<H, TR, TC>;
@@ -144,6 +151,7 @@ __device__ __forceinline__ bool moments_phase(char* ldsRaw, const MapGeom& g, co
     MomentA* const PA = reinterpret_cast<MomentA*>(ldsRaw + Lay::discBytes);
     MomentB* const PB = reinterpret_cast<MomentB*>(ldsRaw + Lay::discBytes + Lay::recBytes);
     disc_setup<true, TR, TC, H>(d, g, elev, ti0, tj0, r);
+    FPE_TL_MARK(11);
     // z0, the elevation the prefix sums are taken about: a VALID cell near the tile's centre (the sums' cancellation grows with the
     // square of the largest |z - z0| in the tile: the centre halves it against a corner, and a hole at one fixed cell must not
     // leave z0 = 0 — a map at an altitude of 100 m would then sum squares of 10^4).  Every wavefront looks at the same 64 cells —
@@ -189,6 +197,7 @@ __device__ __forceinline__ bool moments_phase(char* ldsRaw, const MapGeom& g, co
         }
     }
     __syncthreads();
+    FPE_TL_MARK(12);
     const int li = threadIdx.x / TC, lj = threadIdx.x % TC;
     const int i = ti0 + li, j = tj0 + lj;
     const float nanf = __builtin_nanf("");
@@ -249,11 +258,12 @@ __device__ __forceinline__ bool moments_phase(char* ldsRaw, const MapGeom& g, co
         Scz += cz;
         Svz += static_cast<double>(o) * z;
     }
+    FPE_TL_MARK(13);
     const int N = static_cast<int>(AnC & 0xFFFFu), SC = static_cast<int>(AnC >> 16);
     const int Sc = SC - cc * N;
     const int Scc = static_cast<int>(ACC) - 2 * cc * SC + cc * cc * N;
     const int Svc = SvC - cc * Sv;
-    return normals_from_moments(g, slopeCritical, roughCritical, invSlopeCritical, invRoughCritical, N, Sc, Scc, Sv, Svv, Svc, Sz, Szz, Scz, Svz, ox, oy, oz, os, orough);
+    return normals_from_moments(g, slopeCritical, roughCritical, invSlopeCritical, invRoughCritical, N, Sc, Scc, Sv, Svv, Svc, Sz, Szz, Scz, Svz, normalsStored, ox, oy, oz, os, orough);
 }
 
 // The cell's iterator walk with the rows' column intervals taken from the lattice shape — the robust half-width of step_shape
@@ -367,6 +377,9 @@ template <int H, int TR, int TC>
 __device__ __forceinline__ void walk_phase(char* ldsRaw, const MapGeom& g, const FilterLayers& L, const StepShape& sp, int ti0, int tj0, double r,
                                            double slopeCritical, double roughCritical, bool needWalk, float stepOut, int kStep, int travOnly) {
     using Lay = FusedLayout<H, TR, TC>;
+#ifdef FPE_NO_WALK  // (measurement builds only: what the kernel costs without its walking phase)
+    return;
+#endif
     if (!__syncthreads_or(needWalk ? 1 : 0)) return;  // (also: every thread is done with the prefix records)
     const DiscLds d = disc_carve(ldsRaw, H, TR, TC);
     int* const count = reinterpret_cast<int*>(ldsRaw + Lay::discBytes);

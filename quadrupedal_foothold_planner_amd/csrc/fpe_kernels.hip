@@ -2158,3 +2158,9 @@ hipError_t set_max_lds(size_t planBytes, size_t searchBytes) {
 }
 
 }  // namespace fpe
+
+#ifdef FPE_FUSED_TIMELINE
+extern "C" int fpe_debug_timeline(void* out, size_t bytes) {
+    return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(fpe::g_fusedTimeline), bytes));
+}
+#endif
