@@ -24,6 +24,9 @@ namespace {
 #ifndef FPE_FUSED_WAVES
 #define FPE_FUSED_WAVES 6
 #endif
+#ifndef FPE_FUSED_WAVES_2CM  // the published chain at 2 cm: four workgroups per CU (64 registers, 21 dwords of scratch in the walk phase): 0.056 -> 0.053 ms; at 1 cm the same trade loses (0.274 -> 0.278)
+#define FPE_FUSED_WAVES_2CM 8
+#endif
 #ifdef FPE_FUSED_TIMELINE  // measurement builds only (scratch/): per-workgroup clock marks of the fused kernel
 __device__ unsigned long long g_fusedTimeline[8192][16];
 #define FPE_TL_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_fusedTimeline[blockIdx.x][k] = wall_clock64(); } while (0)
@@ -759,7 +762,7 @@ __global__ __launch_bounds__(TR * TC) void filter_step_runs_kernel(MapGeom g, co
 // (512-thread workgroups: three of them per CU — six wavefronts per SIMD, 80 registers; without the hint the allocator takes 88
 // and a third of the CU's wavefronts with them: 0.283 -> 0.341 ms at 1 cm)
 template <int H, int TR, int TC, int HS>
-__global__ __launch_bounds__(TR * TC) __attribute__((amdgpu_waves_per_eu(TR * TC == 512 ? FPE_FUSED_WAVES : 4))) void filter_fused_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double rN, double slopeCritical,
+__global__ __launch_bounds__(TR * TC) __attribute__((amdgpu_waves_per_eu(TR * TC == 512 ? ((H == 3 && HS == 5) ? FPE_FUSED_WAVES_2CM : FPE_FUSED_WAVES) : 4))) void filter_fused_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double rN, double slopeCritical,
                                                             double roughCritical, double invSlopeCritical, double invRoughCritical, StepShape sN, double r2nd, int h2nd, StepShape s2, double stepCritical,
                                                             float critDown, int nCritical, int kStep, int travOnly, int tilesX, int nTiles) {
     extern __shared__ __attribute__((aligned(16))) char ldsRaw[];

@@ -2164,3 +2164,8 @@ extern "C" int fpe_debug_timeline(void* out, size_t bytes) {
     return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(fpe::g_fusedTimeline), bytes));
 }
 #endif
+#ifdef FPE_OPT_TRACE
+extern "C" int fpe_debug_opt_trace(void* out, size_t bytes) {
+    return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(fpe::g_optTrace), bytes));
+}
+#endif

@@ -173,8 +173,7 @@ struct OptBest {
 };
 // The optimiser's problem of one cycle as wavefront 0 publishes it to the helper wavefronts (W > 1).
 struct OptProblem {
-    int run;  // 1: search the rows; 0: nothing to search in this cycle; -1: the track has stopped for good
-    int pad;
+    int pad[2];
     int nIdx[8], cIdx[8], lo[8], up[8];
     double x[8];  // start point with the columns already decided
     double lfRow, rhRow;
@@ -193,18 +192,30 @@ __device__ __forceinline__ void divmod_lattice(int t, int d, float dinv, int& q,
 }
 
 // oracle/fpo_opt.cpp::solveLattice, first part (one wavefront): start x = x0 = centroidIndex (cpp:1180-1183), NLopt's
-// precondition (status 1), the four column variables.  Returns -1 when the row search is to run, else the final status.
-__device__ int opt_solve_begin(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8],
-                               double lfRow, double rhRow, int lane, double (&x)[8], double& minf) {
-    const double inf = __builtin_huge_val();
+// precondition (status 1) and the size of the row lattice (status 3) — both known from the bounds alone, before any search:
+// -1 when the row search is to run (the helper wavefronts can be told at once), else the final status.
+__device__ int opt_solve_check(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8],
+                               double lfRow, double rhRow, double (&x)[8], double& minf) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] = cIdx[k];
-    minf = opt_objective(x, oc, nIdx, cIdx, lfRow, rhRow);
+    minf = 0.0;
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < 8; ++k) bad = bad || lo[k] > up[k] || x[k] < lo[k] || x[k] > up[k];
-    if (bad) return 1;
-    // columns x[1], x[3], x[5], x[7]: each the minimiser of the objective over its interval, smallest integer on ties
+    if (bad) {
+        minf = opt_objective(x, oc, nIdx, cIdx, lfRow, rhRow);
+        return 1;
+    }
+    const double points = static_cast<double>(up[0] - lo[0] + 1) * static_cast<double>(up[2] - lo[2] + 1) *
+                          static_cast<double>(up[4] - lo[4] + 1) * static_cast<double>(up[6] - lo[6] + 1);
+    if (points > static_cast<double>(kMaxLatticePoints)) return 3;
+    return -1;
+}
+// ... the four column variables x[1], x[3], x[5], x[7] (statuses -1 and 3): each the minimiser of the objective over its
+// interval with the others where they stand, smallest integer on ties; one after the other.
+__device__ void opt_solve_columns(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8],
+                                  double lfRow, double rhRow, int lane, double (&x)[8]) {
+    const double inf = __builtin_huge_val();
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         constexpr int kk[4] = {1, 3, 5, 7};
@@ -222,78 +233,91 @@ __device__ int opt_solve_begin(const OptConsts& oc, const int (&nIdx)[8], const 
         opt_wave_min(key, bestF, bestV);
         x[k] = lo[k] + static_cast<int>(bestV);
     }
-    minf = opt_objective(x, oc, nIdx, cIdx, lfRow, rhRow);
-    const double points = static_cast<double>(up[0] - lo[0] + 1) * static_cast<double>(up[2] - lo[2] + 1) *
-                          static_cast<double>(up[4] - lo[4] + 1) * static_cast<double>(up[6] - lo[6] + 1);
-    if (points > static_cast<double>(kMaxLatticePoints)) return 3;
-    return -1;
 }
 
-// Second part, on every wavefront of the workgroup: row points (x[0], x[2], x[4], x[6]) = lo + (a, b, c, d), enumeration
-// index t = ((a n2 + b) n4 + c) n6 + d.  Wavefront w takes the (a, b) pairs w, w + W, ..., its lanes the (c, d) pairs;
-// per lane t only grows, so "strictly better" keeps the first of equals, and the reduction orders by (violation,
-// objective, t): the lexicographically first minimum, as the oracle's nested loops find it.
-// The same search with the objective and the constraints taken apart by what they depend on (round 4): every f64 operation
-// below is one of the reference's expression, on the same operands, in the same order — a point's objective is
-//   ((w1 * S1 + w2 * S2) + w3 * (Uab + Ucd)) + w4 * (V1 + V2),   S = ((((((A0 + C1) + A2) + C3) + A4) + C5) + A6) + C7
-// (cpp:61-72, left to right) — but the sub-expressions of (x0, x2) alone are evaluated once per (a, b) pair and those of
-// (x4, x6) alone once per LANE (a lane keeps its one or two (c, d) pairs for the whole search): 31 operations per point
-// instead of ~110, and the values are bit for bit the ones opt_objective / opt_violation return (tests/test_gpu_opt.py).
-// Boxes with more than 128 (c, d) pairs take the plain loop (opt_solve_rows_plain).
-template <int W>
 __device__ OptBest opt_solve_rows_plain(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8],
-                                        double lfRow, double rhRow, int lane, int wave, const double (&x)[8]);
+                                        double lfRow, double rhRow, int lane, int slice, int nSearch, const double (&x)[8]);
 constexpr int kOptListCap = 1024;  // surviving points a wavefront lists (LDS, 4 bytes each); more: every point is searched
-// LDS of the listed search: the lists (one per wavefront) and, for W > 1, what the wavefronts tell each other about their
-// share of the Dab values (per lane and (c, d) slot: smallest violation, mask of the values that attain it)
+// LDS of the listed search: the lists (one per searching wavefront) and, for W > 1, what the wavefronts tell each other about
+// their share of the Dab values (per lane and (c, d) slot: smallest violation, mask of the values that attain it)
 template <int W>
 struct OptListLds {
     unsigned list[W][W == 1 ? kOptListCap : kOptListCap / 4];
     double partMin[W == 1 ? 1 : W][W == 1 ? 1 : 2][W == 1 ? 1 : 64];
     unsigned long long partGood[W == 1 ? 1 : W][W == 1 ? 1 : 2][W == 1 ? 1 : 64];
 };
+// Wavefronts of one workgroup meeting WITHOUT the workgroup barrier (round 5): a counter in LDS every arriving wavefront adds
+// one to, and a wait for it to reach a target that only grows (nothing is ever reset: no race on re-use).  The waves of a
+// workgroup are resident together, so the wait cannot starve what it waits for; s_sleep keeps the poll off the SIMD's issue
+// slots.  Release before the add / acquire after the wait order the LDS stores around it.
+__device__ __forceinline__ void opt_arrive(int* cnt, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void opt_publish(int* seq, int value, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(seq, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void opt_wait_ge(int* cnt, int target) {
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// What a wavefront carries from the row search's first part (the bounds and the rows: everything but the objective) to its
+// second (the columns decided).
+struct OptRowsState {
+    int mode;   // 0: the listed search (count entries in the wavefront's list); 1: every point, (c, d) pairs in the lanes' slots; 2: the plain loop
+    int count;
+    double minKey;
+    bool live[2], feasCD[2];
+    double A4n[2], A4c[2], A6n[2], A6c[2], Dcd[2], Ucd[2], hcd[2], V2[2], rmCD[2];
+};
+// First part of the row search: nothing here reads the column variables, so the helper wavefronts of a W > 1 workgroup run it
+// WHILE wavefront 0 decides the columns (round 5; before, they waited for the columns and the whole search followed them).
+// slice / nSearch: this wavefront's share (k = slice, slice + nSearch, ...) among the nSearch searching wavefronts;
+// meet / meets: their meeting point for the exchange of the Dab shares (nSearch > 1) and how often this wavefront has met there.
 template <int W>
-__device__ OptBest opt_solve_rows(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8],
-                                  double lfRow, double rhRow, int lane, int wave, const double (&x)[8], OptListLds<W>* ll = nullptr) {
+__device__ __forceinline__ void opt_rows_prepare(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8], double lfRow,
+                                 double rhRow, int lane, int slice, int nSearch, OptListLds<W>* ll, int* meet, int& meets, OptRowsState& st) {
     const double inf = __builtin_huge_val();
     const int n0 = up[0] - lo[0] + 1, n2 = up[2] - lo[2] + 1, n4 = up[4] - lo[4] + 1, n6 = up[6] - lo[6] + 1;
     const int nAB = n0 * n2, nCD = n4 * n6;
     constexpr int kSlots = 2;
-    if (nCD > 64 * kSlots) return opt_solve_rows_plain<W>(oc, nIdx, cIdx, lo, up, lfRow, rhRow, lane, wave, x);
-    const double w1 = oc.w1, w2 = oc.w2, w3 = oc.w3, w4 = oc.w4, wr = oc.wr, wc = oc.wc;
+    st.count = 0;
+    st.minKey = 0.0;
+    if (nCD > 64 * kSlots) {
+        st.mode = 2;  // (uniform over the workgroup — every wavefront is given the same problem — like every early return below: nobody is left waiting at the exchange)
+        return;
+    }
+    st.mode = 1;
+    const double wr = oc.wr;
     const double L = oc.lbOverRes, K = oc.skew2OverRes;  // lengthBase/mapResolution, 2*skew/mapResolution
     const double t1 = oc.t1, t2 = oc.t2, t3 = oc.t3, t4 = oc.t4, ctol = oc.ctol;
     const double dlr = fabs(lfRow - rhRow), hlr = 0.5 * dlr;  // abs(lfCurrentRow - rhCurrentRow), 0.5*abs(...)
-    // column terms (the columns are decided: opt_solve_begin)
-    const double C1n = wc * fabs(x[1] - nIdx[1]), C3n = wc * fabs(x[3] - nIdx[3]), C5n = wc * fabs(x[5] - nIdx[5]), C7n = wc * fabs(x[7] - nIdx[7]);
-    const double C1c = wc * fabs(x[1] - cIdx[1]), C3c = wc * fabs(x[3] - cIdx[3]), C5c = wc * fabs(x[5] - cIdx[5]), C7c = wc * fabs(x[7] - cIdx[7]);
     // this lane's (c, d) pairs
     const float n6Inv = rcp_small(n6), n2Inv = rcp_small(n2);
-    bool live[kSlots], feasCD[kSlots];
-    double A4n[kSlots], A4c[kSlots], A6n[kSlots], A6c[kSlots], Dcd[kSlots], Ucd[kSlots], hcd[kSlots], V2[kSlots], rmCD[kSlots];
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) {
         const int cd = lane + 64 * s;
-        live[s] = cd < nCD;
+        st.live[s] = cd < nCD;
         int c, d;
-        divmod_lattice(live[s] ? cd : 0, n6, n6Inv, c, d);
+        divmod_lattice(st.live[s] ? cd : 0, n6, n6Inv, c, d);
         const double y4 = lo[4] + c, y6 = lo[6] + d;
-        A4n[s] = wr * fabs(y4 - nIdx[4]);
-        A4c[s] = wr * fabs(y4 - cIdx[4]);
-        A6n[s] = wr * fabs(y6 - nIdx[6]);
-        A6c[s] = wr * fabs(y6 - cIdx[6]);
-        Dcd[s] = fabs(y4 - y6);
-        Ucd[s] = fabs(Dcd[s] - L);
-        hcd[s] = 0.5 * Dcd[s];
-        V2[s] = fabs(fabs(hcd[s] - hlr) - K);
-        const double c3 = t1 - Dcd[s], c4 = Dcd[s] - t2, G = 0.5 * fabs(Dcd[s] - dlr), c7 = t3 - G, c8 = G - t4;
-        feasCD[s] = c3 <= ctol && c4 <= ctol && c7 <= ctol && c8 <= ctol;
+        st.A4n[s] = wr * fabs(y4 - nIdx[4]);
+        st.A4c[s] = wr * fabs(y4 - cIdx[4]);
+        st.A6n[s] = wr * fabs(y6 - nIdx[6]);
+        st.A6c[s] = wr * fabs(y6 - cIdx[6]);
+        st.Dcd[s] = fabs(y4 - y6);
+        st.Ucd[s] = fabs(st.Dcd[s] - L);
+        st.hcd[s] = 0.5 * st.Dcd[s];
+        st.V2[s] = fabs(fabs(st.hcd[s] - hlr) - K);
+        const double c3 = t1 - st.Dcd[s], c4 = st.Dcd[s] - t2, G = 0.5 * fabs(st.Dcd[s] - dlr), c7 = t3 - G, c8 = G - t4;
+        st.feasCD[s] = c3 <= ctol && c4 <= ctol && c7 <= ctol && c8 <= ctol;
         double rm = 0.0;
         rm = c3 > rm ? c3 : rm;
         rm = c4 > rm ? c4 : rm;
         rm = c7 > rm ? c7 : rm;
         rm = c8 > rm ? c8 : rm;
-        rmCD[s] = rm;
+        st.rmCD[s] = rm;
     }
     // ---- the points that can win, listed (round 4) ----
     // The search orders points by (violation, objective, index), and the violation depends on a point only through
@@ -303,132 +327,167 @@ __device__ OptBest opt_solve_rows(const OptConsts& oc, const int (&nIdx)[8], con
     // has no feasible point and the smallest violation is attained along a curve of (Dab, Dcd) combinations: 1.5-4 % of the
     // box — but they are spread over most (a, b) pairs, one to six lanes each (profiles/round4_opt_stage_trace.txt), so the
     // wavefront LISTS them (ballot prefix into LDS: integer work only) and evaluates the objective on the list, 64 points at
-    // a time, with the same expressions on the same operands: the same winner, bit for bit.  Longer lists than kOptListCap
-    // (feasible problems: the whole band of violation 0), boxes with more than 64 values of Dab or 128 (c, d) pairs, and the
-    // eight-wavefront form search every point as before.
-    if (ll != nullptr && oc.useConstraints) {  // (uniform over the workgroup: every wavefront searches the same problem)
-        unsigned* list = ll->list[wave];
-        constexpr int kCap = W == 1 ? kOptListCap : kOptListCap / 4;
-        const int dLo = lo[0] - up[2], dHi = up[0] - lo[2];  // x0 - x2 takes every integer of [dLo, dHi]
-        const int dMin = (dLo <= 0 && dHi >= 0) ? 0 : min(abs(dLo), abs(dHi)), dMax = max(abs(dLo), abs(dHi));
-        const int nD = dMax - dMin + 1;
-        if (nD <= 64 && nAB <= 0xFFFF) {
-            double myMin[kSlots];
-            unsigned long long good[kSlots];
+    // a time, with the same expressions on the same operands: the same winner, bit for bit.  Longer lists than the cap
+    // (feasible problems: the whole band of violation 0), boxes with more than 64 values of Dab or 128 (c, d) pairs search
+    // every point.
+    if (ll == nullptr || !oc.useConstraints) return;  // (uniform over the workgroup: every wavefront searches the same problem)
+    unsigned* list = ll->list[slice];
+    constexpr int kCap = W == 1 ? kOptListCap : kOptListCap / 4;
+    const int dLo = lo[0] - up[2], dHi = up[0] - lo[2];  // x0 - x2 takes every integer of [dLo, dHi]
+    const int dMin = (dLo <= 0 && dHi >= 0) ? 0 : min(abs(dLo), abs(dHi)), dMax = max(abs(dLo), abs(dHi));
+    const int nD = dMax - dMin + 1;
+    if (!(nD <= 64 && nAB <= 0xFFFF)) return;
+    double myMin[kSlots];
+    unsigned long long good[kSlots];
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s) {
-                myMin[s] = inf;
-                good[s] = 0ull;
-            }
-            for (int k = wave; k < nD; k += W) {  // (W > 1: this wavefront's share of the values; exchanged below)
-                const double Dab = dMin + k;
-                const double c1 = t1 - Dab, c2 = Dab - t2;
-                const bool feasAB = c1 <= ctol && c2 <= ctol;
-                double rmAB = 0.0;
-                rmAB = c1 > rmAB ? c1 : rmAB;
-                rmAB = c2 > rmAB ? c2 : rmAB;
+    for (int s = 0; s < kSlots; ++s) {
+        myMin[s] = inf;
+        good[s] = 0ull;
+    }
+    for (int k = slice; k < nD; k += nSearch) {  // (nSearch > 1: this wavefront's share of the values; exchanged below)
+        const double Dab = dMin + k;
+        const double c1 = t1 - Dab, c2 = Dab - t2;
+        const bool feasAB = c1 <= ctol && c2 <= ctol;
+        double rmAB = 0.0;
+        rmAB = c1 > rmAB ? c1 : rmAB;
+        rmAB = c2 > rmAB ? c2 : rmAB;
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) {
-                    const double E = 0.5 * fabs(Dab - Dcd[s]), c5 = t3 - E, c6 = E - t4;
-                    const bool feasible = feasAB && feasCD[s] && c5 <= ctol && c6 <= ctol;
-                    double rm = rmAB;
-                    rm = rmCD[s] > rm ? rmCD[s] : rm;
-                    rm = c5 > rm ? c5 : rm;
-                    rm = c6 > rm ? c6 : rm;
-                    const double key = feasible ? 0.0 : rm;
-                    if (live[s]) {
-                        if (key < myMin[s]) {
-                            myMin[s] = key;
-                            good[s] = 1ull << k;
-                        } else if (key == myMin[s]) {
-                            good[s] |= 1ull << k;
-                        }
-                    }
+        for (int s = 0; s < kSlots; ++s) {
+            const double E = 0.5 * fabs(Dab - st.Dcd[s]), c5 = t3 - E, c6 = E - t4;
+            const bool feasible = feasAB && st.feasCD[s] && c5 <= ctol && c6 <= ctol;
+            double rm = rmAB;
+            rm = st.rmCD[s] > rm ? st.rmCD[s] : rm;
+            rm = c5 > rm ? c5 : rm;
+            rm = c6 > rm ? c6 : rm;
+            const double key = feasible ? 0.0 : rm;
+            if (st.live[s]) {
+                if (key < myMin[s]) {
+                    myMin[s] = key;
+                    good[s] = 1ull << k;
+                } else if (key == myMin[s]) {
+                    good[s] |= 1ull << k;
                 }
-            }
-            if constexpr (W > 1) {
-#pragma unroll
-                for (int s = 0; s < kSlots; ++s) {
-                    ll->partMin[wave][s][lane] = myMin[s];
-                    ll->partGood[wave][s][lane] = good[s];
-                }
-                __syncthreads();
-#pragma unroll
-                for (int s = 0; s < kSlots; ++s) {
-                    double mn = inf;
-                    for (int w = 0; w < W; ++w) {
-                        const double o = ll->partMin[w][s][lane];
-                        mn = o < mn ? o : mn;
-                    }
-                    unsigned long long g = 0ull;
-                    for (int w = 0; w < W; ++w)
-                        if (ll->partMin[w][s][lane] == mn) g |= ll->partGood[w][s][lane];
-                    myMin[s] = mn;
-                    good[s] = g;
-                }
-            }
-            double minKey = myMin[0] < myMin[1] ? myMin[0] : myMin[1];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const double o = __shfl_xor(minKey, off);
-                minKey = o < minKey ? o : minKey;
-            }
-#pragma unroll
-            for (int s = 0; s < kSlots; ++s)
-                if (!(myMin[s] == minKey)) good[s] = 0ull;
-            // list the surviving points in enumeration order: entry = ab | cd << 16
-            int count = 0;
-            for (int ab = wave; ab < nAB; ab += W) {
-                int a, b;
-                divmod_lattice(ab, n2, n2Inv, a, b);
-                const int k = abs((lo[0] + a) - (lo[2] + b)) - dMin;
-#pragma unroll
-                for (int s = 0; s < kSlots; ++s) {
-                    const bool hit = ((good[s] >> k) & 1ull) != 0ull;
-                    const unsigned long long bal = __ballot(hit);
-                    if (bal != 0ull) {
-                        const int at = count + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
-                        if (hit && at < kCap) list[at] = static_cast<unsigned>(ab) | (static_cast<unsigned>(lane + 64 * s) << 16);
-                        count += __builtin_popcountll(bal);
-                    }
-                }
-                if (count > kCap) break;
-            }
-            if (count <= kCap) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                double bestF = inf;
-                unsigned bestT = 0xFFFFFFFFu;
-                for (int p = lane; p < count; p += 64) {
-                    const unsigned e = list[p];
-                    const int ab = static_cast<int>(e & 0xFFFFu), cd = static_cast<int>(e >> 16);
-                    int a, b, c, d;
-                    divmod_lattice(ab, n2, n2Inv, a, b);
-                    divmod_lattice(cd, n6, n6Inv, c, d);
-                    const double y0 = lo[0] + a, y2 = lo[2] + b, y4 = lo[4] + c, y6 = lo[6] + d;
-                    const double Pn = ((wr * fabs(y0 - nIdx[0]) + C1n) + wr * fabs(y2 - nIdx[2])) + C3n;
-                    const double Pc = ((wr * fabs(y0 - cIdx[0]) + C1c) + wr * fabs(y2 - cIdx[2])) + C3c;
-                    const double Dab = fabs(y0 - y2), Uab = fabs(Dab - L), hab = 0.5 * Dab;
-                    const double a4n = wr * fabs(y4 - nIdx[4]), a4c = wr * fabs(y4 - cIdx[4]), a6n = wr * fabs(y6 - nIdx[6]), a6c = wr * fabs(y6 - cIdx[6]);
-                    const double dcd = fabs(y4 - y6), ucd = fabs(dcd - L), hcdP = 0.5 * dcd, v2 = fabs(fabs(hcdP - hlr) - K);
-                    const double S1 = (((Pn + a4n) + C5n) + a6n) + C7n;
-                    const double S2 = (((Pc + a4c) + C5c) + a6c) + C7c;
-                    const double V1 = fabs(fabs(hab - hcdP) - K);
-                    const double f = ((w1 * S1 + w2 * S2) + w3 * (Uab + ucd)) + w4 * (V1 + v2);
-                    if (f < bestF) {  // (per lane the index only grows: the first of equals stays)
-                        bestF = f;
-                        bestT = static_cast<unsigned>(ab) * static_cast<unsigned>(nCD) + static_cast<unsigned>(cd);
-                    }
-                }
-                double bestKey = minKey;
-                opt_wave_min(bestKey, bestF, bestT);
-                return OptBest{bestKey, bestF, bestT, 0u};
             }
         }
     }
+    if constexpr (W > 1) {
+        if (nSearch > 1) {
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s) {
+                ll->partMin[slice][s][lane] = myMin[s];
+                ll->partGood[slice][s][lane] = good[s];
+            }
+            ++meets;
+            opt_arrive(meet, lane);
+            opt_wait_ge(meet, nSearch * meets);
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s) {
+                double mn = inf;
+                for (int w = 0; w < nSearch; ++w) {
+                    const double o = ll->partMin[w][s][lane];
+                    mn = o < mn ? o : mn;
+                }
+                unsigned long long g = 0ull;
+                for (int w = 0; w < nSearch; ++w)
+                    if (ll->partMin[w][s][lane] == mn) g |= ll->partGood[w][s][lane];
+                myMin[s] = mn;
+                good[s] = g;
+            }
+        }
+    }
+    double minKey = myMin[0] < myMin[1] ? myMin[0] : myMin[1];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double o = __shfl_xor(minKey, off);
+        minKey = o < minKey ? o : minKey;
+    }
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s)
+        if (!(myMin[s] == minKey)) good[s] = 0ull;
+    // list the surviving points in enumeration order: entry = ab | cd << 16
+    int count = 0;
+    for (int ab = slice; ab < nAB; ab += nSearch) {
+        int a, b;
+        divmod_lattice(ab, n2, n2Inv, a, b);
+        const int k = abs((lo[0] + a) - (lo[2] + b)) - dMin;
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+            const bool hit = ((good[s] >> k) & 1ull) != 0ull;
+            const unsigned long long bal = __ballot(hit);
+            if (bal != 0ull) {
+                const int at = count + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                if (hit && at < kCap) list[at] = static_cast<unsigned>(ab) | (static_cast<unsigned>(lane + 64 * s) << 16);
+                count += __builtin_popcountll(bal);
+            }
+        }
+        if (count > kCap) break;
+    }
+    if (count <= kCap) {
+        st.mode = 0;
+        st.count = count;
+        st.minKey = minKey;
+    }
+}
+// Second part, with the columns decided (x[1], x[3], x[5], x[7]): row points (x[0], x[2], x[4], x[6]) = lo + (a, b, c, d),
+// enumeration index t = ((a n2 + b) n4 + c) n6 + d.  A searching wavefront takes the (a, b) pairs slice, slice + nSearch, ...,
+// its lanes the (c, d) pairs; per lane t only grows, so "strictly better" keeps the first of equals, and the reduction orders
+// by (violation, objective, t): the lexicographically first minimum, as the oracle's nested loops find it.
+// The objective and the constraints are taken apart by what they depend on (round 4): every f64 operation below is one of the
+// reference's expression, on the same operands, in the same order — a point's objective is
+//   ((w1 * S1 + w2 * S2) + w3 * (Uab + Ucd)) + w4 * (V1 + V2),   S = ((((((A0 + C1) + A2) + C3) + A4) + C5) + A6) + C7
+// (cpp:61-72, left to right) — but the sub-expressions of (x0, x2) alone are evaluated once per (a, b) pair and those of
+// (x4, x6) alone once per LANE (a lane keeps its one or two (c, d) pairs for the whole search): 31 operations per point
+// instead of ~110, and the values are bit for bit the ones opt_objective / opt_violation return (tests/test_gpu_opt.py).
+template <int W>
+__device__ __forceinline__ OptBest opt_rows_finish(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8], double lfRow,
+                                   double rhRow, int lane, int slice, int nSearch, const double (&x)[8], OptListLds<W>* ll, const OptRowsState& st) {
+    if (st.mode == 2) return opt_solve_rows_plain(oc, nIdx, cIdx, lo, up, lfRow, rhRow, lane, slice, nSearch, x);
+    const double inf = __builtin_huge_val();
+    const int n0 = up[0] - lo[0] + 1, n2 = up[2] - lo[2] + 1, n4 = up[4] - lo[4] + 1, n6 = up[6] - lo[6] + 1;
+    const int nAB = n0 * n2, nCD = n4 * n6;
+    constexpr int kSlots = 2;
+    const double w1 = oc.w1, w2 = oc.w2, w3 = oc.w3, w4 = oc.w4, wr = oc.wr, wc = oc.wc;
+    const double L = oc.lbOverRes, K = oc.skew2OverRes;
+    const double t1 = oc.t1, t2 = oc.t2, t3 = oc.t3, t4 = oc.t4, ctol = oc.ctol;
+    const double hlr = 0.5 * fabs(lfRow - rhRow);
+    const float n6Inv = rcp_small(n6), n2Inv = rcp_small(n2);
+    // column terms (the columns are decided: opt_solve_columns)
+    const double C1n = wc * fabs(x[1] - nIdx[1]), C3n = wc * fabs(x[3] - nIdx[3]), C5n = wc * fabs(x[5] - nIdx[5]), C7n = wc * fabs(x[7] - nIdx[7]);
+    const double C1c = wc * fabs(x[1] - cIdx[1]), C3c = wc * fabs(x[3] - cIdx[3]), C5c = wc * fabs(x[5] - cIdx[5]), C7c = wc * fabs(x[7] - cIdx[7]);
+    if (st.mode == 0) {
+        const unsigned* list = ll->list[slice];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        double bestF = inf;
+        unsigned bestT = 0xFFFFFFFFu;
+        for (int p = lane; p < st.count; p += 64) {
+            const unsigned e = list[p];
+            const int ab = static_cast<int>(e & 0xFFFFu), cd = static_cast<int>(e >> 16);
+            int a, b, c, d;
+            divmod_lattice(ab, n2, n2Inv, a, b);
+            divmod_lattice(cd, n6, n6Inv, c, d);
+            const double y0 = lo[0] + a, y2 = lo[2] + b, y4 = lo[4] + c, y6 = lo[6] + d;
+            const double Pn = ((wr * fabs(y0 - nIdx[0]) + C1n) + wr * fabs(y2 - nIdx[2])) + C3n;
+            const double Pc = ((wr * fabs(y0 - cIdx[0]) + C1c) + wr * fabs(y2 - cIdx[2])) + C3c;
+            const double Dab = fabs(y0 - y2), Uab = fabs(Dab - L), hab = 0.5 * Dab;
+            const double a4n = wr * fabs(y4 - nIdx[4]), a4c = wr * fabs(y4 - cIdx[4]), a6n = wr * fabs(y6 - nIdx[6]), a6c = wr * fabs(y6 - cIdx[6]);
+            const double dcd = fabs(y4 - y6), ucd = fabs(dcd - L), hcdP = 0.5 * dcd, v2 = fabs(fabs(hcdP - hlr) - K);
+            const double S1 = (((Pn + a4n) + C5n) + a6n) + C7n;
+            const double S2 = (((Pc + a4c) + C5c) + a6c) + C7c;
+            const double V1 = fabs(fabs(hab - hcdP) - K);
+            const double f = ((w1 * S1 + w2 * S2) + w3 * (Uab + ucd)) + w4 * (V1 + v2);
+            if (f < bestF) {  // (per lane the index only grows: the first of equals stays)
+                bestF = f;
+                bestT = static_cast<unsigned>(ab) * static_cast<unsigned>(nCD) + static_cast<unsigned>(cd);
+            }
+        }
+        double bestKey = st.minKey;
+        opt_wave_min(bestKey, bestF, bestT);
+        return OptBest{bestKey, bestF, bestT, 0u};
+    }
     double bestKey = inf, bestF = inf;
     unsigned bestT = 0xFFFFFFFFu;
-    for (int ab = wave; ab < nAB; ab += W) {
+    for (int ab = slice; ab < nAB; ab += nSearch) {
         int a, b;
         divmod_lattice(ab, n2, n2Inv, a, b);
         const double y0 = lo[0] + a, y2 = lo[2] + b;
@@ -443,18 +502,18 @@ __device__ OptBest opt_solve_rows(const OptConsts& oc, const int (&nIdx)[8], con
         const unsigned tAB = static_cast<unsigned>(ab) * static_cast<unsigned>(nCD);
 #pragma unroll
         for (int s = 0; s < kSlots; ++s) {
-            const double S1 = (((Pn + A4n[s]) + C5n) + A6n[s]) + C7n;
-            const double S2 = (((Pc + A4c[s]) + C5c) + A6c[s]) + C7c;
-            const double V1 = fabs(fabs(hab - hcd[s]) - K);
-            const double f = ((w1 * S1 + w2 * S2) + w3 * (Uab + Ucd[s])) + w4 * (V1 + V2[s]);
-            const double E = 0.5 * fabs(Dab - Dcd[s]), c5 = t3 - E, c6 = E - t4;
-            const bool feasible = feasAB && feasCD[s] && c5 <= ctol && c6 <= ctol;
+            const double S1 = (((Pn + st.A4n[s]) + C5n) + st.A6n[s]) + C7n;
+            const double S2 = (((Pc + st.A4c[s]) + C5c) + st.A6c[s]) + C7c;
+            const double V1 = fabs(fabs(hab - st.hcd[s]) - K);
+            const double f = ((w1 * S1 + w2 * S2) + w3 * (Uab + st.Ucd[s])) + w4 * (V1 + st.V2[s]);
+            const double E = 0.5 * fabs(Dab - st.Dcd[s]), c5 = t3 - E, c6 = E - t4;
+            const bool feasible = feasAB && st.feasCD[s] && c5 <= ctol && c6 <= ctol;
             double rm = rmAB;  // (the maximum of the eight values and 0: the order of the comparisons does not matter)
-            rm = rmCD[s] > rm ? rmCD[s] : rm;
+            rm = st.rmCD[s] > rm ? st.rmCD[s] : rm;
             rm = c5 > rm ? c5 : rm;
             rm = c6 > rm ? c6 : rm;
             const double key = oc.useConstraints ? (feasible ? 0.0 : rm) : 0.0;
-            if (live[s] && (key < bestKey || (key == bestKey && f < bestF))) {  // (per lane t only grows: the first of equals stays)
+            if (st.live[s] && (key < bestKey || (key == bestKey && f < bestF))) {  // (per lane t only grows: the first of equals stays)
                 bestKey = key;
                 bestF = f;
                 bestT = tAB + static_cast<unsigned>(lane + 64 * s);
@@ -465,9 +524,9 @@ __device__ OptBest opt_solve_rows(const OptConsts& oc, const int (&nIdx)[8], con
     return OptBest{bestKey, bestF, bestT, 0u};
 }
 
-template <int W>
+// Boxes with more than 128 (c, d) pairs: the plain loop over every point with the literal expressions.
 __device__ OptBest opt_solve_rows_plain(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8],
-                                        double lfRow, double rhRow, int lane, int wave, const double (&x)[8]) {
+                                        double lfRow, double rhRow, int lane, int slice, int nSearch, const double (&x)[8]) {
     const double inf = __builtin_huge_val();
     const int n0 = up[0] - lo[0] + 1, n2 = up[2] - lo[2] + 1, n4 = up[4] - lo[4] + 1, n6 = up[6] - lo[6] + 1;
     const int nAB = n0 * n2, nCD = n4 * n6;
@@ -477,7 +536,7 @@ __device__ OptBest opt_solve_rows_plain(const OptConsts& oc, const int (&nIdx)[8
     double y[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) y[k] = x[k];
-    for (int ab = wave; ab < nAB; ab += W) {
+    for (int ab = slice; ab < nAB; ab += nSearch) {
         int a, b;
         divmod_lattice(ab, n2, n2Inv, a, b);
         y[0] = lo[0] + a;
@@ -517,6 +576,12 @@ __device__ int opt_solve_end(const OptBest& best, const int (&lo)[8], const int 
     return best.key > 0.0 ? 2 : 0;
 }
 
+#ifdef FPE_OPT_TRACE  // measurement builds only (profiles/collect_opt_trace.sh): wall-clock stamps of workgroup 0's stages, per gait cycle
+__device__ unsigned long long g_optTrace[256][16];
+#define FPE_OPT_STAMP(k) do { if (blockIdx.x == 0 && lane == 0 && cyc < 256) g_optTrace[cyc][k] = wall_clock64(); } while (0)
+#else
+#define FPE_OPT_STAMP(k) do { } while (0)
+#endif
 struct OptShared {
     double cur[4][3];  // RF,RH,LH,LF_optCurrentPosition_
     float vals[4][kOptBoxCells];  // per-leg scratch of the mean heights
@@ -529,7 +594,7 @@ struct OptShared {
 // wavefront, cycle after cycle.  Wavefront 0 runs the track; the others wait at the workgroup barrier (they consume no
 // issue slots there), take their slice of the row search when wavefront 0 publishes a problem, and hand back their best.
 template <int W>
-__global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts pc, OptConsts oc, const fpe_pose* __restrict__ poses, int B,
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2))) void opt_track_kernel(DevMap m, PlanConsts pc, OptConsts oc, const fpe_pose* __restrict__ poses, int B,
                                                            int nCycles, const uint8_t* __restrict__ cycleOk, fpe_opt_out out) {
     __shared__ OptShared sh;
     __shared__ OptBest slots[W];
@@ -539,27 +604,48 @@ __global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts 
     if (b >= B) return;
     const int lane = static_cast<int>(threadIdx.x) & 63;
     const int wave = static_cast<int>(threadIdx.x) >> 6;
+    // (W > 1) wavefront 0 and its helpers meet through sequence numbers and counters in LDS, never at the workgroup barrier:
+    // sync[0] = cycles whose problem (bounds, rows) is published, sync[1] = cycles whose columns are, sync[2] = helpers arrived at the
+    // Dab exchange, sync[3] = helpers' results handed back
+    __shared__ int sync[4];
+    // a cycle's verdict for the helpers — 1: search its rows, 0: nothing to search, -1: the track has stopped for good — one entry per
+    // cycle (the track's records count cycles in a byte): wavefront 0 does not wait for anybody in a cycle without a search, and a
+    // slot shared by cycle parity could be two cycles ahead of a helper that has not looked yet
+    __shared__ signed char runOf[256];
     if constexpr (W > 1) {
+        if (threadIdx.x < 4) sync[threadIdx.x] = 0;
+        __syncthreads();
         if (wave > 0) {  // helper wavefronts: the row search only
+            int nRuns = 0, meets = 0;
             for (int cyc = 0; cyc < nCycles; ++cyc) {
-                __syncthreads();  // (A) the cycle's problem is published
+                opt_wait_ge(&sync[0], cyc + 1);  // the cycle's problem is published
+                if (wave == 1) FPE_OPT_STAMP(10);
                 const OptProblem& prob = probs[cyc & 1];
-                const int run = prob.run;
+                const int run = runOf[cyc & 255];
                 if (run < 0) return;
                 if (run == 0) continue;
+                ++nRuns;
                 int nIdx[8], cIdx[8], lo[8], up[8];
-                double x[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     nIdx[k] = prob.nIdx[k];
                     cIdx[k] = prob.cIdx[k];
                     lo[k] = prob.lo[k];
                     up[k] = prob.up[k];
-                    x[k] = prob.x[k];
                 }
-                const OptBest mine = opt_solve_rows<W>(oc, nIdx, cIdx, lo, up, prob.lfRow, prob.rhRow, lane, wave, x, &optLists);
+                const double lfRowP = prob.lfRow, rhRowP = prob.rhRow;
+                OptRowsState st;
+                opt_rows_prepare<W>(oc, nIdx, cIdx, lo, up, lfRowP, rhRowP, lane, wave - 1, W - 1, &optLists, &sync[2], meets, st);  // while wavefront 0 decides the columns
+                if (wave == 1) FPE_OPT_STAMP(11);
+                opt_wait_ge(&sync[1], cyc + 1);  // the columns are decided
+                if (wave == 1) FPE_OPT_STAMP(12);
+                double x[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[k] = prob.x[k];
+                const OptBest mine = opt_rows_finish<W>(oc, nIdx, cIdx, lo, up, lfRowP, rhRowP, lane, wave - 1, W - 1, x, &optLists, st);
                 if (lane == 0) slots[wave] = mine;
-                __syncthreads();  // (B) every slice's best is in place
+                opt_arrive(&sync[3], lane);
+                if (wave == 1) FPE_OPT_STAMP(13);
             }
             return;
         }
@@ -601,6 +687,7 @@ __global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts 
     int failCycle = 255;
     bool stopped = gait != 0;  // the walk gait (build-defined) has no opt track: zero records
     bool helpersGone = false;  // (W > 1) the helper wavefronts have been told to leave
+    int nRuns = 0;             // (W > 1) cycles whose row search ran: the helpers hand back W - 1 results each
 
     for (int cyc = 0; cyc < nCycles; ++cyc) {
         const size_t oCyc = static_cast<size_t>(b) * nCycles + cyc;
@@ -613,6 +700,7 @@ __global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts 
         SubGeom gm;
         gm.ok = false;
         double nextX = 0.0, nextY = 0.0;
+        FPE_OPT_STAMP(0);
         if (!stopped) {
             // ---- STEP(1) getGaitCycleSearchGridMap, cpp:2307-2408 ----
             nextX = polygon_center_x(sh.cur) + pc.step;  // cpp:2322-2327
@@ -626,8 +714,8 @@ __global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts 
         }
         if constexpr (W > 1) {
             if (stopped && !helpersGone) {
-                if (lane == 0) probs[cyc & 1].run = -1;
-                __syncthreads();  // (A) of this cycle: the helpers read run = -1 and return
+                if (lane == 0) runOf[cyc & 255] = -1;
+                opt_publish(&sync[0], cyc + 1, lane);  // the helpers read -1 and return
                 helpersGone = true;
             }
         }
@@ -642,6 +730,7 @@ __global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts 
             // (getMapIndex, cpp:965-976)
             const double nx = nextX + biasX, ny = nextY + biasY;
             const int nomI = index_of(nx, gm.g.orgX, gm.g.posX, gm.g.res), nomJ = index_of(ny, gm.g.orgY, gm.g.posY, gm.g.res);
+            FPE_OPT_STAMP(1);
             // ---- STEP(3) checkFootholdUseCentroidMethod(gaitMap_, next, result, beginRow, endRow), cpp:1010-1013 ----
             int code = 6, beginRow = 0, endRow = 0;
             double cenX = 0.0, cenY = 0.0;
@@ -672,6 +761,7 @@ __global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts 
                     if (r0 < 64) blkLo |= mk << r0;
                     else if (r0 < 128) blkHi |= mk << (r0 - 64);
                 }
+                FPE_OPT_STAMP(2);
                 const bool whole = ni * nj > 0 && !g.any(anyBelow);
                 const int minRow = blkLo ? __builtin_ctzll(blkLo) : (blkHi ? 64 + __builtin_ctzll(blkHi) : 0);
                 const int maxRow = blkHi ? 127 - __builtin_clzll(blkHi) : (blkLo ? 63 - __builtin_clzll(blkLo) : 0);
@@ -753,11 +843,14 @@ __global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts 
             }
             // ---- STEP(4) the optimiser (build-defined) ----
             double x[8], minf;
-            int status = opt_solve_begin(oc, nIdx, cIdx, lo, up, lfRow, rhRow, lane, x, minf);
+            int status = opt_solve_check(oc, nIdx, cIdx, lo, up, lfRow, rhRow, x, minf);
             if constexpr (W > 1) {
+                // the bounds and the rows are all the helpers' first part needs: published BEFORE the column searches, which the
+                // helpers' Dab analysis and listing then overlap (round 5: 8.3 k of a cycle's 39 k clocks were the columns with seven
+                // wavefronts waiting, 18.9 k the row search with wavefront 0 as one of eight searchers)
                 OptProblem& prob = probs[cyc & 1];
                 if (lane == 0) {
-                    prob.run = status < 0 ? 1 : 0;
+                    runOf[cyc & 255] = status < 0 ? 1 : 0;
                     prob.lfRow = lfRow;
                     prob.rhRow = rhRow;
                 }
@@ -768,23 +861,39 @@ __global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts 
                         prob.cIdx[k] = cIdx[k];
                         prob.lo[k] = lo[k];
                         prob.up[k] = up[k];
-                        prob.x[k] = x[k];
                     }
                 }
-                __syncthreads();  // (A)
+                opt_publish(&sync[0], cyc + 1, lane);
             }
+            FPE_OPT_STAMP(3);
+            if (status != 1) opt_solve_columns(oc, nIdx, cIdx, lo, up, lfRow, rhRow, lane, x);
+            if (status == 3) minf = opt_objective(x, oc, nIdx, cIdx, lfRow, rhRow);
             if (status < 0) {
-                OptBest best = opt_solve_rows<W>(oc, nIdx, cIdx, lo, up, lfRow, rhRow, lane, 0, x, &optLists);
+                OptBest best;
                 if constexpr (W > 1) {
-                    if (lane == 0) slots[0] = best;
-                    __syncthreads();  // (B)
+                    OptProblem& prob = probs[cyc & 1];
+                    if (lane == 0) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) prob.x[k] = x[k];
+                    }
+                    opt_publish(&sync[1], cyc + 1, lane);
+                    FPE_OPT_STAMP(4);
+                    ++nRuns;
+                    opt_wait_ge(&sync[3], (W - 1) * nRuns);  // every helper's best is in place
+                    FPE_OPT_STAMP(5);
                     OptBest o{__builtin_huge_val(), __builtin_huge_val(), 0xFFFFFFFFu, 0u};
-                    if (lane < W) o = slots[lane];
+                    if (lane < W - 1) o = slots[1 + lane];
                     opt_wave_min(o.key, o.f, o.t);
                     best = o;
+                } else {
+                    OptRowsState st;
+                    int meets = 0;
+                    opt_rows_prepare<W>(oc, nIdx, cIdx, lo, up, lfRow, rhRow, lane, 0, 1, &optLists, nullptr, meets, st);
+                    best = opt_rows_finish<W>(oc, nIdx, cIdx, lo, up, lfRow, rhRow, lane, 0, 1, x, &optLists, st);
                 }
                 status = opt_solve_end(best, lo, up, x, minf);
             }
+            FPE_OPT_STAMP(6);
             rec.solver_status = static_cast<uint8_t>(status);
             rec.minf = minf;
 #pragma unroll
@@ -815,6 +924,7 @@ __global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts 
                     myJ = j;
                 }
             }
+            FPE_OPT_STAMP(7);
             const bool commit = ((okMask[(cyc >> 6) & 3] >> (cyc & 63)) & 1ull) != 0ull;  // footholdValidation_ of the NOMINAL track (cpp:1323-1332)
             // (heights feed the footholds' z and nothing the chain reads later — getPolygonCenter's x uses x and y only: a caller
             // that asked for no footholds, the service's gate-only call, skips the elevation round trip; uniform over the workgroup)
@@ -843,6 +953,7 @@ __global__ __launch_bounds__(64 * W) void opt_track_kernel(DevMap m, PlanConsts 
             }
             pose_sync<16>();
             adjY += pc.drift;  // cpp:1578
+            FPE_OPT_STAMP(8);
         }
         if (lane == 0 && out.cycles) out.cycles[oCyc] = rec;
         if (g.sub == 0 && out.footholds) out.footholds[oCyc * 4 + leg] = fh;
