@@ -29,7 +29,8 @@ print(f"opt track, 1 pose, {n} gait cycles; per cycle (us), mean over the cycles
 rows = [("wavefront 0: cycle start -> gait-cycle submap, nominal index", 1, 0), ("  -> rows scanned (traversability loads)", 2, 1),
         ("  -> centroid method, gather, problem published", 3, 2), ("  -> columns decided and published", 4, 3),
         ("  -> the helpers' results are in", 5, 4), ("  -> merged, winner's point", 6, 5), ("  -> positions (and heights)", 7, 6), ("  -> commit", 8, 7),
-        ("helper 1: problem seen -> Dab analysis, exchange, list (first part)", 11, 10), ("  -> columns seen (waiting for wavefront 0)", 12, 11),
+        ("helper 1: problem seen -> its pairs' terms, its share of the Dab values", 14, 10), ("  -> shares exchanged, smallest violation", 15, 14),
+        ("  -> survivors listed (end of the first part)", 11, 15), ("  -> columns seen (waiting for wavefront 0)", 12, 11),
         ("  -> list evaluated, result handed back", 13, 12)]
 for name, a, b in rows:
     d = us(a, b)

@@ -129,6 +129,7 @@ struct BufferPool {
 // their own context.
 struct CallCtx {
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;  // the opt track's chain of a small plan + opt call runs beside the plan kernel (plan_host)
     unsigned char* dev = nullptr;
     size_t devCap = 0;
     unsigned char* pinned = nullptr;
@@ -144,6 +145,15 @@ struct CallCtx {
         if (dev) (void)hipFree(dev);
         if (pinned) (void)hipHostFree(pinned);
         if (stream) (void)hipStreamDestroy(stream);
+        if (side) (void)hipStreamDestroy(side);
+    }
+    hipError_t side_stream(hipStream_t* out) {
+        if (!side) {
+            hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+            if (e != hipSuccess) return e;
+        }
+        *out = side;
+        return hipSuccess;
     }
     hipError_t event(size_t k, hipEvent_t* out) {
         while (events.size() <= k) {
@@ -203,6 +213,7 @@ struct CtxLease {  // returns the context to the pool on every exit path
     ~CtxLease() {
         if (ctx && ctx->inFlight && ctx->stream) {
             (void)hipStreamSynchronize(ctx->stream);  // best effort: an early exit after work was queued
+            if (ctx->side) (void)hipStreamSynchronize(ctx->side);
             ctx->inFlight = false;
         }
         pool.give(std::move(ctx));
@@ -751,7 +762,8 @@ int fpe_set_tuning(fpe_handle h, const char* key, int32_t value) {
     else if (k == "service_opt_gate") {
         if (value < 0 || value > 2) return fail(FPE_E_INVALID_ARG, "service_opt_gate is 0 (exact gates only), 1 (advisory) or 2 (enforce)");
         h->tuning.serviceOptGate = value;
-    } else if (k == "service_cycle0_gate_only") h->tuning.serviceOptGate = value ? 0 : 2;  // (older name)
+    } else if (k == "service_overlap") h->tuning.serviceOverlap = value ? 1 : 0;
+    else if (k == "service_cycle0_gate_only") h->tuning.serviceOptGate = value ? 0 : 2;  // (older name)
     else return fail(FPE_E_INVALID_ARG, "unknown tuning key: " + k);
     return FPE_OK;
 }
@@ -1015,7 +1027,14 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
     const size_t szOc = (oout && oout->cycles) ? align256(nCyc * sizeof(fpe_opt_cycle)) : 0;
     const size_t szOg = (oout && oout->gate_fail_cycle) ? align256(static_cast<size_t>(B)) : 0;
     const size_t szOr = (oout && oout->rows_after) ? align256(static_cast<size_t>(B) * 2 * sizeof(double)) : 0;
-    const size_t total = szPose + szNom + szCen + szDef + szOk + szSt + szSel + szPs + szPk + szOf + szOc + szOg + szOr;
+    // A small call that runs the plan AND the opt track (the service: one pose) launches the two kernels side by side: the opt
+    // track's chain needs the nominal track's cycle flags only to decide whether a cycle's result is committed, and the flags are
+    // all 1 unless a nominal search fails — the chain runs on a second stream on flags of 1 (szSpec) while the plan kernel produces
+    // the real ones, and runs again, after it, in the rare call whose flags turn out otherwise (round 5: the plan kernel's ~18 us
+    // off the service's latency).
+    const bool specWanted = runPlan && oout != nullptr && !cycleOkIn && B <= 4;
+    const size_t szSpec = specWanted ? align256(nCyc) : 0;
+    const size_t total = szPose + szNom + szCen + szDef + szOk + szSt + szSel + szPs + szPk + szOf + szOc + szOg + szOr + szSpec;
     if (!h) return fail(FPE_E_INVALID_ARG, "null handle or params");
     CallPlan cp;  // declared before the lease: on an early exit the lease waits for the stream BEFORE the snapshot / bit planes are released
     CtxLease lease(h->ctxPool);
@@ -1052,13 +1071,19 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
     const size_t oOf = off; off += szOf;
     const size_t oOc = off; off += szOc;
     const size_t oOg = off; off += szOg;
-    const size_t oOr = off;
+    const size_t oOr = off; off += szOr;
+    const size_t oSpec = off;
     std::memcpy(hp, poses, static_cast<size_t>(B) * sizeof(fpe_pose));
     if (oout && cycleOkIn) std::memcpy(hp + oOk, cycleOkIn, nCyc);
     // Small calls (the plan_global_footholds service: one pose) skip both DMA copies: the kernels read the
     // poses from, and write their few KB of results straight into, the pinned (coherent, device-mapped) host
     // arena — two copy-engine round trips (~10 us each) less on a call whose kernel runs ~25 us.
     const bool zeroCopy = total <= kZeroCopyBytes;
+    bool speculate = specWanted && zeroCopy && oout != nullptr;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (!h->tuning.serviceOverlap) speculate = false;
+    }
     const fpe_pose* dPoses = nullptr;  // where the kernels read the poses (null: the head of the device arena)
     if (zeroCopy) {
         void* arena = nullptr;
@@ -1092,15 +1117,21 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
         rc = launch_plan(h, cp, dPoses ? dPoses : reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, d, cx.stream);
         if (rc != FPE_OK) return rc;
     }
+    fpe_opt_out od;
+    std::memset(&od, 0, sizeof(od));
     if (oout) {
-        fpe_opt_out od;
-        std::memset(&od, 0, sizeof(od));
         if (oout->footholds) od.footholds = reinterpret_cast<fpe_opt_foothold*>(dp + oOf);
         if (oout->cycles) od.cycles = reinterpret_cast<fpe_opt_cycle*>(dp + oOc);
         if (oout->gate_fail_cycle) od.gate_fail_cycle = dp + oOg;
         if (oout->rows_after) od.rows_after = reinterpret_cast<double*>(dp + oOr);
-        FPE_HIP(fpe::launch_opt_track(dev_map(*cp.snap), cp.pc, oc, dPoses ? dPoses : reinterpret_cast<const fpe_pose*>(dp), B, n_cycles,
-                                      dp + oOk, od, cx.stream));
+        hipStream_t os = cx.stream;
+        const unsigned char* okDev = dp + oOk;
+        if (speculate) {
+            std::memset(hp + oSpec, 1, nCyc);
+            FPE_HIP(cx.side_stream(&os));
+            okDev = dp + oSpec;
+        }
+        FPE_HIP(fpe::launch_opt_track(dev_map(*cp.snap), cp.pc, oc, dPoses ? dPoses : reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, okDev, od, os));
     }
     // ---- results to the caller ----
     struct Seg {
@@ -1126,6 +1157,16 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
     if (oout && szOr) add(oOr, static_cast<size_t>(B) * 2 * sizeof(double), oout->rows_after);
     if (zeroCopy) {  // the kernels wrote into the pinned arena itself
         FPE_HIP(hipStreamSynchronize(cx.stream));
+        if (oout && speculate) {
+            FPE_HIP(hipStreamSynchronize(cx.side));
+            bool allCommitted = true;
+            for (size_t c = 0; c < nCyc; ++c) allCommitted = allCommitted && hp[oOk + c] != 0;
+            if (!allCommitted) {  // a nominal search failed in some cycle: the chain again, on the flags as they are
+                FPE_HIP(fpe::launch_opt_track(dev_map(*cp.snap), cp.pc, oc, dPoses ? dPoses : reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, dp + oOk, od,
+                                              cx.stream));
+                FPE_HIP(hipStreamSynchronize(cx.stream));
+            }
+        }
         cx.inFlight = false;
         for (int k = 0; k < nSeg; ++k) std::memcpy(segs[k].dst, hp + segs[k].off, segs[k].len);
         return FPE_OK;

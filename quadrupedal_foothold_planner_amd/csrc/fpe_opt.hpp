@@ -237,6 +237,12 @@ __device__ void opt_solve_columns(const OptConsts& oc, const int (&nIdx)[8], con
 
 __device__ OptBest opt_solve_rows_plain(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8],
                                         double lfRow, double rhRow, int lane, int slice, int nSearch, const double (&x)[8]);
+#ifdef FPE_OPT_TRACE  // measurement builds only (profiles/collect_opt_trace.sh): wall-clock stamps of workgroup 0's stages, per gait cycle
+__device__ unsigned long long g_optTrace[256][16];
+#define FPE_OPT_STAMP(k) do { if (blockIdx.x == 0 && lane == 0 && cyc < 256) g_optTrace[cyc][k] = wall_clock64(); } while (0)
+#else
+#define FPE_OPT_STAMP(k) do { } while (0)
+#endif
 constexpr int kOptListCap = 1024;  // surviving points a wavefront lists (LDS, 4 bytes each); more: every point is searched
 // LDS of the listed search: the lists (one per searching wavefront) and, for W > 1, what the wavefronts tell each other about
 // their share of the Dab values (per lane and (c, d) slot: smallest violation, mask of the values that attain it)
@@ -277,7 +283,7 @@ struct OptRowsState {
 // meet / meets: their meeting point for the exchange of the Dab shares (nSearch > 1) and how often this wavefront has met there.
 template <int W>
 __device__ __forceinline__ void opt_rows_prepare(const OptConsts& oc, const int (&nIdx)[8], const int (&cIdx)[8], const int (&lo)[8], const int (&up)[8], double lfRow,
-                                 double rhRow, int lane, int slice, int nSearch, OptListLds<W>* ll, int* meet, int& meets, OptRowsState& st) {
+                                 double rhRow, int lane, int slice, int nSearch, OptListLds<W>* ll, int* meet, int& meets, OptRowsState& st, int cyc = 0) {
     const double inf = __builtin_huge_val();
     const int n0 = up[0] - lo[0] + 1, n2 = up[2] - lo[2] + 1, n4 = up[4] - lo[4] + 1, n6 = up[6] - lo[6] + 1;
     const int nAB = n0 * n2, nCD = n4 * n6;
@@ -370,6 +376,7 @@ __device__ __forceinline__ void opt_rows_prepare(const OptConsts& oc, const int 
             }
         }
     }
+    if (slice == 0 && nSearch > 1) FPE_OPT_STAMP(14);
     if constexpr (W > 1) {
         if (nSearch > 1) {
 #pragma unroll
@@ -404,6 +411,7 @@ __device__ __forceinline__ void opt_rows_prepare(const OptConsts& oc, const int 
 #pragma unroll
     for (int s = 0; s < kSlots; ++s)
         if (!(myMin[s] == minKey)) good[s] = 0ull;
+    if (slice == 0 && nSearch > 1) FPE_OPT_STAMP(15);
     // list the surviving points in enumeration order: entry = ab | cd << 16
     int count = 0;
     for (int ab = slice; ab < nAB; ab += nSearch) {
@@ -576,12 +584,6 @@ __device__ int opt_solve_end(const OptBest& best, const int (&lo)[8], const int 
     return best.key > 0.0 ? 2 : 0;
 }
 
-#ifdef FPE_OPT_TRACE  // measurement builds only (profiles/collect_opt_trace.sh): wall-clock stamps of workgroup 0's stages, per gait cycle
-__device__ unsigned long long g_optTrace[256][16];
-#define FPE_OPT_STAMP(k) do { if (blockIdx.x == 0 && lane == 0 && cyc < 256) g_optTrace[cyc][k] = wall_clock64(); } while (0)
-#else
-#define FPE_OPT_STAMP(k) do { } while (0)
-#endif
 struct OptShared {
     double cur[4][3];  // RF,RH,LH,LF_optCurrentPosition_
     float vals[4][kOptBoxCells];  // per-leg scratch of the mean heights
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2))) voi
                 }
                 const double lfRowP = prob.lfRow, rhRowP = prob.rhRow;
                 OptRowsState st;
-                opt_rows_prepare<W>(oc, nIdx, cIdx, lo, up, lfRowP, rhRowP, lane, wave - 1, W - 1, &optLists, &sync[2], meets, st);  // while wavefront 0 decides the columns
+                opt_rows_prepare<W>(oc, nIdx, cIdx, lo, up, lfRowP, rhRowP, lane, wave - 1, W - 1, &optLists, &sync[2], meets, st, cyc);  // while wavefront 0 decides the columns
                 if (wave == 1) FPE_OPT_STAMP(11);
                 opt_wait_ge(&sync[1], cyc + 1);  // the columns are decided
                 if (wave == 1) FPE_OPT_STAMP(12);

@@ -288,6 +288,49 @@ def test_service_gate_kinds_default_advisory_enforce(planner):
     planner.params = _capi.params_yaml()
 
 
+def _same(a, b, path="result"):
+    """Deep equality of two service results (dicts / lists / arrays / scalars), bit for bit."""
+    if isinstance(a, dict):
+        assert isinstance(b, dict) and a.keys() == b.keys(), path
+        for k in a:
+            _same(a[k], b[k], f"{path}[{k!r}]")
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), path
+        for k, (x, y) in enumerate(zip(a, b)):
+            _same(x, y, f"{path}[{k}]")
+    elif isinstance(a, np.ndarray):
+        assert a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes(), path
+    else:
+        assert a == b or (a != a and b != b), path
+
+
+def test_service_with_the_opt_chain_beside_the_plan_kernel_equals_one_after_the_other(planner):
+    """A one-pose service call runs the opt track's chain on a second stream BESIDE the plan kernel, on cycle flags of 1, and
+    again after it when the nominal track's real flags turn out otherwise (fpe_engine.cpp, plan_host; "service_overlap").
+    Every product of the call — all tracks, reports, gate — must be what the sequential call returns, bit for bit, on a map where
+    nominal searches do fail (cycles that are not committed between cycles that are)."""
+    planner.params = _capi.params_yaml()
+    trav, elev = synth.rough_map(400, 400, 0.02, seed=1, bad_frac=0.3)
+    planner.gridmapCallback(trav, elev, 0.02)
+    omap = fpo.OracleMap(trav, elev, 0.02)
+    rng = np.random.default_rng(2718)
+    reran = answered = 0
+    for _ in range(40):
+        pos = [rng.uniform(-3.2, -2.0), rng.uniform(-3, 3), 0.0]
+        res = []
+        for overlap in (1, 0, 1):
+            with planner.tuning(service_overlap=overlap, service_opt_gate=1):  # (advisory: the call answers, the chain's verdict is reported)
+                r = planner.globalFootholdPlan(6, pos, all_tracks=True)
+                res.append((r, planner.last_service_gate()))
+        _same(res[0], res[1])
+        _same(res[2], res[1])
+        if res[0][0] is not False:
+            answered += 1
+            ok = omap.plan(util.to_oracle_params(planner.params), util.to_oracle_poses(make_poses([pos])), 6)["cycle_ok"][0].astype(bool)
+            reran += int(not ok.all())
+    assert answered >= 10 and reran >= 5, "need calls whose nominal flags differ from the flags the chain first ran on"
+
+
 def test_service_survives_a_geometry_the_opt_track_does_not_support(planner):
     """ADVICE r3: on a fine map with a large search radius the opt track is unsupported (its blocked-row mask holds 128 rows);
     the service call — which no longer needs the chain for its return value — still answers, under every gate mode."""
