@@ -151,19 +151,88 @@ __device__ __forceinline__ double opt_violation(const double (&x)[8], const OptC
     return feasible ? 0.0 : resmax;
 }
 
-// wave-wide lexicographic minimum of (key, f, t): every lane ends with the winner
-// (round 5: four DPP exchanges inside a row of 16 and the rows' winners by v_readlane instead of the six bpermute rounds were
-// measured — correct, and SLOWER: one pose 160 -> 168 us; the lane reads' wait states cost more than the LDS round trips they save)
-__device__ __forceinline__ void opt_wave_min(double& key, double& f, unsigned& t) {
-#pragma unroll
+// Wave-wide reductions on 32-bit words by DPP row shifts and row broadcasts (gfx9: row_shr 1 / 2 / 4 / 8 inside a row of 16, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3): six VALU operations and a v_readlane where the butterfly of
+// ds_bpermute exchanges takes six dependent LDS-crossbar round trips (~0.2 us each way on a lone wavefront — the opt track's
+// chain is ONE wavefront's latency, stage after stage).  Lanes without a source keep the operation's identity.
+#ifndef FPE_OPT_NO_DPP
+#define FPE_DPP_STEP(op, ident, v, ctrl, rmask) v = op(v, static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(ident), static_cast<int>(v), ctrl, rmask, 0xF, false)))
+__device__ __forceinline__ unsigned dpp_min_op(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned dpp_or_op(unsigned a, unsigned b) { return a | b; }
+__device__ __forceinline__ unsigned dpp_add_op(unsigned a, unsigned b) { return a + b; }
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    FPE_DPP_STEP(dpp_min_op, 0xFFFFFFFFu, v, 0x111, 0xF);
+    FPE_DPP_STEP(dpp_min_op, 0xFFFFFFFFu, v, 0x112, 0xF);
+    FPE_DPP_STEP(dpp_min_op, 0xFFFFFFFFu, v, 0x114, 0xF);
+    FPE_DPP_STEP(dpp_min_op, 0xFFFFFFFFu, v, 0x118, 0xF);
+    FPE_DPP_STEP(dpp_min_op, 0xFFFFFFFFu, v, 0x142, 0xA);
+    FPE_DPP_STEP(dpp_min_op, 0xFFFFFFFFu, v, 0x143, 0xC);
+    return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+    FPE_DPP_STEP(dpp_or_op, 0u, v, 0x111, 0xF);
+    FPE_DPP_STEP(dpp_or_op, 0u, v, 0x112, 0xF);
+    FPE_DPP_STEP(dpp_or_op, 0u, v, 0x114, 0xF);
+    FPE_DPP_STEP(dpp_or_op, 0u, v, 0x118, 0xF);
+    FPE_DPP_STEP(dpp_or_op, 0u, v, 0x142, 0xA);
+    FPE_DPP_STEP(dpp_or_op, 0u, v, 0x143, 0xC);
+    return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+__device__ __forceinline__ int wave_inclusive_sum(int x) {  // every lane: the sum of the lanes up to and including itself
+    unsigned v = static_cast<unsigned>(x);
+    FPE_DPP_STEP(dpp_add_op, 0u, v, 0x111, 0xF);
+    FPE_DPP_STEP(dpp_add_op, 0u, v, 0x112, 0xF);
+    FPE_DPP_STEP(dpp_add_op, 0u, v, 0x114, 0xF);
+    FPE_DPP_STEP(dpp_add_op, 0u, v, 0x118, 0xF);
+    FPE_DPP_STEP(dpp_add_op, 0u, v, 0x142, 0xA);
+    FPE_DPP_STEP(dpp_add_op, 0u, v, 0x143, 0xC);
+    return static_cast<int>(v);
+}
+#undef FPE_DPP_STEP
+#else  // the same by ds_bpermute exchanges (measurement builds)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     for (int off = 32; off >= 1; off >>= 1) {
-        const double k2 = __shfl_xor(key, off), f2 = __shfl_xor(f, off);
-        const unsigned t2 = __shfl_xor(t, off);
-        const bool take = k2 < key || (k2 == key && (f2 < f || (f2 == f && t2 < t)));
-        key = take ? k2 : key;
-        f = take ? f2 : f;
-        t = take ? t2 : t;
+        const unsigned o = __shfl_xor(v, off);
+        v = o < v ? o : v;
     }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+    for (int off = 32; off >= 1; off >>= 1) v |= __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ int wave_inclusive_sum(int x) {
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(x, off);
+        if (lane >= off) x += o;
+    }
+    return x;
+}
+#endif
+// wave-wide minimum of a NON-NEGATIVE double (violations, objectives: sums of absolute values; +inf allowed): such doubles order
+// like their bit patterns — the high words' minimum, then the low words' among the lanes that hold it
+__device__ __forceinline__ double wave_min_nonneg(double v) {
+    const unsigned hi = static_cast<unsigned>(__double2hiint(v)), lo = static_cast<unsigned>(__double2loint(v));
+    const unsigned mh = wave_min_u32(hi);
+    const unsigned ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+    return __hiloint2double(static_cast<int>(mh), static_cast<int>(ml));
+}
+// wave-wide lexicographic minimum of (key, f, t), key and f non-negative: every lane ends with the winner.  Word by word: the
+// minimum of a word among the lanes still level on the words before it.
+__device__ __forceinline__ void opt_wave_min(double& key, double& f, unsigned& t) {
+    const unsigned w[5] = {static_cast<unsigned>(__double2hiint(key)), static_cast<unsigned>(__double2loint(key)),
+                           static_cast<unsigned>(__double2hiint(f)), static_cast<unsigned>(__double2loint(f)), t};
+    unsigned m[5];
+    bool level = true;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        m[q] = wave_min_u32(level ? w[q] : 0xFFFFFFFFu);
+        level = level && w[q] == m[q];
+    }
+    key = __hiloint2double(static_cast<int>(m[0]), static_cast<int>(m[1]));
+    f = __hiloint2double(static_cast<int>(m[2]), static_cast<int>(m[3]));
+    t = m[4];
 }
 
 // One candidate of the cross-wavefront minimum (W > 1: the waves of a pose's workgroup each search a slice of the box)
@@ -402,33 +471,45 @@ __device__ __forceinline__ void opt_rows_prepare(const OptConsts& oc, const int 
             }
         }
     }
-    double minKey = myMin[0] < myMin[1] ? myMin[0] : myMin[1];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double o = __shfl_xor(minKey, off);
-        minKey = o < minKey ? o : minKey;
-    }
+    const double minKey = wave_min_nonneg(myMin[0] < myMin[1] ? myMin[0] : myMin[1]);
 #pragma unroll
     for (int s = 0; s < kSlots; ++s)
         if (!(myMin[s] == minKey)) good[s] = 0ull;
     if (slice == 0 && nSearch > 1) FPE_OPT_STAMP(15);
-    // list the surviving points in enumeration order: entry = ab | cd << 16
-    int count = 0;
-    for (int ab = slice; ab < nAB; ab += nSearch) {
-        int a, b;
-        divmod_lattice(ab, n2, n2Inv, a, b);
-        const int k = abs((lo[0] + a) - (lo[2] + b)) - dMin;
-#pragma unroll
-        for (int s = 0; s < kSlots; ++s) {
-            const bool hit = ((good[s] >> k) & 1ull) != 0ull;
-            const unsigned long long bal = __ballot(hit);
-            if (bal != 0ull) {
-                const int at = count + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
-                if (hit && at < kCap) list[at] = static_cast<unsigned>(ab) | (static_cast<unsigned>(lane + 64 * s) << 16);
-                count += __builtin_popcountll(bal);
-            }
+    // list the surviving points in enumeration order: entry = ab | cd << 16.
+    // Whether (ab, cd) survives depends on ab only through its Dab value k: the (c, d) pairs of value k are two 64-bit masks
+    // (the ballots of bit k of the lanes' `good`), kept by lane k.  A lane then takes an (a, b) pair of the wavefront's share,
+    // fetches its value's masks, a prefix sum over the lanes gives it its place in the list, and it writes its entries itself
+    // (round 5; before: the pairs one after the other with two ballots and a dependent prefix each — 2.4 of a cycle's 14.8 us)
+    const unsigned long long anyMine = good[0] | good[1];
+    const unsigned long long anyK = static_cast<unsigned long long>(wave_or_u32(static_cast<unsigned>(anyMine))) |
+                                    (static_cast<unsigned long long>(wave_or_u32(static_cast<unsigned>(anyMine >> 32))) << 32);
+    unsigned long long mk0 = 0ull, mk1 = 0ull;  // lane k: the (c, d) pairs (slot 0 / slot 1) that survive beside Dab value k
+    for (unsigned long long left = anyK; left != 0ull; left &= left - 1ull) {
+        const int k = __builtin_ctzll(left);
+        const unsigned long long b0 = __ballot(((good[0] >> k) & 1ull) != 0ull), b1 = __ballot(((good[1] >> k) & 1ull) != 0ull);
+        if (lane == k) {
+            mk0 = b0;
+            mk1 = b1;
         }
-        if (count > kCap) break;
+    }
+    int count = 0;
+    for (int ab0 = slice; ab0 < nAB && count <= kCap; ab0 += 64 * nSearch) {
+        const int ab = ab0 + nSearch * lane;
+        const bool mine = ab < nAB;
+        int a, b;
+        divmod_lattice(mine ? ab : 0, n2, n2Inv, a, b);
+        const int k = abs((lo[0] + a) - (lo[2] + b)) - dMin;  // in [0, nD)
+        unsigned long long m0 = __shfl(mk0, k), m1 = __shfl(mk1, k);
+        if (!mine) m0 = m1 = 0ull;
+        const int cnt = __builtin_popcountll(m0) + __builtin_popcountll(m1);
+        const int incl = wave_inclusive_sum(cnt);
+        int at = count + incl - cnt;
+        count += __builtin_amdgcn_readlane(incl, 63);
+        for (; m0 != 0ull; m0 &= m0 - 1ull, ++at)
+            if (at < kCap) list[at] = static_cast<unsigned>(ab) | (static_cast<unsigned>(__builtin_ctzll(m0)) << 16);
+        for (; m1 != 0ull; m1 &= m1 - 1ull, ++at)
+            if (at < kCap) list[at] = static_cast<unsigned>(ab) | (static_cast<unsigned>(64 + __builtin_ctzll(m1)) << 16);
     }
     if (count <= kCap) {
         st.mode = 0;
