@@ -694,12 +694,12 @@ def main():
         # the actual drop-in call: plan_global_footholds for ONE pose x 8 cycles (fpe_plan_service: plan kernel + the opt
         # track's chain for the handler's return value, zero-copy through the pinned arena), wall time per call through
         # ctypes; on a steady map and as the first call after a fresh map message (bit planes pre-built by the upload)
-        def service_us(fresh_map, no_bits, reps_s=60, opt_gate=2):
+        def service_us(fresh_map, no_bits, reps_s=60, opt_gate=2, overlap=1):
             svc = FootholdPlanner(local_rank)
             svc.params = planner.params.copy()
             if no_bits:
                 svc.set_tuning(no_bits=1)
-            svc.set_tuning(service_opt_gate=opt_gate)
+            svc.set_tuning(service_opt_gate=opt_gate, service_overlap=overlap)
             svc.gridmapCallback(trav, elev, res)
             pos = poses["position"][0].copy()
             svc.globalFootholdPlan(8, pos)
@@ -716,12 +716,14 @@ def main():
         line["service_latency_us"] = {
             "steady_map": {"bit_window": service_us(False, False), "direct": service_us(False, True)},
             "first_call_after_a_map": {"bit_window": service_us(True, False, 12), "direct": service_us(True, True, 12)},
+            "steady_map_one_kernel_after_the_other": {"bit_window": service_us(False, False, overlap=0)},
             "steady_map_exact_gates_only": {"bit_window": service_us(False, False, opt_gate=0)},
             "first_call_after_a_map_exact_gates_only": {"bit_window": service_us(True, False, 12, opt_gate=0)},
             "note": "median wall time of fpe_plan_service (1 pose x 8 cycles, response assembled) per call, ctypes overhead included.  Default "
-                    "(service_opt_gate 2, enforce): the plan kernel and, on a stream of its own, the opt track's chain (cpp:913-1319: eight "
+                    "(service_opt_gate 2, enforce): the plan kernel and, BESIDE it on a second stream, the opt track's chain (cpp:913-1319: eight "
                     "optimiser searches of 14 641 lattice points each, one after the other) whose gate verdict the call honours like the "
-                    "reference's handler (cpp:920-934).  *_exact_gates_only = fpe_set_tuning('service_opt_gate', 0): the chain is not run; the "
+                    "reference's handler (cpp:920-934); the chain runs on nominal cycle flags of 1 and again on the real ones in the call where "
+                    "they differ (service_overlap, include/fpe.h; *_one_kernel_after_the_other = service_overlap 0).  *_exact_gates_only = fpe_set_tuning('service_opt_gate', 0): the chain is not run; the "
                     "handler's `return false` is decided for its optimiser-independent kinds only — first gait cycle, lateral side of every "
                     "cycle (include/fpe.h, fpe_service_gate) — for latency-critical callers",
         }

@@ -265,12 +265,16 @@ int fpe_destroy(fpe_handle h);
  * chain runs next to the plan (its own stream) and the call returns FPE_E_SERVICE_FALSE on its verdict too, as the
  * reference's handler does at that gate whatever its optimiser (cpp:920-934); 1 advisory: the chain runs, its verdict is
  * reported by fpe_last_service_gate, the return value stays optimiser-independent; 0: the chain is not run for the gate
- * (latency-critical callers: 49 us instead of 181 us per call; it still runs when an opt product is asked for) and the call
+ * (latency-critical callers: 48 us instead of 114 us per call; it still runs when an opt product is asked for) and the call
  * returns FPE_E_SERVICE_FALSE only on the optimiser-independent failures.  In modes 0 and 1 a call whose chain stopped at
  * its gate still answers FPE_OK with the nominal / centroid / default products, but the OPT products (message, report, the
  * opt points of the centroid path) come back EMPTY — never the truncated track of an aborted chain — and
  * fpe_last_service_gate names kind FPE_GATE_BUILD_DEFINED and the cycle: a caller that wants the handler's behaviour checks
  * fail_kind, not only the return value.  "service_cycle0_gate_only" (older name): 1 = service_opt_gate 0, 0 = 2.
+ * "service_overlap" (default 1): a call that runs the plan AND the opt track for at most four poses launches the opt
+ * track's chain on a second stream beside the plan kernel, on nominal cycle flags of 1 (the flags only decide which cycles the
+ * chain commits, cpp:1323-1332, and are 1 unless a nominal search fails), and runs it again on the real flags in the call where
+ * they differ: the same products as 0 (one kernel after the other), the plan kernel's time off the common call's latency.
  * Thread-safe: every plan / search call copies the knobs once, under the engine's lock, so a concurrent call runs
  * entirely with the values before or entirely with the values after a change (one key per call: callers that change
  * several keys while other threads plan get each key's change at its own moment). */

@@ -39,6 +39,7 @@ PY
   python3 profiles/probe_filters_terrain.py 2>/dev/null | grep "ms per chain"
 } > gpurun_out/r5p_filters.txt 2>&1
 bash profiles/collect_filters_timeline.sh > /dev/null 2>&1
+bash profiles/collect_opt_trace.sh > /dev/null 2>&1
 python3 profiles/probe_batch_scaling.py 2>&1 | grep "n_cycles" > gpurun_out/r5p_batch_scaling.txt
 python3 profiles/probe_service_latency.py > gpurun_out/r5p_service_latency.txt 2>&1
 ls gpurun_out | grep r5p_ | wc -l
