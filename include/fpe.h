@@ -265,7 +265,7 @@ int fpe_destroy(fpe_handle h);
  * chain runs next to the plan (its own stream) and the call returns FPE_E_SERVICE_FALSE on its verdict too, as the
  * reference's handler does at that gate whatever its optimiser (cpp:920-934); 1 advisory: the chain runs, its verdict is
  * reported by fpe_last_service_gate, the return value stays optimiser-independent; 0: the chain is not run for the gate
- * (latency-critical callers: 48 us instead of 114 us per call; it still runs when an opt product is asked for) and the call
+ * (latency-critical callers: 48 us instead of 110 us per call; it still runs when an opt product is asked for) and the call
  * returns FPE_E_SERVICE_FALSE only on the optimiser-independent failures.  In modes 0 and 1 a call whose chain stopped at
  * its gate still answers FPE_OK with the nominal / centroid / default products, but the OPT products (message, report, the
  * opt points of the centroid path) come back EMPTY — never the truncated track of an aborted chain — and

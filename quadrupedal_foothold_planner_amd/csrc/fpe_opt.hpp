@@ -699,6 +699,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2))) voi
         if (threadIdx.x < 4) sync[threadIdx.x] = 0;
         __syncthreads();
         if (wave > 0) {  // helper wavefronts: the row search only
+#ifndef FPE_OPT_NO_PRIO
+            // wavefront 4 shares its SIMD with wavefront 0, whose column searches are done long before anybody needs them: the helpers
+            // go first (they sleep in their polls while wavefront 0 has the critical path), or the seven wait for the one at their exchange
+            __builtin_amdgcn_s_setprio(3);
+#endif
             int nRuns = 0, meets = 0;
             for (int cyc = 0; cyc < nCycles; ++cyc) {
                 opt_wait_ge(&sync[0], cyc + 1);  // the cycle's problem is published
@@ -899,19 +904,20 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2))) voi
             }
             // centroidIndex (cpp:1030-1041): getMapIndex of the result — (0, 0) when it was left untouched
             const int cenI = index_of(cenX, gm.g.orgX, gm.g.posX, gm.g.res), cenJ = index_of(cenY, gm.g.orgY, gm.g.posY, gm.g.res);
-            // gather the four legs (lane 16 * leg holds the leg's values); optimiser order LF, RH, RF, LH
+            // gather the four legs (lane 16 * leg holds the leg's values; constant lanes: v_readlane, no LDS-crossbar round trip);
+            // optimiser order LF, RH, RF, LH
             int nIdx[8], cIdx[8], lo[8], up[8];
             {
                 constexpr int order[4] = {3, 1, 0, 2};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int src = 16 * order[k];
-                    nIdx[2 * k] = __shfl(nomI, src);
-                    nIdx[2 * k + 1] = __shfl(nomJ, src);
-                    cIdx[2 * k] = __shfl(cenI, src);
-                    cIdx[2 * k + 1] = __shfl(cenJ, src);
-                    lo[2 * k] = __shfl(beginRow, src);  // xBounds rows, cpp:1067-1076
-                    up[2 * k] = __shfl(endRow, src);
+                    nIdx[2 * k] = __builtin_amdgcn_readlane(nomI, src);
+                    nIdx[2 * k + 1] = __builtin_amdgcn_readlane(nomJ, src);
+                    cIdx[2 * k] = __builtin_amdgcn_readlane(cenI, src);
+                    cIdx[2 * k + 1] = __builtin_amdgcn_readlane(cenJ, src);
+                    lo[2 * k] = __builtin_amdgcn_readlane(beginRow, src);  // xBounds rows, cpp:1067-1076
+                    up[2 * k] = __builtin_amdgcn_readlane(endRow, src);
                 }
                 lo[1] = lo[7] = oc.colLoA;  // cpp:1063-1066
                 up[1] = up[7] = oc.colUpA;
@@ -919,9 +925,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2))) voi
                 up[3] = up[5] = oc.colUpB;
 #pragma unroll
                 for (int l = 0; l < 4; ++l) {
-                    rec.traversable_row[0][l] = __shfl(beginRow, 16 * l);
-                    rec.traversable_row[1][l] = __shfl(endRow, 16 * l);
-                    rec.centroid_code[l] = static_cast<uint8_t>(__shfl(code, 16 * l));
+                    rec.traversable_row[0][l] = __builtin_amdgcn_readlane(beginRow, 16 * l);
+                    rec.traversable_row[1][l] = __builtin_amdgcn_readlane(endRow, 16 * l);
+                    rec.centroid_code[l] = static_cast<uint8_t>(__builtin_amdgcn_readlane(code, 16 * l));
                 }
             }
             // ---- STEP(4) the optimiser (build-defined) ----
@@ -1031,8 +1037,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2))) voi
                     sh.cur[leg][2] = static_cast<double>(z);
                 }
                 const int rowOnGait = index_of(myX, gm.g.orgX, gm.g.posX, gm.g.res);  // gaitMap_.getIndex(...).x()
-                lfRow = static_cast<double>(__shfl(rowOnGait, 16 * 3));
-                rhRow = static_cast<double>(__shfl(rowOnGait, 16 * 1));
+                lfRow = static_cast<double>(__builtin_amdgcn_readlane(rowOnGait, 16 * 3));
+                rhRow = static_cast<double>(__builtin_amdgcn_readlane(rowOnGait, 16 * 1));
             }
             pose_sync<16>();
             adjY += pc.drift;  // cpp:1578
