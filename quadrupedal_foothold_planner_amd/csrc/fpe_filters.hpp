@@ -764,7 +764,7 @@ __global__ __launch_bounds__(TR * TC) void filter_step_runs_kernel(MapGeom g, co
 template <int H, int TR, int TC, int HS>
 __global__ __launch_bounds__(TR * TC) __attribute__((amdgpu_waves_per_eu(TR * TC == 512 ? ((H == 3 && HS == 5) ? FPE_FUSED_WAVES_2CM : FPE_FUSED_WAVES) : 4))) void filter_fused_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double rN, double slopeCritical,
                                                             double roughCritical, double invSlopeCritical, double invRoughCritical, StepShape sN, double r2nd, int h2nd, StepShape s2, double stepCritical,
-                                                            float critDown, int nCritical, int kStep, int travOnly, int tilesX, int nTiles) {
+                                                            float critDown, int nCritical, int kStepFlags, int travOnly, int tilesX, int nTiles) {
     extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
     int ty, tx;
     xcd_tile(tilesX, nTiles, ty, tx);
@@ -779,16 +779,23 @@ __global__ __launch_bounds__(TR * TC) __attribute__((amdgpu_waves_per_eu(TR * TC
         g_fusedTimeline[blockIdx.x][7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
     }
 #endif
+    // kStepFlags: bit 0 = the second step window rides in this launch, bit 1 = the first step window is at least as wide as the
+    // normals' disc (a step height of exactly 0 then certifies a disc of equal elevations: normals_from_moments, `flat`)
+    const int kStep = kStepFlags & 1;
+    float stepHeightHere = __builtin_nanf("");  // the cell's own step height (first window)
     if (kStep) {
-        float hi, lo, centre;
+        float hi, lo;
         int cnt;
-        step_runs_phase<true, TR, TC, HS>(ldsRaw, g, L.stepHeight, r2nd, h2nd, s2, critDown, ti0, tj0, live, hi, lo, cnt, centre);
+        step_runs_phase<true, TR, TC, HS>(ldsRaw, g, L.stepHeight, r2nd, h2nd, s2, critDown, ti0, tj0, live, hi, lo, cnt, stepHeightHere);
         stepOut = step_value(hi, cnt, stepCritical, nCritical);
         __syncthreads();  // the moment phase reuses the LDS
+    } else if (live && (kStepFlags & 2)) {
+        stepHeightHere = L.stepHeight[static_cast<size_t>(i) * g.cols + j];
     }
+    const bool flat = (kStepFlags & 2) != 0 && stepHeightHere == 0.0f;
     FPE_TL_MARK(1);
     float ox, oy, oz, os, orough;
-    const bool needWalk = moments_phase<H, TR, TC>(ldsRaw, g, elev, ti0, tj0, rN, travOnly == 0, sN, slopeCritical, roughCritical, invSlopeCritical, invRoughCritical, live, ox,
+    const bool needWalk = moments_phase<H, TR, TC>(ldsRaw, g, elev, ti0, tj0, rN, travOnly == 0, flat, sN, slopeCritical, roughCritical, invSlopeCritical, invRoughCritical, live, ox,
                                                    oy, oz, os, orough);
     if (live && !needWalk) {
         const size_t cell = static_cast<size_t>(i) * g.cols + j;
@@ -841,8 +848,8 @@ hipError_t launch_fused_one(const MapGeom& g, const FilterConsts& fc, const floa
     }
     const int tilesX = (g.cols + TC - 1) / TC, nTiles = tilesX * ((g.rows + TR - 1) / TR);
     hipLaunchKernelGGL((filter_fused_kernel<H, TR, TC, HS>), dim3(nTiles), dim3(TR * TC), rt.fusedBytes, stream, g, d_elev, L, fc.normalRadius, fc.slopeCritical,
-                       fc.roughnessCritical, 1.0 / fc.slopeCritical, 1.0 / fc.roughnessCritical, rt.sN, fc.stepSecondRadius, rt.h2, rt.s2, fc.stepCritical, critDown, fc.stepCriticalCells, rt.stepFused, travOnly,
-                       tilesX, nTiles);
+                       fc.roughnessCritical, 1.0 / fc.slopeCritical, 1.0 / fc.roughnessCritical, rt.sN, fc.stepSecondRadius, rt.h2, rt.s2, fc.stepCritical, critDown, fc.stepCriticalCells,
+                       rt.stepFused | (fc.normalRadius <= fc.stepFirstRadius ? 2 : 0), travOnly, tilesX, nTiles);
     return hipGetLastError();
 }
 // The fused kernel's tile: 32 rows x 16 columns (512 threads) for halos up to eight cells, 32 x 32 beyond.  Rows amortise: the

@@ -88,8 +88,23 @@ __device__ __forceinline__ double acos_unit(double x) {
 // the workgroup's walking phase (walk_phase below).
 __device__ __forceinline__ bool normals_from_moments(const MapGeom& g, double slopeCritical, double roughCritical, double invSlopeCritical,
                                                      double invRoughCritical, int N, int Sc, int Scc, int Sv, int Svv, int Svc, double Sz, double Szz, double Scz,
-                                                     double Svz, bool normalsStored, float& ox, float& oy, float& oz, float& os, float& orough) {
+                                                     double Svz, bool normalsStored, bool flat, double zAbs, float& ox, float& oy, float& oz, float& os, float& orough) {
     const double nd = static_cast<double>(N);
+    // `flat`: the first step window (a disc at least as wide as this one, same centre) found max == min — every member has the
+    // centre's elevation, bit for bit.  The published filters then leave no choice: the covariance's z row is rounding noise of the
+    // mean (|dz| <= (N + 1) eps |z|), its smallest eigenvalue fails the rank test against any xy scatter (and 0 > 0 fails it for
+    // one member), the normal is the z axis exactly, acos(1.0f) = 0, and the roughness sqrt(N dz^2 / (N - 1)) vanishes in the float
+    // result as long as it stays below 2^-26 of the critical value (two members at least: one gives 0 / 0 and takes the walk, as
+    // do elevations too large for the bound).  Flat synthetic ground — every cell rank-deficient, every cell on the literal
+    // walks until now — and the plateaus between the test terrain's risers stay on this path, in both chains.
+    if (flat && N >= 2 && zAbs * (nd + 1.0) * 2.5e-16 < 1.4e-8 * roughCritical) {
+        ox = 0.0f;
+        oy = 0.0f;
+        oz = 1.0f;
+        os = 0.0 < slopeCritical ? 1.0f : 0.0f;
+        orough = 1.0f;
+        return false;
+    }
     const double invN = rcp_refined(nd);
     const double Avv = static_cast<double>(N * Svv - Sv * Sv) * invN, Acc = static_cast<double>(N * Scc - Sc * Sc) * invN;
     const double Avc = static_cast<double>(N * Svc - Sv * Sc) * invN;
@@ -140,7 +155,7 @@ __device__ __forceinline__ bool normals_from_moments(const MapGeom& g, double sl
 // The moment phase of one tile: tables and source tile (disc_setup, one barrier), the prefix records (one barrier), then the
 // calling thread's cell.  `live`: the thread's cell is inside the map (every thread takes part in the barriers).
 template <int H, int TR, int TC>
-__device__ __forceinline__ bool moments_phase(char* ldsRaw, const MapGeom& g, const float* __restrict__ elev, int ti0, int tj0, double r, bool normalsStored,
+__device__ __forceinline__ bool moments_phase(char* ldsRaw, const MapGeom& g, const float* __restrict__ elev, int ti0, int tj0, double r, bool normalsStored, bool flat,
                                               const StepShape& sp, double slopeCritical, double roughCritical, double invSlopeCritical,
                                               double invRoughCritical, bool live, float& ox, float& oy, float& oz, float& os, float& orough) {
     using Lay = FusedLayout<H, TR, TC>;
@@ -263,7 +278,8 @@ __device__ __forceinline__ bool moments_phase(char* ldsRaw, const MapGeom& g, co
     const int Sc = SC - cc * N;
     const int Scc = static_cast<int>(ACC) - 2 * cc * SC + cc * cc * N;
     const int Svc = SvC - cc * Sv;
-    return normals_from_moments(g, slopeCritical, roughCritical, invSlopeCritical, invRoughCritical, N, Sc, Scc, Sv, Svv, Svc, Sz, Szz, Scz, Svz, normalsStored, ox, oy, oz, os, orough);
+    return normals_from_moments(g, slopeCritical, roughCritical, invSlopeCritical, invRoughCritical, N, Sc, Scc, Sv, Svv, Svc, Sz, Szz, Scz, Svz, normalsStored, flat,
+                                fabs(static_cast<double>(d.tile[(li + H) * W + lj + H])), ox, oy, oz, os, orough);
 }
 
 // The cell's iterator walk with the rows' column intervals taken from the lattice shape — the robust half-width of step_shape
