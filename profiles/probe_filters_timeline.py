@@ -36,6 +36,8 @@ if b[:, 8].max() > 0:
     ok = (b[:, 8] > 0) & (b[:, 9] > 0) & (b[:, 10] > 0) & (b[:, 11] > 0) & (b[:, 12] > 0) & (b[:, 13] > 0)
     q = lambda a, c: float(np.mean((b[ok, a] - b[ok, c]) / 100.0))
     print(f"  step: tile+tables {q(8,0):.2f}  runs+barrier {q(9,8):.2f}  fold {q(10,9):.2f}  edges+close {q(1,10):.2f} | moments: tile+tables {q(11,1):.2f}  z0+scans+barrier {q(12,11):.2f}  row records {q(13,12):.2f}  normals+stores {q(2,13):.2f}  walk vote/end {q(3,2):.2f}")
+wk = end - m2
+print(f"  walking phase per workgroup: {int((wk > 3).sum())} of {n} workgroups above 3 us, {int((wk > 10).sum())} above 10 us, longest {wk.max():.1f} us; workgroup lives above 1.5 x the median: {int(((end - start) > 1.5 * np.median(end - start)).sum())}")
 print("distinct CUs", len(set(cuid.tolist())), "per XCD:", [int((xcc == x).sum()) for x in range(8)])
 # per-XCD finish times and per-CU workgroup counts
 for x in range(8):

@@ -86,6 +86,10 @@ __device__ __forceinline__ double acos_unit(double x) {
 // float layers' rounding (tests/test_gpu_filters.py: one float ulp, >= 99.99 % of the cells bit-identical to the oracle).
 // Returns true when the cell has to take the literal walks instead (the outputs are then not set): the caller queues it for
 // the workgroup's walking phase (walk_phase below).
+#ifdef FPE_DBG_COUNT_WALKS
+__device__ unsigned g_walkWhy[4];
+__device__ double g_walkDbg[64][8];
+#endif
 __device__ __forceinline__ bool normals_from_moments(const MapGeom& g, double slopeCritical, double roughCritical, double invSlopeCritical,
                                                      double invRoughCritical, int N, int Sc, int Scc, int Sv, int Svv, int Svc, double Sz, double Szz, double Scz,
                                                      double Svz, bool normalsStored, bool flat, double zAbs, float& ox, float& oy, float& oz, float& os, float& orough) {
@@ -135,6 +139,14 @@ __device__ __forceinline__ bool normals_from_moments(const MapGeom& g, double sl
     // 2 cm, 32 of 300 at 1 cm, all of it the tail of the few workgroups that hold such a cell) stay on the moment path.  A gap
     // below 1e-4 is a genuine degeneracy (members on a line): the oracle's normal is then decided by its own rounding — walk.
     const double cMin = fmin(fmin(fabs(ex), fabs(ey)), fabs(ez));
+#ifdef FPE_DBG_COUNT_WALKS
+    if (walk) {
+        const unsigned k = atomicAdd(&g_walkWhy[0], 1u);
+        if (k < 64) { g_walkDbg[k][0] = static_cast<double>(N); g_walkDbg[k][1] = a00; g_walkDbg[k][2] = a11; g_walkDbg[k][3] = a22; g_walkDbg[k][4] = a01; g_walkDbg[k][5] = a02; g_walkDbg[k][6] = a12; g_walkDbg[k][7] = gapRel; }
+    }
+    else if (!(eigS > 1e-10 * eigL)) atomicAdd(&g_walkWhy[1], 1u);
+    else if (normalsStored ? !(cMin * fmin(gapRel, 0.3) > 1e-7) : !(gapRel > 1e-4)) atomicAdd(&g_walkWhy[2], 1u);
+#endif
     if (walk || !(eigS > 1e-10 * eigL)) return true;
     if (normalsStored ? !(cMin * fmin(gapRel, 0.3) > 1e-7) : !(gapRel > 1e-4)) return true;
     {

@@ -2169,3 +2169,12 @@ extern "C" int fpe_debug_opt_trace(void* out, size_t bytes) {
     return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(fpe::g_optTrace), bytes));
 }
 #endif
+#ifdef FPE_DBG_COUNT_WALKS
+extern "C" int fpe_debug_walk_dbg(double* out) { return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(fpe::g_walkDbg), 64 * 8 * 8)); }
+extern "C" int fpe_debug_walk_counts(unsigned* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(fpe::g_walkWhy), 16);
+    if (reset) { unsigned z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(fpe::g_walkWhy), z, 16); }
+    return static_cast<int>(e);
+}
+#endif
+
