@@ -35,7 +35,7 @@ PY
     bash profiles/collect_filters_counters.sh $m tree 2>/dev/null | grep -v "^==" | sed 's/^/  counters: /'
     bash profiles/collect_filters_traffic.sh $m 2>/dev/null | grep -v "^map" | sed 's/^/  fabric: /'
   done
-  echo "# flat ground (every cell rank-deficient: every cell takes the literal walks) and a tilted plane with noise (none does):"
+  echo "# flat ground (every disc of equal elevations: the z axis from the step height, no walk) and a tilted plane with noise:"
   python3 profiles/probe_filters_terrain.py 2>/dev/null | grep "ms per chain"
 } > gpurun_out/r5p_filters.txt 2>&1
 bash profiles/collect_filters_timeline.sh > /dev/null 2>&1

@@ -256,6 +256,9 @@ __device__ __forceinline__ void normal_from_scatter(double a00, double a01, doub
 // bit in every cell that converges within the iteration cap (scratch/eig_proto.py: 99.9-100 % of the cells; mean 3.9
 // iterations per cell, 4.1 per wavefront); a cell that does not — eigenvalues within a few per cent of each other — reports
 // false and takes the sweeps.  wS / wL as normal_from_scatter, wL being the trace (>= the largest eigenvalue, <= 3 x).
+#ifndef FPE_NEWTON_CAP
+#define FPE_NEWTON_CAP 32
+#endif
 __device__ __forceinline__ double rcp_refined(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
@@ -284,7 +287,7 @@ __device__ __forceinline__ bool normal_newton(double a00, double a01, double a02
     // at 1 cm — and the iteration halves its error step by step until it is inside their gap: 13-20 steps.  At a cap of 16 such
     // cells fell to the sweeps and, their gap being below 1e-3, to the literal walks: 196 cells of the 1 cm probe map, each holding
     // its workgroup for 20-40 us.  The loop leaves when the wavefront's last lane is done.)
-    for (int it = 0; it < 32; ++it) {
+    for (int it = 0; it < FPE_NEWTON_CAP; ++it) {
         const double f = __builtin_fma(__builtin_fma(lam - c2, lam, c1), lam, -c0);
         const double fp = __builtin_fma(__builtin_fma(3.0, lam, -2.0 * c2), lam, c1);
         const double dl = f * rcp_refined(fp);
