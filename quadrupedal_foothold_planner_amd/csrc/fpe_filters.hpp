@@ -897,6 +897,9 @@ FilterRoute filter_route(const FilterConsts& fc, const MapGeom& g) {
         return 16;
     };
     rt.t1 = tile_of(rt.h1, rt.s1.nClasses);
+#ifdef FPE_FILTER_T1_ENV  // (measurement builds: the first window's tile from the environment)
+    if (std::getenv("FPE_FILTER_T1")) rt.t1 = std::atoi(std::getenv("FPE_FILTER_T1"));
+#endif
     rt.t2 = tile_of(rt.h2, rt.s2.nClasses);
     if (rt.tF) {
         rt.fusedBytes = fused_moment_bytes(rt.hN, kFusedRows, rt.tF);
@@ -951,6 +954,10 @@ hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float*
             FPE_RUNS(32, 32, 0);
         }
         if (tcode == 24) {
+#ifdef FPE_FILTER_T1_ENV
+            if (!kSecond && H == 5) FPE_RUNS(32, 16, 5);
+            if (!kSecond && H == 9) FPE_RUNS(32, 16, 9);
+#endif
             if (H == 17) FPE_RUNS(32, 16, 17);  // the published windows (0.08 m) at 0.5 cm
             FPE_RUNS(32, 16, 0);
         }
