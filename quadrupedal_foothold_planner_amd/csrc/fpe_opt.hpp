@@ -704,7 +704,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2))) voi
             // go first (they sleep in their polls while wavefront 0 has the critical path), or the seven wait for the one at their exchange
             __builtin_amdgcn_s_setprio(3);
 #endif
-            int nRuns = 0, meets = 0;
+            int meets = 0;
             for (int cyc = 0; cyc < nCycles; ++cyc) {
                 opt_wait_ge(&sync[0], cyc + 1);  // the cycle's problem is published
                 if (wave == 1) FPE_OPT_STAMP(10);
@@ -712,7 +712,6 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2))) voi
                 const int run = runOf[cyc & 255];
                 if (run < 0) return;
                 if (run == 0) continue;
-                ++nRuns;
                 int nIdx[8], cIdx[8], lo[8], up[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
