@@ -155,9 +155,13 @@ struct CallCtx {
             // 150 us per service call against 138 with the kernels one after the other and 105 in a process of its own
             int lo = 0, hi = 0;
             hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
-            if (e != hipSuccess) return e;
-            e = hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi);
-            if (e != hipSuccess) return e;
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi);
+            if (e != hipSuccess) {  // (no priorities on this runtime: a plain stream — correct, possibly behind the plan kernel)
+                (void)hipGetLastError();
+                side = nullptr;
+                e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+                if (e != hipSuccess) return e;
+            }
         }
         *out = side;
         return hipSuccess;
