@@ -672,10 +672,12 @@ struct OptShared {
 
 }  // namespace
 
-// W wavefronts per pose: 1 for batches (throughput: a pose per wavefront), 8 for a handful of poses (512 threads keep the 256-register budget: 1024 halve it and spill) — the service call
-// plans ONE pose, and the optimiser's box (14 641 row points per cycle at 2 cm) would otherwise be walked by one
-// wavefront, cycle after cycle.  Wavefront 0 runs the track; the others wait at the workgroup barrier (they consume no
-// issue slots there), take their slice of the row search when wavefront 0 publishes a problem, and hand back their best.
+// W wavefronts per pose: 1 for batches (throughput: a pose per wavefront, two per SIMD), 8 for a handful of poses (512 threads
+// keep the 256-register budget: 1024 halve it and spill) — the service call plans ONE pose, and the optimiser's box (14 641 row
+// points per cycle at 2 cm) would otherwise be walked by one wavefront, cycle after cycle.  Wavefront 0 runs the track and decides
+// the columns; the seven helpers poll a sequence number in LDS (s_sleep between polls), analyse and list the row lattice as soon as
+// a cycle's bounds are published — beside the column searches —, evaluate their lists once the columns are, and hand back their
+// best (round 5; until then they waited at the workgroup barrier and the whole search followed the columns).
 template <int W>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2))) void opt_track_kernel(DevMap m, PlanConsts pc, OptConsts oc, const fpe_pose* __restrict__ poses, int B,
                                                            int nCycles, const uint8_t* __restrict__ cycleOk, fpe_opt_out out) {
