@@ -280,6 +280,8 @@ def main():
     # staging buffers).  K = --gather-every (default 8: "fewer, larger collectives" — a collective has a fixed cost of tens
     # of microseconds against a 29 us headline step); K = 1 is measured as well (config.exchange_alt).  Every gathered step's
     # footholds reach every rank; the timed region ends after the last all-gather has completed.
+    ev_blocks_ = []  # HIP-event time per step of every timed block of the last run()
+
     def run(batch):
         ex_ = fdist.BatchedFootholdExchange(n_rec * xrec, dev, batch=batch, force_collective=force_nccl) if exchanging else None
         k_ = [0]
@@ -331,6 +333,7 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
             walls.append(float(t.item()))
             evs.append(ev0.elapsed_time(ev1) / args.steps)
+        ev_blocks_[:] = evs
         return walls, float(np.median(evs)), ex_, last_run[0]
 
     # HIP events on the launch stream bracket the K launches of the timed region; at N=1 the region
@@ -339,6 +342,7 @@ def main():
     # the all-gather shares the stream, so a second, kernel-only pass measures the launch duration.
     gather_batch = max(1, args.gather_every) if exchanging else 1
     walls, kernel_ms, ex, last_step = run(gather_batch)
+    ev_blocks = list(ev_blocks_)
     elapsed = float(np.median(walls))  # the median block of K steps
     alt = None
     n_collectives = ex.collectives if ex else 0
@@ -372,7 +376,9 @@ def main():
     # first dispatch pays the queue's wake-up — ~30 us per block, i.e. 1.3 us per step at K = 20, 0.1 us at K = 200 (measured:
     # 25.0 / 24.6 / 23.7 us per launch at K = 20 / 50 / 200 on one box).  One extra, untimed pass of >= 200 back-to-back launches
     # gives the kernel's own steady-state duration; `frac` keeps using the timed region's figure.
-    nb2b = max(200, args.steps)
+    # Sized to keep the GPU busy for >= 0.25 s (the timed region of a 25 us step is ~13 ms of a 20 s run, below what a
+    # utilisation sampler at 1-5 Hz can see; this pass — 10 000 launches at the headline — is the run's visibly busy stretch).
+    nb2b = int(min(20000, max(200, args.steps, np.ceil(250.0 / max(kernel_ms, 1e-3)))))
     s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     for rep_ in range(2):
@@ -452,8 +458,13 @@ def main():
 
     line = {
         "metric": "footholds/sec (4 legs x N cycles x B poses) on 1k^2 @2cm map; `value` = device-resident (poses and every product stay in HBM), "
-                  "`value_survey_8d` = SURVEY 8(d)'s wall time of fpe_plan with host buffers, result D2H included",
+                  "`value_8d` / `ms_per_step_8d` = SURVEY 8(d)'s wall time of fpe_plan with host buffers, result D2H included (pinned destinations; "
+                  "pageable ones in value_survey_8d)",
         "value": value,
+        # SURVEY 8(d)'s own definition of the metric, filled in below at N = 1: wall time of fpe_plan with HOST buffers (poses H2D +
+        # kernel + all seven products D2H into pinned destinations from fpe_host_alloc); null where the leg does not run
+        "value_8d": None,
+        "ms_per_step_8d": None,
         "unit": "footholds/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -462,6 +473,17 @@ def main():
         "ms_per_step_is": f"the median of {args.blocks} timed blocks of {args.steps} steps (each block between barrier + synchronize pairs, MAX over ranks)",
         "ms_per_step_min": min(walls) / args.steps * 1e3,
         "ms_per_step_max": max(walls) / args.steps * 1e3,
+        "ms_per_step_p10": float(np.percentile(walls, 10)) / args.steps * 1e3,
+        "ms_per_step_p90": float(np.percentile(walls, 90)) / args.steps * 1e3,
+        "ms_per_step_blocks": [round(w / args.steps * 1e3, 6) for w in walls],
+        "ms_per_step_slowest_block": {"index": int(np.argmax(walls)), "of": len(walls),
+                                      "is_first_block": bool(int(np.argmax(walls)) == 0),
+                                      "blocks_over_1.5x_median": [int(i) for i in np.nonzero(np.array(walls) > 1.5 * elapsed)[0]],
+                                      "note": "host wall clock around each block (barrier + synchronize on both sides); block 0 follows the "
+                                              "untimed warm-up directly, every later block follows the previous block's synchronize.  An outlier "
+                                              "here that the HIP-event time of the same block (kernel_ms_blocks) does not show is host-side "
+                                              "(scheduler, a collector pause), not the GPU"},
+        "kernel_ms_blocks": [round(e, 6) for e in ev_blocks],
         "timed_region_ms": sum(walls) * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
@@ -603,6 +625,8 @@ def main():
                                                  "seven products D2H; map upload excluded), median of 20 calls; `pinned_destinations`: the same call with "
                                                  "result arrays from fpe_host_alloc.  Bound by the PCIe link (plain_d2h_copy_GB/s_on_this_box in "
                                                  "value_incl_d2h), not by the kernel: `value` is 13-18 x this"}
+        line["value_8d"] = 4 * n_cycles * B / dt_p
+        line["ms_per_step_8d"] = dt_p * 1e3
         line["value_incl_d2h_pinned"] = {"value": 4 * n_cycles * B / dt_p, "unit": "footholds/s", "ms_per_call": dt_p * 1e3,
                                          "result_bytes": res_bytes, "GB/s_results": res_bytes / dt_p / 1e9,
                                          "note": "same call, result arrays from fpe_host_alloc (pinned): every product is written by DMA straight "

@@ -328,7 +328,11 @@ int fpe_filter_params_defaults(fpe_filter_params* out);
  * (optional, FPE_FILTER_LAYERS * rows * cols floats) come back CANONICAL (row-major, start index 0).  Synchronous. */
 int fpe_traversability(fpe_handle h, const fpe_map_desc* desc, const fpe_filter_params* fp, const float* elevation,
                        float* traversability, float* layers);
-/* Device buffers, asynchronous on `stream`; d_layers optional (scratch from the engine's pool when null). */
+/* Device buffers, asynchronous on `stream`; d_layers optional (scratch from the engine's pool when null).
+ * Several producers may call on different streams concurrently (the reference's callbacks run under AsyncSpinner(0),
+ * foothold_planner_node.cpp:12): no call synchronises the device or blocks the host — the engine keeps up to four
+ * internal step-height buffers, each guarded by an event recorded behind the chain that used it last; a fifth concurrent
+ * stream waits GPU-side for the least recently used one.  `stream` must outlive the chains queued on it. */
 int fpe_traversability_device(fpe_handle h, const fpe_map_desc* desc, const fpe_filter_params* fp, const float* d_elevation,
                               float* d_traversability, float* d_layers, void* stream);
 

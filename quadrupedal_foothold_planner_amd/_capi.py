@@ -252,6 +252,12 @@ def lib():
     except OSError as e:
         raise EngineUnavailable(f"cannot load {path}: {e}") from e
     vp, i32, f32, f64 = C.c_void_p, C.c_int32, C.c_float, C.c_double
+    # a library that predates a symbol of include/fpe.h (FPE_LIB pointing at an old scratch build) is "unavailable", not an
+    # AttributeError out of ctypes that callers catching EngineUnavailable would not see
+    missing = [name for name in EXPORTED_SYMBOLS if not hasattr(L, name)]
+    if missing:
+        raise EngineUnavailable(f"{path} predates include/fpe.h (ABI version {ABI_VERSION}): it does not export {', '.join(missing[:4])}"
+                                + (" ..." if len(missing) > 4 else ""))
     L.fpe_version.restype = C.c_char_p
     L.fpe_abi_version.restype = C.c_int
     if L.fpe_abi_version() != ABI_VERSION:

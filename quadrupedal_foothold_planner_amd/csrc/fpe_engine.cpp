@@ -403,13 +403,24 @@ struct fpe_engine {
     std::vector<int32_t> ringStart;   // host copy of the rank table's ring offsets
     float maxLegSearchRadius = 0.0f;  // fpe_set_max_leg_search_radius
     fpe::Tuning tuning;               // fpe_set_tuning; seeded from the environment once, in fpe_create
-    // The filter chain's step_height scratch, kept per STREAM: chains enqueued on one stream run in order, so the layer is
-    // reused from call to call without the pool's device synchronisation (a 10-20 Hz producer on its own stream never
-    // synchronises); a call on another stream swaps the buffer through the pool (dirty -> one synchronisation).
+    // The traversability-only filter chain's step_height scratch: up to kFilterSlots buffers, each with the event recorded behind
+    // the last chain that used it.  A chain takes, in this order: the buffer its own stream used last (chains of one stream run in
+    // order: nothing to wait for — a 10-20 Hz producer on its own stream never waits and never synchronises), a buffer whose last
+    // chain has completed (neither when it is more than four times too large: a single huge map must not pin memory for good), a fresh buffer while there are free slots, and only then the least recently used busy buffer, behind
+    // a GPU-side hipStreamWaitEvent on its event.  No path synchronises the device or blocks the host (round 5 kept ONE buffer
+    // keyed to one stream: two producers alternating streams paid a hipDeviceSynchronize per call).
+    // A stream handed to fpe_traversability_device must outlive the chains queued on it (include/fpe.h).
+    static constexpr int kFilterSlots = 4;
+    struct FilterSlot {
+        float* buf = nullptr;
+        size_t cap = 0;
+        hipEvent_t done = nullptr;
+        hipStream_t last = nullptr;
+        unsigned long long use = 0;
+    };
     std::mutex filterMu;
-    hipStream_t filterStream = nullptr;
-    float* filterScratch = nullptr;
-    size_t filterCap = 0;
+    FilterSlot filterSlots[kFilterSlots];
+    unsigned long long filterClock = 0;
 
     fpe::SpiralLut lut() const {
         return fpe::SpiralLut{d_di, d_dj, d_ring, d_ringStart, maxRing, ringStart.empty() ? 0 : ringStart[static_cast<size_t>(maxRing) + 1], d_packed, d_fast16};
@@ -601,6 +612,10 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
     if (!pairs.empty() && travThroughKernel && desc->rows < (1 << 24) - 2 && desc->cols < (1 << 24) - 64) {
         rc = alloc_mask(*snap, pairs[0].first, pairs[0].second, false, folded);
         if (rc != FPE_OK) return rc;
+        // the canonicalising kernel below writes this buffer asynchronously: should any later step of the upload fail, the buffer
+        // goes back to the pool DIRTY (its next taker synchronises) — a dirty return costs a synchronisation, a clean one of a
+        // buffer with work queued on it would be a race.  Cleared again once `ready` is recorded, below.
+        folded->asyncUsed.store(true, std::memory_order_release);
     }
     for (int l = 0; l < 2; ++l) {
         uint32_t* planeWords = (l == 0 && folded) ? folded->d_words : nullptr;
@@ -626,6 +641,8 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
     if (folded) {
         rc = mask_ready(*folded, stream);
         if (rc != FPE_OK) return rc;
+        // from here on ~MaskSet waits for `ready` (recorded behind the kernel that wrote the planes) before it gives the buffer back
+        folded->asyncUsed.store(false, std::memory_order_release);
         folded->lastUse.store(++snap->useClock);
         snap->masks.push_back(folded);
     }
@@ -756,7 +773,10 @@ int fpe_destroy(fpe_handle h) {
     if (h->d_ringStart) (void)hipFree(h->d_ringStart);
     if (h->d_packed) (void)hipFree(h->d_packed);
     if (h->d_fast16) (void)hipFree(h->d_fast16);
-    if (h->filterScratch) (void)hipFree(h->filterScratch);
+    for (auto& fs : h->filterSlots) {
+        if (fs.buf) (void)hipFree(fs.buf);
+        if (fs.done) (void)hipEventDestroy(fs.done);
+    }
     h->map.reset();
     delete h;
     return FPE_OK;
@@ -887,17 +907,45 @@ int filters_common(fpe_engine* h, const fpe_map_desc* desc, const fpe_filter_par
         float* d_trav = trav;
         if (!onDevice) FPE_HIP(take(n, &d_trav));
         {
-            // the lock is held until the chain is QUEUED: a concurrent call on another stream swaps the scratch out through the
-            // pool (dirty: its next taker synchronises the device — which only covers work already queued)
+            // the lock is held until the chain is QUEUED and its event recorded (see fpe_engine::filterSlots)
             std::lock_guard<std::mutex> lk(h->filterMu);
-            if (!(h->filterScratch && h->filterStream == stream && h->filterCap >= n)) {
-                if (h->filterScratch) h->pool->give(h->filterCap, h->filterScratch, true);
-                h->filterScratch = nullptr;
-                FPE_HIP(alloc_units(*h->pool, n, &h->filterScratch, &h->filterCap));
-                h->filterStream = stream;
+            fpe_engine::FilterSlot* slot = nullptr;
+            bool wait = false;
+            for (auto& fs : h->filterSlots)  // (1) this stream's own buffer
+                if (fs.buf && fs.cap >= n && fs.cap <= 4 * n + 4096 && fs.last == stream && (!slot || fs.use > slot->use)) slot = &fs;
+            if (!slot)
+                for (auto& fs : h->filterSlots)  // (2) an idle buffer
+                    if (fs.buf && fs.cap >= n && fs.cap <= 4 * n + 4096 && hipEventQuery(fs.done) == hipSuccess) {
+                        slot = &fs;
+                        break;
+                    }
+            (void)hipGetLastError();  // hipErrorNotReady of the queries above is not an error
+            if (!slot) {
+                for (auto& fs : h->filterSlots)  // (3) a free slot, else (4) the least recently used one
+                    if (!fs.buf) {
+                        slot = &fs;
+                        break;
+                    }
+                if (!slot) {
+                    slot = &h->filterSlots[0];
+                    for (auto& fs : h->filterSlots)
+                        if (fs.use < slot->use) slot = &fs;
+                    wait = true;
+                }
+                if (slot->buf && slot->cap < n) {  // too small (also reached by (4)): back to the pool, dirty — its last chain may still run
+                    h->pool->give(slot->cap, slot->buf, true);
+                    slot->buf = nullptr;
+                    wait = false;
+                }
+                if (!slot->buf) FPE_HIP(alloc_units(*h->pool, n, &slot->buf, &slot->cap, true));  // cleanOnly: never a device synchronisation
+                if (!slot->done) FPE_HIP(hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
             }
-            const fpe::FilterLayers L{nullptr, nullptr, nullptr, nullptr, h->filterScratch, nullptr, nullptr, d_trav};
+            if (wait) FPE_HIP(hipStreamWaitEvent(stream, slot->done, 0));
+            const fpe::FilterLayers L{nullptr, nullptr, nullptr, nullptr, slot->buf, nullptr, nullptr, d_trav};
             FPE_HIP(fpe::launch_filters(g, fc, d_elev, L, true, stream));
+            FPE_HIP(hipEventRecord(slot->done, stream));
+            slot->last = stream;
+            slot->use = ++h->filterClock;
         }
         if (!onDevice) {
             FPE_HIP(hipMemcpyAsync(trav, d_trav, n * sizeof(float), hipMemcpyDeviceToHost, stream));
@@ -1125,6 +1173,10 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
         if (speculate) {
             std::memset(hp + oSpec, 1, nCyc);
             FPE_HIP(cx.side_stream(&os));
+            // the chain reads both layers: the side stream waits for an asynchronous upload (fpe_upload_map_device) exactly as
+            // prepare_call made cx.stream wait (the speculative chain used to start while the canonicalise / copy
+            // kernels of the snapshot were still writing d_trav / d_elev)
+            FPE_HIP(cp.snap->wait_ready(os));
             okDev = dp + oSpec;
         }
         FPE_HIP(fpe::launch_opt_track(dev_map(*cp.snap), cp.pc, oc, dPoses ? dPoses : reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, okDev, od, os));

@@ -297,20 +297,32 @@ __device__ __forceinline__ bool normal_newton(double a00, double a01, double a02
         done = done || fabs(dl) <= tol;
         if (__ballot(!done) == 0ull) break;
     }
-    const double m00 = b00 - lam, m11 = b11 - lam, m22 = b22 - lam;
+    // The scaled entries are formed AGAIN here from the caller's matrix instead of being kept across the iteration (the compiler is
+    // kept from reusing the first set by an empty asm on the scale): six multiplications against twelve registers held through the
+    // loop — with them the 2 cm instantiation (64 registers, eight wavefronts per SIMD) spilled four doubles of the caller's matrix
+    // in EVERY cell, 32 B of scratch stores per thread and launch (47 MB written per 1000 x 1000 launch for 4 MB of
+    // layers).  Same operands, same operation: the same values bit for bit.
+#ifndef FPE_NEWTON_KEEP_SCALED
+    double inv2 = inv;
+    asm volatile("" : "+v"(inv2));
+    const double d00 = a00 * inv2, d01 = a01 * inv2, d02 = a02 * inv2, d11 = a11 * inv2, d12 = a12 * inv2, d22 = a22 * inv2;
+#else
+    const double d00 = b00, d01 = b01, d02 = b02, d11 = b11, d12 = b12, d22 = b22;
+#endif
+    const double m00 = d00 - lam, m11 = d11 - lam, m22 = d22 - lam;
     // cross products of the rows of A - lambda I: where the lattice's x and y spread dominate the matrix (terrain below ~45
-    // degrees on a disc that is not cut down to a sliver: entries b00, b11 of order 1 after the scaling) rows 0 and 1 give the
+    // degrees on a disc that is not cut down to a sliver: entries d00, d11 of order 1 after the scaling) rows 0 and 1 give the
     // long product, squared length of order 1.  Below 0.05 — steep faces, whose z variance takes the scale and leaves rows 0
     // and 1 small and their product cancellation-limited (the round-5 campaign's seeds 2505080, 2514166: normals 2-9 float ulps
     // off with a looser bar), slivers at map borders — the other two are formed and the longest of the three taken, per lane:
     // a cell's value never depends on the cells it shares a wavefront with.
-    const double p0 = __builtin_fma(b01, b12, -(b02 * m11)), p1 = __builtin_fma(b02, b01, -(m00 * b12)), p2 = __builtin_fma(m00, m11, -(b01 * b01));
+    const double p0 = __builtin_fma(d01, d12, -(d02 * m11)), p1 = __builtin_fma(d02, d01, -(m00 * d12)), p2 = __builtin_fma(m00, m11, -(d01 * d01));
     const double np = __builtin_fma(p0, p0, __builtin_fma(p1, p1, p2 * p2));
     double v0 = p0, v1 = p1, v2 = p2, nn = np;
     const bool shortP = !(np > 0.05);
     if (__ballot(shortP) != 0ull) {
-        const double q0 = __builtin_fma(b01, m22, -(b02 * b12)), q1 = __builtin_fma(b02, b02, -(m00 * m22)), q2 = __builtin_fma(m00, b12, -(b01 * b02));
-        const double t0 = __builtin_fma(m11, m22, -(b12 * b12)), t1 = __builtin_fma(b12, b02, -(b01 * m22)), t2 = __builtin_fma(b01, b12, -(m11 * b02));
+        const double q0 = __builtin_fma(d01, m22, -(d02 * d12)), q1 = __builtin_fma(d02, d02, -(m00 * m22)), q2 = __builtin_fma(m00, d12, -(d01 * d02));
+        const double t0 = __builtin_fma(m11, m22, -(d12 * d12)), t1 = __builtin_fma(d12, d02, -(d01 * m22)), t2 = __builtin_fma(d01, d12, -(m11 * d02));
         const double nq = __builtin_fma(q0, q0, __builtin_fma(q1, q1, q2 * q2)), nt = __builtin_fma(t0, t0, __builtin_fma(t1, t1, t2 * t2));
         if (shortP && nq > nn) { v0 = q0; v1 = q1; v2 = q2; nn = nq; }
         if (shortP && nt > nn) { v0 = t0; v1 = t1; v2 = t2; nn = nt; }

@@ -20,6 +20,7 @@
 #include <rccl/rccl.h>
 
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -45,15 +46,29 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
     bool ok = false;
+    bool sameDeviceRanks = false;  // the bound library lets one device stand for several ranks (tests/probe/collective_shim.cpp only)
 };
 Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) {
-            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (r.lib) break;
+        // FPE_RCCL_LIB (read once per process): the collective library to bind instead of the system's RCCL — a site's own RCCL
+        // build, or the test suite's device-local stand-in that runs the gather's n > 1 logic on a one-GPU box.  When it is set
+        // nothing else is tried: a typo must not fall back silently to another library.
+        const char* forced = std::getenv("FPE_RCCL_LIB");
+        if (forced && *forced) {
+            r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!r.lib) {
+                r.err = std::string("FPE_RCCL_LIB=") + forced + " not loadable: " + dlerror();
+                return;
+            }
+            r.sameDeviceRanks = dlsym(r.lib, "fpe_test_collective_shim") != nullptr;
+        } else {
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char* n : names) {
+                r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+                if (r.lib) break;
+            }
         }
         if (!r.lib) {
             r.err = std::string("librccl.so.1 not loadable: ") + dlerror();
@@ -246,13 +261,13 @@ int ensure_stage(fpe_multi* h, size_t k, size_t bytes, hipStream_t st) {
 
 int ensure_comms(fpe_multi* h) {
     if (!h->comms.empty()) return FPE_OK;
-    // (a group may list one device several times — independent engines for the host-buffer form — but a communicator needs
-    // distinct devices)
-    for (size_t a = 0; a < h->devices.size(); ++a)
-        for (size_t b = a + 1; b < h->devices.size(); ++b)
-            if (h->devices[a] == h->devices[b]) return mfail(h, FPE_E_UNSUPPORTED, "the RCCL all-gather needs distinct devices: one appears twice in the group");
     Rccl& r = rccl();
     if (!r.ok) return mfail(h, FPE_E_UNSUPPORTED, "RCCL unavailable: " + r.err);
+    // (a group may list one device several times — independent engines for the host-buffer form — but an RCCL communicator
+    // needs distinct devices; only the test suite's stand-in library, which says so itself, takes one device as several ranks)
+    for (size_t a = 0; a < h->devices.size() && !r.sameDeviceRanks; ++a)
+        for (size_t b = a + 1; b < h->devices.size(); ++b)
+            if (h->devices[a] == h->devices[b]) return mfail(h, FPE_E_UNSUPPORTED, "the RCCL all-gather needs distinct devices: one appears twice in the group");
     std::vector<ncclComm_t> comms(h->engines.size(), nullptr);
     const ncclResult_t rc = r.CommInitAll(comms.data(), static_cast<int>(comms.size()), h->devices.data());
     if (rc != ncclSuccess) return mfail(h, FPE_E_HIP, std::string("ncclCommInitAll: ") + r.GetErrorString(rc));

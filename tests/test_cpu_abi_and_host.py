@@ -261,3 +261,37 @@ def test_three_operation_division_by_three_is_exact(tmp_path):
     subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm"], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.strip()
     assert out == "0", f"{out} mismatches between the three-operation form and x / 3.0"
+
+
+def test_collective_stand_in_builds_and_exports_what_the_engine_binds():
+    """tests/probe/collective_shim.cpp (the device-local stand-in that lets one GPU act as n ranks in the GPU suite) must export
+    every entry point csrc/fpe_multi.cpp resolves from its collective library, plus the marker that identifies it."""
+    import re
+    import subprocess
+
+    from tests.test_gpu_device_api import build_collective_shim
+
+    so = build_collective_shim()
+    src = open(os.path.join(ROOT, "quadrupedal_foothold_planner_amd", "csrc", "fpe_multi.cpp")).read()
+    wanted = set(re.findall(r'sym\("(nccl\w+)"\)', src))
+    assert len(wanted) >= 7
+    exported = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    for name in sorted(wanted) + ["fpe_test_collective_shim"]:
+        assert re.search(r"\b" + name + r"\b", exported), name
+
+
+def test_a_library_that_predates_the_header_is_unavailable_not_an_attribute_error(tmp_path):
+    """FPE_LIB pointing at a library built before a symbol of include/fpe.h existed must surface as EngineUnavailable
+    (what callers and tests catch), not as ctypes' AttributeError."""
+    import subprocess
+    import sys
+
+    src = tmp_path / "old.c"
+    src.write_text('const char* fpe_version(void) { return "0"; }\nint fpe_create(int d, void** h) { (void)d; (void)h; return -1; }\n')
+    so = tmp_path / "libfpe_old.so"
+    assert subprocess.run(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)]).returncode == 0
+    code = ("from quadrupedal_foothold_planner_amd import _capi\n"
+            "try:\n    _capi.lib()\n    print('loaded')\n"
+            "except _capi.EngineUnavailable as e:\n    print('unavailable', 'fpe_abi_version' in str(e) or 'does not export' in str(e))\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, FPE_LIB=str(so)))
+    assert r.returncode == 0 and r.stdout.strip() == "unavailable True", r.stdout + r.stderr

@@ -331,6 +331,47 @@ def test_service_with_the_opt_chain_beside_the_plan_kernel_equals_one_after_the_
     assert answered >= 10 and reran >= 5, "need calls whose nominal flags differ from the flags the chain first ran on"
 
 
+def test_service_right_after_an_asynchronous_upload_waits_on_the_side_stream_too(planner):
+    """the overlapped service call launches the opt track's chain on a SECOND stream; after an asynchronous
+    fpe_upload_map_device (elevation -> filters -> upload -> service, all on the device) that stream has to wait for the snapshot's
+    upload exactly as the plan's stream does, or the chain reads layers the canonicalise / copy kernels are still writing.  The
+    upload's stream is kept busy (a spin kernel queued ahead of the upload), every round uploads a map never seen before into
+    recycled buffers, and the overlapped call made while the upload is still pending must equal the sequential call made after
+    it has completed — every product, the gate included."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    planner.params = _capi.params_yaml()
+    s_up = torch.cuda.Stream(device=dev)
+    rng = np.random.default_rng(31337)
+    flat_t, flat_e = np.ones((400, 400), np.float32), np.zeros((400, 400), np.float32)
+    answered = differed = 0
+    for k in range(8):
+        planner.gridmapCallback(flat_t, flat_e, 0.02)  # the snapshot the pending upload replaces: a chain reading IT answers differently
+        pos = [rng.uniform(-3.2, -2.0), rng.uniform(-3, 3), 0.0]
+        with planner.tuning(service_overlap=0, service_opt_gate=1):
+            on_flat = (planner.globalFootholdPlan(6, pos, all_tracks=True), planner.last_service_gate())
+        trav, elev = synth.rough_map(400, 400, 0.02, seed=900 + k, bad_frac=0.25)
+        with torch.cuda.stream(s_up):
+            d_trav = torch.from_numpy(trav).to(dev)
+            d_elev = torch.from_numpy(elev).to(dev)
+            torch.cuda._sleep(100_000_000)  # tens of milliseconds (at least) of spinning ahead of the upload on its stream
+            planner.upload_map_device(d_trav.data_ptr(), d_elev.data_ptr(), 400, 400, 0.02, stream=s_up.cuda_stream)
+        assert not s_up.query(), "the upload must still be pending when the service call starts"
+        with planner.tuning(service_overlap=1, service_opt_gate=1):
+            early = (planner.globalFootholdPlan(6, pos, all_tracks=True), planner.last_service_gate())
+        s_up.synchronize()
+        with planner.tuning(service_overlap=0, service_opt_gate=1):
+            late = (planner.globalFootholdPlan(6, pos, all_tracks=True), planner.last_service_gate())
+        _same(early, late)
+        answered += int(late[0] is not False)
+        try:
+            _same(on_flat, late)
+        except AssertionError:
+            differed += 1
+    assert answered >= 3 and differed >= 6, "the rounds must be able to tell the old snapshot from the new one"
+
+
 def test_service_survives_a_geometry_the_opt_track_does_not_support(planner):
     """ADVICE r3: on a fine map with a large search radius the opt track is unsupported (its blocked-row mask holds 128 rows);
     the service call — which no longer needs the chain for its return value — still answers, under every gate mode."""
@@ -421,6 +462,70 @@ def test_multi_plan_device_gathers_over_rccl(planner):
             mp.set_tuning(gather_padded=0)
     finally:
         mp.close()
+
+
+def build_collective_shim():
+    """tests/probe/collective_shim.cpp -> tests/probe/_build/libcollective_shim.so (hipcc: host code + the HIP runtime)."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_dir = os.path.join(root, "tests", "probe", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libcollective_shim.so")
+    src = os.path.join(root, "tests", "probe", "collective_shim.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-Wall", "-shared", "-fPIC", src, "-o", so], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    return so
+
+
+def test_multi_plan_device_with_2_3_and_8_ranks_on_one_gpu():
+    """the gather's n > 1 logic had never executed anywhere (RCCL refuses two ranks on one device; the boxes have one).
+    The engine binds its collective library at run time, so a device-local stand-in (tests/probe/collective_shim.cpp, bound through
+    FPE_RCCL_LIB in a fresh process) lets ONE GPU stand for 2, 3 and 8 ranks: uneven and even batches, both record kinds, the caller's
+    streams and the group's, each call twice (staging reuse), a growing and a shrinking batch (staging growth) — every rank's
+    d_gathered byte-equal to the single-device plan of the whole batch.  tests/probe/multi_shim_run.py is the script."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FPE_RCCL_LIB=build_collective_shim(), PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "probe", "multi_shim_run.py")], capture_output=True, text=True, env=env, cwd=root,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.strip().splitlines()[-1] == "ok 36", r.stdout[-2000:]
+
+
+def test_a_collective_library_that_does_not_load_is_an_error_not_a_fallback():
+    """FPE_RCCL_LIB names the library to bind; when it cannot be loaded the gather fails with FPE_E_UNSUPPORTED and says why — it
+    never falls back to another library behind the caller's back."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np, torch\n"
+        "from quadrupedal_foothold_planner_amd import _capi, synth\n"
+        "from quadrupedal_foothold_planner_amd.planner import MultiFootholdPlanner, FpeError\n"
+        "mp = MultiFootholdPlanner([0])\n"
+        "t, e = synth.rough_map(100, 100, 0.02, seed=1)\n"
+        "mp.gridmapCallback(t, e, 0.02)\n"
+        "p = synth.poses_in_map(4, 2.0, 2.0, 2, 0.18, seed=2, margin=0.7)\n"
+        "d = torch.device('cuda:0')\n"
+        "dp = torch.from_numpy(p.view(np.uint8).reshape(4, -1).copy()).to(d)\n"
+        "rec = torch.zeros(4 * 2 * 4 * 8, dtype=torch.uint8, device=d); al = torch.zeros_like(rec)\n"
+        "try:\n"
+        "    mp.plan_device(4, 2, [{'d_poses': dp.data_ptr(), 'selected_packed': rec.data_ptr(), 'd_gathered': al.data_ptr()}], record_kind=_capi.EXCHANGE_PACKED)\n"
+        "    print('accepted')\n"
+        "except FpeError as x:\n"
+        "    print('refused', x.code == _capi.FPE_E_UNSUPPORTED, 'FPE_RCCL_LIB' in str(x))\n"
+    )
+    env = dict(os.environ, FPE_RCCL_LIB="/nonexistent/librccl_typo.so", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "refused True True", r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.skipif(__import__("torch").cuda.device_count() < 2, reason="needs two GPUs (the driver's multi-GPU node; this pool's boxes have one)")
