@@ -118,10 +118,21 @@ __device__ __forceinline__ bool normals_from_moments(const MapGeom& g, double sl
     const double a00 = res2 * Avv, a01 = res2 * Avc, a02 = -(res * Avz), a11 = res2 * Acc, a12 = -(res * Acz), a22 = Azz;
     double ex, ey, ez, eigS, eigL, gapRel;
     bool walk = false;
+#ifdef FPE_NEWTON_FAIL_SWEEPS
+    // (rounds 4-5: a cell whose iteration fails took the Jacobi sweeps on the moment matrix right here, and the literal walks only
+    // when its eigenvalues were closer than 1e-3)
     if (!normal_newton(a00, a01, a02, a11, a12, a22, ex, ey, ez, eigS, eigL, gapRel)) {
         normal_from_scatter(a00, a01, a02, a11, a12, a22, ex, ey, ez, eigS, eigL);
         walk = !(gapRel > 1e-3);  // eigenvalues this close: the sweeps on THIS matrix and on the oracle's (another order of summation) part ways
     }
+#else
+    // Round 6: a cell whose iteration fails (no convergence inside the cap, eigenvalues within 1e-6, degenerate input) takes the
+    // LITERAL WALKS — the oracle's own arithmetic — instead of the Jacobi sweeps on the moment matrix inlined here: the sweeps'
+    // eighteen registers of eigenvectors were live beside everything the cell still needs, and at the 2 cm instantiation's 64
+    // registers the compiler spilled the iteration's results around the (never taken) branch in EVERY cell.  The cells concerned
+    // are the ones that mostly walked anyway (their gap is below 1e-3 in all but a handful per map: profiles/round6_filters.txt).
+    walk = !normal_newton(a00, a01, a02, a11, a12, a22, ex, ey, ez, eigS, eigL, gapRel);
+#endif
     // The matrix entries carry ~1e-15 of their scale (prefix differences instead of the oracle's two-pass sums), the eigenvector
     // that error over the relative gap to the next eigenvalue: dv ~ 1e-15 / gap.  A float component c is allowed its last bit
     // (the tests' bar: one ulp, 6e-8 |c|) but not two: dv must stay well below 6e-8 |c|, i.e. |c| x gap well above 1.7e-8.
@@ -312,6 +323,9 @@ __device__ __forceinline__ void disc_walk_rows(const DiscLds& d, const int8_t* r
     const int maxL = j - d.bj0[lj], maxR = d.bj1[lj] - j;
     const int dyC = lj * D + H;
     const double* const yRow = d.yP + lj + H;
+    // (not unrolled: the walks are the kernel's cold path — one cell in 10^4 — and three unrolled copies of the visitor per row
+    // were what pushed the 2 cm instantiation past its 64 registers)
+#pragma unroll 1
     for (int oo = 0; oo < D; ++oo) {
         const int o = oo - H;
         const int w0 = rowW[oo];
@@ -353,18 +367,25 @@ __device__ __forceinline__ void disc_walk_rows(const DiscLds& d, const int8_t* r
     }
 }
 // normals_cell_exact (fpe_filters.hpp) on disc_walk_rows: the published filters' three passes, expression for expression.
+// stash: four doubles of LDS of the calling lane's own (the walking phase's list area has them to spare): the mean and the member
+// count wait there while the Jacobi sweeps run, and the cell's coordinates pass through an empty asm before every walk so that
+// nothing derived from them is carried from one walk to the next — the sweeps' eighteen registers of eigenvectors beside three
+// walks' worth of addresses were what the 2 cm instantiation's 64 registers could not hold (13 registers of scratch, cold but
+// there; round 6: none).
 template <int H>
 __device__ __forceinline__ void normals_cell_exact_rows(const DiscLds& d, const int8_t* rowW, unsigned long long edgeRows, int li, int lj, int ti0, int tj0, double r, double slopeCritical,
-                                                        double roughCritical, float& ox, float& oy, float& oz, float& os, float& orough) {
+                                                        double roughCritical, double* stash, float& ox, float& oy, float& oz, float& os, float& orough) {
     const double r2 = r * r;
     int np = 0;
     double sx = 0.0, sy = 0.0, sz = 0.0;
     disc_walk_rows<H>(d, rowW, edgeRows, li, lj, ti0, tj0, r2, [&](double x, double y, float z) {
         if (isfinite(z)) { ++np; sx += x; sy += y; sz += static_cast<double>(z); }
     });
-    const double nd = static_cast<double>(np);
-    const double mx = sx / nd, my = sy / nd, mz = sz / nd;
+    double nd = static_cast<double>(np);
+    double mx = sx / nd, my = sy / nd, mz = sz / nd;
+    stash[3] = nd;  // (not needed before the roughness: it waits in LDS from here)
     double a00 = 0.0, a01 = 0.0, a02 = 0.0, a11 = 0.0, a12 = 0.0, a22 = 0.0;
+    asm volatile("" : "+v"(li), "+v"(lj));
     disc_walk_rows<H>(d, rowW, edgeRows, li, lj, ti0, tj0, r2, [&](double x, double y, float z) {
         if (isfinite(z)) {
             const double dx = x - mx, dy = y - my, dz = static_cast<double>(z) - mz;
@@ -372,8 +393,16 @@ __device__ __forceinline__ void normals_cell_exact_rows(const DiscLds& d, const 
             a11 += dy * dy; a12 += dy * dz; a22 += dz * dz;
         }
     });
+    stash[0] = mx;
+    stash[1] = my;
+    stash[2] = mz;
     double ex, ey, ez, wS, wL;
     normal_from_scatter(a00, a01, a02, a11, a12, a22, ex, ey, ez, wS, wL);
+    asm volatile("" : "+v"(li), "+v"(lj), "+v"(stash));
+    mx = stash[0];
+    my = stash[1];
+    mz = stash[2];
+    nd = stash[3];
     ox = static_cast<float>(ex);
     oy = static_cast<float>(ey);
     oz = static_cast<float>(ez);
@@ -414,7 +443,7 @@ __device__ __forceinline__ void walk_phase(char* ldsRaw, const MapGeom& g, const
     uint2* const list = reinterpret_cast<uint2*>(ldsRaw + Lay::discBytes + 16);  // (thread, step value bits); TR * TC entries fit the records' space
     static_assert(2 * Lay::recBytes >= 16 + 8 * static_cast<size_t>(TR) * TC, "the walk list lives where the prefix records were");
     int8_t* const rowW = reinterpret_cast<int8_t*>(list + TR * TC);  // the shape's half-widths (the walk's row loop reads them by index)
-    static_assert(2 * Lay::recBytes >= 16 + 8 * static_cast<size_t>(TR) * TC + 64, "... and the shape's half-widths behind it");
+    static_assert(2 * Lay::recBytes >= 16 + 8 * static_cast<size_t>(TR) * TC + 64 + 32 * static_cast<size_t>(TR) * TC, "... the shape's half-widths and four doubles per walking lane behind it");
     if (threadIdx.x == 0) *count = 0;
     if (threadIdx.x < 2 * H + 1) rowW[threadIdx.x] = sp.rowW[threadIdx.x];
     __syncthreads();
@@ -422,11 +451,20 @@ __device__ __forceinline__ void walk_phase(char* ldsRaw, const MapGeom& g, const
     __syncthreads();
     const int n = *count;
     if (static_cast<int>(threadIdx.x) >= n) return;
-    const uint2 e = list[threadIdx.x];
+    const int waveBase = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) & ~63);
+    float ox, oy, oz, os, orough;
+    {
+        const int tid = static_cast<int>(list[threadIdx.x].x);
+        double* const stash = reinterpret_cast<double*>(rowW + 64) + 4 * threadIdx.x;
+        normals_cell_exact_rows<H>(d, rowW, sp.edgeRows, tid / TC, tid % TC, ti0, tj0, r, slopeCritical, roughCritical, stash, ox, oy, oz, os, orough);
+    }
+    // (the entry is read again rather than kept, by an index rebuilt from the wavefront's scalar base and the lane number: nothing
+    // of the cell's identity — not even the thread id — stays in a vector register across the walks and the sweeps)
+    int lane = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+    asm volatile("" : "+v"(lane));
+    const uint2 e = list[waveBase + lane];
     const int li = static_cast<int>(e.x) / TC, lj = static_cast<int>(e.x) % TC;
     const float step = __uint_as_float(e.y);
-    float ox, oy, oz, os, orough;
-    normals_cell_exact_rows<H>(d, rowW, sp.edgeRows, li, lj, ti0, tj0, r, slopeCritical, roughCritical, ox, oy, oz, os, orough);
     const size_t cell = static_cast<size_t>(ti0 + li) * g.cols + (tj0 + lj);
     if (!travOnly) {
         L.nx[cell] = ox;
