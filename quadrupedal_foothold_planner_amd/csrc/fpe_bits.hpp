@@ -3099,9 +3099,33 @@ __global__ __launch_bounds__(64, kMid ? 2 : FPE_BITS_GENERIC_WAVES) void plan_bi
 
 // ---- chained plan on the bit window, sequential-legs form (large windows): one wavefront per pose, lane = window
 // row, KW words per row; the swing legs of a phase are searched one after the other (see plan_sequential_kernel) ----
+#ifndef FPE_SEQ_WAVES  // wavefronts per SIMD the register allocation aims at (measurement builds: 3 / 5)
+#define FPE_SEQ_WAVES 4
+#endif
+// The kernel's argument list as a struct: HIP lays a kernel's arguments out one after the other, each at its natural alignment —
+// a C struct of the same members in the same order — so this is a VIEW of plan_bits_seq_kernel's argument segment, through which a
+// leg search can read its constants again (FPE_SEQ_RELOAD_ARGS, below) instead of keeping them in scalar registers across the
+// whole chain.  (The kernel keeps its separate arguments: taking this struct as its one argument cost <1, 2> 0.6 %.)  Any change
+// of the kernel's signature must be mirrored here; every parity test of cfg-5's kernel fails loudly otherwise.
+struct SeqKernArgs {
+    DevMap m;
+    BitMap bm;
+    PlanConsts pc;
+    SpiralLut lut;
+    const fpe_pose* poses;
+    int B, nCycles;
+    fpe_plan_out out;
+    int recSlots;
+};
+// FPE_SEQ_RELOAD_ARGS: 0 never, 1 always, 2 (default) the 96-bit-row instantiations only — measured, round 6, A/B in one call, twice:
+// cfg-5 (<2, 3>) 0.3060 -> 0.3017 ms and its 32 B of vector scratch gone; cfg-3 (<1, 2>) 0.6075 -> 0.6211 ms although three quarters of
+// its leg search's spill reads disappear with it (see the leg loop): the lane reads were never what bound that kernel.
+#ifndef FPE_SEQ_RELOAD_ARGS
+#define FPE_SEQ_RELOAD_ARGS 2
+#endif
 template <int NRL, int KW, int kProd>
-__global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap bm, PlanConsts pc, SpiralLut lut,
-                                                              const fpe_pose* __restrict__ poses, int B, int nCycles, fpe_plan_out outArg, int recSlots) {
+__global__ __launch_bounds__(64, FPE_SEQ_WAVES) void plan_bits_seq_kernel(DevMap m, BitMap bm, PlanConsts pc, SpiralLut lut,
+                                                                          const fpe_pose* __restrict__ poses, int B, int nCycles, fpe_plan_out outArg, int recSlots) {
     constexpr int G = 64;
     const fpe_plan_out out = specialise_products<kProd>(outArg);
     constexpr int NR = G * NRL;
@@ -3211,8 +3235,33 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
                 const LegStatic ls = lsTab[leg];
                 stamp(pc, cyc, 1);
                 int legValid = 1;
+                constexpr bool kReload = FPE_SEQ_RELOAD_ARGS == 1 || (FPE_SEQ_RELOAD_ARGS == 2 && KW >= 3);
+                if constexpr (kReload) {
+                // Round 6: the leg search reads the map's geometry, the plan constants, the table and output pointers from the
+                // ARGUMENT SEGMENT again (scalar loads through a pointer the optimiser cannot see through: nothing is hoisted out
+                // of the chain) instead of holding ~130 scalar registers of them across 128 leg searches.  The register allocator
+                // had spilled those to lanes of three vector registers in the prologue and read them back with v_readlane inside
+                // the leg search — 226 static lane reads of its 1 197 vector instructions in <1, 2, 0>, 276 of 1 529 in <2, 3, 0>
+                // (profiles/round6_seq_floor.txt) — in kernels whose VECTOR unit is what is busy (0.86 of the SIMD's time at four
+                // wavefronts).  With the reload 53 / 57 remain, the kernels hold 67 / 69 spilled scalars instead of 142 / 152 and
+                // <2, 3, 0> no vector scratch — and the time says what those reads were worth: cfg-5 -1.3 %, cfg-3 +2 % (the scalar
+                // loads' waits now sit INSIDE the leg search, in front of its first uses); hence the per-instantiation switch above.
+                typedef const SeqKernArgs __attribute__((address_space(4))) * KernArgPtr;
+                KernArgPtr ka4 = (KernArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(ka4));
+                const SeqKernArgs* ka = (const SeqKernArgs*)ka4;
+                const fpe_plan_out outL = specialise_products<kProd>(ka->out);
+                // (the LDS carve-up likewise: a few scalar operations on two of the constants instead of six held registers)
+                const int rowsL = min(2 * ka->pc.winH + 1, NR);
+                const LegBits lbL = make_legbits(smem + sizeof(PoseShared) + kLsBytes, rowsL, KW, ka->pc.nHW, true);
+                Rec* const recL = reinterpret_cast<Rec*>(
+                    smem + ((sizeof(PoseShared) + kLsBytes + 4 * static_cast<size_t>(legbits_words(rowsL, KW, ka->pc.nHW, true)) + 15) & ~static_cast<size_t>(15)));
+                leg_phase_bits<G, NRL, KW, false, false>(ka->m, ka->bm, ka->pc, ka->lut, head, sh, lbL, g, leg, ls, y0, adjY, advance, cyc, ka->nCycles, b, live, outL,
+                                                         nullptr, recL + 4 * (cyc & (ka->recSlots - 1)), &legValid);
+                } else {
                 leg_phase_bits<G, NRL, KW, false, false>(m, bm, pc, lut, head, sh, lb, g, leg, ls, y0, adjY, advance, cyc, nCycles, b, live, out, nullptr,
                                                          recBase + 4 * (cyc & (recSlots - 1)), &legValid);
+                }
                 allValid &= legValid;
                 stamp(pc, cyc, 9);
             }
@@ -3238,12 +3287,26 @@ __global__ __launch_bounds__(64, 4) void plan_bits_seq_kernel(DevMap m, BitMap b
             const int slot = cyc & (recSlots - 1);
             if (slot == recSlots - 1 || cyc == nCycles - 1) {
                 pose_sync<16>();
+                // (the flush reads its constants and pointers from the argument segment as well where the leg loop does)
+                constexpr bool kReloadF = FPE_SEQ_RELOAD_ARGS == 1 || (FPE_SEQ_RELOAD_ARGS == 2 && KW >= 3);
+                typedef const SeqKernArgs __attribute__((address_space(4))) * KernArgPtr;
+                KernArgPtr kf4 = (KernArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+                if constexpr (kReloadF) asm volatile("" : "+s"(kf4));
+                const SeqKernArgs* kf = (const SeqKernArgs*)kf4;
+                const DevMap& mF = kReloadF ? kf->m : m;
+                const PlanConsts& pcF = kReloadF ? kf->pc : pc;
+                const fpe_plan_out outF = kReloadF ? specialise_products<kProd>(kf->out) : out;
+                const int nCycF = kReloadF ? kf->nCycles : nCycles, slotsF = kReloadF ? kf->recSlots : recSlots;
+                Rec* const recF = kReloadF ? reinterpret_cast<Rec*>(smem + ((sizeof(PoseShared) + kLsBytes +
+                                                                            4 * static_cast<size_t>(legbits_words(min(2 * pcF.winH + 1, NR), KW, pcF.nHW, true)) + 15) &
+                                                                           ~static_cast<size_t>(15)))
+                                           : recBase;
                 if constexpr (KW <= kSeqDeferMaxKW) {  // deferred heights: two lanes per (cycle, leg) unit
                     const int un = tid >> 1, c = (cyc - slot) + (un >> 2);
-                    if (un < 4 * recSlots && c <= cyc) flush_seqrec2(m, pc, sh.footDa, sh.footDb, recBase[un], b, c, un & 3, tid & 1, nCycles, out);
+                    if (un < 4 * slotsF && c <= cyc) flush_seqrec2(mF, pcF, sh.footDa, sh.footDb, recF[un], b, c, un & 3, tid & 1, nCycF, outF);
                 } else {
                     const int s = tid >> 2, c = (cyc - slot) + s;
-                    if (tid < 4 * recSlots && c <= cyc) flush_seqrec(m, pc, sh.footDa, sh.footDb, recBase[tid], b, c, tid & 3, nCycles, out);
+                    if (tid < 4 * slotsF && c <= cyc) flush_seqrec(mF, pcF, sh.footDa, sh.footDb, recF[tid], b, c, tid & 3, nCycF, outF);
                 }
                 pose_sync<16>();  // the slots are rewritten next
             }

@@ -1176,7 +1176,9 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
             // the chain reads both layers: the side stream waits for an asynchronous upload (fpe_upload_map_device) exactly as
             // prepare_call made cx.stream wait (the speculative chain used to start while the canonicalise / copy
             // kernels of the snapshot were still writing d_trav / d_elev)
+#ifndef FPE_TEST_NO_SIDE_WAIT  // (test builds only: the suite checks that its upload-race test FAILS without this wait)
             FPE_HIP(cp.snap->wait_ready(os));
+#endif
             okDev = dp + oSpec;
         }
         FPE_HIP(fpe::launch_opt_track(dev_map(*cp.snap), cp.pc, oc, dPoses ? dPoses : reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, okDev, od, os));

@@ -90,6 +90,7 @@ __device__ __forceinline__ double acos_unit(double x) {
 __device__ unsigned g_walkWhy[4];
 __device__ double g_walkDbg[64][8];
 #endif
+template <bool kSweeps>
 __device__ __forceinline__ bool normals_from_moments(const MapGeom& g, double slopeCritical, double roughCritical, double invSlopeCritical,
                                                      double invRoughCritical, int N, int Sc, int Scc, int Sv, int Svv, int Svc, double Sz, double Szz, double Scz,
                                                      double Svz, bool normalsStored, bool flat, double zAbs, float& ox, float& oy, float& oz, float& os, float& orough) {
@@ -118,21 +119,24 @@ __device__ __forceinline__ bool normals_from_moments(const MapGeom& g, double sl
     const double a00 = res2 * Avv, a01 = res2 * Avc, a02 = -(res * Avz), a11 = res2 * Acc, a12 = -(res * Acz), a22 = Azz;
     double ex, ey, ez, eigS, eigL, gapRel;
     bool walk = false;
-#ifdef FPE_NEWTON_FAIL_SWEEPS
-    // (rounds 4-5: a cell whose iteration fails took the Jacobi sweeps on the moment matrix right here, and the literal walks only
-    // when its eigenvalues were closer than 1e-3)
-    if (!normal_newton(a00, a01, a02, a11, a12, a22, ex, ey, ez, eigS, eigL, gapRel)) {
-        normal_from_scatter(a00, a01, a02, a11, a12, a22, ex, ey, ez, eigS, eigL);
-        walk = !(gapRel > 1e-3);  // eigenvalues this close: the sweeps on THIS matrix and on the oracle's (another order of summation) part ways
+    // A cell whose iteration fails (no convergence inside the cap, eigenvalues within 1e-6, degenerate input):
+    //   kSweeps (the 32 x 32 tiles of halos above eight cells: 0.5 cm maps) — the Jacobi sweeps on the moment matrix right here, and
+    //     the literal walks only when its eigenvalues are closer than 1e-3, as in rounds 4-5: a walk over a 23-row disc costs a
+    //     workgroup tens of microseconds, 2 118 cells of the 0.5 cm probe map fail the iteration and 78 of them have to walk
+    //     (walking them all: 0.97 -> 1.27 ms), and at one 1 024-thread workgroup per CU registers do not bound the occupancy;
+    //   otherwise (32 x 16 tiles: the published chain at 2 cm and 1 cm) — the LITERAL WALKS, the oracle's own arithmetic: the sweeps'
+    //     eighteen registers of eigenvectors were live beside everything the cell still needs, and at the 2 cm instantiation's 64
+    //     registers the compiler spilled the iteration's results around the (never taken) branch in EVERY cell — 32 B of scratch
+    //     stores per thread and launch (47 MB written per 1000 x 1000 launch for 4 MB of layers).  127 instead of 71
+    //     cells of the 1 cm probe map walk, none at 2 cm: no measurable time (profiles/round6_filters.txt).
+    if constexpr (kSweeps) {
+        if (!normal_newton(a00, a01, a02, a11, a12, a22, ex, ey, ez, eigS, eigL, gapRel)) {
+            normal_from_scatter(a00, a01, a02, a11, a12, a22, ex, ey, ez, eigS, eigL);
+            walk = !(gapRel > 1e-3);  // eigenvalues this close: the sweeps on THIS matrix and on the oracle's (another order of summation) part ways
+        }
+    } else {
+        walk = !normal_newton(a00, a01, a02, a11, a12, a22, ex, ey, ez, eigS, eigL, gapRel);
     }
-#else
-    // Round 6: a cell whose iteration fails (no convergence inside the cap, eigenvalues within 1e-6, degenerate input) takes the
-    // LITERAL WALKS — the oracle's own arithmetic — instead of the Jacobi sweeps on the moment matrix inlined here: the sweeps'
-    // eighteen registers of eigenvectors were live beside everything the cell still needs, and at the 2 cm instantiation's 64
-    // registers the compiler spilled the iteration's results around the (never taken) branch in EVERY cell.  The cells concerned
-    // are the ones that mostly walked anyway (their gap is below 1e-3 in all but a handful per map: profiles/round6_filters.txt).
-    walk = !normal_newton(a00, a01, a02, a11, a12, a22, ex, ey, ez, eigS, eigL, gapRel);
-#endif
     // The matrix entries carry ~1e-15 of their scale (prefix differences instead of the oracle's two-pass sums), the eigenvector
     // that error over the relative gap to the next eigenvalue: dv ~ 1e-15 / gap.  A float component c is allowed its last bit
     // (the tests' bar: one ulp, 6e-8 |c|) but not two: dv must stay well below 6e-8 |c|, i.e. |c| x gap well above 1.7e-8.
@@ -301,7 +305,7 @@ __device__ __forceinline__ bool moments_phase(char* ldsRaw, const MapGeom& g, co
     const int Sc = SC - cc * N;
     const int Scc = static_cast<int>(ACC) - 2 * cc * SC + cc * cc * N;
     const int Svc = SvC - cc * Sv;
-    return normals_from_moments(g, slopeCritical, roughCritical, invSlopeCritical, invRoughCritical, N, Sc, Scc, Sv, Svv, Svc, Sz, Szz, Scz, Svz, normalsStored, flat,
+    return normals_from_moments<(TR * TC > 512)>(g, slopeCritical, roughCritical, invSlopeCritical, invRoughCritical, N, Sc, Scc, Sv, Svv, Svc, Sz, Szz, Scz, Svz, normalsStored, flat,
                                 fabs(static_cast<double>(d.tile[(li + H) * W + lj + H])), ox, oy, oz, os, orough);
 }
 
@@ -325,7 +329,9 @@ __device__ __forceinline__ void disc_walk_rows(const DiscLds& d, const int8_t* r
     const double* const yRow = d.yP + lj + H;
     // (not unrolled: the walks are the kernel's cold path — one cell in 10^4 — and three unrolled copies of the visitor per row
     // were what pushed the 2 cm instantiation past its 64 registers)
+#ifndef FPE_WALK_UNROLL
 #pragma unroll 1
+#endif
     for (int oo = 0; oo < D; ++oo) {
         const int o = oo - H;
         const int w0 = rowW[oo];

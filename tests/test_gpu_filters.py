@@ -4,7 +4,44 @@ the oracle's restatement (oracle/fpo_filters.cpp) on the same seeded elevation l
 Bar: the layers are float, computed through f64 like the published filters.  Engine and oracle run the same expression
 order, so the layers agree bit for bit except where the device's and the host's `acos` differ in the last place of the f64
 slope (the float result may then round the other way): every layer within ONE float ulp (the weighted sum of three such
-layers within two), and bit-identical on all but a handful of cells.  Holes (NaN) must coincide exactly."""
+layers within two), and bit-identical on all but a handful of cells.  Holes (NaN) must coincide exactly.
+
+THE BAR IS FROZEN (VERDICT r5 #4 / ADVICE r5).  Two modes, chosen by the caller of assert_layers_equal:
+
+  STRICT   (every fixed, parametrised map of this file and the default-parameter chain) — the bar as first written:
+           1 ulp per layer, 2 for the sum, holes identical, at most max(4, 1e-4 x cells) CELLS not bit-identical, no absolute
+           floors, at most max(4, 1e-5 x cells) cells whose normal is an ulp off (the `loose` class below).
+  CAMPAIGN (random_filter_case only: maps of a few dozen to a few thousand cells, adversarial terrain and parameters) — the
+           strict bar plus the allowances of the table, each forced by a seed of the differential campaign and argued once here.
+
+  tolerance                         | arithmetic that justifies it                                              | seed / first seen
+  ----------------------------------+---------------------------------------------------------------------------+--------------------
+  1 float ulp, every layer          | same f64 expression order; device acos / sqrt / rcp differ from the host's | round 3, by design
+                                    | in the last f64 place, the float rounding may then go the other way        |
+  2 ulp, `traversability`           | float sum of three layers that may each be 1 ulp off                      | ~1 map in 1e4
+  normals: |d| <= 1e-10 counts as   | a unit normal's component is good to ~1e-12 ABSOLUTE on the steepest faces | 3196309 (68 deg,
+    at most 1 ulp (campaign)        | (row-moment sums carry the face's height range): below a float ulp for any | 3.6e-12), 6338683
+                                    | component > 2e-5, a few ulps of a component of 7e-6                         | (vertical, 3e-11)
+  chained layers: |d| <= 1e-13      | slope / roughness = float(1 - x / critical); beside the critical value the | 3103907 (slope 1e-10,
+    counts as identical (campaign)  | float result is the remainder of a cancellation: an f64 ulp of x is many   | 2e-16 apart), 4536505
+                                    | float ulps of it.  1e-13 is six orders below the layers' resolution at 1    | (roughness 1.6e-7)
+  `loose` cells: <= 64 ulp on       | where the engine's FLOAT normal is an ulp off the oracle's, the oracle's   | 2505080, 2514166,
+    roughness / traversability,     | slope and roughness belong to a different input: slope must be the oracle's | 6067888 (89 deg face:
+    slope by the oracle's own       | formula on the ENGINE's nz within 1 ulp; n^T A n moves by up to 64 float   | 4 ulp = 4e-9)
+    formula on the engine's nz      | ulps per ulp of the normal on a steep face                                 |
+  share of not-bit-identical values | counts DISTINCT (engine, oracle) pairs, never fewer than 4: noise-free     | 5109923 (48 cells, 3
+    1e-2 (noise > 0) / 1e-1 (none)  | terrain repeats ONE computation in dozens of cells, and a smooth analytic  | with one value),
+    (campaign)                      | surface is locally an exact plane — roughness is the remainder of moments a | 3306992, 6093041,
+                                    | million times larger, good to a fraction of a float ulp only               | 6146764, 6160547
+  step_height, step                 | max / min / count windows: bit-identical or wrong                         | —
+  no threshold crossing             | the planner only compares the layer with thresholds (cpp:2057, 2138): on   | ADVICE r4; the sweep
+                                    | 64 thresholds in [0.05, 0.95] (fpe_params: a caller may set any) and the   | over 64 thresholds:
+                                    | two yaml values no cell may sit on the other side in engine and oracle     | VERDICT r5
+  `loose` cells are few             | <= max(4, 1e-5 x cells) strict, <= max(4, LOOSE_SHARE_CAMPAIGN x cells)    | ADVICE r5: the class
+                                    | campaign: the class that gets 64 ulps must not grow silently               | is now bounded
+
+Any further loosening needs a justification in ADVICE's sight; a cell that breaks the bar is to be routed to the literal walks
+(csrc/fpe_filters_fused.hpp, normals_from_moments), not excused here."""
 import ctypes as C
 
 import numpy as np
@@ -36,15 +73,32 @@ def ulps(a, b):
     return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
 
 
-def assert_layers_equal(eng, ora, max_ulp_cells=1e-4, slope_critical=1.0):
+LOOSE_SHARE_STRICT = 1e-5     # cells whose float normal is an ulp off the oracle's (they get the 64-ulp chained bar): share allowed
+XX
+SWEEP_THRESHOLDS = np.linspace(0.05, 0.95, 64).astype(np.float32)
+
+
+def assert_no_threshold_crossing(eng, ora, what=""):
+    """No cell may sit on the other side of ANY of 64 thresholds in [0.05, 0.95] (a caller may set any: fpe_params) or of the two
+    yaml thresholds in engine and oracle: `v < thr` must agree.  (The number of thresholds <= v is the same on both sides.)"""
+    prm = _capi.params_yaml()
+    thr = np.unique(np.concatenate([SWEEP_THRESHOLDS, [np.float32(prm["defaultFootholdThreshold"][0]), np.float32(prm["candidateFootholdThreshold"][0])]]))
+    ok = ~np.isnan(ora)
+    a, b = np.searchsorted(thr, eng[ok], side="right"), np.searchsorted(thr, ora[ok], side="right")
+    bad = int((a != b).sum())
+    assert bad == 0, f"{what}{bad} cells cross one of {thr.size} thresholds (first: engine {eng[ok][a != b][0]!r}, oracle {ora[ok][a != b][0]!r})"
+
+
+def assert_layers_equal(eng, ora, max_ulp_cells=1e-4, slope_critical=1.0, campaign=False):
     """Every layer within ONE float ulp of the oracle (the weighted sum of three such layers within two), holes identical,
-    all but a share `max_ulp_cells` of the cells bit-identical.
+    all but a share `max_ulp_cells` of the cells bit-identical.  `campaign` False: the STRICT bar; True: with the campaign's
+    allowances — see the table in the module docstring, which is the one place where each tolerance is argued.
     The layers form a chain: slope and roughness are functions of the FLOAT normal.  Where the engine's normal is the oracle's
     bit for bit (all but a handful of cells in 10^8) the bar applies to them as it stands.  Where a component of the normal
     rounded the other way (allowed: one ulp), the oracle's slope and roughness belong to a different input and are no
     yardstick: there the slope must be within one ulp of the oracle's own formula, float(1 - acos(nz) / critical), applied to
     the ENGINE's nz, and roughness / traversability within the sensitivity of their formulas to one ulp of the normal (64 ulps:
-    steep faces, where n^T A n moves most; such a cell is counted as not bit-identical)."""
+    steep faces, where n^T A n moves most; such a cell is counted as not bit-identical, and the class is bounded)."""
     for name in _capi.FILTER_LAYERS:
         assert eng[name].shape == ora[name].shape, name
         assert np.array_equal(np.isnan(eng[name]), np.isnan(ora[name])), f"{name}: holes differ"
@@ -52,32 +106,23 @@ def assert_layers_equal(eng, ora, max_ulp_cells=1e-4, slope_critical=1.0):
     same_normal = np.ones(eng["normal_z"].shape, bool)
     for name in ("normal_x", "normal_y", "normal_z"):
         d = ulps(eng[name], ora[name])
-        # (a unit normal's component is good to ~1e-12 ABSOLUTE on the steepest faces — the row-moment sums carry the face's height
-        # range inside the tile — which is below a float ulp for any component above 2e-5 and a few ulps of a component of 7e-6:
-        # campaign seeds 3196309 and 6338683, one cell in 2.2e8 and one in 1e9: a 68-degree face, 3.6e-12 apart, and a vertical
-        # one — normal_z 1.8e-4 — 3e-11 apart (the matrix's 1e-13 over a gap of 3e-3).  Components within 1e-10 of each other are
-        # the same component; nothing downstream can tell them apart: slope reads normal_z, roughness n^T A n.)
-        d = np.where(np.abs(eng[name].astype(np.float64) - ora[name].astype(np.float64)) <= 1e-10, np.minimum(d, 1), d)
+        if campaign:  # (table: normals' absolute floor)
+            d = np.where(np.abs(eng[name].astype(np.float64) - ora[name].astype(np.float64)) <= 1e-10, np.minimum(d, 1), d)
         assert d[ok_n].max(initial=0) <= 1, f"{name}: {int((d[ok_n] > 1).sum())} cells differ by more than 1 float ulp (max {int(d[ok_n].max())})"
         same_normal &= (d == 0) | ~ok_n
+    n_loose = int((ok_n & ~same_normal).sum())
+    loose_cap = max(4, int((LOOSE_SHARE_CAMPAIGN if campaign else LOOSE_SHARE_STRICT) * ok_n.sum()))
+    assert n_loose <= loose_cap, f"{n_loose} cells of {int(ok_n.sum())} have a normal an ulp off the oracle's (allowed {loose_cap}): the class with the 64-ulp bar has grown"
     for name in _capi.FILTER_LAYERS:
         a, b = eng[name], ora[name]
         ok = ~np.isnan(a)
         d = ulps(a, b)
-        if name.startswith("normal_"):  # (the absolute floor of a unit normal's components, see above)
+        if campaign and name.startswith("normal_"):
             d = np.where(np.abs(a.astype(np.float64) - b.astype(np.float64)) <= 1e-10, np.minimum(d, 1), d)
-        # (the weighted sum adds three layers that may each be one ulp off: two ulps; 1 map in ~10^4 of the campaign has such a cell)
         bar = 2 if name == "traversability" else 1
         chained = name in ("slope", "roughness", "traversability")
         strict = ok & same_normal if chained else ok
-        if chained:
-            # slope / roughness are float(1 - x / critical) with x good to an f64 ulp or two (device acos / sqrt / reciprocal against
-            # the host's): where x comes within 1e-9 of the critical value the float result is the remainder of a cancellation,
-            # and an f64 ulp of x is many float ulps of it (campaign seed 3103907: a slope value of 1e-10, 16 float ulps = 2e-16
-            # apart).  x itself — a square root of row-moment sums — is good to ~1e-14 RELATIVE on rough ground (the sums carry 1e-15 of
-            # their scale), so beside the critical value the remainder is good to a few 1e-14 absolute: campaign seed 4536505, a
-            # roughness value of 1.6e-7, 2 float ulps = 3e-14 apart, one cell in 1.8e8.  Values within 1e-13 of each other — six orders
-            # below the layers' float resolution at 1 — are the same value.
+        if chained and campaign:  # (table: values within 1e-13 of each other are the same value)
             near = np.abs(a.astype(np.float64) - b.astype(np.float64)) <= 1e-13
             d = np.where(near & ok, 0, d)
         assert d[strict].max(initial=0) <= bar, f"{name}: {int((d[strict] > bar).sum())} cells differ by more than {bar} float ulp (max {int(d[strict].max())})"
@@ -90,11 +135,11 @@ def assert_layers_equal(eng, ora, max_ulp_cells=1e-4, slope_critical=1.0):
                 assert ulps(a[loose], want).max() <= 1, "slope: not the oracle's formula on the engine's own normal_z"
             else:
                 assert d[loose].max() <= 64, f"{name}: {int(d[loose].max())} float ulps where the normal is one ulp off"
-        # (a share of the cells — and never fewer than four where any are allowed: the campaign's maps go down to a few dozen cells,
-        # and neighbours on an exact plane are the SAME computation: seed 5109923, 48 cells, three of them with one roughness value of
-        # 1 - 1.6e-6 that rounds the other way, together)
         allowed = max(4, int(max_ulp_cells * ok.sum())) if max_ulp_cells > 0 else 0
-        assert distinct_differences(a, b, ok & (d != 0)) <= allowed, f"{name}: {int((d[ok] != 0).sum())} of {int(ok.sum())} cells not bit-identical"
+        if campaign:  # (table: distinct pairs)
+            assert distinct_differences(a, b, ok & (d != 0)) <= allowed, f"{name}: {int((d[ok] != 0).sum())} of {int(ok.sum())} cells not bit-identical"
+        else:
+            assert int((d[ok] != 0).sum()) <= allowed, f"{name}: {int((d[ok] != 0).sum())} of {int(ok.sum())} cells not bit-identical (allowed {allowed})"
     return same_normal
 
 
@@ -109,7 +154,7 @@ def distinct_differences(a, b, where):
     return len(np.unique(pairs, axis=0))
 
 
-def assert_traversability_only(only, layers, ora, same_normal, max_ulp_cells=1e-4):
+def assert_traversability_only(only, layers, ora, same_normal, max_ulp_cells=1e-4, campaign=False):
     """The chain without a layer buffer against the oracle, at the bar of the `traversability` layer above.  It keeps the normals
     in registers, and a cell whose normal has a component at rounding level stays on the row-moment path there (nobody reads
     the x and y components; fpe_filters_fused.hpp, normals_from_moments) where the chain that stores the normals walks it: the
@@ -117,17 +162,19 @@ def assert_traversability_only(only, layers, ora, same_normal, max_ulp_cells=1e-
     a, b, c = only, ora["traversability"], layers["traversability"]
     assert np.array_equal(np.isnan(a), np.isnan(b)), "traversability only: holes differ"
     ok = ~np.isnan(a)
-    d = np.where(np.abs(a.astype(np.float64) - b.astype(np.float64)) <= 1e-13, 0, ulps(a, b))
+    floor = 1e-13 if campaign else -1.0
+    d = np.where(np.abs(a.astype(np.float64) - b.astype(np.float64)) <= floor, 0, ulps(a, b))
     strict = ok & same_normal
     # (two ulps; up to 64 — the sensitivity of roughness to one ulp of the normal on a steep face, as in assert_layers_equal — in
     # the few cells counted below: THIS chain's normal is not stored, and where the other chain walked a cell that this one keeps on
     # the moment path its normal may be the one that is an ulp off.  Campaign seed 6067888: an 89-degree face, roughness 0.0287,
     # traversability 0.0096, four ulps = 4e-9 apart.)
     allowed = max(4, int(max_ulp_cells * ok.sum())) if max_ulp_cells > 0 else 0
+    count = (lambda x, y, w: distinct_differences(x, y, w)) if campaign else (lambda x, y, w: int(w.sum()))
     assert d[ok].max(initial=0) <= 64 and int((d[strict] > 2).sum()) <= allowed, f"traversability only: {int((d[strict] > 2).sum())} cells more than 2 float ulps from the oracle (max {int(d[ok].max(initial=0))})"
-    assert distinct_differences(a, b, ok & (d != 0)) <= allowed, f"traversability only: {int((d[ok] != 0).sum())} of {int(ok.sum())} cells not bit-identical to the oracle"
-    dc = np.where(np.abs(a.astype(np.float64) - c.astype(np.float64)) <= 1e-13, 0, ulps(a, c))
-    assert dc[ok].max(initial=0) <= 64 and int((dc[ok] > 2).sum()) <= allowed and distinct_differences(a, c, ok & (dc != 0)) <= allowed, "the two chains' layers are further apart than either from the oracle"
+    assert count(a, b, ok & (d != 0)) <= allowed, f"traversability only: {int((d[ok] != 0).sum())} of {int(ok.sum())} cells not bit-identical to the oracle"
+    dc = np.where(np.abs(a.astype(np.float64) - c.astype(np.float64)) <= floor, 0, ulps(a, c))
+    assert dc[ok].max(initial=0) <= 64 and int((dc[ok] > 2).sum()) <= allowed and count(a, c, ok & (dc != 0)) <= allowed, "the two chains' layers are further apart than either from the oracle"
 
 
 @pytest.mark.parametrize("rows,cols,res,seed", [(160, 144, 0.02, 21), (150, 170, 0.01, 22), (96, 112, 0.005, 23), (130, 90, 0.03, 24)])
@@ -142,10 +189,8 @@ def test_filter_chain_matches_the_oracle(planner, rows, cols, res, seed):
     assert_traversability_only(only, layers, ora, same_normal)
     # what the planner does with the layer is compare it with its two thresholds (cpp:2057, 2138): a last-place difference of a
     # layer value matters only AT a threshold — none of the cells may sit on the other side of one
-    prm = _capi.params_yaml()
-    for thr in (np.float32(prm["defaultFootholdThreshold"][0]), np.float32(prm["candidateFootholdThreshold"][0])):
-        assert np.array_equal(trav < thr, ora["traversability"] < thr), f"a cell crosses the threshold {thr}"
-        assert np.array_equal(only < thr, ora["traversability"] < thr), f"a cell crosses the threshold {thr} (traversability only)"
+    assert_no_threshold_crossing(trav, ora["traversability"])
+    assert_no_threshold_crossing(only, ora["traversability"], "traversability only: ")
     t = ora["traversability"]
     assert np.isfinite(t).mean() > 0.9 and np.nanmin(t) < 0.5 < 0.9 < np.nanmax(t)  # the terrain spans the planner's thresholds
 
@@ -291,20 +336,20 @@ def random_filter_case(planner, seed):
     # remainder of moments a million times larger, good to a fraction of a float ulp only — seed 6093041, 14 of 219 roughness values
     # of 1 - 1e-5 one ulp off, all different.  (One ulp is the bar; the share is a statistic of terrain that has a texture.)
     share = 1e-2 if sigma > 0.0 else 1e-1
-    same_normal = assert_layers_equal(layers, ora, max_ulp_cells=share, slope_critical=fp.slope_critical)
+    same_normal = assert_layers_equal(layers, ora, max_ulp_cells=share, slope_critical=fp.slope_critical, campaign=True)
     for name in ("step_height", "step"):  # max / min / count windows: bit-identical or wrong
         assert np.array_equal(layers[name], ora[name], equal_nan=True), f"seed {seed}: {name} not bit-identical"
     # without a layer buffer the chain keeps the intermediate layers in registers where its kernels allow
     only = planner.traversability_from_elevation(elev, res, position=pos, params=fp)
     try:
-        assert_traversability_only(only, layers, ora, same_normal, max_ulp_cells=share)
+        assert_traversability_only(only, layers, ora, same_normal, max_ulp_cells=share, campaign=True)
     except AssertionError as e:
         raise AssertionError(f"seed {seed}: {e}") from None
-    # end to end: the planner only compares the layer with its thresholds — no cell may cross one
-    prm = _capi.params_yaml()
-    for thr in (np.float32(prm["defaultFootholdThreshold"][0]), np.float32(prm["candidateFootholdThreshold"][0])):
-        assert np.array_equal(only < thr, ora["traversability"] < thr), f"seed {seed}: a cell crosses the threshold {thr}"
-    return rows * cols, float(np.isfinite(ora["traversability"]).mean())
+    # end to end: the planner only compares the layer with its thresholds — no cell may cross one, on a sweep of 64
+    # thresholds and the two yaml values, both chains
+    assert_no_threshold_crossing(only, ora["traversability"], f"seed {seed}: traversability only: ")
+    assert_no_threshold_crossing(layers["traversability"], ora["traversability"], f"seed {seed}: ")
+    return rows * cols, float(np.isfinite(ora["traversability"]).mean()), int((~same_normal).sum())
 
 
 @pytest.mark.parametrize("seed", range(16))
@@ -317,13 +362,16 @@ def test_random_filter_campaign(planner):
     comes from a run with tens of thousands), seeds from FPE_FILTER_FUZZ_SEED."""
     import os
     n_cases, seed0 = int(os.environ.get("FPE_FILTER_FUZZ_CASES", "1500")), int(os.environ.get("FPE_FILTER_FUZZ_SEED", "100"))
-    cells, valid = 0, []
+    cells, valid, loose, loose_maps = 0, [], 0, 0
     for seed in range(seed0, seed0 + n_cases):
-        c, v = random_filter_case(planner, seed)
+        c, v, nl = random_filter_case(planner, seed)
         cells += c
         valid.append(v)
+        loose += nl
+        loose_maps += int(nl > 0)
     print(f"random filter campaign: seeds {seed0} .. {seed0 + n_cases - 1} ({n_cases} maps, {cells} cells, mean valid share {np.mean(valid):.3f}): "
-          "every layer within one float ulp of the oracle, step heights and step layers bit-identical")
+          "every layer within one float ulp of the oracle, step heights and step layers bit-identical, no cell across any of 66 thresholds; "
+          f"{loose} cells on {loose_maps} maps with a normal one ulp off (the class with the 64-ulp chained bar)")
 
 
 @pytest.mark.parametrize("res,r1,r2,pos", [(0.01, 0.05, 0.10, (0.0, 0.0)), (0.01, 0.13, 0.05, (1234.567, -987.654)), (0.02, 0.10, 0.26, (55.5, 44.25)),
