@@ -25,6 +25,13 @@ for rows, res in MAPS:
         for _ in range(reps): run()
         e1.record(s); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
+    # FPE_PROBE_MODE=trav | layers: ONE chain only (counter passes: every launch of the run then belongs to that chain, so per-kernel
+    # averages are per MODE — round 5's traffic file averaged the two chains' launches together)
+    mode = os.environ.get('FPE_PROBE_MODE', 'both')
+    if mode in ('trav', 'layers'):
+        ms1 = timed(0 if mode == 'trav' else d_l.data_ptr())
+        print(f"{rows}x{rows} @ {res} m: mode {mode}: {ms1:.3f} ms per chain")
+        continue
     ms = timed(d_l.data_ptr())       # every layer stored (the caller passed a layer buffer): 4 B read + 32 B written per cell
     t = d_t.cpu().numpy()
     ms_t = timed(0)                   # traversability only: step_height and traversability stored (12 B per cell by layers)

@@ -100,6 +100,17 @@ if "FETCH_SIZE" in allc and "WRITE_SIZE" in allc:
                "kernel_sources_sha16": bench["roofline"].get("kernel_sources_sha16"),  # (of the tree the counters were taken on: bench.py's traffic_stale)
                "file": f"profiles/{rnd}_{cfg}_counters.json"}
     json.dump(tr, open(tp, "w"), indent=1)
+    # The bench line of this same collect.sh call was printed BEFORE pmc_traffic.json existed for its tree, so it carried the previous
+    # round's counters marked traffic_stale.  Counters and line come from one tree and one box: the committed line
+    # states the traffic measured beside it.
+    rf = bench["roofline"]
+    rf["traffic"] = fetch_b + write_b
+    rf["traffic_source"] = {"file": f"profiles/{rnd}_{cfg}_counters.json", "round": rnd, "commit": commit, "kernel": plan_row["Name"][:60],
+                            "kernel_sources_sha16": rf.get("kernel_sources_sha16"), "traffic_stale": False,
+                            "note": "measured by the rocprofv3 --pmc passes of the same profiles/collect.sh call as this line (same tree, same box); "
+                                    "filled in by profiles/summarise.py after the run"}
+    if rf.get("kernel_ms"):
+        rf["frac_by_counter_bytes"] = (fetch_b + write_b) / (rf["kernel_ms"] * 1e-3) / 1e9 / rf["peak"]
 waves = allc.get("SQ_WAVES")
 if waves:
     pw = {k: v / waves for k, v in sorted(allc.items()) if k.startswith("SQ_")}

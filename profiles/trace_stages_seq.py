@@ -53,3 +53,10 @@ print("last successful search per pose (n=%d): P rows %.0f, erosion %.0f, ring s
 m8 = min(n, 8)
 print("tail of a leg: spiral end -> sums start %.0f, three height sums %.0f, -> staged results %.0f, record stores (to the kernel's stamp 9) %.0f" % (
     np.median(t[:, :m8, 11] - t[:, :m8, 8]), np.median(t[:, :m8, 12] - t[:, :m8, 11]), np.median(t[:, :m8, 13] - t[:, :m8, 12]), np.median(t[:, :m8, 9] - t[:, :m8, 13])))
+
+fl, nf = t[:, 7, 14], t[:, 7, 15]
+if nf.max() > 0:
+    pro = t[:, 7, 13] - t[:, 6, 14]
+    cyc2cyc = np.mean(t[:, 1:, 0] - t[:, :-1, 0])
+    print("budget per pose (clocks, mean over the first 256 poses): prologue %.0f + %d cycles x %.0f (cycle to cycle over cycles 0-6) = %.0f + flushes %.0f (%.1f of %.0f each) = %.0f against a lifetime of %.0f" % (
+        pro.mean(), n, cyc2cyc, n * cyc2cyc, fl.mean(), nf.mean(), (fl / np.maximum(nf, 1)).mean(), pro.mean() + n * cyc2cyc + fl.mean(), life.mean()))

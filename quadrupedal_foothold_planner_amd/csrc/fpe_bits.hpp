@@ -3197,6 +3197,10 @@ __global__ __launch_bounds__(64, FPE_SEQ_WAVES) void plan_bits_seq_kernel(DevMap
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         cycLag = (static_cast<int>(hwid & 3u) * nCycles) / 16;
     }
+#ifdef FPE_TRACE
+    long long flushClocks = 0, nFlushes = 0;
+    stamp(pc, 7, 13);  // end of the prologue
+#endif
     for (int cyc = 0; cyc < nCycles; ++cyc) {
         {
             // Issue priority by PROGRESS (s_setprio, four levels): the SIMD's arbiter serves the oldest wavefront first, so the
@@ -3286,6 +3290,9 @@ __global__ __launch_bounds__(64, FPE_SEQ_WAVES) void plan_bits_seq_kernel(DevMap
         {   // the staged records of the last recSlots cycles: lane = (cycle slot, leg)
             const int slot = cyc & (recSlots - 1);
             if (slot == recSlots - 1 || cyc == nCycles - 1) {
+#ifdef FPE_TRACE
+                const long long tFlush0 = static_cast<long long>(__builtin_readcyclecounter());
+#endif
                 pose_sync<16>();
                 // (the flush reads its constants and pointers from the argument segment as well where the leg loop does)
                 constexpr bool kReloadF = FPE_SEQ_RELOAD_ARGS == 1 || (FPE_SEQ_RELOAD_ARGS == 2 && KW >= 3);
@@ -3309,11 +3316,18 @@ __global__ __launch_bounds__(64, FPE_SEQ_WAVES) void plan_bits_seq_kernel(DevMap
                     if (tid < 4 * slotsF && c <= cyc) flush_seqrec(mF, pcF, sh.footDa, sh.footDb, recF[tid], b, c, tid & 3, nCycF, outF);
                 }
                 pose_sync<16>();  // the slots are rewritten next
+#ifdef FPE_TRACE
+                __builtin_amdgcn_s_waitcnt(0);
+                flushClocks += static_cast<long long>(__builtin_readcyclecounter()) - tFlush0;
+                ++nFlushes;
+#endif
             }
         }
     }
     stamp(pc, 6, 15);
 #ifdef FPE_TRACE
+    stamp_value(pc, 7, 14, flushClocks);  // clocks inside the flushes (records + deferred heights) and their number
+    stamp_value(pc, 7, 15, nFlushes);
     stamp_value(pc, 6, 13, static_cast<long long>(sh.pad[0]) << 4);  // clocks inside the spiral search,
     stamp_value(pc, 6, 12, sh.pad[1]);                               // searches, and searches without a hit
     stamp_value(pc, 6, 11, sh.pad[2]);

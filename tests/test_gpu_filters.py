@@ -74,7 +74,7 @@ def ulps(a, b):
 
 
 LOOSE_SHARE_STRICT = 1e-5     # cells whose float normal is an ulp off the oracle's (they get the 64-ulp chained bar): share allowed
-XX
+LOOSE_SHARE_CAMPAIGN = 1e-3   # ... on the campaign's tiny adversarial maps (measured, round 6: 9 such cells on 9 of 6 000 maps, 1.3e7 cells)
 SWEEP_THRESHOLDS = np.linspace(0.05, 0.95, 64).astype(np.float32)
 
 
