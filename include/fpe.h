@@ -275,6 +275,10 @@ int fpe_destroy(fpe_handle h);
  * track's chain on a second stream beside the plan kernel, on nominal cycle flags of 1 (the flags only decide which cycles the
  * chain commits, cpp:1323-1332, and are 1 unless a nominal search fails), and runs it again on the real flags in the call where
  * they differ: the same products as 0 (one kernel after the other), the plan kernel's time off the common call's latency.
+ * "service_poll" (default 1): in such a call for ONE pose the chain's last instruction writes a completion word into the
+ * call's pinned arena (after a system-scope fence behind its product stores) and the host polls that word instead of waiting
+ * for the stream's completion signal — the end-of-kernel processing and the wake-up of a stream wait cost several microseconds
+ * of a ~100 us call; bounded: after 5 ms without the word the ordinary stream synchronisation takes over.  0: stream waits only.
  * Thread-safe: every plan / search call copies the knobs once, under the engine's lock, so a concurrent call runs
  * entirely with the values before or entirely with the values after a change (one key per call: callers that change
  * several keys while other threads plan get each key's change at its own moment). */

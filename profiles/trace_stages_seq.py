@@ -56,7 +56,10 @@ print("tail of a leg: spiral end -> sums start %.0f, three height sums %.0f, -> 
 
 fl, nf = t[:, 7, 14], t[:, 7, 15]
 if nf.max() > 0:
-    pro = t[:, 7, 13] - t[:, 6, 14]
-    cyc2cyc = np.mean(t[:, 1:, 0] - t[:, :-1, 0])
-    print("budget per pose (clocks, mean over the first 256 poses): prologue %.0f + %d cycles x %.0f (cycle to cycle over cycles 0-6) = %.0f + flushes %.0f (%.1f of %.0f each) = %.0f against a lifetime of %.0f" % (
-        pro.mean(), n, cyc2cyc, n * cyc2cyc, fl.mean(), nf.mean(), (fl / np.maximum(nf, 1)).mean(), pro.mean() + n * cyc2cyc + fl.mean(), life.mean()))
+    pro = t[:, 5, 14] - t[:, 6, 14]
+    legs, nl = t[:, 5, 15], t[:, 1, 14]
+    rest = life - pro - legs - fl
+    print("budget per pose (clocks at four wavefronts per SIMD, mean over the first 256 poses): prologue %.0f + %.1f leg searches x %.0f = %.0f + %.1f flushes x %.0f = %.0f "
+          "+ everything between the leg searches (feet-polygon centres, commit, hand-offs, priority levels) %.0f = lifetime %.0f" % (
+              pro.mean(), nl.mean(), (legs / np.maximum(nl, 1)).mean(), legs.mean(), nf.mean(), (fl / np.maximum(nf, 1)).mean(), fl.mean(), rest.mean(), life.mean()))
+    print("shares of the lifetime: prologue %.3f, leg searches %.3f, flushes %.3f, between %.3f" % (pro.mean() / life.mean(), legs.mean() / life.mean(), fl.mean() / life.mean(), rest.mean() / life.mean()))

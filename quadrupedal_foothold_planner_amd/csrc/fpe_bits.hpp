@@ -3198,8 +3198,8 @@ __global__ __launch_bounds__(64, FPE_SEQ_WAVES) void plan_bits_seq_kernel(DevMap
         cycLag = (static_cast<int>(hwid & 3u) * nCycles) / 16;
     }
 #ifdef FPE_TRACE
-    long long flushClocks = 0, nFlushes = 0;
-    stamp(pc, 7, 13);  // end of the prologue
+    long long flushClocks = 0, nFlushes = 0, legClocks = 0, nLegs = 0;
+    stamp(pc, 5, 14);  // end of the prologue
 #endif
     for (int cyc = 0; cyc < nCycles; ++cyc) {
         {
@@ -3238,6 +3238,9 @@ __global__ __launch_bounds__(64, FPE_SEQ_WAVES) void plan_bits_seq_kernel(DevMap
                 if (!((mask >> leg) & 1u)) continue;
                 const LegStatic ls = lsTab[leg];
                 stamp(pc, cyc, 1);
+#ifdef FPE_TRACE
+                const long long tLeg0 = static_cast<long long>(__builtin_readcyclecounter());
+#endif
                 int legValid = 1;
                 constexpr bool kReload = FPE_SEQ_RELOAD_ARGS == 1 || (FPE_SEQ_RELOAD_ARGS == 2 && KW >= 3);
                 if constexpr (kReload) {
@@ -3268,6 +3271,10 @@ __global__ __launch_bounds__(64, FPE_SEQ_WAVES) void plan_bits_seq_kernel(DevMap
                 }
                 allValid &= legValid;
                 stamp(pc, cyc, 9);
+#ifdef FPE_TRACE
+                legClocks += static_cast<long long>(__builtin_readcyclecounter()) - tLeg0;
+                ++nLegs;
+#endif
             }
             pose_sync<16>();
             // footholdValidation_ = AND of the swing legs' flags (cpp:1323); commit or skip (cpp:1332-1576)
@@ -3328,6 +3335,8 @@ __global__ __launch_bounds__(64, FPE_SEQ_WAVES) void plan_bits_seq_kernel(DevMap
 #ifdef FPE_TRACE
     stamp_value(pc, 7, 14, flushClocks);  // clocks inside the flushes (records + deferred heights) and their number
     stamp_value(pc, 7, 15, nFlushes);
+    stamp_value(pc, 5, 15, legClocks);    // clocks inside the leg searches of ALL cycles, and their number
+    stamp_value(pc, 1, 14, nLegs);
     stamp_value(pc, 6, 13, static_cast<long long>(sh.pad[0]) << 4);  // clocks inside the spiral search,
     stamp_value(pc, 6, 12, sh.pad[1]);                               // searches, and searches without a hit
     stamp_value(pc, 6, 11, sh.pad[2]);

@@ -47,6 +47,7 @@ struct Tuning {
     int32_t noMidVariant = 0;
     int32_t noBits = 0;
     int32_t serviceOverlap = 1;  // small plan + opt calls: the opt chain beside the plan kernel on the flags it will most likely produce (fpe_engine.cpp, plan_host); 0: one after the other
+    int32_t servicePoll = 1;     // one-pose overlapped calls: the host polls the chain's completion word in the pinned arena instead of waiting for the stream's signal
     int32_t serviceOptGate = 2;  // fpe_plan_service*: 2 enforce (default: the handler's behaviour), 1 advisory (chain runs, reported), 0 exact gates only (no opt chain) (include/fpe.h)
 };
 

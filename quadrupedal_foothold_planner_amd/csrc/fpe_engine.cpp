@@ -3,6 +3,7 @@
 // started with — the reference races on gridmap_, cpp:506 vs cpp:818) and the spiral rank table.
 // There is NO CPU compute path: without a usable GPU every compute entry point fails.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <atomic>
@@ -46,7 +47,7 @@ hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts&
                             const fpe_pose* d_poses, int B, int nCycles, const fpe_plan_out& d_out, hipStream_t stream);
 // opt track (fpe_opt.hpp part of fpe_kernels.hip)
 hipError_t launch_opt_track(const DevMap& m, const PlanConsts& pc, const OptConsts& oc, const fpe_pose* d_poses, int B, int nCycles,
-                            const uint8_t* d_cycleOk, const fpe_opt_out& d_out, hipStream_t stream);
+                            const uint8_t* d_cycleOk, const fpe_opt_out& d_out, hipStream_t stream, uint32_t* doneFlag = nullptr, uint32_t doneValue = 0);
 }  // namespace fpe
 
 namespace {
@@ -140,6 +141,7 @@ struct CallCtx {
     // kernels were queued) hands the context back with the flag set, and the lease waits for the stream before the next
     // call's memcpy can touch the arena the kernels are still reading.
     bool inFlight = false;
+    uint32_t doneSeq = 0;  // sequence number of the completion word of polled one-pose calls (plan_host)
     ~CallCtx() {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         if (dev) (void)hipFree(dev);
@@ -794,6 +796,7 @@ int fpe_set_tuning(fpe_handle h, const char* key, int32_t value) {
         if (value < 0 || value > 2) return fail(FPE_E_INVALID_ARG, "service_opt_gate is 0 (exact gates only), 1 (advisory) or 2 (enforce)");
         h->tuning.serviceOptGate = value;
     } else if (k == "service_overlap") h->tuning.serviceOverlap = value ? 1 : 0;
+    else if (k == "service_poll") h->tuning.servicePoll = value ? 1 : 0;
     else if (k == "service_cycle0_gate_only") h->tuning.serviceOptGate = value ? 0 : 2;  // (older name)
     else return fail(FPE_E_INVALID_ARG, "unknown tuning key: " + k);
     return FPE_OK;
@@ -1043,6 +1046,22 @@ int prepare_opt(const fpe_params* params, const fpe_opt_params* opt, const CallP
 // The host-buffer form of the plan and / or the opt track: one device arena, the launches back to back on one
 // stream, the results copied out.  `out` NULL: no plan products are returned (the plan still runs when the opt track
 // needs its cycle flags and the caller gave none).
+#ifdef FPE_HOST_TIMING  // measurement builds only: where a small host-buffer call spends its time on the HOST (profiles/probe_host_timing.py)
+static double g_hostT[16];
+static long g_hostN = 0;
+struct HostTimer {
+    std::chrono::steady_clock::time_point t[16];
+    int last = -1;
+    void mark(int k) { t[k] = std::chrono::steady_clock::now(); last = k; }
+    void commit() {
+        for (int k = 1; k <= last; ++k) g_hostT[k] += std::chrono::duration<double, std::micro>(t[k] - t[k - 1]).count();
+        ++g_hostN;
+    }
+};
+#define FPE_HT_MARK(k) ht.mark(k)
+#else
+#define FPE_HT_MARK(k) do { } while (0)
+#endif
 struct GateGeom {  // what the service call's host-side (lateral) gate needs from the call's snapshot and constants
     fpe::MapGeom g;
     double isosLen, isosWid, drift;
@@ -1050,6 +1069,10 @@ struct GateGeom {  // what the service call's host-side (lateral) gate needs fro
 int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt, const fpe_pose* poses, int32_t B, int32_t n_cycles,
               const fpe_plan_out* out, const uint8_t* cycleOkIn, const fpe_opt_out* oout, GateGeom* gateGeom = nullptr,
               bool* optDropped = nullptr) {
+#ifdef FPE_HOST_TIMING
+    HostTimer ht;
+#endif
+    FPE_HT_MARK(0);
     if (!poses || (!out && !oout)) return fail(FPE_E_INVALID_ARG, "null argument");
     if (B <= 0 || n_cycles <= 0 || n_cycles > 255) return fail(FPE_E_INVALID_ARG, "B and n_cycles must be in [1, ..] / [1, 255]");
     float maxRadius = 0.0f;
@@ -1093,7 +1116,8 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
     // off the service's latency).
     const bool specWanted = runPlan && oout != nullptr && !cycleOkIn && B <= 4;
     const size_t szSpec = specWanted ? align256(nCyc) : 0;
-    const size_t total = szPose + szNom + szCen + szDef + szOk + szSt + szSel + szPs + szPk + szOf + szOc + szOg + szOr + szSpec;
+    const size_t szDone = specWanted ? 256 : 0;  // the chain's completion word (one-pose calls: polled by the host, below)
+    const size_t total = szPose + szNom + szCen + szDef + szOk + szSt + szSel + szPs + szPk + szOf + szOc + szOg + szOr + szSpec + szDone;
     if (!h) return fail(FPE_E_INVALID_ARG, "null handle or params");
     CallPlan cp;  // declared before the lease: on an early exit the lease waits for the stream BEFORE the snapshot / bit planes are released
     CtxLease lease(h->ctxPool);
@@ -1101,8 +1125,10 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
     FPE_HIP(hipSetDevice(h->device));
     FPE_HIP(cx.reserve(total));
     cx.inFlight = true;  // (prepare_call may already queue a bit-plane build)
+    FPE_HT_MARK(1);
     int rc = prepare_call(h, params, maxRadius, cp, cx.stream, runPlan);
     if (rc != FPE_OK) return rc;
+    FPE_HT_MARK(2);
     if (gateGeom) *gateGeom = GateGeom{cp.snap->g, cp.pc.isosLen, cp.pc.isosWid, cp.pc.drift};
     fpe::OptConsts oc;
     if (oout) {
@@ -1131,7 +1157,8 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
     const size_t oOc = off; off += szOc;
     const size_t oOg = off; off += szOg;
     const size_t oOr = off; off += szOr;
-    const size_t oSpec = off;
+    const size_t oSpec = off; off += szSpec;
+    const size_t oDone = off;
     std::memcpy(hp, poses, static_cast<size_t>(B) * sizeof(fpe_pose));
     if (oout && cycleOkIn) std::memcpy(hp + oOk, cycleOkIn, nCyc);
     // Small calls (the plan_global_footholds service: one pose) skip both DMA copies: the kernels read the
@@ -1162,6 +1189,14 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
     }
     fpe_opt_out od;
     std::memset(&od, 0, sizeof(od));
+    // One-pose overlapped calls (the service): the chain's last instruction writes a completion word into the pinned arena and the
+    // host POLLS it (tuning key service_poll, default 1) instead of waiting for the side stream's completion signal.
+    bool pollDone = false;
+    uint32_t doneValue = 0;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        pollDone = speculate && B == 1 && h->tuning.servicePoll != 0;
+    }
     const auto queue_opt = [&]() -> int {
         if (!oout) return FPE_OK;
         if (oout->footholds) od.footholds = reinterpret_cast<fpe_opt_foothold*>(dp + oOf);
@@ -1170,6 +1205,11 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
         if (oout->rows_after) od.rows_after = reinterpret_cast<double*>(dp + oOr);
         hipStream_t os = cx.stream;
         const unsigned char* okDev = dp + oOk;
+        uint32_t* doneDev = nullptr;
+        if (speculate && pollDone) {
+            doneValue = ++cx.doneSeq ? cx.doneSeq : ++cx.doneSeq;  // (never 0, never the value the word holds from the last call)
+            doneDev = reinterpret_cast<uint32_t*>(dp + oDone);
+        }
         if (speculate) {
             std::memset(hp + oSpec, 1, nCyc);
             FPE_HIP(cx.side_stream(&os));
@@ -1181,15 +1221,21 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
 #endif
             okDev = dp + oSpec;
         }
-        FPE_HIP(fpe::launch_opt_track(dev_map(*cp.snap), cp.pc, oc, dPoses ? dPoses : reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, okDev, od, os));
+        FPE_HIP(fpe::launch_opt_track(dev_map(*cp.snap), cp.pc, oc, dPoses ? dPoses : reinterpret_cast<const fpe_pose*>(dp), B, n_cycles, okDev, od, os, doneDev, doneValue));
         return FPE_OK;
     };
     // (the overlapped form queues the LONGER kernel first — the chain is the call's critical path; the plan kernel's launch then costs
     // it nothing)
+    FPE_HT_MARK(3);
     if (speculate) {
         rc = queue_opt();
         if (rc != FPE_OK) return rc;
+        // A polled call never enters a stream wait, and it is a stream wait (or query) that makes the runtime hand queued work to
+        // the hardware at once: without it the chain was seen to END 12 us later than under hipStreamSynchronize (measured, round 6:
+        // profiles/round6_service_latency.txt).  One non-blocking query per stream, right behind its launch.
+        if (pollDone && hipStreamQuery(cx.side) != hipSuccess) (void)hipGetLastError();
     }
+    FPE_HT_MARK(4);
     if (runPlan) {
         fpe_plan_out d;
         std::memset(&d, 0, sizeof(d));
@@ -1210,6 +1256,8 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
         rc = queue_opt();
         if (rc != FPE_OK) return rc;
     }
+    if (pollDone && hipStreamQuery(cx.stream) != hipSuccess) (void)hipGetLastError();  // (see the side stream's query above)
+    FPE_HT_MARK(5);
     // ---- results to the caller ----
     struct Seg {
         size_t off, len;
@@ -1233,9 +1281,32 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
     if (oout && szOg) add(oOg, static_cast<size_t>(B), oout->gate_fail_cycle);
     if (oout && szOr) add(oOr, static_cast<size_t>(B) * 2 * sizeof(double), oout->rows_after);
     if (zeroCopy) {  // the kernels wrote into the pinned arena itself
-        FPE_HIP(hipStreamSynchronize(cx.stream));
+        bool polled = false;
+        if (pollDone && doneValue != 0) {
+            // The chain is the call's critical path (~90 us against the plan kernel's ~20): wait for ITS word first.  Bounded: after
+            // 5 ms the ordinary synchronisation below takes over (a word that never arrives must not hang the caller).
+            volatile uint32_t* word = reinterpret_cast<volatile uint32_t*>(hp + oDone);
+            const auto t0 = std::chrono::steady_clock::now();
+            int spins = 0;
+            while (*word != doneValue) {
+                __builtin_ia32_pause();
+                if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+            }
+            polled = *word == doneValue;
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        // (the plan kernel ended long before the chain; when the runtime has not yet seen that, wait for it the ordinary way)
+        if (!(polled && hipStreamQuery(cx.stream) == hipSuccess)) {
+            (void)hipGetLastError();
+            FPE_HIP(hipStreamSynchronize(cx.stream));
+        }
+        FPE_HT_MARK(6);
         if (oout && speculate) {
-            FPE_HIP(hipStreamSynchronize(cx.side));
+            // polled: every product of the chain is in the arena (its stores precede the word); the stream's own completion is
+            // looked at without waiting — the context's next call queues behind it in stream order
+            if (!polled) FPE_HIP(hipStreamSynchronize(cx.side));
+            else if (hipStreamQuery(cx.side) != hipSuccess) (void)hipGetLastError();
+            FPE_HT_MARK(7);
             bool allCommitted = true;
             for (size_t c = 0; c < nCyc; ++c) allCommitted = allCommitted && hp[oOk + c] != 0;
             if (!allCommitted) {  // a nominal search failed in some cycle: the chain again, on the flags as they are
@@ -1246,6 +1317,11 @@ int plan_host(fpe_engine* h, const fpe_params* params, const fpe_opt_params* opt
         }
         cx.inFlight = false;
         for (int k = 0; k < nSeg; ++k) std::memcpy(segs[k].dst, hp + segs[k].off, segs[k].len);
+#ifdef FPE_HOST_TIMING
+        if (ht.last < 7) ht.mark(7);
+        ht.mark(8);
+        ht.commit();
+#endif
         return FPE_OK;
     }
     // Only what the caller asked for crosses PCIe.  A product whose destination is pinned / registered host memory
@@ -1625,3 +1701,18 @@ int fpe_plan_service_opt(fpe_handle h, const fpe_params* params, const fpe_opt_p
 }
 
 }  // extern "C"
+
+#ifdef FPE_HOST_TIMING
+// mean microseconds per zero-copy plan_host call between its marks: [1] lease + reserve, [2] prepare_call, [3] opt constants + pose
+// copy + device pointers, [4] chain queued (overlapped form), [5] plan kernel queued, [6] main stream synchronised, [7] side stream
+// synchronised, [8] results copied out; out[0] = calls
+extern "C" int fpe_debug_host_timing(double* out, int reset) {
+    out[0] = static_cast<double>(g_hostN);
+    for (int k = 1; k < 16; ++k) out[k] = g_hostN ? g_hostT[k] / static_cast<double>(g_hostN) : 0.0;
+    if (reset) {
+        for (double& v : g_hostT) v = 0.0;
+        g_hostN = 0;
+    }
+    return 0;
+}
+#endif

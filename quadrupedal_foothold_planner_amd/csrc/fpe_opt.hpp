@@ -680,7 +680,7 @@ struct OptShared {
 // best (round 5; until then they waited at the workgroup barrier and the whole search followed the columns).
 template <int W>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2))) void opt_track_kernel(DevMap m, PlanConsts pc, OptConsts oc, const fpe_pose* __restrict__ poses, int B,
-                                                           int nCycles, const uint8_t* __restrict__ cycleOk, fpe_opt_out out) {
+                                                           int nCycles, const uint8_t* __restrict__ cycleOk, fpe_opt_out out, uint32_t* doneFlag, uint32_t doneValue) {
     __shared__ OptShared sh;
     __shared__ OptBest slots[W];
     __shared__ OptProblem probs[2];  // by cycle parity: wavefront 0 may publish cycle g + 1 while a helper still reads cycle g
@@ -1053,14 +1053,20 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2))) voi
         out.rows_after[2 * static_cast<size_t>(b)] = lfRow;
         out.rows_after[2 * static_cast<size_t>(b) + 1] = rhRow;
     }
+    // One-pose service call (round 6): wavefront 0 — the only one that stores products — says so in the caller's host-mapped arena
+    // with a system-scope RELEASE store behind its product stores; the host polls that word instead of waiting for the stream's
+    // completion signal (fpe_engine.cpp, plan_host: -4 us of a ~100 us call).  (Measured: an additional __threadfence_system, or a
+    // relaxed store behind s_waitcnt 0, end at the same time — the ordering is not what the word costs.)
+    if (doneFlag && lane == 0) __hip_atomic_store(doneFlag, doneValue, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 hipError_t launch_opt_track(const DevMap& m, const PlanConsts& pc, const OptConsts& oc, const fpe_pose* d_poses, int B, int nCycles,
-                            const uint8_t* d_cycleOk, const fpe_opt_out& d_out, hipStream_t stream) {
+                            const uint8_t* d_cycleOk, const fpe_opt_out& d_out, hipStream_t stream, uint32_t* doneFlag, uint32_t doneValue) {
+    if (B != 1) doneFlag = nullptr;  // (one workgroup per pose: a single word can only speak for one of them)
 #ifndef FPE_OPT_W_SMALL
 #define FPE_OPT_W_SMALL 8
 #endif
-    if (B <= 64) hipLaunchKernelGGL(opt_track_kernel<FPE_OPT_W_SMALL>, dim3(B), dim3(64 * FPE_OPT_W_SMALL), 0, stream, m, pc, oc, d_poses, B, nCycles, d_cycleOk, d_out);
-    else hipLaunchKernelGGL(opt_track_kernel<1>, dim3(B), dim3(64), 0, stream, m, pc, oc, d_poses, B, nCycles, d_cycleOk, d_out);
+    if (B <= 64) hipLaunchKernelGGL(opt_track_kernel<FPE_OPT_W_SMALL>, dim3(B), dim3(64 * FPE_OPT_W_SMALL), 0, stream, m, pc, oc, d_poses, B, nCycles, d_cycleOk, d_out, doneFlag, doneValue);
+    else hipLaunchKernelGGL(opt_track_kernel<1>, dim3(B), dim3(64), 0, stream, m, pc, oc, d_poses, B, nCycles, d_cycleOk, d_out, doneFlag, doneValue);
     return hipGetLastError();
 }

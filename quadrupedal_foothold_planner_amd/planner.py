@@ -51,7 +51,7 @@ def make_poses(xyz, gait=0, leg_search_radius=None, leg_polygon_kind=None):
 
 
 # fpe_set_tuning's knobs whose engine default is not 0 (tuning() restores these after a with-block)
-TUNING_DEFAULTS = {"service_opt_gate": 2, "service_overlap": 1}
+TUNING_DEFAULTS = {"service_opt_gate": 2, "service_overlap": 1, "service_poll": 1}
 
 
 class FootholdPlanner:
@@ -162,7 +162,7 @@ class FootholdPlanner:
         return buf.value.decode()
 
     def set_tuning(self, **kw):
-        """fpe_set_tuning: plan_group, literal_discs, no_mid_variant, no_bits, service_opt_gate, service_overlap (build-defined test / tuning knobs)."""
+        """fpe_set_tuning: plan_group, literal_discs, no_mid_variant, no_bits, service_opt_gate, service_overlap, service_poll (build-defined test / tuning knobs)."""
         for k, v in kw.items():
             self._check(self._lib.fpe_set_tuning(self._h, k.encode(), int(v)))
             self._tuning[k] = int(v)

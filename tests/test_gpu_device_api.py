@@ -318,12 +318,15 @@ def test_service_with_the_opt_chain_beside_the_plan_kernel_equals_one_after_the_
     for _ in range(40):
         pos = [rng.uniform(-3.2, -2.0), rng.uniform(-3, 3), 0.0]
         res = []
-        for overlap in (1, 0, 1):
-            with planner.tuning(service_overlap=overlap, service_opt_gate=1):  # (advisory: the call answers, the chain's verdict is reported)
+        # (overlap, poll): the overlapped call whose host POLLS the chain's completion word in the pinned arena (the default since
+        # round 6), the sequential call, the overlapped call that waits for the side stream's signal
+        for overlap, poll in ((1, 1), (0, 1), (1, 0), (1, 1)):
+            with planner.tuning(service_overlap=overlap, service_poll=poll, service_opt_gate=1):  # (advisory: the call answers, the chain's verdict is reported)
                 r = planner.globalFootholdPlan(6, pos, all_tracks=True)
                 res.append((r, planner.last_service_gate()))
         _same(res[0], res[1])
         _same(res[2], res[1])
+        _same(res[3], res[1])
         if res[0][0] is not False:
             answered += 1
             ok = omap.plan(util.to_oracle_params(planner.params), util.to_oracle_poses(make_poses([pos])), 6)["cycle_ok"][0].astype(bool)

@@ -139,8 +139,9 @@ def test_random_differential_campaign():
     print("opt track: solver statuses", opt_status.tolist(), "poses with a failed gate", opt_gates)
     print("kernels exercised:", kernels)
     assert (src[:3] > 0).all() and (codes > 0).all(), (src, codes)
-    if focus == "seq":
-        assert all(k.startswith("plan_bits_seq_kernel") for k in kernels) or n_cases < 20, kernels
+    if focus == "seq" and n_cases >= 20:  # (a case whose window proof fails, or whose radius leaves the 96 columns, takes a direct kernel)
+        n_seq = sum(v for k, v in kernels.items() if k.startswith("plan_bits_seq_kernel"))
+        assert n_seq >= 0.6 * sum(kernels.values()) and any(k.startswith("plan_bits_seq_kernel<2, 3>") for k in kernels), kernels
     if n_cases >= 100 and not focus:
         assert (opt_status[:3] > 0).all() and opt_gates > 0, (opt_status, opt_gates)
         assert any(k.startswith("plan_bits_kernel") for k in kernels) and any(k.startswith("plan_bits_seq_kernel") for k in kernels), kernels
