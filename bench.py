@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="poses per GPU (default: the config's B; cfg4: B/8 = one shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the ingest / open-loop / D2H side measurements (profiling runs)")
+    ap.add_argument("--b2b-seconds", type=float, default=0.25,
+                    help="length of the untimed back-to-back pass (>= 200 launches in any case); profiles/collect.sh passes 0 so that the "
+                         "profiler's per-kernel average is taken over the TIMED region's launches, like roofline.kernel_ms")
     ap.add_argument("--no-bits", action="store_true", help="run the direct kernels (fpe_set_tuning no_bits=1) instead of the bit-window kernels")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target seconds of oracle work per baseline leg")
     ap.add_argument("--gather-every", type=int, default=8, help="N>1: one all-gather per K steps, carrying all K steps' records (1: a collective per step; measured as config.exchange_alt)")
@@ -376,9 +379,9 @@ def main():
     # first dispatch pays the queue's wake-up — ~30 us per block, i.e. 1.3 us per step at K = 20, 0.1 us at K = 200 (measured:
     # 25.0 / 24.6 / 23.7 us per launch at K = 20 / 50 / 200 on one box).  One extra, untimed pass of >= 200 back-to-back launches
     # gives the kernel's own steady-state duration; `frac` keeps using the timed region's figure.
-    # Sized to keep the GPU busy for >= 0.25 s (the timed region of a 25 us step is ~13 ms of a 20 s run, below what a
+    # Sized to keep the GPU busy for >= --b2b-seconds = 0.25 s (the timed region of a 25 us step is ~13 ms of a 20 s run, below what a
     # utilisation sampler at 1-5 Hz can see; this pass — 10 000 launches at the headline — is the run's visibly busy stretch).
-    nb2b = int(min(20000, max(200, args.steps, np.ceil(250.0 / max(kernel_ms, 1e-3)))))
+    nb2b = int(min(20000, max(200, args.steps, np.ceil(args.b2b_seconds * 1e3 / max(kernel_ms, 1e-3)))))
     s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     for rep_ in range(2):

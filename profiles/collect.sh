@@ -14,7 +14,9 @@ OUT=gpurun_out
 export TMPDIR=/tmp
 STEPS=50
 case $CFG in cfg3|cfg4|cfg5) STEPS=20;; esac
-BENCH="python3 bench.py --config $CFG --steps $STEPS --warmup 5 --blocks 3 --no-cpu-baseline --no-extras $EXTRA"
+# (--b2b-seconds 0: the untimed back-to-back pass stays at its minimum of 200 launches — the profiler's per-kernel AVERAGE must describe the
+#  timed region's launches, which start from an idle GPU block by block and run ~7 % longer than launches that keep the queue busy)
+BENCH="python3 bench.py --config $CFG --steps $STEPS --warmup 5 --blocks 3 --b2b-seconds 0 --no-cpu-baseline --no-extras $EXTRA"
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o $TAG -- $BENCH > $OUT/${TAG}_stats.log 2>&1
 if [ "$MODE" != "stats" ]; then

@@ -13,5 +13,5 @@ export FPE_LIB=$GRAFT_REPO_ROOT/scratch/libfpe_tl.so
   for m in 0 1; do FPE_PROBE_MAP=$m python3 profiles/probe_filters_timeline.py 2>/dev/null | grep -v "^ xcd\|start times"; done
   echo "# the same on a tilted plane with noise (no cell takes the literal walks):"
   TL_MAP=noise FPE_PROBE_MAP=0 python3 profiles/probe_filters_timeline.py 2>/dev/null | grep "workgroups\|step:\|resident"
-} > gpurun_out/r5p_filters_timeline.txt
-cat gpurun_out/r5p_filters_timeline.txt | cut -c1-200 | head -8
+} > gpurun_out/r6p_filters_timeline.txt
+cat gpurun_out/r6p_filters_timeline.txt | cut -c1-200 | head -8

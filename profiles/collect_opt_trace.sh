@@ -11,5 +11,5 @@ mkdir -p scratch gpurun_out
   echo "# opt_track_kernel<8>, one pose x 8 gait cycles, headline map and yaml parameters: wall_clock64 stamps (100 MHz) of wavefront 0's"
   echo "# stages and of the first helper's (measurement build, see the script); footholds requested, so heights are part of the last stage."
   FPE_LIB=$GRAFT_REPO_ROOT/scratch/libfpe_opttrace.so python3 profiles/probe_opt_trace.py 2>/dev/null | grep -v "Warn\|amdgpu.ids"
-} > gpurun_out/r5p_opt_stage_trace.txt
-cat gpurun_out/r5p_opt_stage_trace.txt | head -20
+} > gpurun_out/r6p_opt_stage_trace.txt
+cat gpurun_out/r6p_opt_stage_trace.txt | head -20

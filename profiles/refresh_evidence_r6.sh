@@ -12,3 +12,5 @@ cp gpurun_out/r6p_batch_scaling.txt profiles/round6_batch_scaling.txt
 grep -v "Warn\|amdgpu.ids" gpurun_out/r6p_service_latency.txt > profiles/round6_service_latency.txt
 grep "^{" gpurun_out/r6p_bench_nccl1_packed.json | tail -1 > profiles/round6_bench_line_nccl_one_rank_packed.json
 grep "^{" gpurun_out/r6p_bench_2rank.json | tail -1 > profiles/round6_bench_line_2rank_one_gpu.json
+cp gpurun_out/r6p_stage_traces.txt profiles/round6_seq_stage_traces.txt
+{ cat profiles/round6_service_latency.txt; echo; echo "# host side of the one-pose service call (profiles/probe_host_timing.py, -DFPE_HOST_TIMING build):"; cat gpurun_out/r6p_host_timing.txt; } > profiles/round6_service_latency.tmp && mv profiles/round6_service_latency.tmp profiles/round6_service_latency.txt

@@ -47,4 +47,8 @@ if [ -f scratch/libfpe_trace.so ]; then
   { echo "== cfg3 (plan_bits_seq_kernel<1,2>)"; FPE_LIB=scratch/libfpe_trace.so python3 profiles/trace_stages_seq.py cfg3 4096 2>&1 | grep -v "Warn\|amdgpu.ids\|RuntimeWarning\|ret = \|_methods";
     echo "== cfg5 (plan_bits_seq_kernel<2,3>)"; FPE_LIB=scratch/libfpe_trace.so python3 profiles/trace_stages_seq.py cfg5 4096 2>&1 | grep -v "Warn\|amdgpu.ids\|RuntimeWarning\|ret = \|_methods"; } > gpurun_out/r6p_stage_traces.txt
 fi
+# where a one-pose service call spends its time on the host (measurement build scratch/libfpe_ht.so: -DFPE_HOST_TIMING), polled and stream-wait forms
+if [ -f scratch/libfpe_ht.so ]; then
+  for poll in 1 0; do echo "== service_poll $poll"; FPE_PROBE_POLL=$poll FPE_LIB=scratch/libfpe_ht.so python3 profiles/probe_host_timing.py 2>&1 | grep -v "amdgpu.ids"; done > gpurun_out/r6p_host_timing.txt
+fi
 ls gpurun_out | grep r6p_ | wc -l
