@@ -3123,15 +3123,38 @@ struct SeqKernArgs {
 #ifndef FPE_SEQ_RELOAD_ARGS
 #define FPE_SEQ_RELOAD_ARGS 2
 #endif
+#ifndef FPE_SEQ_GROUP16  // 0: always one pose per workgroup (measurement builds)
+#define FPE_SEQ_GROUP16 1
+#endif
+// One pose's chain, from its stance to its last gait cycle: a FUNCTION the kernel calls once per wavefront, not inlined.  Round 6:
+// as a callee the body reads everything uniform from the kernel's ARGUMENT SEGMENT (scalar loads through `kaIn`) instead of holding the
+// arguments in scalar registers the allocator spills to vector lanes (no spilled scalars in the kernel, 60-150 before: cfg-3 0.6046 ->
+// 0.5959 ms), and the kernel can put SIXTEEN poses in one workgroup (one workgroup per CU instead of sixteen: cfg-5 0.3023 -> 0.2959 ms;
+// plan_bits_seq_kernel below).  A/B in one call, three repetitions: profiles/round6_seq_floor.txt.
 template <int NRL, int KW, int kProd>
-__global__ __launch_bounds__(64, FPE_SEQ_WAVES) void plan_bits_seq_kernel(DevMap m, BitMap bm, PlanConsts pc, SpiralLut lut,
-                                                                          const fpe_pose* __restrict__ poses, int B, int nCycles, fpe_plan_out outArg, int recSlots) {
+__device__ __attribute__((noinline)) void seq_run_pose(const SeqKernArgs __attribute__((address_space(4))) * kaIn, int slotOffIn, int bInV, int tid, unsigned hwidIn,
+                                                       const LutHead& head) {
     constexpr int G = 64;
-    const fpe_plan_out out = specialise_products<kProd>(outArg);
     constexpr int NR = G * NRL;
-    stamp(pc, 6, 14);  // (profiling builds: lifetime of the wavefront, with the stamp after the cycle loop)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = static_cast<int>(threadIdx.x);
+    // (a function's arguments arrive in VECTOR registers: the uniform ones go back to scalars here, or every address and index derived
+    // from them would be vector arithmetic — and the argument-segment pointer could not feed scalar loads at all)
+    typedef const SeqKernArgs __attribute__((address_space(4))) * KernArgPtrS;
+    const unsigned long long kaBits = reinterpret_cast<unsigned long long>(kaIn);
+    const KernArgPtrS kaArg = reinterpret_cast<KernArgPtrS>((static_cast<unsigned long long>(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(kaBits >> 32)))) << 32) |
+                                                              static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(kaBits))));
+    const int slotOff = __builtin_amdgcn_readfirstlane(slotOffIn), b = __builtin_amdgcn_readfirstlane(bInV);
+    const unsigned hwid = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(hwidIn)));
+    const SeqKernArgs* kaG = (const SeqKernArgs*)kaArg;
+    const DevMap& m = kaG->m;
+    const BitMap& bm = kaG->bm;
+    const PlanConsts& pc = kaG->pc;
+    const SpiralLut& lut = kaG->lut;
+    const fpe_pose* __restrict__ poses = kaG->poses;
+    const int nCycles = kaG->nCycles, recSlots = kaG->recSlots;
+    const fpe_plan_out out = specialise_products<kProd>(kaG->out);
+    // (the workgroup's LDS by its own symbol: a pointer PARAMETER would be a generic one, and every LDS access a flat instruction)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemAll[];
+    unsigned char* const smem = smemAll + slotOff;
     const Grp<G> g(tid);
     PoseShared& sh = *reinterpret_cast<PoseShared*>(smem);
 #ifdef FPE_TRACE
@@ -3148,14 +3171,11 @@ __global__ __launch_bounds__(64, FPE_SEQ_WAVES) void plan_bits_seq_kernel(DevMap
     using Rec = SeqRecOf<KW>;
     Rec* recBase = reinterpret_cast<Rec*>(
         smem + ((sizeof(PoseShared) + kLsBytes + 4 * static_cast<size_t>(legbits_words(min(2 * pc.winH + 1, NR), KW, pc.nHW, true)) + 15) & ~static_cast<size_t>(15)));
-    const int b = blockIdx.x;
-    if (b >= B) return;
     const bool live = true;
 
     const fpe_pose* pp = poses + b;
     const double x0 = pp->position[0], y0 = pp->position[1], z0 = pp->position[2];
     const int gait = pp->gait;
-    const LutHead head = load_lut_head(lut, g);
     for (int k = tid; k < pc.nFoot; k += G) {
         sh.footDa[k] = pc.footDa[k];
         sh.footDb[k] = pc.footDb[k];
@@ -3191,12 +3211,7 @@ __global__ __launch_bounds__(64, FPE_SEQ_WAVES) void plan_bits_seq_kernel(DevMap
     const double advance = (gait == 1) ? pc.stepQuarter : pc.step;
     const int walkOrder = pc.RF_FIRST ? ((0) | (2 << 2) | (3 << 4) | (1 << 6)) : ((3) | (1 << 2) | (0 << 4) | (2 << 6));
 
-    int cycLag;  // launch order of this wavefront on its SIMD (HW_ID.WAVE_ID: 0 oldest .. 3) x a sixteenth of the cycles
-    {
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        cycLag = (static_cast<int>(hwid & 3u) * nCycles) / 16;
-    }
+    const int cycLag = (static_cast<int>(hwid & 3u) * nCycles) / 16;  // launch order of this wavefront on its SIMD (HW_ID.WAVE_ID: 0 oldest .. 3) x a sixteenth of the cycles
 #ifdef FPE_TRACE
     long long flushClocks = 0, nFlushes = 0, legClocks = 0, nLegs = 0;
     stamp(pc, 5, 14);  // end of the prologue
@@ -3254,7 +3269,7 @@ __global__ __launch_bounds__(64, FPE_SEQ_WAVES) void plan_bits_seq_kernel(DevMap
                 // <2, 3, 0> no vector scratch — and the time says what those reads were worth: cfg-5 -1.3 %, cfg-3 +2 % (the scalar
                 // loads' waits now sit INSIDE the leg search, in front of its first uses); hence the per-instantiation switch above.
                 typedef const SeqKernArgs __attribute__((address_space(4))) * KernArgPtr;
-                KernArgPtr ka4 = (KernArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+                KernArgPtr ka4 = (KernArgPtr)kaArg;
                 asm volatile("" : "+s"(ka4));
                 const SeqKernArgs* ka = (const SeqKernArgs*)ka4;
                 const fpe_plan_out outL = specialise_products<kProd>(ka->out);
@@ -3304,7 +3319,7 @@ __global__ __launch_bounds__(64, FPE_SEQ_WAVES) void plan_bits_seq_kernel(DevMap
                 // (the flush reads its constants and pointers from the argument segment as well where the leg loop does)
                 constexpr bool kReloadF = FPE_SEQ_RELOAD_ARGS == 1 || (FPE_SEQ_RELOAD_ARGS == 2 && KW >= 3);
                 typedef const SeqKernArgs __attribute__((address_space(4))) * KernArgPtr;
-                KernArgPtr kf4 = (KernArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+                KernArgPtr kf4 = (KernArgPtr)kaArg;
                 if constexpr (kReloadF) asm volatile("" : "+s"(kf4));
                 const SeqKernArgs* kf = (const SeqKernArgs*)kf4;
                 const DevMap& mF = kReloadF ? kf->m : m;
@@ -3341,6 +3356,25 @@ __global__ __launch_bounds__(64, FPE_SEQ_WAVES) void plan_bits_seq_kernel(DevMap
     stamp_value(pc, 6, 12, sh.pad[1]);                               // searches, and searches without a hit
     stamp_value(pc, 6, 11, sh.pad[2]);
 #endif
+}
+
+// The kernel: kGroup wavefronts — poses — per workgroup, each runs seq_run_pose on its own slot of the workgroup's LDS.  kGroup 16 (one
+// workgroup of 1 024 threads per CU; the launch's choice for batches of at least 64 poses on the 96-bit-row windows) or 1.
+template <int NRL, int KW, int kProd, int kGroup>
+__global__ __launch_bounds__(64 * kGroup, kGroup == 1 ? FPE_SEQ_WAVES : 1) void plan_bits_seq_kernel(DevMap m, BitMap bm, PlanConsts pc, SpiralLut lut,
+                                                                                                const fpe_pose* __restrict__ poses, int B, int nCycles, fpe_plan_out outArg,
+                                                                                                int recSlots, int slotBytes) {
+    stamp(pc, 6, 14);  // (profiling builds: lifetime of the wavefront, with the stamp after the cycle loop)
+    const int tid = static_cast<int>(threadIdx.x) & 63, wv = static_cast<int>(threadIdx.x) >> 6;
+    const int b = static_cast<int>(blockIdx.x) * kGroup + wv;
+    if (b >= B) return;
+    const Grp<64> g(tid);
+    const LutHead head = load_lut_head(lut, g);
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    (void)m; (void)bm; (void)poses; (void)nCycles; (void)outArg; (void)recSlots;
+    typedef const SeqKernArgs __attribute__((address_space(4))) * KernArgPtr0;
+    seq_run_pose<NRL, KW, kProd>((KernArgPtr0)__builtin_amdgcn_kernarg_segment_ptr(), wv * slotBytes, b, tid, hwid, head);
 }
 
 // ---- host side of the bit-window path --------------------------------------------------------------------------
@@ -3435,20 +3469,36 @@ hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts&
         else if (prod == 1) FPE_LAUNCH_BITS_P(NRL, MID, 1);        \
         else FPE_LAUNCH_BITS_P(NRL, MID, 0);                       \
     } while (0)
+#define FPE_LAUNCH_BITS_SEQ_G(NRL, KW, GRP, GRID, LDS, SLOT)                                                                                      \
+    do {                                                                                                                                        \
+        if ((LDS) > 64 * 1024) {                                                                                                                \
+            const hipError_t ea = hipFuncSetAttribute(prod == 1 ? reinterpret_cast<const void*>(plan_bits_seq_kernel<NRL, KW, 1, GRP>)          \
+                                                                : reinterpret_cast<const void*>(plan_bits_seq_kernel<NRL, KW, 0, GRP>),        \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(LDS));                       \
+            if (ea != hipSuccess) return ea;                                                                                                    \
+        }                                                                                                                                       \
+        if (prod == 1)                                                                                                                          \
+            hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW, 1, GRP>), dim3(GRID), dim3(64 * GRP), LDS, stream, m, bm, pc, lut, d_poses, B,    \
+                               nCycles, d_out, recSlots, static_cast<int>(SLOT));                                                              \
+        else                                                                                                                                    \
+            hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW, 0, GRP>), dim3(GRID), dim3(64 * GRP), LDS, stream, m, bm, pc, lut, d_poses, B,    \
+                               nCycles, d_out, recSlots, static_cast<int>(SLOT));                                                              \
+    } while (0)
 #define FPE_LAUNCH_BITS_SEQ(NRL, KW)                                                                                         \
     do {                                                                                                                     \
         const size_t base = (sizeof(PoseShared) + ((4 * sizeof(LegStatic) + 15) & ~static_cast<size_t>(15)) +                            \
                              4 * legbits_words(2 * pc.winH + 1 < 64 * NRL ? 2 * pc.winH + 1 : 64 * NRL, KW, pc.nHW, true) + 15) &        \
                             ~static_cast<size_t>(15);                                                                                 \
-        int recSlots = 8; /* cycles of staged records: as many as keep sixteen blocks per CU (10 KiB each) */                      \
+        int recSlots = 8; /* cycles of staged records: as many as keep sixteen poses per CU (10 KiB each) */                       \
         while (recSlots > 1 && base + recSlots * 4 * sizeof(SeqRecOf<KW>) > 10240) recSlots >>= 1;                                   \
+        const size_t slot = (base + recSlots * 4 * sizeof(SeqRecOf<KW>) + 15) & ~static_cast<size_t>(15);                            \
         /* (the all-seven shape takes the generic instantiation here: compiled on its own it spills more — cfg-5 +2 %, cfg-3 0) */     \
-        if (prod == 1)                                                                                                              \
-            hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW, 1>), dim3(B), block, base + recSlots * 4 * sizeof(SeqRecOf<KW>), stream, m, bm, pc, \
-                               lut, d_poses, B, nCycles, d_out, recSlots);                                                                \
+        /* sixteen poses per workgroup — one workgroup per CU — where it was measured to pay: the 96-bit-row windows (cfg-5 -2 %; the    \
+           64-bit-row kernel of cfg-3 +2 %), batches that fill at least four CUs, slots that fit sixteen times into the LDS */            \
+        if (FPE_SEQ_GROUP16 && KW >= 3 && B >= 64 && 16 * slot <= 160 * 1024)                                                            \
+            FPE_LAUNCH_BITS_SEQ_G(NRL, KW, 16, (B + 15) / 16, 16 * slot, slot);                                                          \
         else                                                                                                                             \
-            hipLaunchKernelGGL((plan_bits_seq_kernel<NRL, KW, 0>), dim3(B), block, base + recSlots * 4 * sizeof(SeqRecOf<KW>), stream, m, bm, pc, \
-                               lut, d_poses, B, nCycles, d_out, recSlots);                                                                \
+            FPE_LAUNCH_BITS_SEQ_G(NRL, KW, 1, B, slot, slot);                                                                            \
     } while (0)
     if (sp.lanes == 8) {
         if (sp.nrl == 2 && mid) FPE_LAUNCH_BITS(2, true);
@@ -3466,5 +3516,6 @@ hipError_t launch_plan_bits(const DevMap& m, const BitMap& bm, const PlanConsts&
 #undef FPE_LAUNCH_BITS
 #undef FPE_LAUNCH_BITS_P
 #undef FPE_LAUNCH_BITS_SEQ
+#undef FPE_LAUNCH_BITS_SEQ_G
     return hipGetLastError();
 }

@@ -663,6 +663,8 @@ int upload_common(fpe_engine* h, const fpe_map_desc* desc, const float* trav, co
         FPE_HIP(hipStreamSynchronize(stream));
         for (auto& ms : snap->masks) ms->readyDone.store(true, std::memory_order_release);
     }
+    // (a host upload has synchronised behind each layer's copy: the snapshot is known complete — its first consumer need not ask the event)
+    if (!srcOnDevice) snap->readyDone.store(true, std::memory_order_release);
     std::shared_ptr<MapSnapshot> old;
     {
         std::lock_guard<std::mutex> lk(h->mu);
