@@ -678,9 +678,28 @@ struct OptShared {
 // the columns; the seven helpers poll a sequence number in LDS (s_sleep between polls), analyse and list the row lattice as soon as
 // a cycle's bounds are published — beside the column searches —, evaluate their lists once the columns are, and hand back their
 // best (round 5; until then they waited at the workgroup barrier and the whole search followed the columns).
+struct OptKernArgs {  // opt_track_kernel's argument list as a struct (the argument segment's layout)
+    DevMap m;
+    PlanConsts pc;
+    OptConsts oc;
+    const fpe_pose* poses;
+    int B, nCycles;
+    const uint8_t* cycleOk;
+    fpe_opt_out out;
+    uint32_t* doneFlag;
+    uint32_t doneValue;
+};
+#ifndef FPE_OPT_RELOAD_ARGS
+#define FPE_OPT_RELOAD_ARGS 1
+#endif
 template <int W>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2))) void opt_track_kernel(DevMap m, PlanConsts pc, OptConsts oc, const fpe_pose* __restrict__ poses, int B,
                                                            int nCycles, const uint8_t* __restrict__ cycleOk, fpe_opt_out out, uint32_t* doneFlag, uint32_t doneValue) {
+    const int nCyclesArg = nCycles;
+    const DevMap& mArg = m;
+    const PlanConsts& pcArg = pc;
+    const OptConsts& ocArg = oc;
+    const fpe_opt_out& outArg = out;
     __shared__ OptShared sh;
     __shared__ OptBest slots[W];
     __shared__ OptProblem probs[2];  // by cycle parity: wavefront 0 may publish cycle g + 1 while a helper still reads cycle g
@@ -778,7 +797,21 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2))) voi
     bool helpersGone = false;  // (W > 1) the helper wavefronts have been told to leave
     int nRuns = 0;             // (W > 1) cycles whose row search ran: the helpers hand back W - 1 results each
 
-    for (int cyc = 0; cyc < nCycles; ++cyc) {
+    for (int cycIt = 0; cycIt < nCyclesArg; ++cycIt) {
+        // Round 6, the one-pose form (W > 1): the cycle reads the map's geometry and the constants from the ARGUMENT SEGMENT again
+        // (scalar loads through a laundered pointer) instead of holding them — spilled to vector lanes — across the chain, as the
+        // one-wavefront-per-pose plan kernels do: the service call 108.3 -> 106.9 us (A/B in one call, three repetitions).
+        constexpr bool kReloadO = FPE_OPT_RELOAD_ARGS != 0 && W > 1;
+        typedef const OptKernArgs __attribute__((address_space(4))) * OptArgPtr;
+        OptArgPtr ka4 = (OptArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        if constexpr (kReloadO) asm volatile("" : "+s"(ka4));
+        const OptKernArgs* ka = (const OptKernArgs*)ka4;
+        const DevMap& m = kReloadO ? ka->m : mArg;
+        const PlanConsts& pc = kReloadO ? ka->pc : pcArg;
+        const OptConsts& oc = kReloadO ? ka->oc : ocArg;
+        const int nCycles = kReloadO ? ka->nCycles : nCyclesArg;
+        const fpe_opt_out out = kReloadO ? ka->out : outArg;
+        const int cyc = cycIt;
         const size_t oCyc = static_cast<size_t>(b) * nCycles + cyc;
         fpe_opt_cycle rec;
         __builtin_memset(&rec, 0, sizeof(rec));
