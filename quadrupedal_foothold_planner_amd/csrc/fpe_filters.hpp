@@ -833,7 +833,7 @@ __global__ __launch_bounds__(TR * TC) __attribute__((amdgpu_waves_per_eu(TR * TC
     if (live && kStep && !travOnly) L.step[static_cast<size_t>(i) * g.cols + j] = stepOut;
     FPE_TL_MARK(2);
     // the cells that take the literal walks (rank-deficient scatter, components at rounding level): a phase of their own
-    walk_phase<H, TR, TC>(ldsRaw, g, L, sN, ti0, tj0, rN, slopeCritical, roughCritical, needWalk, stepOut, kStep, travOnly);
+    walk_phase<H, TR, TC>(ldsRaw, needWalk, stepOut);
     FPE_TL_MARK(3);
 }
 
