@@ -8,6 +8,6 @@ for k in ks[1:]:
     name=re.search(r'\.name:\s+(\S+)',k).group(1)
     g=lambda key: int(re.search(r'\.'+key+r':\s+(\d+)',k).group(1))
     dn=subprocess.run(['c++filt',name],capture_output=True,text=True).stdout.strip()
-    dn=re.sub(r'^void fpe::\(anonymous namespace\)::','',re.sub(r'\(.*','',dn))
+    dn=re.sub(r'\(.*','',dn.replace('(anonymous namespace)::','').replace('void fpe::',''))
     if flt and flt not in dn: continue
     print(f"{dn[:80]:80s} vgpr {g('vgpr_count'):4d} sgpr {g('sgpr_count'):4d} scratch {g('private_segment_fixed_size'):5d} vspill {g('vgpr_spill_count'):4d} sspill {g('sgpr_spill_count'):4d} lds {g('group_segment_fixed_size')}")

@@ -66,17 +66,56 @@ __device__ __forceinline__ DiscLds disc_carve(char* base, int H, int TR = kFT, i
     d.tile = reinterpret_cast<float*>(p);
     return d;
 }
+// The tables of a tile: positions of its rows / columns (halo included), the iterator's bounding box per row / column of the
+// workgroup's cells, and the squared per-axis centre distances.  No barrier.
+template <int TR, int TC, int HS>
+__device__ __forceinline__ void disc_tables(const DiscLds& d, const MapGeom& g, int ti0, int tj0, double r, bool axisTables = true) {
+    const int H = HS > 0 ? HS : d.H, WR = TR + 2 * H, WC = TC + 2 * H, t = threadIdx.x, D = 2 * H + 1;
+    constexpr int kThreads = TR * TC;
+    if (axisTables) {
+        for (int k = t; k < WR + WC; k += kThreads) {
+            if (k < WR) d.xP[k] = cell_pos(g.baseX, g.res, ti0 - H + k);
+            else d.yP[k - WR] = cell_pos(g.baseY, g.res, tj0 - H + (k - WR));
+        }
+    }
+    if (t < TR + TC) {  // CircleIterator::findSubmapParameters per axis (circle_bbox), clamped onto the halo
+        const bool isRow = t < TR;
+        const int l = isRow ? t : t - TR;
+        const int idx = (isRow ? ti0 : tj0) + l, n = isRow ? g.rows : g.cols;
+        const double c = cell_pos(isRow ? g.baseX : g.baseY, g.res, idx);
+        const double org = isRow ? g.orgX : g.orgY, pos = isRow ? g.posX : g.posY, len = isRow ? g.lenX : g.lenY;
+        int a = index_of_fast(bound_axis(c + r, org, pos, len), org, pos, g.res, g.rinv);
+        int b = index_of_fast(bound_axis(c - r, org, pos, len), org, pos, g.res, g.rinv);
+        a = max(a, max(idx - H, 0));
+        b = min(b, min(idx + H, n - 1));
+        (isRow ? d.bi0 : d.bj0)[l] = a;
+        (isRow ? d.bi1 : d.bj1)[l] = b;
+    }
+    if (axisTables) {
+        for (int k = t; k < (TR + TC) * D; k += kThreads) {  // CircleIterator::isInside, per axis
+            const bool isRow = k < TR * D;
+            const int e = isRow ? k : k - TR * D;
+            const int l = e / D, o = e % D;
+            const double base = isRow ? g.baseX : g.baseY;
+            const int first = (isRow ? ti0 : tj0) - H + l;
+            const double dd = cell_pos(base, g.res, first + o) - cell_pos(base, g.res, first + H);
+            (isRow ? d.dx2 : d.dy2)[e] = dd * dd;
+        }
+    }
+}
 // Tables and source tile of the workgroup's cells [ti0, ti0 + kFT) x [tj0, tj0 + kFT); ends with a barrier.
 // One phase, one barrier: every thread first REQUESTS its share of the tile (a wavefront takes every fourth tile row,
 // lane = tile column: no index division, up to 16 loads in flight per lane — the former one-load-one-store loop waited
 // for each of its five to ten loads in turn, and the kernels spent most of a wavefront's life there), computes its
 // table entries from cell_pos itself while the loads fly (the same values the position arrays hold), then stores.
 // kTables false: the tile and the bounding boxes only (the step filter's row runs need no per-axis distance tables).
+// tilesOnly (run time, wave-uniform): the tile alone — the caller knows that nothing on its hot path reads a table (the moment
+// phase of a disc without an offset on the circle) and builds them later if a cell has to walk (disc_tables, walk_phase).
 template <bool kTables = true, int TR = kFT, int TC = kFT, int HS = 0>
-__device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, const float* __restrict__ src, int ti0, int tj0, double r) {
+__device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, const float* __restrict__ src, int ti0, int tj0, double r, bool tileOnly = false) {
     // HS > 0: the halo is a compile-time constant (every loop bound, the divisions by 2 H + 1 and the number of tile rows a
     // lane requests are then constants); 0: run time
-    const int H = HS > 0 ? HS : d.H, WR = TR + 2 * H, WC = TC + 2 * H, t = threadIdx.x, D = 2 * H + 1;
+    const int H = HS > 0 ? HS : d.H, WR = TR + 2 * H, WC = TC + 2 * H, t = threadIdx.x;
     constexpr int kThreads = TR * TC;  // (the launch makes sure that a tile row is at most one wavefront load: TC + 2 H <= 64)
     // a wavefront instruction loads one tile row (WC > 32) or two (lanes 0-31 / 32-63); up to eight rows in flight per lane
     const int perInst = WC <= 32 ? 2 : 1, laneCols = WC <= 32 ? 32 : 64;
@@ -108,36 +147,7 @@ __device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, c
         }
     };
     request(0);
-    if constexpr (kTables) {
-        for (int k = t; k < WR + WC; k += kThreads) {
-            if (k < WR) d.xP[k] = cell_pos(g.baseX, g.res, ti0 - H + k);
-            else d.yP[k - WR] = cell_pos(g.baseY, g.res, tj0 - H + (k - WR));
-        }
-    }
-    if (t < TR + TC) {  // CircleIterator::findSubmapParameters per axis (circle_bbox), clamped onto the halo
-        const bool isRow = t < TR;
-        const int l = isRow ? t : t - TR;
-        const int idx = (isRow ? ti0 : tj0) + l, n = isRow ? g.rows : g.cols;
-        const double c = cell_pos(isRow ? g.baseX : g.baseY, g.res, idx);
-        const double org = isRow ? g.orgX : g.orgY, pos = isRow ? g.posX : g.posY, len = isRow ? g.lenX : g.lenY;
-        int a = index_of_fast(bound_axis(c + r, org, pos, len), org, pos, g.res, g.rinv);
-        int b = index_of_fast(bound_axis(c - r, org, pos, len), org, pos, g.res, g.rinv);
-        a = max(a, max(idx - H, 0));
-        b = min(b, min(idx + H, n - 1));
-        (isRow ? d.bi0 : d.bj0)[l] = a;
-        (isRow ? d.bi1 : d.bj1)[l] = b;
-    }
-    if constexpr (kTables) {
-        for (int k = t; k < (TR + TC) * D; k += kThreads) {  // CircleIterator::isInside, per axis
-            const bool isRow = k < TR * D;
-            const int e = isRow ? k : k - TR * D;
-            const int l = e / D, o = e % D;
-            const double base = isRow ? g.baseX : g.baseY;
-            const int first = (isRow ? ti0 : tj0) - H + l;
-            const double dd = cell_pos(base, g.res, first + o) - cell_pos(base, g.res, first + H);
-            (isRow ? d.dx2 : d.dy2)[e] = dd * dd;
-        }
-    }
+    if (!tileOnly) disc_tables<TR, TC, HS>(d, g, ti0, tj0, r, kTables);
     deposit(0);
     for (int base = rowStep * kBatch; base < WR; base += rowStep * kBatch) {  // (tiles of more rows than a round requests)
         request(base);

@@ -208,11 +208,14 @@ __device__ __forceinline__ bool moments_phase(char* ldsRaw, const MapGeom& g, co
     using Lay = FusedLayout<H, TR, TC>;
     constexpr int WR = Lay::WR, W = Lay::WC, W1 = Lay::W1, D = Lay::D;
     static_assert(W <= 64 && WR <= 64, "a tile row is one wavefront load; the scans run one lane per tile row");
-    static_assert(TR * TC >= 256, "four wavefronts scan the four record field groups");
+    static_assert(TR * TC >= 128, "two wavefronts scan the record fields");
     const DiscLds d = disc_carve(ldsRaw, H, TR, TC);
     MomentA* const PA = reinterpret_cast<MomentA*>(ldsRaw + Lay::discBytes);
     MomentB* const PB = reinterpret_cast<MomentB*>(ldsRaw + Lay::discBytes + Lay::recBytes);
-    disc_setup<true, TR, TC, H>(d, g, elev, ti0, tj0, r);
+    // A disc without an offset on the circle (the published chain at 2 cm) reads no table on this path — the rows' half-widths are
+    // scalars of the shape: the tile alone, and walk_phase builds the tables for the workgroups that walk (round 6: the tables were
+    // ~150 vector instructions of the first wavefront and ~40 of five more, in every workgroup).
+    disc_setup<true, TR, TC, H>(d, g, elev, ti0, tj0, r, sp.edgeRows == 0ull);
     FPE_TL_MARK(11);
     // z0, the elevation the prefix sums are taken about: a VALID cell near the tile's centre (the sums' cancellation grows with the
     // square of the largest |z - z0| in the tile: the centre halves it against a corner, and a hole at one fixed cell must not
@@ -227,9 +230,11 @@ __device__ __forceinline__ bool moments_phase(char* ldsRaw, const MapGeom& g, co
         const unsigned long long fin = __ballot(zs == zs);
         if (fin != 0ull) z0 = static_cast<double>(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(zs), __builtin_ctzll(fin))));
     }
-    {   // prefix records over the tile's columns: wavefront = field group, lane = tile row
+    {   // prefix records over the tile's columns: lane = tile row; the first wavefront scans the integer fields, the second the three
+        // sums of z' — one conversion and one recentring per cell for all three (rounds 4-5 had a wavefront per sum, each converting
+        // and recentring the cell again: 3 x 8 vector instructions per column where this takes 13; same additions in the same order)
         const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-        if (lane < WR && grp < 4) {
+        if (lane < WR && grp < 2) {
             const float* src = d.tile + lane * W;
             if (grp == 0) {
                 uint2* dst = reinterpret_cast<uint2*>(PA + lane * W1);
@@ -244,16 +249,21 @@ __device__ __forceinline__ bool moments_phase(char* ldsRaw, const MapGeom& g, co
                     dst[2 * (c + 1)] = make_uint2(nC, CC);
                 }
             } else {
-                double* dst = grp == 1 ? &PA[lane * W1].z : (grp == 2 ? &PB[lane * W1].zz : &PB[lane * W1].cz);
-                double acc = 0.0;
-                dst[0] = 0.0;
+                typedef double f64x2s __attribute__((ext_vector_type(2)));
+                double* dstZ = &PA[lane * W1].z;
+                f64x2s* dstB = reinterpret_cast<f64x2s*>(PB + lane * W1);
+                double accZ = 0.0, accZZ = 0.0, accCZ = 0.0;
+                dstZ[0] = 0.0;
+                dstB[0] = f64x2s{0.0, 0.0};
 #pragma unroll 4
                 for (int c = 0; c < W; ++c) {
                     const float z = src[c];
                     const double zz = z == z ? static_cast<double>(z) - z0 : 0.0;
-                    const double term = grp == 1 ? zz : (grp == 2 ? zz * zz : static_cast<double>(c) * zz);
-                    acc += term;
-                    dst[2 * (c + 1)] = acc;
+                    accZ += zz;
+                    accZZ += zz * zz;
+                    accCZ += static_cast<double>(c) * zz;
+                    dstZ[2 * (c + 1)] = accZ;
+                    dstB[c + 1] = f64x2s{accZZ, accCZ};
                 }
             }
         }
@@ -499,6 +509,7 @@ __device__ __forceinline__ void walk_phase(char* ldsRaw, bool needWalk, float st
     int8_t* const rowW = reinterpret_cast<int8_t*>(list + TR * TC);  // the shape's half-widths (the walk's row loop reads them by index)
     static_assert(2 * Lay::recBytes >= 16 + 8 * static_cast<size_t>(TR) * TC + 64 + 32 * static_cast<size_t>(TR) * TC, "... the shape's half-widths and four doubles per walking lane behind it");
     if (threadIdx.x == 0) *count = 0;
+    if (sp.edgeRows == 0ull) disc_tables<TR, TC, H>(d, g, ti0, tj0, r);  // (moments_phase left them out; the barrier below publishes them)
     {   // lane o reads the half-width of row o: ONE byte load per lane through a pointer in vector registers (indexing the argument
         // struct by the lane number made the compiler copy twenty bytes of it to scratch for halos above nine cells)
         const int8_t* rw = reinterpret_cast<const int8_t*>(ka) + offsetof(FusedKernArgs, sN) + offsetof(StepShape, rowW);
