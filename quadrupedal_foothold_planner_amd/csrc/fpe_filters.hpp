@@ -111,7 +111,9 @@ __device__ __forceinline__ void disc_tables(const DiscLds& d, const MapGeom& g, 
 // kTables false: the tile and the bounding boxes only (the step filter's row runs need no per-axis distance tables).
 // tilesOnly (run time, wave-uniform): the tile alone — the caller knows that nothing on its hot path reads a table (the moment
 // phase of a disc without an offset on the circle) and builds them later if a cell has to walk (disc_tables, walk_phase).
-template <bool kTables = true, int TR = kFT, int TC = kFT, int HS = 0>
+// kCoherent: the source was written by OTHER workgroups of this launch (filter_chain_kernel): device-scope loads, which do not hit
+// a stale line of this XCD's caches.
+template <bool kTables = true, int TR = kFT, int TC = kFT, int HS = 0, bool kCoherent = false>
 __device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, const float* __restrict__ src, int ti0, int tj0, double r, bool tileOnly = false) {
     // HS > 0: the halo is a compile-time constant (every loop bound, the divisions by 2 H + 1 and the number of tile rows a
     // lane requests are then constants); 0: run time
@@ -134,7 +136,10 @@ __device__ __forceinline__ void disc_setup(const DiscLds& d, const MapGeom& g, c
         for (int q = 0; q < kBatch; ++q) {
             const int row = base + firstRow + rowStep * q, ti = ti0 - H + row;
             v[q] = __builtin_nanf("");
-            if (row < WR && colOk && ti >= 0 && ti < g.rows) v[q] = src[static_cast<size_t>(ti) * g.cols + tj];
+            if (row < WR && colOk && ti >= 0 && ti < g.rows) {
+                if constexpr (kCoherent) v[q] = __hip_atomic_load(&src[static_cast<size_t>(ti) * g.cols + tj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else v[q] = src[static_cast<size_t>(ti) * g.cols + tj];
+            }
         }
     };
     // invalid cells (GridMap::isValid = isfinite) enter the tile as quiet NaNs: the walks test `z == z`, and the float
@@ -621,7 +626,7 @@ __device__ __forceinline__ float min3_skip_nan(float a, float b, float c) {
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-template <bool kSecond, int TR, int TC, int HS>
+template <bool kSecond, int TR, int TC, int HS, bool kCoherent = false>
 __device__ __forceinline__ void step_runs_phase(char* ldsRaw, const MapGeom& g, const float* __restrict__ src, double r, int Hrt, const StepShape& sp,
                                                 float critDown, int ti0, int tj0, bool live, float& hiOut, float& loOut, int& cntOut, float& centreOut) {
     const int H = HS > 0 ? HS : Hrt;
@@ -638,7 +643,7 @@ __device__ __forceinline__ void step_runs_phase(char* ldsRaw, const MapGeom& g, 
     const unsigned storeMask = sp.storeMask;
     // (with the per-axis distance tables: the on-circle offsets' tests below read them instead of recomputing two cell
     // positions per offset and cell)
-    disc_setup<true, TR, TC, HS>(d, g, src, ti0, tj0, r);
+    disc_setup<true, TR, TC, HS, kCoherent>(d, g, src, ti0, tj0, r);
     if (kSecond) FPE_TL_MARK(8);
     const float ninf = -__builtin_huge_valf(), pinf = __builtin_huge_valf();
     for (int e = threadIdx.x; e < WR * TC; e += TR * TC) {  // 1. one run per (tile row, interior column)
@@ -790,13 +795,12 @@ __global__ __launch_bounds__(TR * TC) void filter_step_runs_kernel(MapGeom g, co
 // layer and nothing else.
 // (512-thread workgroups: three of them per CU — six wavefronts per SIMD, 80 registers; without the hint the allocator takes 88
 // and a third of the CU's wavefronts with them: 0.283 -> 0.341 ms at 1 cm)
-template <int H, int TR, int TC, int HS>
-__global__ __launch_bounds__(TR * TC) __attribute__((amdgpu_waves_per_eu(TR * TC == 512 ? ((H == 3 && HS == 5) ? FPE_FUSED_WAVES_2CM : FPE_FUSED_WAVES) : 4))) void filter_fused_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double rN, double slopeCritical,
-                                                            double roughCritical, double invSlopeCritical, double invRoughCritical, StepShape sN, double r2nd, int h2nd, StepShape s2, double stepCritical,
-                                                            float critDown, int nCritical, int kStepFlags, int travOnly, int tilesX, int nTiles) {
-    extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
-    int ty, tx;
-    xcd_tile(tilesX, nTiles, ty, tx);
+// One tile of the fused launch: the second step window, the moment phase, the stores, the walking phase.  kChain: the tile's
+// coordinates come from the caller (filter_chain_kernel) instead of the workgroup number.
+template <int H, int TR, int TC, int HS, bool kChain>
+__device__ __forceinline__ void fused_tile(char* ldsRaw, const MapGeom& g, const float* __restrict__ elev, const FilterLayers& L, double rN, double slopeCritical, double roughCritical,
+                                           double invSlopeCritical, double invRoughCritical, const StepShape& sN, double r2nd, int h2nd, const StepShape& s2, double stepCritical,
+                                           float critDown, int nCritical, int kStepFlags, int travOnly, int ty, int tx) {
     const int ti0 = ty * TR, tj0 = tx * TC;
     const int i = ti0 + static_cast<int>(threadIdx.x) / TC, j = tj0 + static_cast<int>(threadIdx.x) % TC;
     const bool live = i < g.rows && j < g.cols;
@@ -815,7 +819,7 @@ __global__ __launch_bounds__(TR * TC) __attribute__((amdgpu_waves_per_eu(TR * TC
     if (kStep) {
         float hi, lo;
         int cnt;
-        step_runs_phase<true, TR, TC, HS>(ldsRaw, g, L.stepHeight, r2nd, h2nd, s2, critDown, ti0, tj0, live, hi, lo, cnt, stepHeightHere);
+        step_runs_phase<true, TR, TC, HS, kChain>(ldsRaw, g, L.stepHeight, r2nd, h2nd, s2, critDown, ti0, tj0, live, hi, lo, cnt, stepHeightHere);
         stepOut = step_value(hi, cnt, stepCritical, nCritical);
         __syncthreads();  // the moment phase reuses the LDS
     } else if (live && (kStepFlags & 2)) {
@@ -843,8 +847,77 @@ __global__ __launch_bounds__(TR * TC) __attribute__((amdgpu_waves_per_eu(TR * TC
     if (live && kStep && !travOnly) L.step[static_cast<size_t>(i) * g.cols + j] = stepOut;
     FPE_TL_MARK(2);
     // the cells that take the literal walks (rank-deficient scatter, components at rounding level): a phase of their own
-    walk_phase<H, TR, TC>(ldsRaw, needWalk, stepOut);
+    walk_phase<H, TR, TC, kChain>(ldsRaw, needWalk, stepOut, ty, tx);
     FPE_TL_MARK(3);
+}
+
+template <int H, int TR, int TC, int HS>
+__global__ __launch_bounds__(TR * TC) __attribute__((amdgpu_waves_per_eu(TR * TC == 512 ? ((H == 3 && HS == 5) ? FPE_FUSED_WAVES_2CM : FPE_FUSED_WAVES) : 4))) void filter_fused_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double rN, double slopeCritical,
+                                                            double roughCritical, double invSlopeCritical, double invRoughCritical, StepShape sN, double r2nd, int h2nd, StepShape s2, double stepCritical,
+                                                            float critDown, int nCritical, int kStepFlags, int travOnly, int tilesX, int nTiles) {
+    extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
+    int ty, tx;
+    xcd_tile(tilesX, nTiles, ty, tx);
+    fused_tile<H, TR, TC, HS, false>(ldsRaw, g, elev, L, rN, slopeCritical, roughCritical, invSlopeCritical, invRoughCritical, sN, r2nd, h2nd, s2, stepCritical, critDown, nCritical,
+                                     kStepFlags, travOnly, ty, tx);
+}
+
+// ---- the chain as ONE launch (round 6) --------------------------------------------------------------------------------------
+// Every workgroup first computes the step heights of one tile (the first window: step_runs_phase<false>), publishes them (release
+// at device scope, one flag per tile), then runs the fused tile `lag` positions BEHIND in its XCD's order, after the flags of that
+// tile and its eight neighbours.  Order: XCD x = workgroup % 8 owns the strip of `cw` tile columns [x cw, (x + 1) cw), row-major
+// inside the strip (position k = workgroup / 8: tile row k / cw, column x cw + k % cw).  A neighbour of position k - lag lies at
+// most at position k - lag + 2 cw - 1 of its own strip, so with lag = 2 cw every flag a workgroup waits for is set by a
+// workgroup with a SMALLER number, which the dispatcher has started before it (workgroups are dispatched in the order of their
+// numbers) and which waits for nobody before it sets its flag: no cycle.  A wait that never ends (the assumption broken) traps
+// after ~1 s of polling instead of hanging the device.  Flags hold the launch's epoch: nobody clears them.
+template <int H, int TR, int TC, int HS>
+__global__ __launch_bounds__(TR * TC) __attribute__((amdgpu_waves_per_eu(TR * TC == 512 ? ((H == 3 && HS == 5) ? FPE_FUSED_WAVES_2CM : FPE_FUSED_WAVES) : 4))) void filter_chain_kernel(MapGeom g, const float* __restrict__ elev, FilterLayers L, double rN, double slopeCritical,
+                                                            double roughCritical, double invSlopeCritical, double invRoughCritical, StepShape sN, double r2nd, int h2nd, StepShape s2, double stepCritical,
+                                                            float critDown, int nCritical, int kStepFlags, int travOnly, int tilesX, int nTiles, StepShape s1, double r1st,
+                                                            unsigned* flags, unsigned epoch, int cw, int nK, int lag) {
+    extern __shared__ __attribute__((aligned(16))) char ldsRaw[];
+    const int x = static_cast<int>(blockIdx.x & 7u), k = static_cast<int>(blockIdx.x >> 3);
+    const int tilesY = nTiles / tilesX;
+    if (k < nK) {
+        const int ty = k / cw, tx = x * cw + (k - ty * cw);
+        if (tx < tilesX) {  // (wave-uniform)
+            const int ti0 = ty * TR, tj0 = tx * TC;
+            const int i = ti0 + static_cast<int>(threadIdx.x) / TC, j = tj0 + static_cast<int>(threadIdx.x) % TC;
+            const bool live = i < g.rows && j < g.cols;
+            float hi, lo, centre;
+            int cnt;
+            step_runs_phase<false, TR, TC, HS>(ldsRaw, g, elev, r1st, HS, s1, 0.0f, ti0, tj0, live, hi, lo, cnt, centre);
+            // device-scope stores (written through to where every XCD reads them) and device-scope loads on the other side: a release /
+            // acquire pair of FENCES at device scope writes back and invalidates the XCD's whole L2 per workgroup — measured: the
+            // chain at 0.475 ms instead of 0.054
+            if (live)
+                __hip_atomic_store(&L.stepHeight[static_cast<size_t>(i) * g.cols + j],
+                                   isfinite(centre) ? static_cast<float>(static_cast<double>(hi) - static_cast<double>(lo)) : __builtin_nanf(""), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wavefront's stores are acknowledged ...
+            __syncthreads();                                   // ... before the one flag says so (and the next phase reuses the LDS)
+            if (threadIdx.x == 0) __hip_atomic_store(&flags[ty * tilesX + tx], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    const int k2 = k - lag;
+    if (k2 < 0) return;
+    const int ty = k2 / cw, tx = x * cw + (k2 - ty * cw);
+    if (tx >= tilesX) return;
+    if (threadIdx.x < 9) {
+        const int ny = ty + static_cast<int>(threadIdx.x) / 3 - 1, nx = tx + static_cast<int>(threadIdx.x) % 3 - 1;
+        if (ny >= 0 && ny < tilesY && nx >= 0 && nx < tilesX) {
+            const unsigned* f = &flags[ny * tilesX + nx];
+            unsigned polls = 0;
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++polls > (1u << 22)) __builtin_trap();
+            }
+        }
+    }
+    __syncthreads();
+    fused_tile<H, TR, TC, HS, true>(ldsRaw, g, elev, L, rN, slopeCritical, roughCritical, invSlopeCritical, invRoughCritical, sN, r2nd, h2nd, s2, stepCritical, critDown, nCritical,
+                                    kStepFlags, travOnly, ty, tx);
 }
 
 __host__ inline int filter_halo(double r, double res) { return static_cast<int>(r / res) + 1; }
@@ -879,6 +952,26 @@ hipError_t launch_fused_one(const MapGeom& g, const FilterConsts& fc, const floa
     hipLaunchKernelGGL((filter_fused_kernel<H, TR, TC, HS>), dim3(nTiles), dim3(TR * TC), rt.fusedBytes, stream, g, d_elev, L, fc.normalRadius, fc.slopeCritical,
                        fc.roughnessCritical, 1.0 / fc.slopeCritical, 1.0 / fc.roughnessCritical, rt.sN, fc.stepSecondRadius, rt.h2, rt.s2, fc.stepCritical, critDown, fc.stepCriticalCells,
                        rt.stepFused | (fc.normalRadius <= fc.stepFirstRadius ? 2 : 0), travOnly, tilesX, nTiles);
+    return hipGetLastError();
+}
+// The chain as one launch (filter_chain_kernel): flags = one word per tile, holding the epoch of the last launch that wrote the tile.
+template <int H, int TR, int TC, int HS>
+hipError_t launch_chain_one(const MapGeom& g, const FilterConsts& fc, const float* d_elev, const FilterLayers& L, const FilterRoute& rt, float critDown, int travOnly,
+                            unsigned* flags, unsigned epoch, hipStream_t stream) {
+    const void* fn = reinterpret_cast<const void*>(filter_chain_kernel<H, TR, TC, HS>);
+    size_t bytes = rt.fusedBytes;
+    const size_t first = step_lds_bytes(rt.h1, rt.s1.nClasses, TR, TC);
+    if (first > bytes) bytes = first;
+    if (bytes > 150 * 1024) return hipErrorInvalidValue;
+    if (bytes > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+        if (e != hipSuccess) return e;
+    }
+    const int tilesX = (g.cols + TC - 1) / TC, tilesY = (g.rows + TR - 1) / TR, nTiles = tilesX * tilesY;
+    const int cw = (tilesX + 7) / 8, nK = cw * tilesY, lag = 2 * cw;
+    hipLaunchKernelGGL((filter_chain_kernel<H, TR, TC, HS>), dim3(8 * (nK + lag)), dim3(TR * TC), bytes, stream, g, d_elev, L, fc.normalRadius, fc.slopeCritical,
+                       fc.roughnessCritical, 1.0 / fc.slopeCritical, 1.0 / fc.roughnessCritical, rt.sN, fc.stepSecondRadius, rt.h2, rt.s2, fc.stepCritical, critDown, fc.stepCriticalCells,
+                       rt.stepFused | (fc.normalRadius <= fc.stepFirstRadius ? 2 : 0), travOnly, tilesX, nTiles, rt.s1, fc.stepFirstRadius, flags, epoch, cw, nK, lag);
     return hipGetLastError();
 }
 // The fused kernel's tile: 32 rows x 16 columns (512 threads) for halos up to eight cells, 32 x 32 beyond.  Rows amortise: the
@@ -986,6 +1079,17 @@ hipError_t launch_filters(const MapGeom& g, const FilterConsts& fc, const float*
         FPE_RUNS(16, 16, 0);
 #undef FPE_RUNS
     };
+#ifdef FPE_FILTER_CHAIN_EXPERIMENT  // (measurement build: the flags from a process-wide buffer — one chain at a time)
+    if (rt.tF == 16 && rt.stepFused && rt.h1 == rt.h2 && rt.s1.ok && std::getenv("FPE_FILTER_CHAIN")) {
+        static unsigned* gFlags = nullptr;
+        static unsigned gEpoch = 0;
+        if (!gFlags) {
+            if (hipMalloc(&gFlags, 4u << 20) != hipSuccess || hipMemset(gFlags, 0, 4u << 20) != hipSuccess) return hipErrorOutOfMemory;
+        }
+        if (rt.hN == 3 && rt.h2 == 5) return launch_chain_one<3, kFusedRows, 16, 5>(g, fc, d_elev, L, rt, critDown, travOnly ? 1 : 0, gFlags, ++gEpoch, stream);
+        if (rt.hN == 6 && rt.h2 == 9) return launch_chain_one<6, kFusedRows, 16, 9>(g, fc, d_elev, L, rt, critDown, travOnly ? 1 : 0, gFlags, ++gEpoch, stream);
+    }
+#endif
     // 1. step heights (first window)
     if (!launch_runs(std::false_type{}, rt.t1, rt.h1, rt.s1, d_elev, fc.stepFirstRadius))  // (the walking kernel writes L.stepHeight only: fine for travOnly too)
         hipLaunchKernelGGL(filter_step1_kernel, grid, block, disc_lds_bytes(rt.h1), stream, g, d_elev, L, fc.stepFirstRadius, rt.h1);

@@ -483,8 +483,8 @@ struct FusedKernArgs {
     float critDown;
     int nCritical, kStepFlags, travOnly, tilesX, nTiles;
 };
-template <int H, int TR, int TC>
-__device__ __forceinline__ void walk_phase(char* ldsRaw, bool needWalk, float stepOut) {
+template <int H, int TR, int TC, bool kChain = false>
+__device__ __forceinline__ void walk_phase(char* ldsRaw, bool needWalk, float stepOut, int tyIn = 0, int txIn = 0) {
     using Lay = FusedLayout<H, TR, TC>;
 #ifdef FPE_NO_WALK  // (measurement builds only: what the kernel costs without its walking phase)
     return;
@@ -499,8 +499,8 @@ __device__ __forceinline__ void walk_phase(char* ldsRaw, bool needWalk, float st
     const StepShape& sp = ka->sN;
     const double r = ka->rN, slopeCritical = ka->slopeCritical, roughCritical = ka->roughCritical;
     const int kStep = ka->kStepFlags & 1, travOnly = ka->travOnly;
-    int tyW, txW;
-    xcd_tile(ka->tilesX, ka->nTiles, tyW, txW);
+    int tyW = tyIn, txW = txIn;  // (filter_chain_kernel: the tile is not a function of the workgroup number alone)
+    if constexpr (!kChain) xcd_tile(ka->tilesX, ka->nTiles, tyW, txW);
     const int ti0 = tyW * TR, tj0 = txW * TC;
     const DiscLds d = disc_carve(ldsRaw, H, TR, TC);
     int* const count = reinterpret_cast<int*>(ldsRaw + Lay::discBytes);
