@@ -918,6 +918,9 @@ int filters_common(fpe_engine* h, const fpe_map_desc* desc, const fpe_filter_par
             bool wait = false;
             for (auto& fs : h->filterSlots)  // (1) this stream's own buffer
                 if (fs.buf && fs.cap >= n && fs.cap <= 4 * n + 4096 && fs.last == stream && (!slot || fs.use > slot->use)) slot = &fs;
+            // (the wait on the slot's event is queued in this case too: on the same in-order queue it is free, and a caller who destroyed
+            // the stream with work pending and got the same handle value back for a new one is ordered behind the old chain — ADVICE r5)
+            if (slot) wait = true;
             if (!slot)
                 for (auto& fs : h->filterSlots)  // (2) an idle buffer
                     if (fs.buf && fs.cap >= n && fs.cap <= 4 * n + 4096 && hipEventQuery(fs.done) == hipSuccess) {
