@@ -740,13 +740,37 @@ def main():
             svc.close()
             return float(np.median(ts) * 1e6)
 
+        def service_entry_us(reps_s=200):
+            """The C entry point itself: fpe_plan_service called with prebuilt ctypes arguments (what a C or C++ caller pays, plus one
+            foreign-function call of ~1 us) — without the Python mirror's per-call work (response dict, copies)."""
+            from quadrupedal_foothold_planner_amd import _capi as _c
+            svc = FootholdPlanner(local_rank)
+            svc.params = planner.params.copy()
+            svc.gridmapCallback(trav, elev, res)
+            msg = np.zeros(1, dtype=_c.GLOBAL_FOOTHOLDS_DTYPE)
+            pos = np.ascontiguousarray(poses["position"][0], dtype=np.float64).copy()
+            a_par, a_pos, a_msg = _c.ptr(svc.params), _c.ptr(pos), _c.ptr(msg)
+            fn, h = svc._lib.fpe_plan_service, svc._h
+            for _ in range(3):
+                assert fn(h, a_par, a_pos, 8, a_msg) in (_c.FPE_OK, _c.FPE_E_SERVICE_FALSE)
+            ts = []
+            for _ in range(reps_s):
+                t0 = time.perf_counter()
+                fn(h, a_par, a_pos, 8, a_msg)
+                ts.append(time.perf_counter() - t0)
+            svc.close()
+            return float(np.median(ts) * 1e6)
+
         line["service_latency_us"] = {
             "steady_map": {"bit_window": service_us(False, False), "direct": service_us(False, True)},
+            "steady_map_c_entry_point": {"bit_window": service_entry_us()},
             "first_call_after_a_map": {"bit_window": service_us(True, False, 12), "direct": service_us(True, True, 12)},
             "steady_map_one_kernel_after_the_other": {"bit_window": service_us(False, False, overlap=0)},
             "steady_map_exact_gates_only": {"bit_window": service_us(False, False, opt_gate=0)},
             "first_call_after_a_map_exact_gates_only": {"bit_window": service_us(True, False, 12, opt_gate=0)},
-            "note": "median wall time of fpe_plan_service (1 pose x 8 cycles, response assembled) per call, ctypes overhead included.  Default "
+            "note": "median wall time of fpe_plan_service (1 pose x 8 cycles, response assembled) per call through the Python mirror "
+                    "(FootholdPlanner.globalFootholdPlan: ctypes call + response dict); steady_map_c_entry_point = the C function alone, called "
+                    "with prebuilt arguments.  Default "
                     "(service_opt_gate 2, enforce): the plan kernel and, BESIDE it on a second stream, the opt track's chain (cpp:913-1319: eight "
                     "optimiser searches of 14 641 lattice points each, one after the other) whose gate verdict the call honours like the "
                     "reference's handler (cpp:920-934); the chain runs on nominal cycle flags of 1 and again on the real ones in the call where "

@@ -9,6 +9,8 @@ libfpe.so cannot be loaded or no gfx950 GPU is present, construction raises Engi
 import contextlib
 import ctypes as C
 
+import threading
+
 import numpy as np
 
 from . import _capi
@@ -307,14 +309,27 @@ class FootholdPlanner:
         tells the kinds apart); with all_tracks also the centroid message, the default-track
         rows (global_footholds_centroid, globalFootholdsResult_.defaultFootholds), and per track the
         feet-centre path and KPIs (nominal/centroid_feet_center_path, footholdsKPI_)."""
-        msg = np.zeros(1, dtype=GLOBAL_FOOTHOLDS_DTYPE)
-        pos = np.ascontiguousarray(initial_position, dtype=np.float64).reshape(3)
         if not all_tracks:
-            rc = self._lib.fpe_plan_service(self._h, ptr(self.params), ptr(pos), int(gait_cycles) & 0xFF, ptr(msg))
+            # the latency path: message and position buffers of the planner's own, their addresses and the parameter block's taken once
+            # (numpy's .ctypes and a zeroed 5 KB message per call were ~4 us of a 105 us call); the library fills every field it reports
+            tls = self.__dict__.get("_svc_tls")
+            if tls is None:
+                tls = self.__dict__.setdefault("_svc_tls", threading.local())
+            sv = getattr(tls, "sv", None)  # (per thread: the engine serves concurrent callers of one handle)
+            if sv is None or sv[4] is not self.params:
+                m, q = np.zeros(1, dtype=GLOBAL_FOOTHOLDS_DTYPE), np.zeros(3, dtype=np.float64)
+                sv = tls.sv = (m, q, ptr(m), ptr(q), self.params, ptr(self.params),
+                               m["success"], m["gait_cycles"], m["gait_cycles_succeed"], m["n_footholds"], m["footholds"][0])  # field views, made once
+            sv[1][:] = initial_position
+            rc = self._lib.fpe_plan_service(self._h, sv[5], sv[3], int(gait_cycles) & 0xFF, sv[2])
             if rc == _capi.FPE_E_SERVICE_FALSE:
                 return False  # the reference's handler returns false here (cpp:931-934): the ROS call fails
-            self._check(rc)
-            return self._msg(msg[0])
+            if rc != _capi.FPE_OK:
+                self._check(rc)
+            return {"success": bool(sv[6][0]), "gait_cycles": int(sv[7][0]), "gait_cycles_succeed": int(sv[8][0]),
+                    "footholds": sv[10][: int(sv[9][0])].copy()}  # (= self._msg(sv[0][0]))
+        msg = np.zeros(1, dtype=GLOBAL_FOOTHOLDS_DTYPE)
+        pos = np.ascontiguousarray(initial_position, dtype=np.float64).reshape(3)
         cen = np.zeros(1, dtype=GLOBAL_FOOTHOLDS_DTYPE)
         optm = np.zeros(1, dtype=GLOBAL_FOOTHOLDS_DTYPE)
         dflt = np.zeros((1 + int(gait_cycles), 4, 3), dtype=np.float64)
