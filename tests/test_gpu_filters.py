@@ -521,8 +521,10 @@ def test_two_producers_alternating_streams_never_synchronise_the_device(planner)
     """the step-height scratch was keyed to ONE stream, so two producers alternating streams handed it back
     dirty on every call and the next taker called hipDeviceSynchronize — a latency cliff behind an asynchronous entry point.  The
     engine now keeps up to four event-guarded buffers (fpe_engine::filterSlots): 100 calls alternating two streams, none of
-    which may take longer on the host than three times the median call of ONE stream (a device synchronisation would wait for
-    the whole backlog of ~50 us chains).  Best of three rounds: the bar is about the engine, not the host's scheduler."""
+    which may take longer on the host than three times the median call of ONE stream or 250 us, whichever is larger (a device
+    synchronisation waits for the backlog: up to nineteen chains of ~54 us, a millisecond; the absolute floor is for a loaded
+    host — on one box of the pool two of three suite runs saw a 30+ us call with nothing wrong).  Best of three rounds: the bar
+    is about the engine, not the host's scheduler."""
     import gc
     import time
 
@@ -556,7 +558,7 @@ def test_two_producers_alternating_streams_never_synchronise_the_device(planner)
     for k in range(2):
         assert np.array_equal(d_t[k].cpu().numpy(), want[k], equal_nan=True), f"stream {k}: not its own map's layer"
     print(f"filter call on the host: one stream median {single * 1e6:.1f} us; alternating two streams, worst of 100 calls {worst * 1e6:.1f} us")
-    assert worst <= 3.0 * single, f"an alternating call took {worst * 1e6:.1f} us against a single-stream median of {single * 1e6:.1f} us"
+    assert worst <= max(3.0 * single, 250e-6), f"an alternating call took {worst * 1e6:.1f} us against a single-stream median of {single * 1e6:.1f} us"
 
 
 def test_more_producer_streams_than_scratch_buffers(planner):
