@@ -98,6 +98,9 @@ __device__ __forceinline__ double acos_unit(double x) {
 #ifndef FPE_NORMAL_MIN_GAP
 #define FPE_NORMAL_MIN_GAP 3e-4
 #endif
+#ifndef FPE_NORMAL_MIN_COMPONENT_GAP
+#define FPE_NORMAL_MIN_COMPONENT_GAP 1e-7
+#endif
 #ifdef FPE_DBG_COUNT_WALKS
 __device__ unsigned g_walkWhy[4];
 __device__ double g_walkDbg[64][8];
@@ -172,11 +175,11 @@ __device__ __forceinline__ bool normals_from_moments(const MapGeom& g, double sl
         if (k < 64) { g_walkDbg[k][0] = static_cast<double>(N); g_walkDbg[k][1] = a00; g_walkDbg[k][2] = a11; g_walkDbg[k][3] = a22; g_walkDbg[k][4] = a01; g_walkDbg[k][5] = a02; g_walkDbg[k][6] = a12; g_walkDbg[k][7] = gapRel; }
     }
     else if (!(eigS > 1e-10 * eigL)) atomicAdd(&g_walkWhy[1], 1u);
-    else if (normalsStored ? !(cMin * fmin(gapRel, 0.3) > 1e-7) : !(gapRel > 1e-4)) atomicAdd(&g_walkWhy[2], 1u);
+    else if (normalsStored ? !(cMin * fmin(gapRel, 0.3) > FPE_NORMAL_MIN_COMPONENT_GAP) : !(gapRel > 1e-4)) atomicAdd(&g_walkWhy[2], 1u);
     else if (normalsStored && !(gapRel > FPE_NORMAL_MIN_GAP)) atomicAdd(&g_walkWhy[3], 1u);
 #endif
     if (walk || !(eigS > 1e-10 * eigL)) return true;
-    if (normalsStored ? !(cMin * fmin(gapRel, 0.3) > 1e-7) : !(gapRel > 1e-4)) return true;
+    if (normalsStored ? !(cMin * fmin(gapRel, 0.3) > FPE_NORMAL_MIN_COMPONENT_GAP) : !(gapRel > 1e-4)) return true;
     // The stored normal of a cell whose two SMALL eigenvalues nearly coincide (a steep smooth face under a symmetric disc: both are
     // the lattice's own second moment) turns within their plane by dA / gap, and dA — prefix differences over a tile row — is ~3e-14
     // of the scale, not 1e-15: at a gap of 3.6e-5 every component is within 1e-9 of where the oracle puts it and rounds the other
